@@ -1,0 +1,91 @@
+"""Deterministic synthetic inputs: splitmix64 streams.
+
+The same bytes are produced on every host so CPU-baseline and GPU runs see
+identical inputs.  numpy-vectorised.
+"""
+import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(seed, n):
+    """n successive splitmix64 outputs for `seed` (uint64 array)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        s = np.uint64(seed & _M64) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = s
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def uniform_reads(n_reads, read_len, seed=20260001):
+    """config 2: n_reads x read_len i.i.d. uniform ACGT, '\\n' terminated."""
+    z = splitmix64(seed, n_reads * read_len)
+    bases = _ACGT[(z >> np.uint64(62)).astype(np.int64)].reshape(n_reads, read_len)
+    out = np.empty((n_reads, read_len + 1), dtype=np.uint8)
+    out[:, :read_len] = bases
+    out[:, read_len] = 10
+    return out.reshape(-1)
+
+
+def genome(length, seed):
+    z = splitmix64(seed, length)
+    return _ACGT[(z >> np.uint64(62)).astype(np.int64)]
+
+
+def sampled_reads(n_reads, read_len, genome_len, seed=20260003, err=0.005):
+    """config 4 style: reads sampled (forward strand) from a random genome with
+    substitution errors, '\\n' terminated."""
+    g = genome(genome_len, seed)
+    z = splitmix64(seed + 1, n_reads)
+    starts = (z % np.uint64(genome_len - read_len)).astype(np.int64)
+    idx = starts[:, None] + np.arange(read_len, dtype=np.int64)[None, :]
+    bases = g[idx]
+    if err > 0:
+        e = splitmix64(seed + 2, n_reads * read_len).reshape(n_reads, read_len)
+        hit = (e >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53)) < err
+        shift = ((e & np.uint64(3)) % np.uint64(3) + np.uint64(1)).astype(np.int64)
+        code = np.zeros(256, dtype=np.int64)
+        code[_ACGT] = np.arange(4)
+        sub = _ACGT[(code[bases] + shift) % 4]
+        bases = np.where(hit, sub, bases)
+    out = np.empty((n_reads, read_len + 1), dtype=np.uint8)
+    out[:, :read_len] = bases
+    out[:, read_len] = 10
+    return out.reshape(-1)
+
+
+def repetitive_copies(n_copies, length, seed=20260002, rate=1e-3):
+    """config 3 style: n_copies of a pseudo-chromosome, copy k with i.i.d.
+    substitutions at `rate`, one copy per line."""
+    g = genome(length, seed)
+    code = np.zeros(256, dtype=np.int64)
+    code[_ACGT] = np.arange(4)
+    out = np.empty((n_copies, length + 1), dtype=np.uint8)
+    for k in range(n_copies):
+        e = splitmix64(seed + 1 + k, length)
+        hit = (e >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53)) < rate
+        shift = ((e & np.uint64(3)) % np.uint64(3) + np.uint64(1)).astype(np.int64)
+        out[k, :length] = np.where(hit, _ACGT[(code[g] + shift) % 4], g)
+        out[k, length] = 10
+    return out.reshape(-1)
+
+
+def zipf_tokens(n_cells, doc_len=1000, vocab=65000, s=1.1, seed=20260005):
+    """config 5 style: uint16 documents of doc_len tokens ~ Zipf(s) over [1, vocab],
+    separator 0 after each document."""
+    n_docs = n_cells // (doc_len + 1)
+    w = np.arange(1, vocab + 1, dtype=np.float64) ** (-s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    z = splitmix64(seed, n_docs * doc_len)
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    tok = (np.searchsorted(cdf, u) + 1).astype(np.uint16).reshape(n_docs, doc_len)
+    out = np.zeros((n_docs, doc_len + 1), dtype=np.uint16)
+    out[:, :doc_len] = tok
+    return out.reshape(-1)
