@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- input MB/s building the BCR BWT (.rl_bwt image) on MI355X.
+
+A "step" is one pass of the whole parse-then-induce path over the workload,
+input cells already resident in HBM, output .rl_bwt image left in HBM.
+N=1 workload: BASELINE.json configs[1] (1,000,000 x 100 bp uniform ACGT reads,
+101,000,000 bytes).  N>1: records are sharded (weak scaling: one such shard per
+GPU, different seeds), one process per GPU.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, algorithmic bytes
+/ HIP-event time on the engine's stream) and `cpu_baseline` (the CPU oracle,
+"port", single core, on a bounded prefix sample of the same workload).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(name, rounds, levels, cell_bytes, idx_bytes):
+    """Must-touch bytes of ONE launch-set of kernel `name` summed over its launches."""
+    ib = idx_bytes
+    if name == "hash_phrases":        # n_r*w_r read + n_{r+1}*4 slot ids written
+        return sum(r["n_in"] * (cell_bytes if i == 0 else 4) + r["parse_size"] * 4 for i, r in enumerate(rounds))
+    if name == "lms_breaks":          # n_r*w_r read + n_r/8 bits written
+        return sum(r["n_in"] * (cell_bytes if i == 0 else 4) + r["n_in"] // 8 for i, r in enumerate(rounds))
+    if name == "emit_parse":
+        return sum(r["parse_size"] * 8 for r in rounds)
+    if name == "induce_split.scatter":  # stable multi-split of the induced cells: key+index in, key+index out (one pass minimum)
+        return sum(l["induced_cells"] * (4 + ib) * 2 for l in levels)
+    if name == "induce_expand":       # R*(4+ib) runs read + R*4 rewritten + E*(4+4+ib+ib) cells written
+        return sum(l["runs_next"] * (8 + ib) + l["induced_cells"] * (8 + 2 * ib) for l in levels)
+    if name == "induce_count":
+        return sum(l["runs_next"] * (4 + ib) for l in levels)
+    if name == "asm.atoms":
+        return sum(l["atoms"] * (4 + ib) + l["segments"] * (4 + 2 * ib) for l in levels)
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1000000)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--cpu-sample-reads", type=int, default=40000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as g
+    from grlbwt_amd import engine, workloads
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    lib = g.build_hip()
+    # shard of this rank: the named workload (rank 0) / same shape with another seed (other ranks)
+    data = workloads.uniform_reads(args.reads, args.read_len, seed=20260001 + rank)
+    n_bytes = int(data.size)
+    text = torch.from_numpy(data).to(dev)
+    torch.cuda.synchronize()
+
+    ctx = engine.Context(local_rank, 0, lib)
+
+    def step():
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n_bytes * args.steps / dt / 1e6
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: one more step with HIP-event timing of every kernel on the engine's stream
+        ctx.profile_enable(True)
+        step()
+        prof = ctx.profile()
+        ctx.profile_enable(False)
+        nr = 0
+        rounds = []
+        while True:
+            try:
+                rounds.append(ctx.round_info(nr))
+                nr += 1
+            except engine.GrlbwtError:
+                break
+        levels = [ctx.level_info(l) for l in range(nr)]
+        cnt = ctx.counters()
+        ib = cnt["idx_bytes"]
+        total_kernel_ms = sum(ms for _, ms in prof.values())
+        ranked = sorted(prof.items(), key=lambda kv: -kv[1][1])
+        dom = None
+        for name, (launches, ms) in ranked:
+            ab = algorithmic_bytes(name, rounds, levels, 1, ib)
+            if ab is not None:
+                dom = (name, launches, ms, ab)
+                break
+        roofline = None
+        if dom:
+            name, launches, ms, ab = dom
+            achieved = ab / (ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "launches": launches,
+                        "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes": ab, "kernel_ms_total": round(ms, 4),
+                        "avg_launch_ms": round(ms / max(launches, 1), 5),
+                        "share_of_kernel_time": round(ms / max(total_kernel_ms, 1e-9), 4)}
+        top = [{"kernel": k, "launches": c, "ms": round(ms, 3)} for k, (c, ms) in ranked[:12]]
+
+        # ---- CPU baseline leg (reported, not the target): the oracle ("port"), 1 core, bounded sample
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            oracle.build()
+            m = min(args.cpu_sample_reads, args.reads)
+            sample = data[: m * (args.read_len + 1)]
+            with tempfile.TemporaryDirectory() as td:
+                fi, fo = os.path.join(td, "in.txt"), os.path.join(td, "out.rl_bwt")
+                sample.tofile(fi)
+                tc = time.perf_counter()
+                subprocess.check_call([oracle.CLI, fi, fo, "-q"])
+                tcpu = time.perf_counter() - tc
+            cpu = {"value": round(sample.size / 1e6 / tcpu, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+                   "sample": "first %d reads (%d bytes) of the same workload, oracle/oracle_cli, %.1f s"
+                             % (m, sample.size, tcpu),
+                   "host_cpus": os.cpu_count()}
+        out = {
+            "metric": "input MB/s building BCR BWT (.rl_bwt) of DNA reads", "value": round(value, 3), "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d x %d bp uniform ACGT reads per GPU (%d bytes), sigma=5, byte alphabet; "
+                                   "BASELINE configs[1]" % (args.reads, args.read_len, n_bytes),
+                       "input_resident": "HBM", "output": ".rl_bwt image in HBM", "parallelism": "records sharded x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
+            "top_kernels": top, "rounds": nr,
+        }
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,417 @@
+// capi_impl.hpp -- extern "C" layer of include/grlbwt_hip.h over the two index-width
+// instantiations of the engine (grl32 / grl64).  Included by engine_hip.hip.
+#include "../../include/grlbwt_hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#define GRLBWT_FLAG_FORCE_IDX64 4u   /* tests: run the 64-bit index build on small inputs */
+
+struct grlbwt_ctx {
+    uint32_t flags = 0;
+    int device = 0;
+    std::unique_ptr<grl32::Engine> e32;
+    std::unique_ptr<grl64::Engine> e64;
+    std::string err;
+};
+
+namespace {
+
+template <class Fn>
+int guarded(grlbwt_ctx *ctx, Fn fn) {
+    try {
+        fn();
+        return GRLBWT_OK;
+    } catch (const prim::Error &e) {
+        if (ctx) ctx->err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        if (ctx) ctx->err = "host allocation failed";
+        return GRLBWT_ENOMEM;
+    } catch (const std::exception &e) {
+        if (ctx) ctx->err = e.what();
+        return GRLBWT_EINTERNAL;
+    }
+}
+
+template <class E>
+void fill_round(const E &e, int r, grlbwt_round_info *o) {
+    const auto &I = e.levels[r].info;
+    o->n_in = I.n_in; o->n_phrases = I.D; o->dict_syms = I.S; o->n_metasyms = I.M; o->parse_size = I.parse_size;
+    o->sigma = I.sigma; o->max_phrase_len = I.max_phrase_len; o->sort_iters = I.sort_iters;
+}
+template <class E>
+void fill_stats(const E &e, grlbwt_stats *out) {
+    const auto &s = e.stats;
+    out->n_strings = s.n_strings; out->n_syms = s.n_syms; out->min_sym = s.min_sym; out->max_sym = s.max_sym;
+    out->max_sym_freq = s.max_sym_freq; out->sb = s.sb; out->fb = s.fb;
+}
+template <class E>
+void fill_level(const E &e, int l, grlbwt_level_info *o) {
+    const auto &I = e.linfo[l];
+    o->n = I.n; o->n_runs = I.R; o->runs_next = I.R_next; o->induced_cells = I.E; o->prebwt_runs = I.P;
+    o->segments = I.G; o->atoms = I.A;
+}
+template <class E>
+void fill_counters(const E &e, grlbwt_counters *o) {
+    memset(o, 0, sizeof(*o));
+    const auto &t = e.tm;
+    o->t_stats = t.stats; o->t_classify = t.classify; o->t_hash = t.hash; o->t_dict_sort = t.dict_sort;
+    o->t_dict_groups = t.dict_groups; o->t_emit = t.emit; o->t_ind_expand = t.ind_expand; o->t_ind_split = t.ind_sort;
+    o->t_ind_assemble = t.ind_assemble; o->t_finish = t.finish;
+    const uint64_t ib = sizeof(typename std::remove_reference<decltype(e.bwt.len.p[0])>::type);
+    o->idx_bytes = ib;
+    for (size_t r = 0; r < e.levels.size(); r++) {
+        const auto &I = e.levels[r].info;
+        o->bytes_classify_hash += I.n_in * (r == 0 ? (uint64_t)e.cell_bytes : 4ull);
+        o->bytes_emit += I.parse_size * 4ull;
+    }
+    for (size_t l = 0; l + 1 < e.linfo.size(); l++) {
+        const auto &I = e.linfo[l];
+        o->bytes_induce_scatter += I.R_next * (4 + ib) + I.R_next * 4 + I.E * (4 + ib);
+        o->bytes_induce_assemble += (I.P + I.E + I.R_next + I.R) * (4 + ib);
+    }
+}
+
+template <class E>
+void text_download(const E &e, int level, uint64_t *out) {
+    const auto &b = e.kept_texts[level - 1];
+    std::vector<uint32_t> h = b.to_host(b.n);
+    for (uint64_t i = 0; i < b.n; i++) out[i] = (uint64_t)(h[i] >> 1);   // (rank<<2|rep<<1|T) -> (rank<<1|rep)
+}
+template <class E>
+void bwt_download(const E &e, int level, uint64_t *sym, uint64_t *len) {
+    const auto &b = e.kept_bwts[level];
+    auto hs = b.sym.to_host(b.R);
+    auto hl = b.len.to_host(b.R);
+    for (uint64_t i = 0; i < b.R; i++) { sym[i] = hs[i]; len[i] = hl[i]; }
+}
+
+#define ENG(ctx, expr) ((ctx)->e32 ? (ctx)->e32->expr : (ctx)->e64->expr)
+#define HAS_ENG(ctx) ((ctx) && ((ctx)->e32 || (ctx)->e64))
+
+void load(grlbwt_ctx *ctx, const void *cells, uint64_t n, int w, bool host) {
+    ctx->e32.reset();
+    ctx->e64.reset();
+    bool big = (n >= 0xFFFFFF00ull) || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+    bool keep = ctx->flags & GRLBWT_FLAG_KEEP_LEVELS;
+    if (big) {
+        std::unique_ptr<grl64::Engine> e(new grl64::Engine());
+        e->keep_texts = keep;
+        if (host) e->upload_text(cells, n, w); else e->load_text(cells, n, w);
+        ctx->e64 = std::move(e);          // only a successfully loaded text leaves an engine behind
+    } else {
+        std::unique_ptr<grl32::Engine> e(new grl32::Engine());
+        e->keep_texts = keep;
+        if (host) e->upload_text(cells, n, w); else e->load_text(cells, n, w);
+        ctx->e32 = std::move(e);
+    }
+}
+
+// ---- primitive self-test (device vs host loops) -----------------------------
+uint64_t sm64(uint64_t &s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct OddPred {
+    const uint32_t *v;
+    GRL_DEV bool operator()(uint64_t i) const { return (v[i] % 3u) == 1u; }
+};
+struct U32In {
+    const uint32_t *v;
+    GRL_DEV uint64_t operator()(uint64_t i) const { return (uint64_t)(v[i] & 1023u); }
+};
+struct U32Raw {
+    const uint32_t *v;
+    GRL_DEV uint32_t operator()(uint64_t i) const { return v[i]; }
+};
+
+template <class K, class V>
+int test_sort(uint64_t n, uint64_t seed, int bits) {
+    std::vector<K> hk(n);
+    std::vector<V> hv(n);
+    uint64_t s = seed;
+    K mask = bits >= (int)(8 * sizeof(K)) ? ~K(0) : (K)((K(1) << bits) - 1);
+    for (uint64_t i = 0; i < n; i++) { hk[i] = (K)sm64(s) & mask; hv[i] = (V)i; }
+    grl32::DBuf<K> ka(n), kb(n);
+    grl32::DBuf<V> va(n), vb(n);
+    prim::h2d(ka.p, hk.data(), n * sizeof(K));
+    prim::h2d(va.p, hv.data(), n * sizeof(V));
+    int res = prim::sort_pairs<K, V>(ka.p, va.p, kb.p, vb.p, n, 0, bits, "selftest.sort");
+    std::vector<K> ok = (res ? kb : ka).to_host(n);
+    std::vector<V> ov = (res ? vb : va).to_host(n);
+    for (uint64_t i = 0; i < n; i++) {
+        if (ok[i] != hk[(uint64_t)ov[i]]) return 1;                          // pair integrity
+        if (i > 0 && ok[i - 1] > ok[i]) return 2;                            // order
+        if (i > 0 && ok[i - 1] == ok[i] && ov[i - 1] >= ov[i]) return 3;     // stability
+    }
+    return 0;
+}
+
+int selftest(uint64_t n, uint64_t seed) {
+    if (n < 2) n = 2;
+    std::vector<uint32_t> h(n);
+    uint64_t s = seed;
+    for (uint64_t i = 0; i < n; i++) h[i] = (uint32_t)sm64(s);
+    grl32::DBuf<uint32_t> d(n);
+    prim::h2d(d.p, h.data(), n * 4);
+    // 1: exclusive scan (u64) with total
+    {
+        grl32::DBuf<uint64_t> o(n + 1);
+        uint64_t tot = prim::exclusive_scan<uint64_t>(n, U32In{d.p}, o.p, true, "selftest.scan");
+        auto ho = o.to_host(n + 1);
+        uint64_t acc = 0;
+        for (uint64_t i = 0; i < n; i++) { if (ho[i] != acc) return -1; acc += h[i] & 1023u; }
+        if (ho[n] != acc || tot != acc) return -2;
+    }
+    // 2: exclusive scan (u32), in place over a pointer input
+    {
+        std::vector<uint32_t> small(n);
+        for (uint64_t i = 0; i < n; i++) small[i] = h[i] & 7u;
+        grl32::DBuf<uint32_t> o(n);
+        prim::h2d(o.p, small.data(), n * 4);
+        uint32_t tot = prim::exclusive_scan<uint32_t>(n, prim::PtrIn<uint32_t>{o.p}, o.p, false, "selftest.scan32");
+        auto ho = o.to_host(n);
+        uint32_t acc = 0;
+        for (uint64_t i = 0; i < n; i++) { if (ho[i] != acc) return -3; acc += small[i]; }
+        if (tot != acc) return -4;
+    }
+    // 3: reductions
+    {
+        uint64_t sum = 0; uint32_t mn = ~0u, mx = 0;
+        for (uint64_t i = 0; i < n; i++) { sum += h[i] & 1023u; if (h[i] < mn) mn = h[i]; if (h[i] > mx) mx = h[i]; }
+        if (prim::reduce_sum<uint64_t>(n, U32In{d.p}) != sum) return -5;
+        if (prim::reduce_min<uint32_t>(n, U32Raw{d.p}) != mn) return -6;
+        if (prim::reduce_max<uint32_t>(n, U32Raw{d.p}) != mx) return -7;
+    }
+    // 4: ballot bit-vector
+    {
+        uint64_t nw = (n + 63) / 64;
+        grl32::DBuf<uint64_t> w(nw);
+        prim::bitvector_from_pred(n, OddPred{d.p}, w.p, "selftest.bits");
+        auto hw = w.to_host(nw);
+        for (uint64_t i = 0; i < n; i++) {
+            bool b = (hw[i >> 6] >> (i & 63)) & 1ull;
+            if (b != ((h[i] % 3u) == 1u)) return -8;
+        }
+        if (n % 64) if (hw[nw - 1] >> (n % 64)) return -9;
+    }
+    // 5: byte histogram
+    {
+        uint64_t hist[256], ref[256] = {0};
+        const uint8_t *hb = (const uint8_t *)h.data();
+        uint64_t nb = n * 4 - 3;     // odd length: exercises the tail path
+        for (uint64_t i = 0; i < nb; i++) ref[hb[i]]++;
+        prim::byte_histogram((const uint8_t *)d.p, nb, hist);
+        for (int i = 0; i < 256; i++) if (hist[i] != ref[i]) return -10;
+    }
+    // 6: stable radix sort, all key/value widths used by the engine
+    { int r = test_sort<uint32_t, uint32_t>(n, seed + 1, 19); if (r) return -20 - r; }
+    { int r = test_sort<uint64_t, uint32_t>(n, seed + 2, 45); if (r) return -30 - r; }
+    { int r = test_sort<uint32_t, uint64_t>(n, seed + 3, 8); if (r) return -40 - r; }
+    { int r = test_sort<uint64_t, uint32_t>(n, seed + 4, 3); if (r) return -50 - r; }   // heavy duplicates
+    return 0;
+}
+
+}   // namespace
+
+extern "C" {
+
+int grlbwt_abi_version(void) { return GRLBWT_ABI_VERSION; }
+
+const char *grlbwt_strerror(int code) {
+    switch (code) {
+        case GRLBWT_OK: return "ok";
+        case GRLBWT_EINVAL: return "invalid argument or call out of order";
+        case GRLBWT_EDEVICE: return "HIP device/runtime error";
+        case GRLBWT_ENOMEM: return "out of memory";
+        case GRLBWT_EILLFORMED: return "Error: the file is ill formed";
+        case GRLBWT_ERANGE: return "input beyond the supported range";
+        case GRLBWT_ENOSPC: return "phrase table overflow";
+        case GRLBWT_EINTERNAL: return "internal consistency check failed";
+        default: return "unknown error";
+    }
+}
+const char *grlbwt_last_error(const grlbwt_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out) {
+    if (!out) return GRLBWT_EINVAL;
+    *out = nullptr;
+    grlbwt_ctx *c = new (std::nothrow) grlbwt_ctx();
+    if (!c) return GRLBWT_ENOMEM;
+    c->flags = flags;
+    c->device = device_id;
+    int rc = guarded(c, [&] {
+        prim::init(device_id);
+        prim::rt().sync_each_launch = (flags & GRLBWT_FLAG_SYNC_DEBUG) != 0;
+    });
+    if (rc != GRLBWT_OK) { delete c; return rc; }
+    *out = c;
+    return GRLBWT_OK;
+}
+void grlbwt_ctx_destroy(grlbwt_ctx *ctx) {
+    if (!ctx) return;
+    try { ctx->e32.reset(); ctx->e64.reset(); } catch (...) {}
+    delete ctx;
+}
+int grlbwt_ctx_set_stream(grlbwt_ctx *ctx, void *hip_stream) {
+    if (!ctx) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { prim::set_stream(hip_stream); });
+}
+
+int grlbwt_text_upload(grlbwt_ctx *ctx, const void *host_cells, uint64_t n_cells, int cell_bytes) {
+    if (!ctx || !host_cells) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { load(ctx, host_cells, n_cells, cell_bytes, true); });
+}
+int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes) {
+    if (!ctx || !dev_cells || ((uintptr_t)dev_cells & 15)) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { load(ctx, dev_cells, n_cells, cell_bytes, false); });
+}
+int grlbwt_get_stats(const grlbwt_ctx *ctx, grlbwt_stats *out) {
+    if (!HAS_ENG(ctx) || !out) return GRLBWT_EINVAL;
+    if (ctx->e32) fill_stats(*ctx->e32, out); else fill_stats(*ctx->e64, out);
+    return GRLBWT_OK;
+}
+
+int grlbwt_parse_round(grlbwt_ctx *ctx, grlbwt_round_info *info, int *done) {
+    if (!HAS_ENG(ctx)) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        bool d = ENG(ctx, parse_round());
+        if (done) *done = d ? 1 : 0;
+        if (info) { int r = (int)ENG(ctx, levels.size()) - 1; if (ctx->e32) fill_round(*ctx->e32, r, info); else fill_round(*ctx->e64, r, info); }
+    });
+}
+int grlbwt_parse_phase(grlbwt_ctx *ctx, int *n_rounds) {
+    if (!HAS_ENG(ctx)) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { int r = ENG(ctx, parse_phase()); if (n_rounds) *n_rounds = r; });
+}
+int grlbwt_round_info_get(const grlbwt_ctx *ctx, int round, grlbwt_round_info *info) {
+    if (!HAS_ENG(ctx) || !info || round < 0 || round >= (int)ENG(ctx, levels.size())) return GRLBWT_EINVAL;
+    if (ctx->e32) fill_round(*ctx->e32, round, info); else fill_round(*ctx->e64, round, info);
+    return GRLBWT_OK;
+}
+
+int grlbwt_induce_first(grlbwt_ctx *ctx) {
+    if (!HAS_ENG(ctx)) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { ENG(ctx, first_bwt()); });
+}
+int grlbwt_induce_level(grlbwt_ctx *ctx, int *level, grlbwt_level_info *info) {
+    if (!HAS_ENG(ctx)) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        ENG(ctx, induce_level());
+        int l = ENG(ctx, bwt_level);
+        if (level) *level = l;
+        if (info) { if (ctx->e32) fill_level(*ctx->e32, l, info); else fill_level(*ctx->e64, l, info); }
+        if (l == 0) ENG(ctx, finish());
+    });
+}
+int grlbwt_induce_phase(grlbwt_ctx *ctx) {
+    if (!HAS_ENG(ctx)) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { ENG(ctx, induce_phase()); ENG(ctx, finish()); });
+}
+int grlbwt_level_info_get(const grlbwt_ctx *ctx, int level, grlbwt_level_info *info) {
+    if (!HAS_ENG(ctx) || !info || level < 0 || level >= (int)ENG(ctx, linfo.size())) return GRLBWT_EINVAL;
+    if (ctx->e32) fill_level(*ctx->e32, level, info); else fill_level(*ctx->e64, level, info);
+    return GRLBWT_OK;
+}
+int grlbwt_build(grlbwt_ctx *ctx) {
+    if (!HAS_ENG(ctx)) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { ENG(ctx, run_all()); });
+}
+
+int grlbwt_result_size(const grlbwt_ctx *ctx, uint64_t *image_bytes, uint64_t *n_runs) {
+    if (!HAS_ENG(ctx) || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
+    if (image_bytes) *image_bytes = ENG(ctx, image_bytes);
+    if (n_runs) *n_runs = ENG(ctx, bwt.R);
+    return GRLBWT_OK;
+}
+int grlbwt_result_device_ptr(const grlbwt_ctx *ctx, const void **dev_ptr) {
+    if (!HAS_ENG(ctx) || !dev_ptr || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
+    *dev_ptr = ENG(ctx, image.p);
+    return GRLBWT_OK;
+}
+int grlbwt_result_download(const grlbwt_ctx *ctx, void *host_out, uint64_t capacity) {
+    if (!HAS_ENG(ctx) || !host_out || ENG(ctx, image_bytes) == 0 || capacity < ENG(ctx, image_bytes)) return GRLBWT_EINVAL;
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { prim::d2h(host_out, ENG(ctx, image.p), ENG(ctx, image_bytes)); });
+}
+int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path) {
+    if (!HAS_ENG(ctx) || !path || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] {
+        uint64_t nb = ENG(ctx, image_bytes);
+        std::vector<uint8_t> h(nb);
+        prim::d2h(h.data(), ENG(ctx, image.p), nb);
+        FILE *f = fopen(path, "wb");
+        if (!f) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
+        size_t wr = fwrite(h.data(), 1, nb, f);
+        int rc = fclose(f);
+        if (wr != nb || rc != 0) throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path);
+    });
+}
+
+int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells) {
+    if (!HAS_ENG(ctx) || !n_cells || level < 1 || level > (int)ENG(ctx, kept_texts.size())) return GRLBWT_EINVAL;
+    *n_cells = ENG(ctx, kept_texts[level - 1].n);
+    return GRLBWT_OK;
+}
+int grlbwt_level_text_download(const grlbwt_ctx *ctx, int level, uint64_t *cells_out) {
+    if (!HAS_ENG(ctx) || !cells_out || level < 1 || level > (int)ENG(ctx, kept_texts.size())) return GRLBWT_EINVAL;
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] {
+        if (ctx->e32) text_download(*ctx->e32, level, cells_out); else text_download(*ctx->e64, level, cells_out);
+    });
+}
+int grlbwt_level_bwt_size(const grlbwt_ctx *ctx, int level, uint64_t *n_runs) {
+    if (!HAS_ENG(ctx) || !n_runs || level < 0 || level >= (int)ENG(ctx, kept_bwts.size())) return GRLBWT_EINVAL;
+    *n_runs = ENG(ctx, kept_bwts[level].R);
+    return GRLBWT_OK;
+}
+int grlbwt_level_bwt_download(const grlbwt_ctx *ctx, int level, uint64_t *sym_out, uint64_t *len_out) {
+    if (!HAS_ENG(ctx) || !sym_out || !len_out || level < 0 || level >= (int)ENG(ctx, kept_bwts.size())) return GRLBWT_EINVAL;
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] {
+        if (ctx->e32) bwt_download(*ctx->e32, level, sym_out, len_out); else bwt_download(*ctx->e64, level, sym_out, len_out);
+    });
+}
+
+int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out) {
+    if (!HAS_ENG(ctx) || !out) return GRLBWT_EINVAL;
+    if (ctx->e32) fill_counters(*ctx->e32, out); else fill_counters(*ctx->e64, out);
+    return GRLBWT_OK;
+}
+
+int grlbwt_profile_enable(grlbwt_ctx *ctx, int on) {
+    if (!ctx) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        prim::sync();
+        prim::rt().prof.clear();
+        prim::rt().profile = on != 0;
+    });
+}
+int grlbwt_profile_dump(grlbwt_ctx *ctx, char *buf, uint64_t capacity) {
+    if (!ctx || !buf || capacity == 0) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        prim::sync();
+        std::string s;
+        for (const auto &kv : prim::rt().prof) {
+            char line[256];
+            snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.first, kv.second.second);
+            s += line;
+        }
+        size_t n = s.size() < capacity - 1 ? s.size() : (size_t)capacity - 1;
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    });
+}
+
+int grlbwt_selftest(grlbwt_ctx *ctx, uint64_t n, uint64_t seed) {
+    if (!ctx) return GRLBWT_EINVAL;
+    int res = 0;
+    int rc = guarded(ctx, [&] { res = selftest(n, seed); });
+    return rc != GRLBWT_OK ? rc - 1000 : res;
+}
+
+}   // extern "C"

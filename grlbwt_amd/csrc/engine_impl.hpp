@@ -1,0 +1,950 @@
+// engine_impl.hpp -- the parse-then-induce engine (grlBWT exact path) over the
+// device primitives of prim_hip.hpp.
+//
+// Included by engine_hip.hip once per index width:
+//     #define GRL_NS grl32 / grl64,  #define GRL_IDX_T uint32_t / uint64_t
+// (and, for the CPU test-suite only, by tests/hostsim over prim_sim.hpp).
+//
+// Reference map (file:line into ddiazdom/grlBWT):
+//   a1  collection_stats            external/cdt/lib/utils.cpp:100-189      -> Engine::load_text
+//   a2  lms_parsing::operator()     include/parsing_strategies.h:82-145     -> StartPred (phrase-start bit-vector)
+//   a3  ext_hash_functor + hash_table::increment_value
+//                                   exact_par_phase.hpp:14-42, hash_table.hpp:453-539 -> HashInsertFn
+//   a5  dictionary ctor             exact_par_phase.hpp:106-183             -> compact_table / DictBuildFn
+//   a6  suffix_induction            exact_LMS_induction.h:94-158            -> sort_dict_suffixes (radix + prefix doubling)
+//   a7  produce_pre_bwt             exact_par_phase.cpp:136-242             -> GroupAccumFn/GroupDecideFn/GroupEmitFn
+//   a8  produce_grammar             exact_par_phase.cpp:14-95               -> GrammarFn
+//   a9  rank assignment             exact_par_phase.cpp:427-450             -> SlotValFn
+//   a10 ext_parse_functor/parse_text exact_par_phase.hpp:44-84, parsing_strategies.h:644-676 -> MapFn
+//   a11 par_phase loop              exact_par_phase.cpp:338-366,496         -> Engine::parse_phase
+//   a12 parse2bwt                   exact_ind_phase.cpp:603-672             -> Engine::first_bwt
+//   a13 compute_hocc_size           exact_ind_phase.cpp:42-109              -> ChainCountFn
+//   a14 infer_lvl_bwt pass B        exact_ind_phase.cpp:143-258             -> ChainExpandFn + stable radix split
+//   a15 infer_lvl_bwt pass C        exact_ind_phase.cpp:287-361             -> Seg*/Atom* (merge-path style assemble)
+//   a16 bwt_buff_writer format      include/bwt_io.h:377-382,448-490        -> PackRunsFn
+//   a17 final header widths         exact_ind_phase.cpp:274-276 @ level 0   -> Engine::finish
+//
+// Data layout in HBM: every level stays resident; text_0 in its native cell
+// width, text_r (r>=1) as u32 cells  (rank<<2 | rep<<1 | is_terminator);
+// run-length BWTs as struct-of-arrays (u32 sym[], idx_t len[]).
+
+namespace GRL_NS {
+
+using prim::u8;
+using prim::u16;
+using prim::u32;
+using prim::u64;
+typedef GRL_IDX_T idx_t;
+
+// ------------------------------------------------------------------ buffers
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    u64 n = 0;
+    DBuf() {}
+    explicit DBuf(u64 n_) { alloc(n_); }
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf &operator=(DBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void alloc(u64 n_) { release(); p = (T *)prim::dev_alloc((n_ ? n_ : 1) * sizeof(T)); n = n_; }
+    void release() { if (p) prim::dev_free(p); p = nullptr; n = 0; }
+    void zero() { prim::dev_memset(p, 0, n * sizeof(T)); }
+    void fill_ff() { prim::dev_memset(p, 0xFF, n * sizeof(T)); }
+    std::vector<T> to_host(u64 cnt) const { std::vector<T> h(cnt); prim::d2h(h.data(), p, cnt * sizeof(T)); return h; }
+    T get(u64 i) const { T v; prim::d2h(&v, p + i, sizeof(T)); return v; }
+};
+
+static inline unsigned bitlen64(u64 v) { return v == 0 ? 0 : 64 - (unsigned)__builtin_clzll(v); }
+
+// ----------------------------------------------------------------- searches
+// first index i in [0,n) with a[i] > v  (n if none)
+template <class T>
+GRL_HD u64 upper_bound(const T *a, u64 n, T v) {
+    u64 lo = 0, hi = n;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// first index i in [0,n) with a[i] >= v  (n if none)
+template <class T>
+GRL_HD u64 lower_bound(const T *a, u64 n, T v) {
+    u64 lo = 0, hi = n;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// -------------------------------------------------------------- cell access
+// level 0: raw symbols, rep == 1 everywhere (parsing_strategies.h:102-103), terminator == separator;
+// level >= 1: u32 cell = rank<<2 | rep<<1 | is_terminator.
+template <class cell_t, bool FIRST>
+struct CellOps {
+    cell_t sep;
+    GRL_HD u32 sym(cell_t c) const { return FIRST ? (u32)c : (u32)(c >> 2); }
+    GRL_HD bool rep(cell_t c) const { return FIRST ? true : (bool)((c >> 1) & 1); }
+    GRL_HD bool isT(cell_t c) const { return FIRST ? (c == sep) : (bool)(c & 1); }
+};
+
+GRL_HD bool bit_at(const u64 *w, u64 i) { return (w[i >> 6] >> (i & 63)) & 1ull; }
+
+// ------------------------------------------------------- a2: phrase starts
+// A.1 of SURVEY.md: position p starts a phrase iff it starts a string or it is an
+// LMS break: text[p-1] > text[p], type(p) = S, rep[p-1] = rep[p] = 1.
+template <class cell_t, bool FIRST>
+struct StartPred {
+    const cell_t *t;
+    CellOps<cell_t, FIRST> ops;
+    GRL_DEV bool operator()(u64 p) const {
+        if (p == 0) return true;
+        cell_t cp = t[p - 1], c = t[p];
+        if (ops.isT(cp)) return true;
+        u32 sp = ops.sym(cp), s = ops.sym(c);
+        if (!(sp > s) || !ops.rep(cp) || !ops.rep(c)) return false;
+        u64 q = p;
+        cell_t cq = c;
+        for (;;) {                               // type(p): first unequal symbol to the right decides
+            if (ops.isT(cq)) return false;       // equal run reaches the string end: L by definition
+            cell_t nx = t[q + 1];
+            u32 sn = ops.sym(nx);
+            if (sn != s) return sn > s;
+            q++;
+            cq = nx;
+        }
+    }
+};
+
+struct PopcIn {
+    const u64 *w;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)__builtin_popcountll(w[i]); }
+};
+
+// ------------------------------------------------- a3: phrase hashing/count
+static constexpr u64 kPosBits = 40;
+static constexpr u64 kPosMask = (1ull << kPosBits) - 1;
+
+GRL_HD u64 hash_mix(u64 h, u64 v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xFF51AFD7ED558CCDull;
+    h ^= h >> 32;
+    return h;
+}
+GRL_HD u64 hash_fin(u64 h, u64 len) {
+    h ^= len * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+    return h;
+}
+
+template <class cell_t, bool FIRST>
+struct HashInsertFn {
+    const cell_t *t;
+    CellOps<cell_t, FIRST> ops;
+    const u64 *startbits;
+    const idx_t *wordbase;
+    u64 *keys;        // (tag<<40) | (pos+1), 0 = empty
+    idx_t *counts;    // phrase frequency
+    u32 *lens;        // phrase length (written by the inserting thread)
+    u64 mask;
+    u32 *out_slot;    // [n_occ] slot of every phrase occurrence, text order
+    u32 *scal;        // [0] max phrase length, [1] error flag
+    GRL_DEV bool same_phrase(u64 q, u64 p, u64 len) const {
+        for (u64 j = 0; j < len; j++) {
+            if (t[q + j] != t[p + j]) return false;
+            if (j > 0 && bit_at(startbits, q + j) != bit_at(startbits, p + j)) return false;
+        }
+        return true;
+    }
+    GRL_DEV void operator()(u64 p) const {
+        u64 w = startbits[p >> 6];
+        if (!((w >> (p & 63)) & 1ull)) return;
+        u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+        u64 h = 0x243F6A8885A308D3ull, e = p;
+        cell_t c = t[p];
+        for (;;) {
+            h = hash_mix(h, (u64)ops.sym(c));
+            if (ops.isT(c)) break;
+            e++;
+            c = t[e];
+            if (bit_at(startbits, e)) { h = hash_mix(h, (u64)ops.sym(c)); break; }
+        }
+        u64 len = e - p + 1;
+        h = hash_fin(h, len);
+        u64 tag = h >> kPosBits;
+        u64 mine = (tag << kPosBits) | (p + 1);
+        u64 slot = h & mask;
+        for (u64 probes = 0; probes <= mask; probes++) {
+            u64 cur = prim::load_relaxed(&keys[slot]);
+            if (cur == 0) {
+                u64 old = prim::atomic_cas(&keys[slot], 0ull, mine);
+                if (old == 0) {
+                    lens[slot] = (u32)len;
+                    prim::atomic_max(&scal[0], (u32)len);
+                    cur = mine;
+                } else cur = old;
+            }
+            if (cur == mine || ((cur >> kPosBits) == tag && same_phrase((cur & kPosMask) - 1, p, len))) {
+                prim::atomic_add(&counts[slot], (idx_t)1);
+                out_slot[ord] = (u32)slot;
+                return;
+            }
+            slot = (slot + 1) & mask;
+        }
+        scal[1] = 1;   // table full
+    }
+};
+
+struct OccIn {
+    const u64 *keys;
+    GRL_DEV u32 operator()(u64 i) const { return keys[i] != 0 ? 1u : 0u; }
+};
+
+// ------------------------------------------------------ a5: dictionary view
+template <class cell_t, bool FIRST>
+struct CompactTableFn {
+    const cell_t *t;
+    CellOps<cell_t, FIRST> ops;
+    const u64 *keys; const idx_t *counts; const u32 *lens; const u32 *slot_ph;
+    u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
+    GRL_DEV void operator()(u64 s) const {
+        u64 k64 = keys[s];
+        if (!k64) return;
+        u32 k = slot_ph[s];
+        u64 pos = (k64 & kPosMask) - 1;
+        ph_pos[k] = pos; ph_freq[k] = counts[s]; ph_len[k] = lens[s]; ph_slot[k] = (u32)s;
+        ph_lastT[k] = ops.isT(t[pos + lens[s] - 1]) ? 1 : 0;
+    }
+};
+struct LenIn {
+    const u32 *l;
+    GRL_DEV u32 operator()(u64 i) const { return l[i]; }
+};
+template <class cell_t, bool FIRST>
+struct DictBuildFn {
+    const cell_t *t;
+    CellOps<cell_t, FIRST> ops;
+    const u32 *ph_off; u64 D; const u64 *ph_pos;
+    u32 *dict_sym; u32 *dict_phr;
+    GRL_DEV void operator()(u64 q) const {
+        u64 k = upper_bound<u32>(ph_off, D, (u32)q) - 1;
+        dict_phr[q] = (u32)k;
+        dict_sym[q] = ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
+    }
+};
+
+// ------------------------------------------------ a6: dictionary suffix sort
+// Order: lexicographic with the phrase end comparing as +infinity (the sentinel
+// code is all-ones), equal suffixes of different phrases form one group.
+struct Key0Fn {        // first K symbols packed b bits each
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off;
+    int K, b;
+    u64 *keys; u32 *vals;
+    GRL_DEV void operator()(u64 q) const {
+        u64 end = ph_off[dict_phr[q] + 1];
+        u64 sent = (1ull << b) - 1, key = 0;
+        for (int j = 0; j < K; j++) key = (key << b) | ((q + j < end) ? (u64)dict_sym[q + j] : sent);
+        keys[q] = key;
+        vals[q] = (u32)q;
+    }
+};
+struct HeadKeyIn {     // 1 where the sorted key changes
+    const u64 *k;
+    GRL_DEV u32 operator()(u64 t) const { return (t == 0 || k[t] != k[t - 1]) ? 1u : 0u; }
+};
+struct RankWriteFn {   // gid[t] = (#heads before t) + head(t) - 1 ; rank[perm[t]] = gid[t]
+    const u64 *k; const u32 *ex; const u32 *perm; u32 *gid; u32 *rank;
+    GRL_DEV void operator()(u64 t) const {
+        u32 head = (t == 0 || k[t] != k[t - 1]) ? 1u : 0u;
+        u32 g = ex[t] + head - 1;
+        gid[t] = g;
+        rank[perm[t]] = g;
+    }
+};
+struct Key1Fn {        // (rank[q], rank[q+h] or +inf)
+    const u32 *perm_in; const u32 *rank; const u32 *dict_phr; const u32 *ph_off;
+    u64 h; int lowbits;
+    u64 *keys; u32 *vals;
+    GRL_DEV void operator()(u64 t) const {
+        u64 q = perm_in[t];
+        u64 end = ph_off[dict_phr[q] + 1];
+        u64 sent = (1ull << lowbits) - 1;
+        u64 low = (q + h < end) ? (u64)rank[q + h] : sent;
+        keys[t] = ((u64)rank[q] << lowbits) | low;
+        vals[t] = (u32)q;
+    }
+};
+
+// -------------------------------------------- a7: groups -> pre-BWT + ranks
+struct GroupStartFn {
+    const u32 *gid; u64 S; u32 *gstart;
+    GRL_DEV void operator()(u64 t) const {
+        if (t == 0 || gid[t] != gid[t - 1]) gstart[gid[t]] = (u32)t;
+        if (t == S - 1) gstart[gid[t] + 1] = (u32)S;
+    }
+};
+struct GroupAccumFn {
+    const u32 *perm; const u32 *gid; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq;
+    u32 bwt_code;
+    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
+    GRL_DEV void operator()(u64 t) const {
+        u64 q = perm[t];
+        u32 k = dict_phr[q], g = gid[t];
+        bool full = (q == ph_off[k]);
+        u32 left = full ? bwt_code : dict_sym[q - 1];
+        prim::atomic_min(&gmin[g], left);
+        prim::atomic_max(&gmax[g], left);
+        prim::atomic_add(&gacc[g], ph_freq[k]);
+        if (full) gfull[g] = 1;
+    }
+};
+enum : u8 { GF_VALID = 1, GF_RANKED = 2, GF_MULTI = 4 };
+struct GroupDecideFn {
+    const u32 *perm; const u32 *gstart; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
+    const u32 *gmin; const u32 *gmax; const u8 *gfull;
+    u8 *gflag;
+    GRL_DEV void operator()(u64 g) const {
+        u32 t0 = gstart[g], size = gstart[g + 1] - t0;
+        u64 q = perm[t0];
+        u32 k = dict_phr[q];
+        bool pfinal = (q + 1 == ph_off[k + 1]);
+        bool valid = !pfinal || ph_lastT[k];                        // exact_par_phase.cpp:162
+        bool ranked = valid && (gmin[g] != gmax[g] || gfull[g]);    // :187
+        gflag[g] = (valid ? GF_VALID : 0) | (ranked ? GF_RANKED : 0) | (size > 1 ? GF_MULTI : 0);
+    }
+};
+struct FlagIn {
+    const u8 *f; u8 m;
+    GRL_DEV u32 operator()(u64 i) const { return (f[i] & m) ? 1u : 0u; }
+};
+struct GroupEmitFn {
+    const u8 *gflag; const u32 *grank; const u32 *pidx; const u32 *gmin; const idx_t *gacc; const u32 *gstart; const u32 *perm;
+    u32 bwt_code, hocc_code;
+    u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq;
+    GRL_DEV void operator()(u64 g) const {
+        u8 f = gflag[g];
+        if (!(f & GF_VALID)) return;
+        u32 j = pidx[g];
+        u32 s = gmin[g];
+        if (f & GF_RANKED) {
+            s = (f & GF_MULTI) ? hocc_code : bwt_code;
+            u32 u = grank[g];
+            has_hocc[u] = (f & GF_MULTI) ? 1 : 0;
+            repq[u] = perm[gstart[g]];
+        }
+        psym[j] = s;
+        plen[j] = gacc[g];
+    }
+};
+
+// ------------------------------------------------------------- a8: grammar
+struct GrammarFn {
+    const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
+    const u32 *rank; const u8 *gflag; const u32 *grank;
+    u32 sigma3, MD;
+    u32 *g0; u32 *g1;
+    GRL_DEV void operator()(u64 u) const {
+        u64 q = repq[u];
+        u32 k = dict_phr[q];
+        u64 e = (u64)ph_off[k + 1] - 1;
+        if (q == e) { g0[u] = MD; g1[u] = dict_sym[q]; return; }                    // :38-41
+        u64 x = q + 1;
+        for (;;) {
+            u32 gx = rank[x];
+            bool marked = (gflag[gx] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI);
+            if (marked) { g0[u] = dict_sym[x - 1]; g1[u] = grank[gx] + sigma3; return; }   // :49-80
+            if (x == e) { g0[u] = MD; g1[u] = ph_lastT[k] ? dict_sym[e] : dict_sym[e - 1]; return; }   // :81-85
+            x++;
+        }
+    }
+};
+
+// ------------------------------------------- a9 + a10: ranks -> next text
+struct SlotValFn {
+    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *ph_slot; const u32 *rank; const u32 *grank;
+    u32 *slot_val;
+    GRL_DEV void operator()(u64 k) const {
+        u32 r = grank[rank[ph_off[k]]];
+        slot_val[ph_slot[k]] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
+    }
+};
+struct MapFn {
+    const u32 *slot_val; u32 *text;
+    GRL_DEV void operator()(u64 i) const { text[i] = slot_val[text[i]]; }
+};
+
+// ------------------------------------------------------------ run utilities
+struct SymHeadIn {
+    const u32 *s;
+    GRL_DEV u32 operator()(u64 t) const { return (t == 0 || s[t] != s[t - 1]) ? 1u : 0u; }
+};
+template <class L>
+struct IdxIn {
+    const L *p;
+    GRL_DEV idx_t operator()(u64 i) const { return (idx_t)p[i]; }
+};
+struct MergeHeadsFn {
+    const u32 *sym; const idx_t *cum; const idx_t *ex; u64 n;
+    u32 *osym; idx_t *ostart;
+    GRL_DEV void operator()(u64 t) const {
+        if (t == 0 || sym[t] != sym[t - 1]) { idx_t r = ex[t]; osym[r] = sym[t]; ostart[r] = cum[t]; }
+        if (t == n - 1) ostart[ex[t] + ((t == 0 || sym[t] != sym[t - 1]) ? 1 : 0)] = cum[n];
+    }
+};
+struct DiffFn {
+    const idx_t *start; idx_t *len;
+    GRL_DEV void operator()(u64 r) const { len[r] = start[r + 1] - start[r]; }
+};
+struct SymHeadIdxIn {
+    const u32 *s;
+    GRL_DEV idx_t operator()(u64 t) const { return (t == 0 || s[t] != s[t - 1]) ? (idx_t)1 : (idx_t)0; }
+};
+
+struct Runs {
+    DBuf<u32> sym;
+    DBuf<idx_t> len;
+    u64 R = 0;
+};
+
+// merge adjacent equal symbols (bwt_io.h push_back/inc_freq_last idiom): -> maximal runs
+static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n) {
+    Runs out;
+    if (n == 0) { out.sym.alloc(0); out.len.alloc(0); return out; }
+    DBuf<idx_t> cum(n + 1), ex(n + 1);
+    prim::exclusive_scan<idx_t>(n, IdxIn<idx_t>{len}, cum.p, true, "merge_runs.cum");
+    u64 R = (u64)prim::exclusive_scan<idx_t>(n, SymHeadIdxIn{sym}, ex.p, false, "merge_runs.heads");
+    out.sym.alloc(R);
+    out.len.alloc(R);
+    DBuf<idx_t> ostart(R + 1);
+    prim::for_each(n, MergeHeadsFn{sym, cum.p, ex.p, n, out.sym.p, ostart.p}, "merge_runs.heads");
+    prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
+    out.R = R;
+    return out;
+}
+
+// --------------------------------------------------------- a12: parse2bwt
+struct CellSymFn {
+    const u32 *t; u32 *sym; idx_t *len;
+    GRL_DEV void operator()(u64 i) const { sym[i] = t[i] >> 2; len[i] = 1; }
+};
+
+// ----------------------------------------------------- a13/a14: induction
+struct ChainCountFn {
+    const u32 *nsym; const u32 *g1; const u8 *has_hocc; u32 sigma3;
+    GRL_DEV idx_t operator()(u64 i) const {
+        u32 cur = nsym[i];
+        idx_t c = has_hocc[cur] ? 1 : 0;
+        u32 nx = g1[cur];
+        while (nx >= sigma3) { cur = nx - sigma3; c++; nx = g1[cur]; }
+        return c;
+    }
+};
+struct ChainExpandFn {
+    const u32 *nsym; const idx_t *nlen; const u32 *g0; const u32 *g1; const u8 *has_hocc; const idx_t *eoff;
+    u32 sigma3, take_code;
+    u32 *ekey; idx_t *eidx; u32 *esym; idx_t *elen; u32 *term;
+    GRL_DEV void operator()(u64 i) const {
+        u32 cur = nsym[i];
+        idx_t f = nlen[i];
+        u64 e = eoff[i];
+        if (has_hocc[cur]) { ekey[e] = cur; eidx[e] = (idx_t)e; esym[e] = take_code; elen[e] = f; e++; }
+        u32 nx = g1[cur];
+        while (nx >= sigma3) {
+            u32 b = nx - sigma3;
+            ekey[e] = b; eidx[e] = (idx_t)e; esym[e] = g0[cur]; elen[e] = f; e++;
+            cur = b;
+            nx = g1[cur];
+        }
+        term[i] = nx;                                       // exact_ind_phase.cpp:257 write_sym
+    }
+};
+struct GatherCellFn {
+    const idx_t *perm; const u32 *esym; const idx_t *elen; u32 *ssym; idx_t *slen;
+    GRL_DEV void operator()(u64 t) const { u64 e = perm[t]; ssym[t] = esym[e]; slen[t] = elen[e]; }
+};
+
+// --------------------------------------------------------- a15: assemble
+struct CondLenIn {      // len[i] if sym[i] == code else 0
+    const u32 *sym; const idx_t *len; u32 code;
+    GRL_DEV idx_t operator()(u64 i) const { return sym[i] == code ? len[i] : (idx_t)0; }
+};
+struct NotCodeIn {
+    const u32 *sym; u32 code;
+    GRL_DEV idx_t operator()(u64 i) const { return sym[i] != code ? (idx_t)1 : (idx_t)0; }
+};
+struct SegFromPreFn {   // non-HOCC pre-BWT runs -> segments
+    const u32 *psym; const idx_t *plen; const idx_t *PH; const idx_t *nhb; const idx_t *Hpos; u64 E;
+    u32 bwt_code, hocc_code, take_code;
+    u32 *seg_sym; idx_t *seg_len;
+    GRL_DEV void operator()(u64 j) const {
+        u32 s = psym[j];
+        if (s == hocc_code) return;
+        u64 g = (u64)nhb[j] + lower_bound<idx_t>(Hpos, E, PH[j]);
+        seg_sym[g] = (s == bwt_code) ? take_code : s;
+        seg_len[g] = plen[j];
+    }
+};
+struct SegFromCellFn {  // induced cells (H, bucket-major) -> segments
+    const u32 *ssym; const idx_t *slen; const idx_t *Hpos; const idx_t *PH; const idx_t *nhb; u64 P;
+    u32 *seg_sym; idx_t *seg_len;
+    GRL_DEV void operator()(u64 t) const {
+        u64 j = upper_bound<idx_t>(PH, P, Hpos[t]) - 1;
+        u64 g = (u64)nhb[j] + t;
+        seg_sym[g] = ssym[t];
+        seg_len[g] = slen[t];
+    }
+};
+struct AtomCountIn {    // output atoms per segment
+    const u32 *seg_sym; const idx_t *seg_len; const idx_t *Toff; const idx_t *Tpos; u64 R; u32 take_code;
+    GRL_DEV idx_t operator()(u64 g) const {
+        if (seg_sym[g] != take_code) return 1;
+        idx_t a = Toff[g], b = a + seg_len[g];
+        u64 kf = upper_bound<idx_t>(Tpos, R, a) - 1;
+        u64 kl = upper_bound<idx_t>(Tpos, R, (idx_t)(b - 1)) - 1;
+        return (idx_t)(kl - kf + 1);
+    }
+};
+struct AtomFn {
+    const u32 *seg_sym; const idx_t *seg_len; const idx_t *Toff; const idx_t *Tpos; const idx_t *abase; const u32 *term;
+    u64 R, G; u32 take_code;
+    u32 *osym; idx_t *olen;
+    GRL_DEV void operator()(u64 x) const {
+        u64 g = upper_bound<idx_t>(abase, G, (idx_t)x) - 1;
+        if (seg_sym[g] != take_code) { osym[x] = seg_sym[g]; olen[x] = seg_len[g]; return; }
+        idx_t a = Toff[g], b = a + seg_len[g];
+        u64 kf = upper_bound<idx_t>(Tpos, R, a) - 1;
+        u64 k = kf + (x - abase[g]);
+        idx_t s = Tpos[k] > a ? Tpos[k] : a;
+        idx_t e = Tpos[k + 1] < b ? Tpos[k + 1] : b;
+        osym[x] = term[k];
+        olen[x] = e - s;
+    }
+};
+
+// ------------------------------------------------------- a16: .rl_bwt image
+struct PackRunsFn {
+    const u32 *sym; const idx_t *len; u32 sb, fb; u8 *out;
+    GRL_DEV void operator()(u64 i) const {
+        u8 *p = out + 16 + i * (u64)(sb + fb);
+        u64 s = sym[i], l = len[i];
+        for (u32 b = 0; b < sb; b++) p[b] = (u8)(s >> (8 * b));
+        for (u32 b = 0; b < fb; b++) p[sb + b] = (u8)(l >> (8 * b));
+    }
+};
+
+// -------------------------------------------------------------- stats (a1)
+template <class cell_t>
+struct EqIn {
+    const cell_t *t; cell_t v;
+    GRL_DEV u64 operator()(u64 i) const { return t[i] == v ? 1ull : 0ull; }
+};
+template <class cell_t>
+struct CellIn {
+    const cell_t *t;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)t[i]; }
+};
+
+// =========================================================================
+struct RoundInfo {
+    u64 n_in = 0, D = 0, S = 0, M = 0, parse_size = 0, sigma = 0, max_phrase_len = 0, sort_iters = 0;
+};
+struct LevelInfo {
+    u64 R_next = 0, E = 0, P = 0, G = 0, A = 0, R = 0, n = 0;
+};
+struct Stats {
+    u64 n_strings = 0, n_syms = 0, min_sym = 0, max_sym = 0, max_sym_freq = 0, sb = 0, fb = 0;
+};
+struct Timers {
+    double classify = 0, hash = 0, dict_sort = 0, dict_groups = 0, emit = 0, ind_expand = 0, ind_sort = 0, ind_assemble = 0,
+           stats = 0, finish = 0;
+};
+
+struct LevelData {
+    u32 sigma = 0, M = 0;
+    DBuf<u32> g0, g1;
+    DBuf<u8> has_hocc;
+    Runs prebwt;
+    RoundInfo info;
+};
+
+static inline double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+struct StageTimer {
+    double *acc, t0;
+    explicit StageTimer(double *a) : acc(a) { prim::sync(); t0 = now_s(); }
+    ~StageTimer() { try { prim::sync(); } catch (...) {} *acc += now_s() - t0; }
+};
+
+class Engine {
+  public:
+    int cell_bytes = 1;
+    const void *text0 = nullptr;      // device pointer (owned by own0 or borrowed)
+    DBuf<u8> own0;
+    u64 n0 = 0;
+    Stats stats;
+    Timers tm;
+    std::vector<LevelData> levels;    // one per parsing round
+    std::vector<LevelInfo> linfo;
+    DBuf<u32> cur_text;               // text of the current level (level >= 1)
+    u64 cur_n = 0;
+    u32 cur_sigma = 0;
+    bool parse_done = false;
+    Runs bwt;                         // BWT of level `bwt_level`
+    int bwt_level = -1;
+    DBuf<u8> image;                   // .rl_bwt bytes (device)
+    u64 image_bytes = 0;
+    bool keep_texts = false;          // debug/parity: keep every level's text
+    std::vector<DBuf<u32>> kept_texts;
+    std::vector<Runs> kept_bwts;      // debug/parity: BWT of every level (index = level)
+
+    // ---- a1 ------------------------------------------------------------
+    template <class cell_t>
+    void stats_t(const cell_t *t, u64 n) {
+        StageTimer st(&tm.stats);
+        cell_t sep;
+        prim::d2h(&sep, t + (n - 1), sizeof(cell_t));
+        u64 mn, mx, F = n;
+        if (sizeof(cell_t) == 1) {
+            u64 h[256];
+            prim::byte_histogram((const u8 *)t, n, h);
+            mn = 0; while (h[mn] == 0) mn++;
+            mx = 255; while (h[mx] == 0) mx--;
+            F = 0; for (int i = 0; i < 256; i++) if (h[i] > F) F = h[i];      // utils.cpp:161-175
+            stats.n_strings = h[(u64)sep];
+        } else {
+            mn = prim::reduce_min<u64>(n, CellIn<cell_t>{t}, "stats.min");
+            mx = prim::reduce_max<u64>(n, CellIn<cell_t>{t}, "stats.max");
+            stats.n_strings = prim::reduce_sum<u64>(n, EqIn<cell_t>{t, sep}, "stats.nstr");
+        }
+        if ((u64)sep != mn) throw prim::Error(-84, "Error: the file is ill formed");   // utils.cpp:177-180
+        stats.n_syms = n; stats.min_sym = mn; stats.max_sym = mx; stats.max_sym_freq = F;
+        if (mx + 8 >= (1ull << 30)) throw prim::Error(-75, "symbols >= 2^30 are not supported by this build");
+        stats.sb = (bitlen64(mx + 4) + 7) / 8;                                          // a17
+        stats.fb = (bitlen64(F) + 7) / 8;
+    }
+
+    void load_text(const void *dev_cells, u64 n, int w) {
+        if (n == 0 || !(w == 1 || w == 2 || w == 4 || w == 8)) throw prim::Error(-22, "bad input size or cell width");
+        if (sizeof(idx_t) == 4 && n >= 0xFFFFFF00ull) throw prim::Error(-75, "input too large for the 32-bit index build");
+        if (n >= kPosMask) throw prim::Error(-75, "input too large");
+        cell_bytes = w; text0 = dev_cells; n0 = n;
+        levels.clear(); linfo.clear(); kept_texts.clear(); kept_bwts.clear();
+        parse_done = false; bwt_level = -1; image_bytes = 0;
+        tm = Timers();
+        switch (w) {
+            case 1: stats_t<u8>((const u8 *)dev_cells, n); break;
+            case 2: stats_t<u16>((const u16 *)dev_cells, n); break;
+            case 4: stats_t<u32>((const u32 *)dev_cells, n); break;
+            default: stats_t<u64>((const u64 *)dev_cells, n); break;
+        }
+        cur_n = n;
+        cur_sigma = (u32)(stats.max_sym + 1);
+    }
+    void upload_text(const void *host_cells, u64 n, int w) {
+        own0.alloc(n * (u64)w + 16);
+        prim::h2d(own0.p, host_cells, n * (u64)w);
+        load_text(own0.p, n, w);
+    }
+
+    // ---- one parsing round (par_round, exact_par_phase.cpp:374-497) ------
+    template <class cell_t, bool FIRST>
+    void par_round_t(const cell_t *t, u64 n, u32 sigma, cell_t sep) {
+        CellOps<cell_t, FIRST> ops{sep};
+        LevelData L;
+        L.sigma = sigma;
+        L.info.n_in = n;
+        L.info.sigma = sigma;
+        const u64 nwords = (n + 63) / 64;
+        DBuf<u64> startbits(nwords + 1);
+        DBuf<idx_t> wordbase(nwords + 1);
+        u64 n_occ;
+        {
+            StageTimer st(&tm.classify);
+            prim::bitvector_from_pred(n, StartPred<cell_t, FIRST>{t, ops}, startbits.p, "lms_breaks");
+            n_occ = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{startbits.p}, wordbase.p, true, "phrase_ordinals");
+        }
+        L.info.parse_size = n_occ;
+        if (n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "parse too large for u32 phrase ordinals");
+
+        // ---- a3: hash every phrase occurrence ------------------------------
+        u64 cap = 1024;
+        while (cap < 2 * n_occ) cap <<= 1;
+        DBuf<u64> keys(cap);
+        DBuf<idx_t> counts(cap);
+        DBuf<u32> lens(cap);
+        DBuf<u32> next_text(n_occ);
+        DBuf<u32> scal(4);
+        u32 maxlen;
+        {
+            StageTimer st(&tm.hash);
+            keys.zero(); counts.zero(); scal.zero();
+            prim::for_each(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, counts.p, lens.p,
+                                                          cap - 1, next_text.p, scal.p}, "hash_phrases");
+            std::vector<u32> sc = scal.to_host(2);
+            if (sc[1]) throw prim::Error(-28, "phrase hash table overflow");
+            maxlen = sc[0];
+        }
+        L.info.max_phrase_len = maxlen;
+        startbits.release();
+        wordbase.release();
+
+        // ---- a5: flatten the dictionary -------------------------------------
+        u64 D, S;
+        DBuf<u32> slot_ph(cap);
+        DBuf<u64> ph_pos; DBuf<idx_t> ph_freq; DBuf<u32> ph_len, ph_slot, ph_off; DBuf<u8> ph_lastT;
+        DBuf<u32> dict_sym, dict_phr;
+        {
+            StageTimer st(&tm.dict_sort);
+            D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "table_compact");
+            ph_pos.alloc(D); ph_freq.alloc(D); ph_len.alloc(D); ph_slot.alloc(D); ph_lastT.alloc(D); ph_off.alloc(D + 1);
+            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, keys.p, counts.p, lens.p, slot_ph.p, ph_pos.p,
+                                                              ph_freq.p, ph_len.p, ph_slot.p, ph_lastT.p}, "table_compact");
+            u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dict_syms");
+            if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
+            S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dict_offsets");
+            dict_sym.alloc(S); dict_phr.alloc(S);
+            prim::for_each(S, DictBuildFn<cell_t, FIRST>{t, ops, ph_off.p, D, ph_pos.p, dict_sym.p, dict_phr.p}, "dict_build");
+        }
+        keys.release(); counts.release(); lens.release(); slot_ph.release();
+        L.info.D = D; L.info.S = S;
+
+        // ---- a6: sort all phrase suffixes (radix + prefix doubling) ----------
+        DBuf<u32> perm(S), gid(S), rank(S);
+        u64 G;
+        {
+            StageTimer st(&tm.dict_sort);
+            DBuf<u64> ka(S), kb(S);
+            DBuf<u32> va(S), vb(S), ex(S + 1);
+            int b = (int)bitlen64(sigma);
+            if (b < 1) b = 1;
+            int K = 64 / b;
+            if (K > 16) K = 16;
+            u64 *kA = ka.p, *kB = kb.p;          // (kA, vA) always holds the current sorted order
+            u32 *vA = va.p, *vB = vb.p;
+            prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off.p, K, b, kA, vA}, "suffix_keys0");
+            if (prim::sort_pairs<u64, u32>(kA, vA, kB, vB, S, 0, K * b, "suffix_sort0")) { std::swap(kA, kB); std::swap(vA, vB); }
+            G = prim::exclusive_scan<u32>(S, HeadKeyIn{kA}, ex.p, false, "suffix_heads");
+            prim::for_each(S, RankWriteFn{kA, ex.p, vA, gid.p, rank.p}, "suffix_ranks");
+            u64 Lres = (u64)K, iters = 1;
+            while (Lres < maxlen) {              // prefix doubling: Lres symbols resolved so far
+                int lowbits = (int)bitlen64(G);
+                prim::for_each(S, Key1Fn{vA, rank.p, dict_phr.p, ph_off.p, Lres, lowbits, kB, vB}, "suffix_keys");
+                if (prim::sort_pairs<u64, u32>(kB, vB, kA, vA, S, 0, 2 * lowbits, "suffix_sort") == 0) {
+                    std::swap(kA, kB); std::swap(vA, vB);
+                }
+                G = prim::exclusive_scan<u32>(S, HeadKeyIn{kA}, ex.p, false, "suffix_heads");
+                prim::for_each(S, RankWriteFn{kA, ex.p, vA, gid.p, rank.p}, "suffix_ranks");
+                Lres *= 2;
+                iters++;
+            }
+            const u32 *vs = vA;
+            prim::d2d(perm.p, vs, S * sizeof(u32));
+            prim::sync();
+            L.info.sort_iters = iters;
+        }
+
+        // ---- a7: equal-suffix groups -> pre-BWT, ranks -----------------------
+        const u32 bwt_code = sigma + 1, hocc_code = sigma + 2, sigma3 = sigma + 3;
+        DBuf<u32> gstart(G + 1), grank(G + 1), pidx(G + 1), gmin(G), gmax(G);
+        DBuf<idx_t> gacc(G);
+        DBuf<u8> gfull(G), gflag(G);
+        DBuf<u32> repq;
+        u64 M, P0;
+        {
+            StageTimer st(&tm.dict_groups);
+            gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
+            prim::for_each(S, GroupStartFn{gid.p, S, gstart.p}, "group_starts");
+            prim::for_each(S, GroupAccumFn{perm.p, gid.p, dict_sym.p, dict_phr.p, ph_off.p, ph_freq.p, bwt_code, gmin.p,
+                                           gmax.p, gacc.p, gfull.p}, "group_accum");
+            prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off.p, ph_lastT.p, gmin.p, gmax.p, gfull.p,
+                                            gflag.p}, "group_decide");
+            M = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
+            P0 = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
+            if ((u64)sigma3 + M + 8 >= (1ull << 30)) throw prim::Error(-75, "alphabet of the next level >= 2^30");
+            L.M = (u32)M;
+            L.has_hocc.alloc(M); repq.alloc(M);
+            DBuf<u32> psym0(P0);
+            DBuf<idx_t> plen0(P0);
+            prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code,
+                                          psym0.p, plen0.p, L.has_hocc.p, repq.p}, "prebwt_emit");
+            L.prebwt = merge_runs(psym0.p, plen0.p, P0);
+            // ---- a8: grammar ------------------------------------------------
+            L.g0.alloc(M); L.g1.alloc(M);
+            u32 MD = sigma3 + (u32)M + 1;
+            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off.p, ph_lastT.p, rank.p, gflag.p, grank.p,
+                                        sigma3, MD, L.g0.p, L.g1.p}, "grammar");
+        }
+        L.info.M = M;
+
+        // ---- a9/a10: metasymbols -> next text ---------------------------------
+        {
+            StageTimer st(&tm.emit);
+            DBuf<u32> slot_val(cap);
+            prim::for_each(D, SlotValFn{ph_off.p, ph_freq.p, ph_lastT.p, ph_slot.p, rank.p, grank.p, slot_val.p}, "slot_values");
+            prim::for_each(n_occ, MapFn{slot_val.p, next_text.p}, "emit_parse");
+            prim::sync();
+        }
+        if (keep_texts) {
+            DBuf<u32> cp(n_occ);
+            prim::d2d(cp.p, next_text.p, n_occ * sizeof(u32));
+            prim::sync();
+            kept_texts.push_back(std::move(cp));
+        }
+        cur_text = std::move(next_text);
+        cur_n = n_occ;
+        cur_sigma = (u32)M;
+        levels.push_back(std::move(L));
+        if (n_occ == stats.n_strings) parse_done = true;      // exact_par_phase.cpp:496
+    }
+
+    // returns true when the parsing phase is complete
+    bool parse_round() {
+        if (parse_done) return true;
+        if (levels.empty()) {
+            switch (cell_bytes) {
+                case 1: par_round_t<u8, true>((const u8 *)text0, n0, cur_sigma, (u8)stats.min_sym); break;
+                case 2: par_round_t<u16, true>((const u16 *)text0, n0, cur_sigma, (u16)stats.min_sym); break;
+                case 4: par_round_t<u32, true>((const u32 *)text0, n0, cur_sigma, (u32)stats.min_sym); break;
+                default: par_round_t<u64, true>((const u64 *)text0, n0, cur_sigma, (u64)stats.min_sym); break;
+            }
+        } else {
+            DBuf<u32> t = std::move(cur_text);
+            par_round_t<u32, false>(t.p, cur_n, cur_sigma, 0u);
+        }
+        if (levels.size() > 64) throw prim::Error(-75, "too many parsing rounds");
+        return parse_done;
+    }
+    int parse_phase() {                                          // exact_par_phase.cpp:338-366
+        while (!parse_round()) {}
+        return (int)levels.size();
+    }
+
+    // ---- a12 ---------------------------------------------------------------
+    void first_bwt() {
+        if (!parse_done) throw prim::Error(-22, "parse phase not finished");
+        StageTimer st(&tm.ind_assemble);
+        DBuf<u32> s(cur_n);
+        DBuf<idx_t> l(cur_n);
+        prim::for_each(cur_n, CellSymFn{cur_text.p, s.p, l.p}, "parse2bwt");
+        bwt = merge_runs(s.p, l.p, cur_n);
+        bwt_level = (int)levels.size();
+        cur_text.release();
+        linfo.assign(levels.size() + 1, LevelInfo());
+        linfo[bwt_level].R = bwt.R;
+        linfo[bwt_level].n = cur_n;
+        if (keep_texts) { kept_bwts.clear(); kept_bwts.resize(levels.size() + 1); keep_bwt(bwt_level); }
+    }
+    void keep_bwt(int lvl) {
+        Runs c;
+        c.sym.alloc(bwt.R); c.len.alloc(bwt.R); c.R = bwt.R;
+        prim::d2d(c.sym.p, bwt.sym.p, bwt.R * sizeof(u32));
+        prim::d2d(c.len.p, bwt.len.p, bwt.R * sizeof(idx_t));
+        prim::sync();
+        kept_bwts[lvl] = std::move(c);
+    }
+
+    // ---- a13-a15: BWT_r from BWT_{r+1} -------------------------------------
+    void induce_level() {
+        if (bwt_level <= 0) throw prim::Error(-22, "no level left to induce");
+        const int r = bwt_level - 1;
+        LevelData &L = levels[r];
+        const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
+        const u64 R = bwt.R, P = L.prebwt.R;
+        LevelInfo &I = linfo[r];
+        I.R_next = R; I.P = P;
+
+        DBuf<idx_t> eoff(R + 1);
+        DBuf<u32> term(R);
+        DBuf<u32> ssym; DBuf<idx_t> slen;
+        u64 E;
+        {
+            StageTimer st(&tm.ind_expand);
+            E = (u64)prim::exclusive_scan<idx_t>(R, ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p, true,
+                                                 "induce_count");
+        }
+        I.E = E;
+        {
+            DBuf<u32> ekey(E), ekey2(E), esym(E);
+            DBuf<idx_t> eidx(E), eidx2(E), elen(E);
+            {
+                StageTimer st(&tm.ind_expand);
+                prim::for_each(R, ChainExpandFn{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                                                ekey.p, eidx.p, esym.p, elen.p, term.p}, "induce_expand");
+            }
+            ssym.alloc(E); slen.alloc(E);
+            {
+                StageTimer st(&tm.ind_sort);
+                int bits = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
+                if (bits < 1) bits = 1;
+                int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
+                const idx_t *perm = res ? eidx2.p : eidx.p;
+                prim::for_each(E, GatherCellFn{perm, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
+                prim::sync();
+            }
+        }
+        eoff.release();
+        {
+            StageTimer st(&tm.ind_assemble);
+            DBuf<idx_t> PH(P + 1), nhb(P + 1), Hpos(E + 1), Tpos(R + 1);
+            prim::exclusive_scan<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code}, PH.p, true, "asm.PH");
+            u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.prebwt.sym.p, hocc_code}, nhb.p, true, "asm.nhb");
+            u64 Hsum = (u64)prim::exclusive_scan<idx_t>(E, IdxIn<idx_t>{slen.p}, Hpos.p, true, "asm.Hpos");
+            u64 Tsum = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
+            u64 PHsum = (u64)PH.get(P);
+            if (Hsum != PHsum) throw prim::Error(-71, "induction: induced symbols do not match the pre-BWT (level " +
+                                                            std::to_string(r) + ": " + std::to_string(Hsum) + " vs " +
+                                                            std::to_string(PHsum) + ")");
+            const u64 G = NH + E;
+            I.G = G;
+            DBuf<u32> seg_sym(G);
+            DBuf<idx_t> seg_len(G), Toff(G + 1), abase(G + 1);
+            prim::for_each(P, SegFromPreFn{L.prebwt.sym.p, L.prebwt.len.p, PH.p, nhb.p, Hpos.p, E, bwt_code, hocc_code,
+                                           take_code, seg_sym.p, seg_len.p}, "asm.seg_pre");
+            prim::for_each(E, SegFromCellFn{ssym.p, slen.p, Hpos.p, PH.p, nhb.p, P, seg_sym.p, seg_len.p}, "asm.seg_cell");
+            u64 Tused = (u64)prim::exclusive_scan<idx_t>(G, CondLenIn{seg_sym.p, seg_len.p, take_code}, Toff.p, true, "asm.Toff");
+            if (Tused != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) +
+                                                           ": " + std::to_string(Tused) + " vs " + std::to_string(Tsum) + ")");
+            u64 A = (u64)prim::exclusive_scan<idx_t>(G, AtomCountIn{seg_sym.p, seg_len.p, Toff.p, Tpos.p, R, take_code}, abase.p,
+                                                     true, "asm.atoms");
+            I.A = A;
+            DBuf<u32> osym(A);
+            DBuf<idx_t> olen(A);
+            prim::for_each(A, AtomFn{seg_sym.p, seg_len.p, Toff.p, Tpos.p, abase.p, term.p, R, G, take_code, osym.p, olen.p},
+                           "asm.atoms");
+            bwt = merge_runs(osym.p, olen.p, A);
+        }
+        bwt_level = r;
+        I.R = bwt.R;
+        I.n = L.info.n_in;
+        if (keep_texts) keep_bwt(r);
+        // the level's grammar is no longer needed
+        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+    }
+    void induce_phase() {                                        // exact_ind_phase.cpp:674-697
+        first_bwt();
+        while (bwt_level > 0) induce_level();
+    }
+
+    // ---- a16/a17: .rl_bwt image in HBM --------------------------------------
+    void finish() {
+        if (bwt_level != 0) throw prim::Error(-22, "induction not finished");
+        StageTimer st(&tm.finish);
+        u32 sb = (u32)stats.sb, fb = (u32)stats.fb;
+        image_bytes = 16 + bwt.R * (u64)(sb + fb);
+        image.alloc(image_bytes);
+        u8 hdr[16] = {0};
+        for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
+        prim::h2d(image.p, hdr, 16);
+        prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, bwt.len.p, sb, fb, image.p}, "pack_rl_bwt");
+    }
+    void run_all() {
+        parse_phase();
+        induce_phase();
+        finish();
+    }
+};
+
+}   // namespace GRL_NS

@@ -1,0 +1,517 @@
+// prim_hip.hpp -- device primitives for gfx950 (MI355X), hand-written HIP.
+//
+// Everything the engine (engine_impl.hpp) needs from the device besides its own
+// kernels: memory, grid-stride element kernels, wave64-ballot bit-vector
+// construction, reductions, a reduce-then-scan exclusive scan, an LDS byte
+// histogram and a stable LSD radix sort whose in-tile ranking is done with
+// wave64 ballots (match-by-bit) and LDS per-wave digit counters.
+//
+// wave = 64 lanes everywhere (CDNA4); block = 256 threads = 4 waves, one per SIMD.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <map>
+#include <utility>
+
+#define GRL_HD __host__ __device__ __forceinline__
+#define GRL_DEV __device__ __forceinline__
+
+namespace prim {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+static constexpr bool kIsDevice = true;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define GRL_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            throw prim::Error(-5, std::string(#expr) + ": " + hipGetErrorString(e_) +        \
+                                      " at " + __FILE__ + ":" + std::to_string(__LINE__));  \
+    } while (0)
+
+// ---------------------------------------------------------------- runtime state
+struct Runtime {
+    hipStream_t stream = nullptr;
+    int device = 0;
+    int num_cus = 256;
+    u64 bytes_allocated = 0, peak_bytes = 0;
+    bool sync_each_launch = false;   // debug: catch faults at the launch site
+    // per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
+    bool profile = false;
+    struct Prof { std::string name; hipEvent_t a, b; };
+    std::vector<Prof> pending;
+    std::map<std::string, std::pair<u64, double>> prof;   // name -> (launches, total ms)
+};
+inline Runtime &rt() {
+    static Runtime r;
+    return r;
+}
+
+inline void init(int device) {
+    GRL_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t p;
+    GRL_HIP_CHECK(hipGetDeviceProperties(&p, device));
+    rt().device = device;
+    rt().num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    if (!rt().stream) GRL_HIP_CHECK(hipStreamCreateWithFlags(&rt().stream, hipStreamNonBlocking));
+}
+inline void set_stream(void *s) { rt().stream = (hipStream_t)s; }
+inline void prof_collect();
+inline void sync() {
+    GRL_HIP_CHECK(hipStreamSynchronize(rt().stream));
+    if (rt().profile) prof_collect();
+}
+inline void prof_begin(const std::string &name) {
+    if (!rt().profile) return;
+    Runtime::Prof p;
+    p.name = name;
+    GRL_HIP_CHECK(hipEventCreate(&p.a));
+    GRL_HIP_CHECK(hipEventCreate(&p.b));
+    GRL_HIP_CHECK(hipEventRecord(p.a, rt().stream));
+    rt().pending.push_back(p);
+}
+inline void prof_end() {
+    if (!rt().profile) return;
+    GRL_HIP_CHECK(hipEventRecord(rt().pending.back().b, rt().stream));
+}
+// fold finished event pairs into the per-name table (call after a stream sync)
+inline void prof_collect() {
+    for (auto &p : rt().pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &e = rt().prof[p.name];
+            e.first += 1;
+            e.second += ms;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    rt().pending.clear();
+}
+inline void after_launch(const char *name) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(-5, std::string("launch ") + name + ": " + hipGetErrorString(e));
+    if (rt().sync_each_launch) {
+        e = hipStreamSynchronize(rt().stream);
+        if (e != hipSuccess) throw Error(-5, std::string("kernel ") + name + ": " + hipGetErrorString(e));
+    }
+}
+
+inline void *dev_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) throw Error(-12, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    return p;
+}
+inline void dev_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+inline void h2d(void *d, const void *h, size_t n) {
+    if (n) GRL_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().stream));
+    sync();
+}
+inline void d2h(void *h, const void *d, size_t n) {
+    if (n) GRL_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().stream));
+    sync();
+}
+inline void d2d(void *dst, const void *src, size_t n) {
+    if (n) GRL_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, rt().stream));
+}
+inline void dev_memset(void *d, int v, size_t n) {
+    if (n) GRL_HIP_CHECK(hipMemsetAsync(d, v, n, rt().stream));
+}
+
+// -------------------------------------------------------------------- atomics
+GRL_DEV u32 atomic_add(u32 *p, u32 v) { return atomicAdd(p, v); }
+GRL_DEV u64 atomic_add(u64 *p, u64 v) {
+    return (u64)atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+GRL_DEV u32 atomic_min(u32 *p, u32 v) { return atomicMin(p, v); }
+GRL_DEV u32 atomic_max(u32 *p, u32 v) { return atomicMax(p, v); }
+GRL_DEV u64 atomic_cas(u64 *p, u64 expect, u64 desired) {
+    return (u64)atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)expect,
+                          (unsigned long long)desired);
+}
+GRL_DEV u64 load_relaxed(const u64 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------ launch geometry
+static constexpr int kBlock = 256;
+inline unsigned grid_for(u64 n, u64 per_block) {
+    u64 blocks = (n + per_block - 1) / per_block;
+    u64 cap = (u64)rt().num_cus * 8;   // >= 2048 workgroups on 256 CUs, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// --------------------------------------------------------------------- for_each
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_for_each(u64 n, F f) {
+    u64 stride = (u64)gridDim.x * kBlock;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) f(i);
+}
+template <class F>
+inline void for_each(u64 n, F f, const char *name = "for_each") {
+    if (n == 0) return;
+    prof_begin(name);
+    hipLaunchKernelGGL(k_for_each<F>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, rt().stream, n, f);
+    prof_end();
+    after_launch(name);
+}
+
+// --------------------------------------------------- bit-vector from predicate
+// words[i/64] bit (i%64) = pred(i); one wave64 ballot per word, lane 0 stores.
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_bitvector(u64 n_padded, u64 n, F pred, u64 *words) {
+    u64 stride = (u64)gridDim.x * kBlock;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n_padded; i += stride) {
+        bool b = (i < n) ? pred(i) : false;
+        unsigned long long m = __ballot(b);
+        if ((threadIdx.x & 63) == 0) words[i >> 6] = m;
+    }
+}
+template <class F>
+inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char *name = "bitvector") {
+    if (n == 0) return;
+    u64 n_padded = (n + 63) & ~u64(63);
+    prof_begin(name);
+    hipLaunchKernelGGL(k_bitvector<F>, dim3(grid_for(n_padded, kBlock)), dim3(kBlock), 0, rt().stream, n_padded, n,
+                       pred, words);
+    prof_end();
+    after_launch(name);
+}
+
+// -------------------------------------------------------------------- reduce
+enum class Op { Sum, Min, Max };
+template <class T, Op OP>
+GRL_HD T op_identity() {
+    if (OP == Op::Sum) return T(0);
+    if (OP == Op::Min) return ~T(0);
+    return T(0);
+}
+template <class T, Op OP>
+GRL_HD T op_apply(T a, T b) {
+    if (OP == Op::Sum) return a + b;
+    if (OP == Op::Min) return a < b ? a : b;
+    return a > b ? a : b;
+}
+template <class T, Op OP>
+GRL_DEV T wave_reduce(T v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        T o = __shfl_down(v, off, 64);
+        v = op_apply<T, OP>(v, o);
+    }
+    return v;
+}
+template <class T, Op OP, class F>
+__global__ void __launch_bounds__(kBlock) k_reduce(u64 n, F f, T *partials) {
+    __shared__ T s_w[4];
+    T acc = op_identity<T, OP>();
+    u64 stride = (u64)gridDim.x * kBlock;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc = op_apply<T, OP>(acc, (T)f(i));
+    acc = wave_reduce<T, OP>(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T r = s_w[0];
+        for (int w = 1; w < 4; w++) r = op_apply<T, OP>(r, s_w[w]);
+        partials[blockIdx.x] = r;
+    }
+}
+template <class T, Op OP, class F>
+inline T reduce(u64 n, F f, const char *name = "reduce") {
+    if (n == 0) return op_identity<T, OP>();
+    unsigned g = grid_for(n, kBlock * 8);
+    T *d = (T *)dev_alloc(sizeof(T) * g);
+    prof_begin(name);
+    hipLaunchKernelGGL((k_reduce<T, OP, F>), dim3(g), dim3(kBlock), 0, rt().stream, n, f, d);
+    prof_end();
+    after_launch(name);
+    std::vector<T> h(g);
+    d2h(h.data(), d, sizeof(T) * g);
+    dev_free(d);
+    T r = op_identity<T, OP>();
+    for (unsigned i = 0; i < g; i++) r = op_apply<T, OP>(r, h[i]);
+    return r;
+}
+template <class T, class F>
+inline T reduce_sum(u64 n, F f, const char *name = "reduce_sum") { return reduce<T, Op::Sum, F>(n, f, name); }
+template <class T, class F>
+inline T reduce_min(u64 n, F f, const char *name = "reduce_min") { return reduce<T, Op::Min, F>(n, f, name); }
+template <class T, class F>
+inline T reduce_max(u64 n, F f, const char *name = "reduce_max") { return reduce<T, Op::Max, F>(n, f, name); }
+
+// ------------------------------------------------------------ exclusive scan
+// reduce-then-scan: tile sums -> (recursive) scan of tile sums -> per-tile scan.
+static constexpr int kScanItems = 8;
+static constexpr int kScanTile = kBlock * kScanItems;
+
+template <class T>
+GRL_DEV T wave_incl_scan(T v) {
+    int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        T o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+// exclusive prefix of `v` over the 256 threads of the block; *block_total = sum
+template <class T>
+GRL_DEV T block_excl_scan(T v, T *s_w /*[4]*/, T *block_total) {
+    T incl = wave_incl_scan<T>(v);
+    int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) s_w[w] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int k = 0; k < 4; k++) {
+        T x = s_w[k];
+        if (k < w) base += x;
+        tot += x;
+    }
+    *block_total = tot;
+    return base + incl - v;
+}
+
+template <class T, class F>
+__global__ void __launch_bounds__(kBlock) k_scan_tile_sums(u64 n, F in, T *tile_sums) {
+    __shared__ T s_w[4];
+    u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanItems;
+    T acc = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        u64 i = base + j;
+        if (i < n) acc += (T)in(i);
+    }
+    acc = wave_reduce<T, Op::Sum>(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+template <class T, class F>
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *tile_offsets, T *out) {
+    __shared__ T s_w[4];
+    u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanItems;
+    T v[kScanItems];
+    T acc = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        u64 i = base + j;
+        v[j] = (i < n) ? (T)in(i) : T(0);
+        acc += v[j];
+    }
+    T tot;
+    T ex = block_excl_scan<T>(acc, s_w, &tot) + tile_offsets[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        u64 i = base + j;
+        if (i < n) out[i] = ex;
+        ex += v[j];
+    }
+}
+template <class T>
+struct PtrIn {
+    const T *p;
+    GRL_HD T operator()(u64 i) const { return p[i]; }
+};
+
+// out[i] = sum_{j<i} in(j) for i in [0,n); returns the grand total (host value).
+// `out` may alias the array `in` reads (each tile is read before it is written
+// and tiles are disjoint).  If out_total_slot, also stores the total at out[n].
+template <class T, class F>
+inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, const char *name = "scan") {
+    if (n == 0) {
+        if (store_total_at_n) {
+            T z = 0;
+            h2d(out, &z, sizeof(T));
+        }
+        return T(0);
+    }
+    u64 tiles = (n + kScanTile - 1) / kScanTile;
+    T *sums = (T *)dev_alloc(sizeof(T) * (tiles + 1));
+    prof_begin(name);
+    hipLaunchKernelGGL((k_scan_tile_sums<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, sums);
+    prof_end();
+    after_launch(name);
+    T total;
+    if (tiles == 1) {
+        d2h(&total, sums, sizeof(T));
+        T z = 0;
+        h2d(sums, &z, sizeof(T));
+    } else {
+        total = exclusive_scan<T, PtrIn<T>>(tiles, PtrIn<T>{sums}, sums, false, name);
+    }
+    prof_begin(name);
+    hipLaunchKernelGGL((k_scan_tiles<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, sums, out);
+    prof_end();
+    after_launch(name);
+    if (store_total_at_n) GRL_HIP_CHECK(hipMemcpyAsync(out + n, &total, sizeof(T), hipMemcpyHostToDevice, rt().stream));
+    sync();   // `total` on the stack is the memcpy source; sums freed below
+    dev_free(sums);
+    return total;
+}
+
+// ------------------------------------------------------------- byte histogram
+__global__ void __launch_bounds__(kBlock) k_byte_hist(const u8 *p, u64 n, u64 *hist) {
+    __shared__ u32 s_h[4][256];
+    for (int i = threadIdx.x; i < 1024; i += kBlock) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    int w = threadIdx.x >> 6;
+    u64 stride = (u64)gridDim.x * kBlock * 16;
+    for (u64 i = ((u64)blockIdx.x * kBlock + threadIdx.x) * 16; i < n; i += stride) {
+        if (i + 16 <= n) {
+            uint4 v = *reinterpret_cast<const uint4 *>(p + i);   // 16 B per lane, base is 16-B aligned
+            u32 ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&s_h[w][ws[k] & 255], 1u);
+                atomicAdd(&s_h[w][(ws[k] >> 8) & 255], 1u);
+                atomicAdd(&s_h[w][(ws[k] >> 16) & 255], 1u);
+                atomicAdd(&s_h[w][ws[k] >> 24], 1u);
+            }
+        } else {
+            for (u64 j = i; j < n; j++) atomicAdd(&s_h[w][p[j]], 1u);
+        }
+    }
+    __syncthreads();
+    u32 t = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+    if (t) atomicAdd(reinterpret_cast<unsigned long long *>(&hist[threadIdx.x]), (unsigned long long)t);
+}
+// hist_host[256] = byte frequencies of p[0..n) (p must be 16-byte aligned)
+inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
+    u64 *d = (u64 *)dev_alloc(256 * 8);
+    dev_memset(d, 0, 256 * 8);
+    if (n) {
+        prof_begin("byte_hist");
+        hipLaunchKernelGGL(k_byte_hist, dim3(grid_for(n, kBlock * 16 * 4)), dim3(kBlock), 0, rt().stream, p, n, d);
+        prof_end();
+        after_launch("byte_hist");
+    }
+    d2h(hist_host, d, 256 * 8);
+    dev_free(d);
+}
+
+// ------------------------------------------------------------------ radix sort
+// Stable LSD radix sort of (key, value) pairs, 8 bits per pass.
+//   pass = k_rs_hist (per-tile digit histogram in LDS)  -> counts[digit][tile]
+//        + exclusive_scan over counts (digit-major = global digit offsets)
+//        + k_rs_scatter (in-tile stable ranking with wave64 ballots)
+static constexpr int kRsItems = 16;                 // rounds of 256 keys per tile
+static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup
+
+template <class K>
+__global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 *counts, u32 tiles) {
+    __shared__ u32 s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    u64 base = (u64)blockIdx.x * kRsTile;
+#pragma unroll 4
+    for (int r = 0; r < kRsItems; r++) {
+        u64 i = base + (u64)r * kBlock + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(u32)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[(u64)threadIdx.x * tiles + blockIdx.x] = s_h[threadIdx.x];
+}
+
+template <class K, class V>
+__global__ void __launch_bounds__(kBlock)
+    k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift,
+                 const u64 *offsets /*[256][tiles] exclusive*/, u32 tiles) {
+    __shared__ u32 s_wc[4][256];   // per-wave count of each digit in the current round
+    __shared__ u64 s_run[256];     // running global write position of each digit for this tile
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    s_run[threadIdx.x] = offsets[(u64)threadIdx.x * tiles + blockIdx.x];
+    u64 base = (u64)blockIdx.x * kRsTile;
+    for (int r = 0; r < kRsItems; r++) {
+        u64 i = base + (u64)r * kBlock + threadIdx.x;
+        bool valid = i < n;
+        if (__syncthreads_or(valid) == 0) break;     // whole round beyond n (also orders s_run init)
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_wc[k][threadIdx.x] = 0;
+        K key = valid ? keys_in[i] : K(0);
+        V val = valid ? vals_in[i] : V(0);
+        u32 d = (u32)(key >> shift) & 255u;
+        // wave64 match: lanes of this wave holding the same digit
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        u32 rank_in_wave = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+        __syncthreads();                               // s_wc zeroed by everyone
+        if (valid && rank_in_wave == 0) s_wc[w][d] = (u32)__popcll(peers);
+        __syncthreads();
+        u64 pos = 0;
+        if (valid) {
+            u32 before = 0;
+            for (int k = 0; k < w; k++) before += s_wc[k][d];
+            pos = s_run[d] + before + rank_in_wave;
+        }
+        __syncthreads();                               // all reads of s_run done
+        s_run[threadIdx.x] += (u64)s_wc[0][threadIdx.x] + s_wc[1][threadIdx.x] + s_wc[2][threadIdx.x] +
+                              s_wc[3][threadIdx.x];
+        if (valid) {
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();                               // s_run / s_wc stable before next round
+    }
+}
+
+struct RsCountIn {
+    const u32 *c;
+    GRL_HD u64 operator()(u64 i) const { return (u64)c[i]; }
+};
+
+// Sorts n pairs by key bits [begin_bit, end_bit).  Buffers a/b ping-pong; returns
+// 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b).
+template <class K, class V>
+inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit,
+                      const char *name = "radix_sort") {
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    u32 tiles = (u32)((n + kRsTile - 1) / kRsTile);
+    u32 *counts = (u32 *)dev_alloc((u64)256 * tiles * sizeof(u32));
+    u64 *offsets = (u64 *)dev_alloc((u64)256 * tiles * sizeof(u64));
+    int cur = 0;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        K *kin = cur ? keys_b : keys_a;
+        V *vin = cur ? vals_b : vals_a;
+        K *kout = cur ? keys_a : keys_b;
+        V *vout = cur ? vals_a : vals_b;
+        prof_begin(std::string(name) + ".hist");
+        hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, counts, tiles);
+        prof_end();
+        after_launch(name);
+        exclusive_scan<u64, RsCountIn>((u64)256 * tiles, RsCountIn{counts}, offsets, false, name);
+        prof_begin(std::string(name) + ".scatter");
+        hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
+                           shift, offsets, tiles);
+        prof_end();
+        after_launch(name);
+        cur ^= 1;
+    }
+    sync();
+    dev_free(counts);
+    dev_free(offsets);
+    return cur;
+}
+
+}   // namespace prim

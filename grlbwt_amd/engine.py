@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's driver interface over the C-ABI library.
+
+Mirrors include/grl_bwt.hpp:23-79 (grl_bwt_algo = par_phase + ind_phase + write
+.rl_bwt) with the same stage names.  Everything runs through
+libgrlbwt_hip.so (include/grlbwt_hip.h); there is no CPU path: if the library
+is missing or no HIP device is usable this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libgrlbwt_hip.so")
+
+FLAG_KEEP_LEVELS = 1
+FLAG_SYNC_DEBUG = 2
+FLAG_FORCE_IDX64 = 4
+
+OK = 0
+EILLFORMED = -84
+
+# every symbol include/grlbwt_hip.h declares
+ABI_SYMBOLS = [
+    "grlbwt_abi_version", "grlbwt_strerror", "grlbwt_last_error", "grlbwt_ctx_create", "grlbwt_ctx_destroy",
+    "grlbwt_ctx_set_stream", "grlbwt_text_upload", "grlbwt_text_attach_device", "grlbwt_get_stats",
+    "grlbwt_parse_round", "grlbwt_parse_phase", "grlbwt_round_info_get", "grlbwt_induce_first",
+    "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
+    "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
+    "grlbwt_level_text_download", "grlbwt_level_bwt_size", "grlbwt_level_bwt_download", "grlbwt_get_counters",
+    "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump",
+]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_strings", "n_syms", "min_sym", "max_sym", "max_sym_freq", "sb", "fb")]
+
+
+class RoundInfo(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_in", "n_phrases", "dict_syms", "n_metasyms", "parse_size", "sigma",
+                                          "max_phrase_len", "sort_iters")]
+
+
+class LevelInfo(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n", "n_runs", "runs_next", "induced_cells", "prebwt_runs", "segments",
+                                          "atoms")]
+
+
+class Counters(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("t_stats", "t_classify", "t_hash", "t_dict_sort", "t_dict_groups", "t_emit",
+                                          "t_ind_expand", "t_ind_split", "t_ind_assemble", "t_finish")] + \
+               [(k, C.c_uint64) for k in ("bytes_classify_hash", "bytes_emit", "bytes_induce_scatter",
+                                          "bytes_induce_assemble", "idx_bytes")]
+
+
+def _as_dict(s):
+    return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+class GrlbwtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("grlbwt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IllFormedInput(GrlbwtError):
+    """The reference prints "Error: the file is ill formed" and exits 1 (utils.cpp:177-180)."""
+
+
+_libs = {}
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library; fails loudly when it has not been built."""
+    path = path or os.environ.get("GRLBWT_HIP_LIB", DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.grlbwt_abi_version.restype = i32
+    L.grlbwt_strerror.restype = C.c_char_p
+    L.grlbwt_strerror.argtypes = [i32]
+    L.grlbwt_last_error.restype = C.c_char_p
+    L.grlbwt_last_error.argtypes = [vp]
+    L.grlbwt_ctx_create.argtypes = [i32, C.c_uint32, C.POINTER(vp)]
+    L.grlbwt_ctx_destroy.argtypes = [vp]
+    L.grlbwt_ctx_destroy.restype = None
+    L.grlbwt_ctx_set_stream.argtypes = [vp, vp]
+    L.grlbwt_text_upload.argtypes = [vp, vp, u64, i32]
+    L.grlbwt_text_attach_device.argtypes = [vp, vp, u64, i32]
+    L.grlbwt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.grlbwt_parse_round.argtypes = [vp, C.POINTER(RoundInfo), C.POINTER(i32)]
+    L.grlbwt_parse_phase.argtypes = [vp, C.POINTER(i32)]
+    L.grlbwt_round_info_get.argtypes = [vp, i32, C.POINTER(RoundInfo)]
+    L.grlbwt_induce_first.argtypes = [vp]
+    L.grlbwt_induce_level.argtypes = [vp, C.POINTER(i32), C.POINTER(LevelInfo)]
+    L.grlbwt_induce_phase.argtypes = [vp]
+    L.grlbwt_level_info_get.argtypes = [vp, i32, C.POINTER(LevelInfo)]
+    L.grlbwt_build.argtypes = [vp]
+    L.grlbwt_result_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.grlbwt_result_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.grlbwt_result_download.argtypes = [vp, vp, u64]
+    L.grlbwt_result_write_file.argtypes = [vp, C.c_char_p]
+    L.grlbwt_level_text_size.argtypes = [vp, i32, C.POINTER(u64)]
+    L.grlbwt_level_text_download.argtypes = [vp, i32, vp]
+    L.grlbwt_level_bwt_size.argtypes = [vp, i32, C.POINTER(u64)]
+    L.grlbwt_level_bwt_download.argtypes = [vp, i32, vp, vp]
+    L.grlbwt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.grlbwt_selftest.argtypes = [vp, u64, u64]
+    L.grlbwt_profile_enable.argtypes = [vp, i32]
+    L.grlbwt_profile_dump.argtypes = [vp, C.c_char_p, u64]
+    _libs[path] = L
+    return L
+
+
+class Context:
+    """One engine context per GPU (grlbwt_ctx)."""
+
+    def __init__(self, device=0, flags=0, lib=None):
+        self.L = load_library(lib)
+        h = C.c_void_p()
+        rc = self.L.grlbwt_ctx_create(device, flags, C.byref(h))
+        if rc != OK:
+            raise GrlbwtError(rc, self.L.grlbwt_strerror(rc).decode())
+        self._h = h
+        self._keep = None
+
+    def _ck(self, rc):
+        if rc != OK:
+            msg = self.L.grlbwt_last_error(self._h).decode() or self.L.grlbwt_strerror(rc).decode()
+            if rc == EILLFORMED:
+                raise IllFormedInput(rc, msg)
+            raise GrlbwtError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.grlbwt_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- input ----------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._ck(self.L.grlbwt_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def upload(self, data, cell_bytes=1):
+        """collection_stats + first-round input from a host buffer (bytes / numpy)."""
+        import numpy as np
+        buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview))
+                                   else np.asarray(data).view(np.uint8).reshape(-1))
+        self._keep = buf
+        self._ck(self.L.grlbwt_text_upload(self._h, buf.ctypes.data_as(C.c_void_p), len(buf) // cell_bytes, cell_bytes))
+
+    def attach_device(self, dev_ptr, n_cells, cell_bytes=1, keepalive=None):
+        """Use cells already resident in HBM (e.g. a torch tensor's data_ptr())."""
+        self._keep = keepalive
+        self._ck(self.L.grlbwt_text_attach_device(self._h, C.c_void_p(dev_ptr), n_cells, cell_bytes))
+
+    def stats(self):
+        s = Stats()
+        self._ck(self.L.grlbwt_get_stats(self._h, C.byref(s)))
+        return _as_dict(s)
+
+    # ---- phases (names follow the reference) -----------------------------
+    def parse_round(self):
+        info, done = RoundInfo(), C.c_int()
+        self._ck(self.L.grlbwt_parse_round(self._h, C.byref(info), C.byref(done)))
+        return _as_dict(info), bool(done.value)
+
+    def par_phase(self):
+        n = C.c_int()
+        self._ck(self.L.grlbwt_parse_phase(self._h, C.byref(n)))
+        return n.value
+
+    def round_info(self, r):
+        info = RoundInfo()
+        self._ck(self.L.grlbwt_round_info_get(self._h, r, C.byref(info)))
+        return _as_dict(info)
+
+    def parse2bwt(self):
+        self._ck(self.L.grlbwt_induce_first(self._h))
+
+    def infer_lvl_bwt(self):
+        lvl, info = C.c_int(), LevelInfo()
+        self._ck(self.L.grlbwt_induce_level(self._h, C.byref(lvl), C.byref(info)))
+        return lvl.value, _as_dict(info)
+
+    def ind_phase(self):
+        self._ck(self.L.grlbwt_induce_phase(self._h))
+
+    def level_info(self, lvl):
+        info = LevelInfo()
+        self._ck(self.L.grlbwt_level_info_get(self._h, lvl, C.byref(info)))
+        return _as_dict(info)
+
+    def build(self):
+        """grl_bwt_algo: par_phase + ind_phase on the loaded text."""
+        self._ck(self.L.grlbwt_build(self._h))
+
+    # ---- output -----------------------------------------------------------
+    def result_size(self):
+        nb, nr = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.grlbwt_result_size(self._h, C.byref(nb), C.byref(nr)))
+        return nb.value, nr.value
+
+    def result_device_ptr(self):
+        p = C.c_void_p()
+        self._ck(self.L.grlbwt_result_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def result_bytes(self):
+        nb, _ = self.result_size()
+        out = (C.c_uint8 * nb)()
+        self._ck(self.L.grlbwt_result_download(self._h, out, nb))
+        return bytes(out)
+
+    def write_file(self, path):
+        self._ck(self.L.grlbwt_result_write_file(self._h, os.fsencode(path)))
+
+    # ---- inspection --------------------------------------------------------
+    def level_text(self, lvl):
+        import numpy as np
+        n = C.c_uint64()
+        self._ck(self.L.grlbwt_level_text_size(self._h, lvl, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint64)
+        self._ck(self.L.grlbwt_level_text_download(self._h, lvl, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def level_bwt(self, lvl):
+        import numpy as np
+        n = C.c_uint64()
+        self._ck(self.L.grlbwt_level_bwt_size(self._h, lvl, C.byref(n)))
+        s = np.zeros(n.value, dtype=np.uint64)
+        l = np.zeros(n.value, dtype=np.uint64)
+        self._ck(self.L.grlbwt_level_bwt_download(self._h, lvl, s.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p)))
+        return s, l
+
+    def counters(self):
+        c = Counters()
+        self._ck(self.L.grlbwt_get_counters(self._h, C.byref(c)))
+        return _as_dict(c)
+
+    def profile_enable(self, on=True):
+        self._ck(self.L.grlbwt_profile_enable(self._h, 1 if on else 0))
+
+    def profile(self):
+        """{kernel name: (launches, total_ms)} measured with HIP events on the engine's stream."""
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self.L.grlbwt_profile_dump(self._h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.rsplit(" ", 2)
+            out[name] = (int(cnt), float(ms))
+        return out
+
+    def selftest(self, n=100000, seed=1):
+        return self.L.grlbwt_selftest(self._h, n, seed)
+
+
+def grl_bwt_algo(data, cell_bytes=1, device=0, flags=0, lib=None):
+    """Bytes of the .rl_bwt the reference would write for `data` (grl_bwt.hpp:23-79)."""
+    with Context(device, flags, lib) as ctx:
+        ctx.upload(data, cell_bytes)
+        ctx.build()
+        return ctx.result_bytes()

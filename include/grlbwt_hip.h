@@ -1,0 +1,157 @@
+/*
+ * grlbwt_hip.h -- C-ABI of the MI355X-native BCR-BWT engine (libgrlbwt_hip.so).
+ *
+ * Drop-in boundary for the parse-then-induce hot path of ddiazdom/grlBWT.  The
+ * reference has no FFI/plugin interface: its seam for this
+ * path is the pair of C++ entry points called by grl_bwt_algo
+ * (include/grl_bwt.hpp:23-79):
+ *
+ *     size_t exact_algo::par_phase<sym_type>(i_file, n_threads, hbuff_frac, ws)   lib/exact_algo/exact_par_phase.cpp:285-372
+ *     void   exact_algo::ind_phase<b_f_r>(ws, p_round)                            lib/exact_algo/exact_ind_phase.cpp:674-697
+ *
+ * plus the file formats at both ends (raw cells in, `.rl_bwt` out, include/bwt_io.h).
+ * Each entry point below names the reference function(s) it replaces.  Plain C
+ * types only; one context per GPU; calls on one context must be serialised by the
+ * caller; every function returns 0 or a negative GRLBWT_E* code, never throws and
+ * never exits; host buffers are borrowed for the duration of the call; device
+ * buffers are owned by the context and released by grlbwt_ctx_destroy.
+ *
+ * There is no CPU fallback: without a usable HIP device grlbwt_ctx_create fails
+ * with GRLBWT_EDEVICE.
+ */
+#ifndef GRLBWT_HIP_H
+#define GRLBWT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRLBWT_ABI_VERSION 1
+
+#define GRLBWT_OK 0
+#define GRLBWT_EINVAL (-22)     /* bad argument / call out of order                                  */
+#define GRLBWT_EDEVICE (-5)     /* HIP runtime error (no device, launch failure, ...)                */
+#define GRLBWT_ENOMEM (-12)     /* device or host allocation failed                                  */
+#define GRLBWT_EILLFORMED (-84) /* reference: "Error: the file is ill formed", exit(1) (utils.cpp:177-180) */
+#define GRLBWT_ERANGE (-75)     /* input beyond what this build supports (symbols >= 2^30, ...)      */
+#define GRLBWT_ENOSPC (-28)     /* phrase table overflow                                              */
+#define GRLBWT_EINTERNAL (-71)  /* internal consistency check failed                                  */
+
+/* ctx flags */
+#define GRLBWT_FLAG_KEEP_LEVELS 1u   /* keep every level's text and BWT for parity inspection        */
+#define GRLBWT_FLAG_SYNC_DEBUG 2u    /* synchronise after every kernel launch (fault localisation)   */
+
+typedef struct grlbwt_ctx grlbwt_ctx;
+
+/* collection_stats<T> result (external/cdt/lib/utils.cpp:100-189, include/utils.h:20-28) + final header */
+typedef struct grlbwt_stats {
+    uint64_t n_strings, n_syms, min_sym, max_sym, max_sym_freq;
+    uint64_t sb, fb;            /* bytes per run symbol / run length in the final .rl_bwt */
+} grlbwt_stats;
+
+/* the "Stats:" block of par_round (lib/exact_algo/exact_par_phase.cpp:484-488) */
+typedef struct grlbwt_round_info {
+    uint64_t n_in;              /* cells of the round's input text                  */
+    uint64_t n_phrases;         /* "Parsing phrases" (distinct)                     */
+    uint64_t dict_syms;         /* "Number of symbols in the phrases"               */
+    uint64_t n_metasyms;        /* "Number of unsolved BWT blocks" (tot_phrases)    */
+    uint64_t parse_size;        /* "Parse size"                                     */
+    uint64_t sigma;             /* alphabet size of the input text of the round     */
+    uint64_t max_phrase_len, sort_iters;
+} grlbwt_round_info;
+
+/* the "Stats:" block of infer_lvl_bwt (lib/exact_algo/exact_ind_phase.cpp:372-384) + kernel shape */
+typedef struct grlbwt_level_info {
+    uint64_t n;                 /* "BWT size (n)"                                   */
+    uint64_t n_runs;            /* "Number of runs (r)"                             */
+    uint64_t runs_next;         /* runs of BWT_{r+1} scanned                        */
+    uint64_t induced_cells;     /* chain steps + TAKE cells scattered (pass B)      */
+    uint64_t prebwt_runs, segments, atoms;
+} grlbwt_level_info;
+
+/* wall-clock seconds per stage (stream-synchronised) and algorithmic byte counts */
+typedef struct grlbwt_counters {
+    double t_stats, t_classify, t_hash, t_dict_sort, t_dict_groups, t_emit;
+    double t_ind_expand, t_ind_split, t_ind_assemble, t_finish;
+    uint64_t bytes_classify_hash;   /* sum_r n_r*w_r  (one read of every level's text per scan) */
+    uint64_t bytes_emit;            /* sum_r n_{r+1}*4 written + read back                                 */
+    uint64_t bytes_induce_scatter;  /* sum_r R_{r+1}*(4+idx) + E_r*(4+idx)   (pass A+B formula) */
+    uint64_t bytes_induce_assemble; /* sum_r P_r + E_r + R_{r+1} read + R_r written, (4+idx) B each        */
+    uint64_t idx_bytes;             /* 4 or 8: width of positions/lengths in HBM for this input            */
+} grlbwt_counters;
+
+/* ---- lifetime ------------------------------------------------------------ */
+int grlbwt_abi_version(void);
+const char *grlbwt_strerror(int code);
+/* last error message of this context (valid until the next call on it) */
+const char *grlbwt_last_error(const grlbwt_ctx *ctx);
+/* replaces tmp_workspace construction in run_int (main.cpp:80-96): all level files
+ * of the reference's workspace become device buffers owned by the context.       */
+int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out);
+void grlbwt_ctx_destroy(grlbwt_ctx *ctx);
+/* run the engine's kernels on a caller-provided hipStream_t (e.g. torch's current stream) */
+int grlbwt_ctx_set_stream(grlbwt_ctx *ctx, void *hip_stream);
+
+/* ---- input: replaces collection_stats<sym_type>(i_file) (utils.cpp:100-189) and
+ * the i_file_stream reads of the first round (file_streams.hpp:93-105) ---------- */
+/* copy n_cells cells of cell_bytes in {1,2,4,8} from host memory to HBM and scan them */
+int grlbwt_text_upload(grlbwt_ctx *ctx, const void *host_cells, uint64_t n_cells, int cell_bytes);
+/* use cells already resident in HBM (borrowed until the context is reset/destroyed; 16-byte aligned) */
+int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes);
+int grlbwt_get_stats(const grlbwt_ctx *ctx, grlbwt_stats *out);
+
+/* ---- parsing phase ------------------------------------------------------- */
+/* one par_round (exact_par_phase.cpp:374-497): LMS breaks, phrase hashing, dictionary
+ * sort, pre-BWT, grammar, parse emission.  *done = 1 after the last round (:496). */
+int grlbwt_parse_round(grlbwt_ctx *ctx, grlbwt_round_info *info, int *done);
+/* exact_algo::par_phase (exact_par_phase.cpp:285-372): all rounds; *n_rounds = rounds run */
+int grlbwt_parse_phase(grlbwt_ctx *ctx, int *n_rounds);
+int grlbwt_round_info_get(const grlbwt_ctx *ctx, int round, grlbwt_round_info *info);
+
+/* ---- induction phase ------------------------------------------------------ */
+/* parse2bwt (exact_ind_phase.cpp:603-672) */
+int grlbwt_induce_first(grlbwt_ctx *ctx);
+/* infer_lvl_bwt<b> (exact_ind_phase.cpp:111-386) for the next level down; *level = level produced.
+ * The reference's -b/--run-len-bytes only sizes its bucket cells and never changes the
+ * result; lengths here are full-width, so there is no b parameter. */
+int grlbwt_induce_level(grlbwt_ctx *ctx, int *level, grlbwt_level_info *info);
+/* exact_algo::ind_phase<b> (exact_ind_phase.cpp:674-697): parse2bwt + every level + .rl_bwt image */
+int grlbwt_induce_phase(grlbwt_ctx *ctx);
+int grlbwt_level_info_get(const grlbwt_ctx *ctx, int level, grlbwt_level_info *info);
+
+/* ---- whole path: grl_bwt_algo<sym_type,false> (include/grl_bwt.hpp:23-79) -- */
+int grlbwt_build(grlbwt_ctx *ctx);   /* parse_phase + induce_phase on the loaded text */
+
+/* ---- output: replaces bwt_buff_writer + rename(bwt_lev_0 -> o_file)
+ * (include/bwt_io.h:174-568, include/grl_bwt.hpp:77) ------------------------- */
+int grlbwt_result_size(const grlbwt_ctx *ctx, uint64_t *image_bytes, uint64_t *n_runs);
+/* device pointer of the .rl_bwt image (16-byte header + records), valid until reset/destroy */
+int grlbwt_result_device_ptr(const grlbwt_ctx *ctx, const void **dev_ptr);
+int grlbwt_result_download(const grlbwt_ctx *ctx, void *host_out, uint64_t capacity);
+int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path);
+
+/* ---- inspection (parity tests; need GRLBWT_FLAG_KEEP_LEVELS) --------------- */
+/* text of level >= 1 as (rank<<1 | rep) cells, the reference's on-disk parse format */
+int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells);
+int grlbwt_level_text_download(const grlbwt_ctx *ctx, int level, uint64_t *cells_out);
+int grlbwt_level_bwt_size(const grlbwt_ctx *ctx, int level, uint64_t *n_runs);
+int grlbwt_level_bwt_download(const grlbwt_ctx *ctx, int level, uint64_t *sym_out, uint64_t *len_out);
+
+int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out);
+
+/* per-kernel timing with HIP events on the engine's stream (bench.py's roofline leg).
+ * enable(1) clears the table and starts recording; dump writes one line per kernel name:
+ * "<name> <launches> <total_ms>\n" (NUL terminated, truncated to capacity). */
+int grlbwt_profile_enable(grlbwt_ctx *ctx, int on);
+int grlbwt_profile_dump(grlbwt_ctx *ctx, char *buf, uint64_t capacity);
+
+/* device self-test of the primitives (scan, radix sort, ballot bit-vectors) against
+ * host loops on seeded data; returns 0 or the index (<0) of the failing check */
+int grlbwt_selftest(grlbwt_ctx *ctx, uint64_t n, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRLBWT_HIP_H */

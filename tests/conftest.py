@@ -17,3 +17,6 @@ def oracle_mod():
     from oracle import oracle
     oracle.build()
     return oracle
+
+# data fixtures named test_*.txt are inputs, not doctest files
+collect_ignore_glob = ["golden/*"]

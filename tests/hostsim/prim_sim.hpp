@@ -1,0 +1,131 @@
+// prim_sim.hpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Serial host stand-in for grlbwt_amd/csrc/prim_hip.hpp with the same API, so
+// that the engine's per-element kernel bodies (engine_impl.hpp functors) and
+// its host orchestration can be exercised by the CPU test-suite in a container
+// without a GPU.  It is compiled only into tests/hostsim/_build/libgrlbwt_sim.so,
+// which nothing in the product (grlbwt_amd/, the C-ABI library, the CLI) loads:
+// the product has no CPU path and fails loudly without the HIP library.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <map>
+#include <utility>
+
+#define GRL_HD inline
+#define GRL_DEV inline
+
+namespace prim {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+static constexpr bool kIsDevice = false;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+struct Runtime {
+    void *stream = nullptr;
+    int device = 0;
+    int num_cus = 1;
+    bool sync_each_launch = false;
+    bool profile = false;
+    std::map<std::string, std::pair<u64, double>> prof;
+};
+inline Runtime &rt() {
+    static Runtime r;
+    return r;
+}
+inline void init(int) {}
+inline void set_stream(void *) {}
+inline void sync() {}
+
+inline void *dev_alloc(size_t bytes) {
+    void *p = std::malloc(bytes ? bytes : 16);
+    if (!p) throw Error(-12, "malloc");
+    return p;
+}
+inline void dev_free(void *p) { std::free(p); }
+inline void h2d(void *d, const void *h, size_t n) { if (n) std::memcpy(d, h, n); }
+inline void d2h(void *h, const void *d, size_t n) { if (n) std::memcpy(h, d, n); }
+inline void d2d(void *dst, const void *src, size_t n) { if (n) std::memmove(dst, src, n); }
+inline void dev_memset(void *d, int v, size_t n) { if (n) std::memset(d, v, n); }
+
+inline u32 atomic_add(u32 *p, u32 v) { u32 o = *p; *p += v; return o; }
+inline u64 atomic_add(u64 *p, u64 v) { u64 o = *p; *p += v; return o; }
+inline u32 atomic_min(u32 *p, u32 v) { u32 o = *p; if (v < o) *p = v; return o; }
+inline u32 atomic_max(u32 *p, u32 v) { u32 o = *p; if (v > o) *p = v; return o; }
+inline u64 atomic_cas(u64 *p, u64 expect, u64 desired) { u64 o = *p; if (o == expect) *p = desired; return o; }
+inline u64 load_relaxed(const u64 *p) { return *p; }
+
+template <class F>
+inline void for_each(u64 n, F f, const char * = "") {
+    for (u64 i = 0; i < n; i++) f(i);
+}
+template <class F>
+inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char * = "") {
+    u64 nw = (n + 63) / 64;
+    for (u64 w = 0; w < nw; w++) {
+        u64 m = 0;
+        for (u64 b = 0; b < 64 && w * 64 + b < n; b++)
+            if (pred(w * 64 + b)) m |= (1ull << b);
+        words[w] = m;
+    }
+}
+template <class T, class F>
+inline T reduce_sum(u64 n, F f, const char * = "") { T r = 0; for (u64 i = 0; i < n; i++) r += (T)f(i); return r; }
+template <class T, class F>
+inline T reduce_min(u64 n, F f, const char * = "") { T r = ~T(0); for (u64 i = 0; i < n; i++) { T v = (T)f(i); if (v < r) r = v; } return r; }
+template <class T, class F>
+inline T reduce_max(u64 n, F f, const char * = "") { T r = 0; for (u64 i = 0; i < n; i++) { T v = (T)f(i); if (v > r) r = v; } return r; }
+
+template <class T>
+struct PtrIn {
+    const T *p;
+    T operator()(u64 i) const { return p[i]; }
+};
+template <class T, class F>
+inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, const char * = "") {
+    T acc = 0;
+    for (u64 i = 0; i < n; i++) { T v = (T)in(i); out[i] = acc; acc += v; }
+    if (store_total_at_n) out[n] = acc;
+    return acc;
+}
+inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
+    std::memset(hist_host, 0, 256 * 8);
+    for (u64 i = 0; i < n; i++) hist_host[p[i]]++;
+}
+template <class K, class V>
+inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit,
+                      const char * = "") {
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    int bits = end_bit - begin_bit;
+    K mask = bits >= (int)(8 * sizeof(K)) ? ~K(0) : (K)(((K(1) << bits) - 1));
+    std::vector<u64> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](u64 a, u64 b) {
+        return ((keys_a[a] >> begin_bit) & mask) < ((keys_a[b] >> begin_bit) & mask);
+    });
+    for (u64 i = 0; i < n; i++) { keys_b[i] = keys_a[idx[i]]; vals_b[i] = vals_a[idx[i]]; }
+    // mimic the ping-pong parity of the HIP version
+    int passes = (bits + 7) / 8;
+    if (passes % 2 == 0) {
+        std::memcpy(keys_a, keys_b, n * sizeof(K));
+        std::memcpy(vals_a, vals_b, n * sizeof(V));
+        return 0;
+    }
+    return 1;
+}
+
+}   // namespace prim

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads and exports every symbol include/grlbwt_hip.h declares
+(no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    import __graft_entry__ as g
+    return g.build_hip()
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "grlbwt_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(grlbwt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(hip_lib):
+    lib = ctypes.CDLL(hip_lib)
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    assert lib.grlbwt_abi_version() == 1
+
+
+def test_python_binding_covers_header():
+    from grlbwt_amd import engine
+    assert sorted(engine.ABI_SYMBOLS) == _declared()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from grlbwt_amd import engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.load_library(str(tmp_path / "nope.so"))
+
+
+def test_no_device_is_an_error(hip_lib):
+    """Without a GPU the product refuses to run instead of falling back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from grlbwt_amd import engine
+    with pytest.raises(engine.GrlbwtError):
+        engine.Context(0, 0, hip_lib)
+
+
+def test_product_does_not_touch_oracle():
+    """The product tree never references oracle/ or the serial test stand-in."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "grlbwt_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
+                s = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle|liboracle|libgrlbwt_sim|prim_sim\.hpp\"", s, flags=re.M):
+                    if "#include" in s and "prim_sim" in s and f == "engine_impl.hpp":
+                        continue
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,88 @@
+"""CPU: host orchestration + per-element kernel bodies of the engine, run over the
+serial test stand-in of the device primitives (tests/hostsim, TEST INFRASTRUCTURE),
+against the oracle.  The real HIP kernels are covered by the -m gpu tests."""
+import hashlib
+import json
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from grlbwt_amd import engine, workloads
+from tests import parity
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def sim():
+    d = os.path.join(HERE, "hostsim")
+    subprocess.check_call(["make", "-s", "-C", d], stdout=subprocess.DEVNULL)
+    return os.path.join(d, "_build", "libgrlbwt_sim.so")
+
+
+def test_primitives_selftest(sim):
+    with engine.Context(0, 0, sim) as ctx:
+        assert ctx.selftest(30000, 5) == 0
+
+
+def test_golden_table(sim, oracle_mod):
+    tab = json.load(open(os.path.join(parity.GOLD, "golden_table.json")))
+    for t in tab["tiny"]:
+        assert parity.run_engine(sim, bytes.fromhex(t["input_hex"]), t["cell_bytes"]).hex() == t["rl_bwt_hex"]
+    for name in ("test_2bytes_alphabet.txt", "test_byte_alphabet.txt"):
+        g = tab[name]
+        out = parity.run_engine(sim, open(os.path.join(parity.GOLD, name), "rb").read(), g["cell_bytes"])
+        assert len(out) == g["size"] and hashlib.md5(out).hexdigest() == g["md5"]
+
+
+def test_stagewise_2bytes(sim, oracle_mod):
+    parity.check_stagewise(sim, open(os.path.join(parity.GOLD, "test_2bytes_alphabet.txt"), "rb").read(), 2)
+
+
+def test_stagewise_reads(sim, oracle_mod):
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.uniform_reads(2000, 100, seed=5).tobytes(), 1)
+
+
+def test_stagewise_repetitive(sim, oracle_mod):
+    parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=3).tobytes(), 1)
+
+
+def test_stagewise_idx64(sim, oracle_mod):
+    parity.check_stagewise(sim, workloads.sampled_reads(1500, 80, 10000, seed=2).tobytes(), 1, engine.FLAG_FORCE_IDX64)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+
+
+@pytest.mark.parametrize("kind", parity.KINDS)
+def test_fuzz(sim, oracle_mod, kind):
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + 1)
+    for i in range(40):
+        data, w = parity.rand_collection(rng, kind)
+        flags = engine.FLAG_FORCE_IDX64 if i % 4 == 3 else 0
+        parity.check_final(sim, data, w, flags)
+
+
+def test_ill_formed(sim):
+    with engine.Context(0, 0, sim) as ctx:
+        with pytest.raises(engine.IllFormedInput):
+            ctx.upload(b"AC\nGT", 1)
+        with pytest.raises(engine.IllFormedInput):
+            ctx.upload(b"B\nA\x01B\n", 1)
+        with pytest.raises(engine.GrlbwtError):
+            ctx.upload(b"", 1)
+        with pytest.raises(engine.GrlbwtError):
+            ctx.build()                      # nothing loaded: call out of order
+
+
+def test_header_edges(sim, oracle_mod):
+    for mx, w in [(251, 1), (252, 1), (255, 1), (65531, 2), (65532, 2), (65535, 2)]:
+        dt = {1: np.uint8, 2: np.uint16}[w]
+        parity.check_final(sim, np.array([3, mx, 5, 1, mx, 1], dtype=dt).tobytes(), w)
+
+
+def test_lf_roundtrip_property(sim):
+    data = workloads.sampled_reads(5000, 100, 30000, seed=21).tobytes()
+    parity.lf_roundtrip(parity.run_engine(sim, data, 1), data, 1)

@@ -1,0 +1,130 @@
+"""GPU (-m gpu): the HIP path through the C-ABI against the oracle, the golden
+fixtures and size-independent properties.  Bit-exact is the bar (integer path)."""
+import hashlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from grlbwt_amd import engine, workloads
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    import __graft_entry__ as g
+    lib = g.build_hip()
+    assert os.path.exists(lib)
+    return lib
+
+
+def test_native_library_is_loaded(hip):
+    engine.load_library(hip)
+    maps = open("/proc/self/maps").read()
+    assert "libgrlbwt_hip.so" in maps
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097, 100000, 3000001])
+def test_primitives_selftest(hip, n):
+    with engine.Context(0, 0, hip) as ctx:
+        assert ctx.selftest(n, 11 + n) == 0
+
+
+def test_golden_table(hip, oracle_mod):
+    tab = json.load(open(os.path.join(parity.GOLD, "golden_table.json")))
+    for t in tab["tiny"]:
+        assert parity.run_engine(hip, bytes.fromhex(t["input_hex"]), t["cell_bytes"]).hex() == t["rl_bwt_hex"]
+    for name in ("test_2bytes_alphabet.txt", "test_byte_alphabet.txt"):
+        g = tab[name]
+        out = parity.run_engine(hip, open(os.path.join(parity.GOLD, name), "rb").read(), g["cell_bytes"])
+        assert len(out) == g["size"] and hashlib.md5(out).hexdigest() == g["md5"]
+
+
+def test_stagewise_golden_files(hip, oracle_mod):
+    parity.check_stagewise(hip, open(os.path.join(parity.GOLD, "test_2bytes_alphabet.txt"), "rb").read(), 2)
+    parity.check_stagewise(hip, open(os.path.join(parity.GOLD, "test_byte_alphabet.txt"), "rb").read(), 1)
+
+
+def test_stagewise_reads(hip, oracle_mod):
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.uniform_reads(20000, 100, seed=5).tobytes(), 1)
+
+
+def test_stagewise_repetitive(hip, oracle_mod):
+    parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1)
+
+
+def test_stagewise_tokens_u16(hip, oracle_mod):
+    parity.check_stagewise(hip, workloads.zipf_tokens(400000, doc_len=500, vocab=20000).tobytes(), 2)
+
+
+def test_stagewise_idx64(hip, oracle_mod):
+    parity.check_stagewise(hip, workloads.sampled_reads(5000, 80, 30000, seed=2).tobytes(), 1, engine.FLAG_FORCE_IDX64)
+
+
+@pytest.mark.parametrize("kind", parity.KINDS)
+def test_fuzz(hip, oracle_mod, kind):
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + 7)
+    for i in range(25):
+        data, w = parity.rand_collection(rng, kind)
+        flags = engine.FLAG_FORCE_IDX64 if i % 4 == 3 else 0
+        parity.check_final(hip, data, w, flags)
+
+
+def test_ill_formed_and_errors(hip):
+    with engine.Context(0, 0, hip) as ctx:
+        with pytest.raises(engine.IllFormedInput):
+            ctx.upload(b"AC\nGT", 1)
+        with pytest.raises(engine.GrlbwtError):
+            ctx.upload(b"", 1)
+        with pytest.raises(engine.GrlbwtError):
+            ctx.build()
+
+
+def test_long_equal_runs_and_long_phrases(hip, oracle_mod):
+    # homopolymers (type scan walks), a single long string, and many empty strings
+    data = b"A" * 50000 + b"C" * 30000 + b"\n" + b"ACGT" * 20000 + b"\n" + b"\n" * 1000 + b"T" * 70000 + b"\n"
+    parity.check_final(hip, data, 1)
+
+
+def test_device_resident_input_torch(hip, oracle_mod):
+    """The bench path: input already in HBM (torch tensor), output image stays in HBM."""
+    import torch
+    data = workloads.sampled_reads(30000, 100, 200000, seed=9)
+    dev = torch.from_numpy(data.copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(dev.data_ptr(), dev.numel(), 1, keepalive=dev)
+        ctx.build()
+        got = ctx.result_bytes()
+        assert ctx.result_device_ptr() != 0
+    assert got == oracle_mod.rl_bwt(data.tobytes(), 1)
+
+
+def test_lf_roundtrip_20mb(hip):
+    data = workloads.sampled_reads(200000, 100, 2000000, seed=21).tobytes()
+    parity.lf_roundtrip(parity.run_engine(hip, data, 1), data, 1)
+
+
+def test_full_size_config_properties(hip):
+    """BASELINE config[1] (1M x 100 bp, 101 MB): properties that do not need the oracle:
+    header, maximal runs, symbol count, per-symbol histogram, and idx32 == idx64 builds."""
+    from tests import bcr_check as bc
+    data = workloads.uniform_reads(1000000, 100)
+    a = parity.run_engine(hip, data, 1)
+    sb, fb, sym, ln = bc.parse_rl_bwt(a)
+    assert (sb, fb) == bc.header_widths(data, 1)
+    assert bc.runs_are_maximal(sym)
+    assert int(ln.sum()) == data.size
+    hist = np.bincount(data, minlength=256)
+    got = np.zeros(256, dtype=np.int64)
+    np.add.at(got, sym.astype(np.int64), ln.astype(np.int64))
+    assert np.array_equal(hist, got)          # the BWT is a permutation of the text
+    b = parity.run_engine(hip, data, 1, engine.FLAG_FORCE_IDX64)
+    assert hashlib.md5(a).hexdigest() == hashlib.md5(b).hexdigest()
