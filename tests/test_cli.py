@@ -1,0 +1,57 @@
+"""CLI contract of the reference (main.cpp:43-154): flags, naming, exit codes."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    import __graft_entry__ as g
+    g.build_hip()
+    return g.build_cli()
+
+
+def run(cli, *args, cwd=None):
+    p = subprocess.run([cli, *args], cwd=cwd, capture_output=True, text=True)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_cli_argument_contract(cli, tmp_path):
+    f = os.path.join(GOLD, "test_2bytes_alphabet.txt")
+    assert run(cli)[0] == 106                                   # TEXT is required
+    assert run(cli, "-v")[0] == 106                             # -v alone still needs TEXT [probe in SURVEY 8b]
+    rc, out, _ = run(cli, f, "-v")
+    assert rc == 0 and out.strip() == "v1.0.1 alpha"
+    assert run(cli, str(tmp_path / "missing.txt"))[0] == 105
+    assert run(cli, f, "-a", "3")[0] == 105
+    assert run(cli, f, "-b", "6")[0] == 105
+    assert run(cli, f, "-f", "1.5")[0] == 105
+    assert run(cli, f, "-T", str(tmp_path / "nodir"))[0] == 105
+    assert run(cli, "--help")[0] == 0
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(cli, tmp_path):
+    tab = json.load(open(os.path.join(GOLD, "golden_table.json")))
+    # default naming: basename(TEXT).rl_bwt in the CWD
+    rc, out, err = run(cli, os.path.join(GOLD, "test_byte_alphabet.txt"), "-t", "4", "-b", "2", cwd=str(tmp_path))
+    assert rc == 0, err
+    blob = open(tmp_path / "test_byte_alphabet.rl_bwt", "rb").read()
+    assert hashlib.md5(blob).hexdigest() == tab["test_byte_alphabet.txt"]["md5"]
+    assert "Parsing round 8" in out and "The resulting BCR BWT was stored in" in out
+    # -o with an extension: the last extension is replaced (main.cpp:112-113)
+    rc, out, err = run(cli, os.path.join(GOLD, "test_2bytes_alphabet.txt"), "-a", "2", "-o", str(tmp_path / "x.y"))
+    assert rc == 0, err
+    blob = open(tmp_path / "x.rl_bwt", "rb").read()
+    assert hashlib.md5(blob).hexdigest() == tab["test_2bytes_alphabet.txt"]["md5"]
+    # ill-formed input: message on stdout, exit 1
+    bad = tmp_path / "bad.txt"
+    bad.write_bytes(b"AC\nGT")
+    rc, out, _ = run(cli, str(bad), cwd=str(tmp_path))
+    assert rc == 1 and "Error: the file is ill formed" in out
