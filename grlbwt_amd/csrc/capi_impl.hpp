@@ -257,7 +257,7 @@ int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out) {
 }
 void grlbwt_ctx_destroy(grlbwt_ctx *ctx) {
     if (!ctx) return;
-    try { ctx->e32.reset(); ctx->e64.reset(); } catch (...) {}
+    try { ctx->e32.reset(); ctx->e64.reset(); prim::sync(); prim::pool_trim(); } catch (...) {}
     delete ctx;
 }
 int grlbwt_ctx_set_stream(grlbwt_ctx *ctx, void *hip_stream) {

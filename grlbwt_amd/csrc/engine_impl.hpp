@@ -122,8 +122,19 @@ struct PopcIn {
 };
 
 // ------------------------------------------------- a3: phrase hashing/count
+// table slot (16 B, one memory transaction per probe): key = tag:12 | len:12 | pos+1:40
 static constexpr u64 kPosBits = 40;
 static constexpr u64 kPosMask = (1ull << kPosBits) - 1;
+static constexpr u64 kLenSat = 4095;               // lengths >= 4095 saturate; verified through the start bits
+struct Slot {
+    u64 key;                                       // 0 = empty
+    idx_t cnt;                                     // phrase frequency
+#if GRL_IDX_BYTES == 4
+    u32 pad;
+#endif
+};
+GRL_HD u64 key_len(u64 k) { return (k >> kPosBits) & 0xFFFull; }
+GRL_HD u64 key_pos(u64 k) { return (k & kPosMask) - 1; }
 
 GRL_HD u64 hash_mix(u64 h, u64 v) {
     h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
@@ -137,28 +148,28 @@ GRL_HD u64 hash_fin(u64 h, u64 len) {
     return h;
 }
 
+// One lane per text position; lanes on a phrase start hash the phrase, find/claim its
+// slot and return the slot id (the caller counts it: prim::for_each_agg).
 template <class cell_t, bool FIRST>
 struct HashInsertFn {
     const cell_t *t;
     CellOps<cell_t, FIRST> ops;
     const u64 *startbits;
     const idx_t *wordbase;
-    u64 *keys;        // (tag<<40) | (pos+1), 0 = empty
-    idx_t *counts;    // phrase frequency
-    u32 *lens;        // phrase length (written by the inserting thread)
+    Slot *slots;
     u64 mask;
     u32 *out_slot;    // [n_occ] slot of every phrase occurrence, text order
     u32 *scal;        // [0] max phrase length, [1] error flag
-    GRL_DEV bool same_phrase(u64 q, u64 p, u64 len) const {
+    GRL_DEV bool same_phrase(u64 q, u64 p, u64 len, bool check_bits) const {
         for (u64 j = 0; j < len; j++) {
             if (t[q + j] != t[p + j]) return false;
-            if (j > 0 && bit_at(startbits, q + j) != bit_at(startbits, p + j)) return false;
+            if (check_bits && j > 0 && bit_at(startbits, q + j) != bit_at(startbits, p + j)) return false;
         }
         return true;
     }
-    GRL_DEV void operator()(u64 p) const {
+    GRL_DEV u32 operator()(u64 p) const {
         u64 w = startbits[p >> 6];
-        if (!((w >> (p & 63)) & 1ull)) return;
+        if (!((w >> (p & 63)) & 1ull)) return prim::kNoBucket;
         u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
         u64 h = 0x243F6A8885A308D3ull, e = p;
         cell_t c = t[p];
@@ -171,33 +182,35 @@ struct HashInsertFn {
         }
         u64 len = e - p + 1;
         h = hash_fin(h, len);
-        u64 tag = h >> kPosBits;
-        u64 mine = (tag << kPosBits) | (p + 1);
+        u64 lsat = len < kLenSat ? len : kLenSat;
+        u64 hi = ((h >> 52) << 12) | lsat;          // tag:12 | len:12
+        u64 mine = (hi << kPosBits) | (p + 1);
         u64 slot = h & mask;
         for (u64 probes = 0; probes <= mask; probes++) {
-            u64 cur = prim::load_relaxed(&keys[slot]);
+            u64 cur = prim::load_relaxed(&slots[slot].key);
             if (cur == 0) {
-                u64 old = prim::atomic_cas(&keys[slot], 0ull, mine);
-                if (old == 0) {
-                    lens[slot] = (u32)len;
-                    prim::atomic_max(&scal[0], (u32)len);
-                    cur = mine;
-                } else cur = old;
+                u64 old = prim::atomic_cas(&slots[slot].key, 0ull, mine);
+                if (old == 0) { prim::atomic_max(&scal[0], (u32)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len)); cur = mine; }
+                else cur = old;
             }
-            if (cur == mine || ((cur >> kPosBits) == tag && same_phrase((cur & kPosMask) - 1, p, len))) {
-                prim::atomic_add(&counts[slot], (idx_t)1);
+            if (cur == mine || ((cur >> kPosBits) == hi && same_phrase(key_pos(cur), p, len, lsat == kLenSat))) {
                 out_slot[ord] = (u32)slot;
-                return;
+                return (u32)slot;
             }
             slot = (slot + 1) & mask;
         }
         scal[1] = 1;   // table full
+        return prim::kNoBucket;
     }
+};
+struct SlotCountAdd {
+    Slot *slots;
+    GRL_DEV void operator()(u32 slot, u32 c) const { prim::atomic_add(&slots[slot].cnt, (idx_t)c); }
 };
 
 struct OccIn {
-    const u64 *keys;
-    GRL_DEV u32 operator()(u64 i) const { return keys[i] != 0 ? 1u : 0u; }
+    const Slot *slots;
+    GRL_DEV u32 operator()(u64 i) const { return slots[i].key != 0 ? 1u : 0u; }
 };
 
 // ------------------------------------------------------ a5: dictionary view
@@ -205,15 +218,21 @@ template <class cell_t, bool FIRST>
 struct CompactTableFn {
     const cell_t *t;
     CellOps<cell_t, FIRST> ops;
-    const u64 *keys; const idx_t *counts; const u32 *lens; const u32 *slot_ph;
+    const u64 *startbits;
+    const Slot *slots; const u32 *slot_ph;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
     GRL_DEV void operator()(u64 s) const {
-        u64 k64 = keys[s];
+        u64 k64 = slots[s].key;
         if (!k64) return;
         u32 k = slot_ph[s];
-        u64 pos = (k64 & kPosMask) - 1;
-        ph_pos[k] = pos; ph_freq[k] = counts[s]; ph_len[k] = lens[s]; ph_slot[k] = (u32)s;
-        ph_lastT[k] = ops.isT(t[pos + lens[s] - 1]) ? 1 : 0;
+        u64 pos = key_pos(k64), len = key_len(k64);
+        if (len == kLenSat) {                      // saturated: walk to the phrase end
+            u64 e = pos;
+            for (;;) { if (ops.isT(t[e])) break; e++; if (bit_at(startbits, e)) break; }
+            len = e - pos + 1;
+        }
+        ph_pos[k] = pos; ph_freq[k] = slots[s].cnt; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
+        ph_lastT[k] = ops.isT(t[pos + len - 1]) ? 1 : 0;
     }
 };
 struct LenIn {
@@ -283,13 +302,35 @@ struct GroupStartFn {
         if (t == S - 1) gstart[gid[t] + 1] = (u32)S;
     }
 };
+// Per equal-suffix group: min/max of the left symbol, sum of frequencies, "contains a whole
+// phrase".  Small groups (the overwhelming majority) are folded by their head lane with plain
+// stores; only groups larger than kSmallGroup fall back to atomics (one lane per member).
+static constexpr u32 kSmallGroup = 32;
 struct GroupAccumFn {
-    const u32 *perm; const u32 *gid; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq;
+    const u32 *perm; const u32 *gid; const u32 *gstart; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off;
+    const idx_t *ph_freq;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
     GRL_DEV void operator()(u64 t) const {
+        u32 g = gid[t];
+        u32 t0 = gstart[g], size = gstart[g + 1] - t0;
+        if (size <= kSmallGroup) {
+            if (t != t0) return;
+            u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
+            for (u32 j = 0; j < size; j++) {
+                u64 q = perm[t0 + j];
+                u32 k = dict_phr[q];
+                bool full = (q == ph_off[k]);
+                u32 left = full ? bwt_code : dict_sym[q - 1];
+                mn = left < mn ? left : mn; mx = left > mx ? left : mx;
+                acc += ph_freq[k];
+                fl |= full ? 1 : 0;
+            }
+            gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
+            return;
+        }
         u64 q = perm[t];
-        u32 k = dict_phr[q], g = gid[t];
+        u32 k = dict_phr[q];
         bool full = (q == ph_off[k]);
         u32 left = full ? bwt_code : dict_sym[q - 1];
         prim::atomic_min(&gmin[g], left);
@@ -320,7 +361,7 @@ struct FlagIn {
 struct GroupEmitFn {
     const u8 *gflag; const u32 *grank; const u32 *pidx; const u32 *gmin; const idx_t *gacc; const u32 *gstart; const u32 *perm;
     u32 bwt_code, hocc_code;
-    u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq;
+    u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq; u32 *u_to_p0;
     GRL_DEV void operator()(u64 g) const {
         u8 f = gflag[g];
         if (!(f & GF_VALID)) return;
@@ -331,10 +372,16 @@ struct GroupEmitFn {
             u32 u = grank[g];
             has_hocc[u] = (f & GF_MULTI) ? 1 : 0;
             repq[u] = perm[gstart[g]];
+            u_to_p0[u] = j;
         }
         psym[j] = s;
         plen[j] = gacc[g];
     }
+};
+
+struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
+    const u32 *u_to_p0; const u32 *merged; u32 *u_to_p;
+    GRL_DEV void operator()(u64 u) const { u_to_p[u] = merged[u_to_p0[u]]; }
 };
 
 // ------------------------------------------------------------- a8: grammar
@@ -373,6 +420,31 @@ struct MapFn {
     GRL_DEV void operator()(u64 i) const { text[i] = slot_val[text[i]]; }
 };
 
+// ------------------------------------------------------------- rank bitmaps
+// A sorted list of boundary positions on an axis of `nbits` positions becomes a bit-vector
+// with a popcount prefix per 64-bit word, so "how many boundaries are < x" (the merge rank
+// of x against the list) costs two loads instead of a binary search.
+struct RankBits {
+    DBuf<u64> words;
+    DBuf<idx_t> base;
+};
+struct SetBitFn {
+    const idx_t *pos; u64 *words;
+    GRL_DEV void operator()(u64 i) const { u64 x = pos[i]; prim::atomic_or(&words[x >> 6], 1ull << (x & 63)); }
+};
+// # boundaries in [0, x)
+GRL_HD u64 rank1(const u64 *words, const idx_t *base, u64 x) {
+    return (u64)base[x >> 6] + (u64)__builtin_popcountll(words[x >> 6] & ((1ull << (x & 63)) - 1ull));
+}
+static inline void build_rankbits(RankBits &rb, const idx_t *pos, u64 count, u64 nbits, const char *name) {
+    u64 nw = nbits / 64 + 2;
+    rb.words.alloc(nw);
+    rb.base.alloc(nw + 1);
+    rb.words.zero();
+    prim::for_each(count, SetBitFn{pos, rb.words.p}, name);
+    prim::exclusive_scan<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, name);
+}
+
 // ------------------------------------------------------------ run utilities
 struct SymHeadIn {
     const u32 *s;
@@ -406,8 +478,12 @@ struct Runs {
     u64 R = 0;
 };
 
+struct MergedIndexFn {   // merged run index of every input run
+    const u32 *sym; const idx_t *ex; u32 *map;
+    GRL_DEV void operator()(u64 t) const { map[t] = (u32)(ex[t] + ((t == 0 || sym[t] != sym[t - 1]) ? 1 : 0) - 1); }
+};
 // merge adjacent equal symbols (bwt_io.h push_back/inc_freq_last idiom): -> maximal runs
-static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n) {
+static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merged_index = nullptr) {
     Runs out;
     if (n == 0) { out.sym.alloc(0); out.len.alloc(0); return out; }
     DBuf<idx_t> cum(n + 1), ex(n + 1);
@@ -418,6 +494,7 @@ static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n) {
     DBuf<idx_t> ostart(R + 1);
     prim::for_each(n, MergeHeadsFn{sym, cum.p, ex.p, n, out.sym.p, ostart.p}, "merge_runs.heads");
     prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
+    if (merged_index) prim::for_each(n, MergedIndexFn{sym, ex.p, merged_index}, "merge_runs.index");
     out.R = R;
     return out;
 }
@@ -439,19 +516,25 @@ struct ChainCountFn {
         return c;
     }
 };
+template <bool PACKED>
 struct ChainExpandFn {
     const u32 *nsym; const idx_t *nlen; const u32 *g0; const u32 *g1; const u8 *has_hocc; const idx_t *eoff;
     u32 sigma3, take_code;
-    u32 *ekey; idx_t *eidx; u32 *esym; idx_t *elen; u32 *term;
+    u32 *ekey; idx_t *eidx; u32 *esym; idx_t *elen; u64 *epack; u32 *term;
+    GRL_DEV void put(u64 e, u32 key, u32 sym, idx_t f) const {
+        ekey[e] = key;
+        if (PACKED) epack[e] = ((u64)sym << 32) | (u64)f;
+        else { eidx[e] = (idx_t)e; esym[e] = sym; elen[e] = f; }
+    }
     GRL_DEV void operator()(u64 i) const {
         u32 cur = nsym[i];
         idx_t f = nlen[i];
         u64 e = eoff[i];
-        if (has_hocc[cur]) { ekey[e] = cur; eidx[e] = (idx_t)e; esym[e] = take_code; elen[e] = f; e++; }
+        if (has_hocc[cur]) put(e++, cur, take_code, f);
         u32 nx = g1[cur];
         while (nx >= sigma3) {
             u32 b = nx - sigma3;
-            ekey[e] = b; eidx[e] = (idx_t)e; esym[e] = g0[cur]; elen[e] = f; e++;
+            put(e++, b, g0[cur], f);
             cur = b;
             nx = g1[cur];
         }
@@ -485,40 +568,43 @@ struct SegFromPreFn {   // non-HOCC pre-BWT runs -> segments
     }
 };
 struct SegFromCellFn {  // induced cells (H, bucket-major) -> segments
-    const u32 *ssym; const idx_t *slen; const idx_t *Hpos; const idx_t *PH; const idx_t *nhb; u64 P;
+    const u32 *skey; const u32 *ssym; const idx_t *slen; const u32 *u_to_p; const idx_t *nhb;
     u32 *seg_sym; idx_t *seg_len;
     GRL_DEV void operator()(u64 t) const {
-        u64 j = upper_bound<idx_t>(PH, P, Hpos[t]) - 1;
+        u64 j = u_to_p[skey[t]];                 // pre-BWT (HOCC) run this bucket belongs to
         u64 g = (u64)nhb[j] + t;
         seg_sym[g] = ssym[t];
         seg_len[g] = slen[t];
     }
 };
-struct AtomCountIn {    // output atoms per segment
-    const u32 *seg_sym; const idx_t *seg_len; const idx_t *Toff; const idx_t *Tpos; u64 R; u32 take_code;
+struct AtomCountIn {    // output atoms per segment: 1 + #(BWT_{r+1} run boundaries strictly inside its T interval)
+    const u32 *seg_sym; const idx_t *seg_len; const idx_t *Toff; const u64 *tw; const idx_t *tb; u32 take_code;
     GRL_DEV idx_t operator()(u64 g) const {
         if (seg_sym[g] != take_code) return 1;
-        idx_t a = Toff[g], b = a + seg_len[g];
-        u64 kf = upper_bound<idx_t>(Tpos, R, a) - 1;
-        u64 kl = upper_bound<idx_t>(Tpos, R, (idx_t)(b - 1)) - 1;
-        return (idx_t)(kl - kf + 1);
+        u64 a = Toff[g], b = a + seg_len[g];
+        return (idx_t)(rank1(tw, tb, b) - rank1(tw, tb, a + 1) + 1);
     }
 };
 struct AtomFn {
     const u32 *seg_sym; const idx_t *seg_len; const idx_t *Toff; const idx_t *Tpos; const idx_t *abase; const u32 *term;
-    u64 R, G; u32 take_code;
+    const u64 *tw; const idx_t *tb; const u64 *aw; const idx_t *ab;
+    u32 take_code;
     u32 *osym; idx_t *olen;
     GRL_DEV void operator()(u64 x) const {
-        u64 g = upper_bound<idx_t>(abase, G, (idx_t)x) - 1;
+        u64 g = rank1(aw, ab, x + 1) - 1;        // segment owning atom x
         if (seg_sym[g] != take_code) { osym[x] = seg_sym[g]; olen[x] = seg_len[g]; return; }
         idx_t a = Toff[g], b = a + seg_len[g];
-        u64 kf = upper_bound<idx_t>(Tpos, R, a) - 1;
+        u64 kf = rank1(tw, tb, (u64)a + 1) - 1;  // run of BWT_{r+1} containing T position a
         u64 k = kf + (x - abase[g]);
         idx_t s = Tpos[k] > a ? Tpos[k] : a;
         idx_t e = Tpos[k + 1] < b ? Tpos[k + 1] : b;
         osym[x] = term[k];
         olen[x] = e - s;
     }
+};
+struct UnpackCellFn {   // (sym<<32 | len) payload carried through the radix split
+    const u64 *v; u32 *ssym; idx_t *slen;
+    GRL_DEV void operator()(u64 t) const { u64 x = v[t]; ssym[t] = (u32)(x >> 32); slen[t] = (idx_t)(x & 0xFFFFFFFFull); }
 };
 
 // ------------------------------------------------------- a16: .rl_bwt image
@@ -563,6 +649,7 @@ struct LevelData {
     u32 sigma = 0, M = 0;
     DBuf<u32> g0, g1;
     DBuf<u8> has_hocc;
+    DBuf<u32> u_to_p;        // metasymbol -> index of the (merged) pre-BWT run emitted by its group
     Runs prebwt;
     RoundInfo info;
 };
@@ -672,23 +759,20 @@ class Engine {
         // ---- a3: hash every phrase occurrence ------------------------------
         u64 cap = 1024;
         while (cap < 2 * n_occ) cap <<= 1;
-        DBuf<u64> keys(cap);
-        DBuf<idx_t> counts(cap);
-        DBuf<u32> lens(cap);
+        DBuf<Slot> slots(cap);
         DBuf<u32> next_text(n_occ);
         DBuf<u32> scal(4);
         u32 maxlen;
         {
             StageTimer st(&tm.hash);
-            keys.zero(); counts.zero(); scal.zero();
-            prim::for_each(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, counts.p, lens.p,
-                                                          cap - 1, next_text.p, scal.p}, "hash_phrases");
+            slots.zero(); scal.zero();
+            prim::for_each_agg(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, slots.p, cap - 1, next_text.p, scal.p},
+                               SlotCountAdd{slots.p}, "hash_phrases");
             std::vector<u32> sc = scal.to_host(2);
             if (sc[1]) throw prim::Error(-28, "phrase hash table overflow");
             maxlen = sc[0];
         }
         L.info.max_phrase_len = maxlen;
-        startbits.release();
         wordbase.release();
 
         // ---- a5: flatten the dictionary -------------------------------------
@@ -698,9 +782,9 @@ class Engine {
         DBuf<u32> dict_sym, dict_phr;
         {
             StageTimer st(&tm.dict_sort);
-            D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "table_compact");
+            D = prim::exclusive_scan<u32>(cap, OccIn{slots.p}, slot_ph.p, false, "table_compact");
             ph_pos.alloc(D); ph_freq.alloc(D); ph_len.alloc(D); ph_slot.alloc(D); ph_lastT.alloc(D); ph_off.alloc(D + 1);
-            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, keys.p, counts.p, lens.p, slot_ph.p, ph_pos.p,
+            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, slots.p, slot_ph.p, ph_pos.p,
                                                               ph_freq.p, ph_len.p, ph_slot.p, ph_lastT.p}, "table_compact");
             u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dict_syms");
             if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
@@ -708,7 +792,7 @@ class Engine {
             dict_sym.alloc(S); dict_phr.alloc(S);
             prim::for_each(S, DictBuildFn<cell_t, FIRST>{t, ops, ph_off.p, D, ph_pos.p, dict_sym.p, dict_phr.p}, "dict_build");
         }
-        keys.release(); counts.release(); lens.release(); slot_ph.release();
+        slots.release(); slot_ph.release(); startbits.release();
         L.info.D = D; L.info.S = S;
 
         // ---- a6: sort all phrase suffixes (radix + prefix doubling) ----------
@@ -757,8 +841,8 @@ class Engine {
             StageTimer st(&tm.dict_groups);
             gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
             prim::for_each(S, GroupStartFn{gid.p, S, gstart.p}, "group_starts");
-            prim::for_each(S, GroupAccumFn{perm.p, gid.p, dict_sym.p, dict_phr.p, ph_off.p, ph_freq.p, bwt_code, gmin.p,
-                                           gmax.p, gacc.p, gfull.p}, "group_accum");
+            prim::for_each(S, GroupAccumFn{perm.p, gid.p, gstart.p, dict_sym.p, dict_phr.p, ph_off.p, ph_freq.p, bwt_code,
+                                           gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off.p, ph_lastT.p, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
             M = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
@@ -768,9 +852,12 @@ class Engine {
             L.has_hocc.alloc(M); repq.alloc(M);
             DBuf<u32> psym0(P0);
             DBuf<idx_t> plen0(P0);
+            DBuf<u32> u_to_p0(M), merged(P0);
             prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code,
-                                          psym0.p, plen0.p, L.has_hocc.p, repq.p}, "prebwt_emit");
-            L.prebwt = merge_runs(psym0.p, plen0.p, P0);
+                                          psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p}, "prebwt_emit");
+            L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
+            L.u_to_p.alloc(M);
+            prim::for_each(M, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
             // ---- a8: grammar ------------------------------------------------
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
@@ -866,22 +953,36 @@ class Engine {
                                                  "induce_count");
         }
         I.E = E;
+        DBuf<u32> skey;                         // bucket of every induced cell, bucket-major order
+        ssym.alloc(E); slen.alloc(E);
         {
-            DBuf<u32> ekey(E), ekey2(E), esym(E);
-            DBuf<idx_t> eidx(E), eidx2(E), elen(E);
-            {
-                StageTimer st(&tm.ind_expand);
-                prim::for_each(R, ChainExpandFn{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
-                                                ekey.p, eidx.p, esym.p, elen.p, term.p}, "induce_expand");
-            }
-            ssym.alloc(E); slen.alloc(E);
-            {
+            DBuf<u32> ekey(E), ekey2(E);
+            int bits = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
+            if (bits < 1) bits = 1;
+            if (sizeof(idx_t) == 4) {           // payload (sym, len) rides through the split as one u64
+                DBuf<u64> ep(E), ep2(E);
+                {
+                    StageTimer st(&tm.ind_expand);
+                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                                                          ekey.p, nullptr, nullptr, nullptr, ep.p, term.p}, "induce_expand");
+                }
                 StageTimer st(&tm.ind_sort);
-                int bits = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
-                if (bits < 1) bits = 1;
+                int res = prim::sort_pairs<u32, u64>(ekey.p, ep.p, ekey2.p, ep2.p, E, 0, bits, "induce_split");
+                prim::for_each(E, UnpackCellFn{res ? ep2.p : ep.p, ssym.p, slen.p}, "induce_unpack");
+                skey = std::move(res ? ekey2 : ekey);
+                prim::sync();
+            } else {
+                DBuf<u32> esym(E);
+                DBuf<idx_t> eidx(E), eidx2(E), elen(E);
+                {
+                    StageTimer st(&tm.ind_expand);
+                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                                                           ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
+                }
+                StageTimer st(&tm.ind_sort);
                 int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
-                const idx_t *perm = res ? eidx2.p : eidx.p;
-                prim::for_each(E, GatherCellFn{perm, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
+                prim::for_each(E, GatherCellFn{res ? eidx2.p : eidx.p, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
+                skey = std::move(res ? ekey2 : ekey);
                 prim::sync();
             }
         }
@@ -903,17 +1004,21 @@ class Engine {
             DBuf<idx_t> seg_len(G), Toff(G + 1), abase(G + 1);
             prim::for_each(P, SegFromPreFn{L.prebwt.sym.p, L.prebwt.len.p, PH.p, nhb.p, Hpos.p, E, bwt_code, hocc_code,
                                            take_code, seg_sym.p, seg_len.p}, "asm.seg_pre");
-            prim::for_each(E, SegFromCellFn{ssym.p, slen.p, Hpos.p, PH.p, nhb.p, P, seg_sym.p, seg_len.p}, "asm.seg_cell");
+            prim::for_each(E, SegFromCellFn{skey.p, ssym.p, slen.p, L.u_to_p.p, nhb.p, seg_sym.p, seg_len.p}, "asm.seg_cell");
+            Hpos.release(); skey.release(); ssym.release(); slen.release();
             u64 Tused = (u64)prim::exclusive_scan<idx_t>(G, CondLenIn{seg_sym.p, seg_len.p, take_code}, Toff.p, true, "asm.Toff");
             if (Tused != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) +
                                                            ": " + std::to_string(Tused) + " vs " + std::to_string(Tsum) + ")");
-            u64 A = (u64)prim::exclusive_scan<idx_t>(G, AtomCountIn{seg_sym.p, seg_len.p, Toff.p, Tpos.p, R, take_code}, abase.p,
-                                                     true, "asm.atoms");
+            RankBits tbits, abits;
+            build_rankbits(tbits, Tpos.p, R, Tsum + 1, "asm.tbits");        // run boundaries of BWT_{r+1} on the T axis
+            u64 A = (u64)prim::exclusive_scan<idx_t>(G, AtomCountIn{seg_sym.p, seg_len.p, Toff.p, tbits.words.p, tbits.base.p, take_code},
+                                                     abase.p, true, "asm.atom_count");
             I.A = A;
+            build_rankbits(abits, abase.p, G, A + 1, "asm.abits");          // first atom of every segment on the atom axis
             DBuf<u32> osym(A);
             DBuf<idx_t> olen(A);
-            prim::for_each(A, AtomFn{seg_sym.p, seg_len.p, Toff.p, Tpos.p, abase.p, term.p, R, G, take_code, osym.p, olen.p},
-                           "asm.atoms");
+            prim::for_each(A, AtomFn{seg_sym.p, seg_len.p, Toff.p, Tpos.p, abase.p, term.p, tbits.words.p, tbits.base.p,
+                                     abits.words.p, abits.base.p, take_code, osym.p, olen.p}, "asm.atoms");
             bwt = merge_runs(osym.p, olen.p, A);
         }
         bwt_level = r;
@@ -921,7 +1026,7 @@ class Engine {
         I.n = L.info.n_in;
         if (keep_texts) keep_bwt(r);
         // the level's grammar is no longer needed
-        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.prebwt.sym.release(); L.prebwt.len.release();
     }
     void induce_phase() {                                        // exact_ind_phase.cpp:674-697
         first_bwt();

@@ -110,15 +110,78 @@ inline void after_launch(const char *name) {
     }
 }
 
+// Caching device allocator: the engine allocates and frees hundreds of scratch arrays per
+// build; hipMalloc/hipFree each cost tens of microseconds and synchronise the device.
+// Freed blocks are kept in size-class free lists (powers of two up to 1 MiB, then 1 MiB
+// granules, exact-size match) and reused; everything is stream-ordered on one stream, so
+// a block freed by the host after its last launch was enqueued may be handed out again
+// to a later launch on the same stream.
+struct Pool {
+    std::multimap<size_t, void *> free_blocks;   // capacity -> ptr
+    std::map<void *, size_t> live;                // ptr -> capacity
+    size_t cached_bytes = 0, live_bytes = 0, peak_bytes = 0;
+    size_t cache_limit = (size_t)64 << 30;        // keep at most this much idle memory
+};
+inline Pool &pool() {
+    static Pool p;
+    return p;
+}
+inline size_t pool_round(size_t bytes) {
+    if (bytes < 256) return 256;
+    if (bytes <= ((size_t)1 << 20)) {
+        size_t c = 256;
+        while (c < bytes) c <<= 1;
+        return c;
+    }
+    const size_t g = (size_t)1 << 20;
+    return (bytes + g - 1) / g * g;
+}
+inline void pool_trim() {
+    Pool &P = pool();
+    for (auto &kv : P.free_blocks) (void)hipFree(kv.second);
+    P.free_blocks.clear();
+    P.cached_bytes = 0;
+}
 inline void *dev_alloc(size_t bytes) {
+    Pool &P = pool();
+    size_t cap = pool_round(bytes);
+    auto it = P.free_blocks.lower_bound(cap);
+    // accept a cached block up to 25 % larger than requested
+    if (it != P.free_blocks.end() && it->first <= cap + cap / 4) {
+        void *p = it->second;
+        size_t c = it->first;
+        P.free_blocks.erase(it);
+        P.cached_bytes -= c;
+        P.live[p] = c;
+        P.live_bytes += c;
+        if (P.live_bytes > P.peak_bytes) P.peak_bytes = P.live_bytes;
+        return p;
+    }
     void *p = nullptr;
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) throw Error(-12, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {      // give the cache back and retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(rt().stream);
+        pool_trim();
+        e = hipMalloc(&p, cap);
+    }
+    if (e != hipSuccess) throw Error(-12, "hipMalloc(" + std::to_string(cap) + "): " + hipGetErrorString(e));
+    P.live[p] = cap;
+    P.live_bytes += cap;
+    if (P.live_bytes > P.peak_bytes) P.peak_bytes = P.live_bytes;
     return p;
 }
 inline void dev_free(void *p) {
-    if (p) (void)hipFree(p);
+    if (!p) return;
+    Pool &P = pool();
+    auto it = P.live.find(p);
+    if (it == P.live.end()) { (void)hipFree(p); return; }
+    size_t c = it->second;
+    P.live.erase(it);
+    P.live_bytes -= c;
+    if (P.cached_bytes + c > P.cache_limit) { (void)hipStreamSynchronize(rt().stream); (void)hipFree(p); return; }
+    P.free_blocks.emplace(c, p);
+    P.cached_bytes += c;
 }
 inline void h2d(void *d, const void *h, size_t n) {
     if (n) GRL_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().stream));
@@ -139,6 +202,9 @@ inline void dev_memset(void *d, int v, size_t n) {
 GRL_DEV u32 atomic_add(u32 *p, u32 v) { return atomicAdd(p, v); }
 GRL_DEV u64 atomic_add(u64 *p, u64 v) {
     return (u64)atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+GRL_DEV void atomic_or(u64 *p, u64 v) {
+    atomicOr(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
 }
 GRL_DEV u32 atomic_min(u32 *p, u32 v) { return atomicMin(p, v); }
 GRL_DEV u32 atomic_max(u32 *p, u32 v) { return atomicMax(p, v); }
@@ -193,6 +259,53 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char *name = "b
     prof_begin(name);
     hipLaunchKernelGGL(k_bitvector<F>, dim3(grid_for(n_padded, kBlock)), dim3(kBlock), 0, rt().stream, n_padded, n,
                        pred, words);
+    prof_end();
+    after_launch(name);
+}
+
+// ------------------------------------------ for_each with LDS count aggregation
+// f(i) returns a bucket id (u32) or kNoBucket; every returned id must be counted once
+// in a global table through add(id, count).  Same-address global atomics serialise at
+// the memory side, so each workgroup first aggregates (id -> count) in a 4096-entry LDS
+// open-addressing cache over its CONTIGUOUS chunk of the index space and flushes one
+// atomic per distinct id at the end; ids that do not fit the cache go straight to add().
+static constexpr u32 kNoBucket = 0xFFFFFFFFu;
+static constexpr int kAggSlots = 4096;
+template <class F, class A>
+__global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F f, A add) {
+    __shared__ u32 c_key[kAggSlots];
+    __shared__ u32 c_cnt[kAggSlots];
+    for (int i = threadIdx.x; i < kAggSlots; i += kBlock) { c_key[i] = kNoBucket; c_cnt[i] = 0; }
+    __syncthreads();
+    u64 start = (u64)blockIdx.x * per_block;
+    u64 end = start + per_block < n ? start + per_block : n;
+    for (u64 i = start + threadIdx.x; i < end; i += kBlock) {
+        u32 s = f(i);
+        if (s != kNoBucket) {
+            u32 h = (s * 2654435761u) >> 20;
+            bool done = false;
+            for (int p = 0; p < 8 && !done; p++) {
+                u32 old = atomicCAS(&c_key[h], kNoBucket, s);
+                if (old == kNoBucket || old == s) { atomicAdd(&c_cnt[h], 1u); done = true; }
+                else h = (h + 1) & (kAggSlots - 1);
+            }
+            if (!done) add(s, 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kAggSlots; i += kBlock) {
+        u32 c = c_cnt[i];
+        if (c) add(c_key[i], c);
+    }
+}
+template <class F, class A>
+inline void for_each_agg(u64 n, F f, A add, const char *name = "for_each_agg") {
+    if (n == 0) return;
+    u64 blocks = (u64)rt().num_cus * 4;
+    u64 per_block = ((n + blocks - 1) / blocks + kBlock - 1) / kBlock * kBlock;
+    blocks = (n + per_block - 1) / per_block;
+    prof_begin(name);
+    hipLaunchKernelGGL((k_for_each_agg<F, A>), dim3((unsigned)blocks), dim3(kBlock), 0, rt().stream, n, per_block, f, add);
     prof_end();
     after_launch(name);
 }

@@ -13,14 +13,18 @@
 
 #define GRL_NS grl32
 #define GRL_IDX_T uint32_t
+#define GRL_IDX_BYTES 4
 #include "../../grlbwt_amd/csrc/engine_impl.hpp"
 #undef GRL_NS
 #undef GRL_IDX_T
+#undef GRL_IDX_BYTES
 
 #define GRL_NS grl64
 #define GRL_IDX_T uint64_t
+#define GRL_IDX_BYTES 8
 #include "../../grlbwt_amd/csrc/engine_impl.hpp"
 #undef GRL_NS
 #undef GRL_IDX_T
+#undef GRL_IDX_BYTES
 
 #include "../../grlbwt_amd/csrc/capi_impl.hpp"

@@ -64,6 +64,7 @@ inline void dev_memset(void *d, int v, size_t n) { if (n) std::memset(d, v, n); 
 
 inline u32 atomic_add(u32 *p, u32 v) { u32 o = *p; *p += v; return o; }
 inline u64 atomic_add(u64 *p, u64 v) { u64 o = *p; *p += v; return o; }
+inline void atomic_or(u64 *p, u64 v) { *p |= v; }
 inline u32 atomic_min(u32 *p, u32 v) { u32 o = *p; if (v < o) *p = v; return o; }
 inline u32 atomic_max(u32 *p, u32 v) { u32 o = *p; if (v > o) *p = v; return o; }
 inline u64 atomic_cas(u64 *p, u64 expect, u64 desired) { u64 o = *p; if (o == expect) *p = desired; return o; }
@@ -83,6 +84,12 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char * = "") {
         words[w] = m;
     }
 }
+static constexpr u32 kNoBucket = 0xFFFFFFFFu;
+template <class F, class A>
+inline void for_each_agg(u64 n, F f, A add, const char * = "") {
+    for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
+}
+inline void pool_trim() {}
 template <class T, class F>
 inline T reduce_sum(u64 n, F f, const char * = "") { T r = 0; for (u64 i = 0; i < n; i++) r += (T)f(i); return r; }
 template <class T, class F>

@@ -86,3 +86,10 @@ def test_header_edges(sim, oracle_mod):
 def test_lf_roundtrip_property(sim):
     data = workloads.sampled_reads(5000, 100, 30000, seed=21).tobytes()
     parity.lf_roundtrip(parity.run_engine(sim, data, 1), data, 1)
+
+
+def test_long_phrases_saturated_length(sim, oracle_mod):
+    # phrases longer than the 12-bit length field of the table key (verified through the start bits)
+    data = b"A" * 6000 + b"\n" + b"A" * 6000 + b"\n" + b"A" * 7000 + b"\n" + b"C" * 5000 + b"A" * 4999 + b"\n"
+    parity.check_final(sim, data, 1)
+    parity.check_stagewise(sim, data, 1, engine.FLAG_FORCE_IDX64)
