@@ -249,7 +249,7 @@ int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out) {
     c->device = device_id;
     int rc = guarded(c, [&] {
         prim::init(device_id);
-        prim::rt().sync_each_launch = (flags & GRLBWT_FLAG_SYNC_DEBUG) != 0;
+        if (flags & GRLBWT_FLAG_SYNC_DEBUG) prim::rt().sync_each_launch = true;
     });
     if (rc != GRLBWT_OK) { delete c; return rc; }
     *out = c;

@@ -159,8 +159,10 @@ struct HashInsertFn {
     Slot *slots;
     u64 mask;
     u32 *out_slot;    // [n_occ] slot of every phrase occurrence, text order
-    u32 *scal;        // [0] max phrase length, [1] error flag
+    u32 *scal;        // [0] max phrase length, [1] error flag, [2..3] debug
+    u64 n, n_occ;
     GRL_DEV bool same_phrase(u64 q, u64 p, u64 len, bool check_bits) const {
+        if (q + len > n) { scal[1] = 3; scal[2] = (u32)q; scal[3] = (u32)len; return false; }
         for (u64 j = 0; j < len; j++) {
             if (t[q + j] != t[p + j]) return false;
             if (check_bits && j > 0 && bit_at(startbits, q + j) != bit_at(startbits, p + j)) return false;
@@ -177,30 +179,36 @@ struct HashInsertFn {
             h = hash_mix(h, (u64)ops.sym(c));
             if (ops.isT(c)) break;
             e++;
+            if (e >= n) { scal[1] = 4; scal[2] = (u32)p; return prim::kNoBucket; }
             c = t[e];
             if (bit_at(startbits, e)) { h = hash_mix(h, (u64)ops.sym(c)); break; }
         }
+        if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; return prim::kNoBucket; }
         u64 len = e - p + 1;
         h = hash_fin(h, len);
         u64 lsat = len < kLenSat ? len : kLenSat;
         u64 hi = ((h >> 52) << 12) | lsat;          // tag:12 | len:12
         u64 mine = (hi << kPosBits) | (p + 1);
         u64 slot = h & mask;
-        for (u64 probes = 0; probes <= mask; probes++) {
+        // NOTE: the result is carried in `found` and written after the loop.  Returning from inside
+        // the probe loop made hipcc 7.2 (gfx950) reuse the return register as a scratch under a
+        // partial exec mask, so lanes that matched an existing key returned a stale value.
+        u32 found = prim::kNoBucket;
+        for (u64 probes = 0; probes <= mask && found == prim::kNoBucket; probes++) {
             u64 cur = prim::load_relaxed(&slots[slot].key);
             if (cur == 0) {
                 u64 old = prim::atomic_cas(&slots[slot].key, 0ull, mine);
                 if (old == 0) { prim::atomic_max(&scal[0], (u32)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len)); cur = mine; }
                 else cur = old;
             }
-            if (cur == mine || ((cur >> kPosBits) == hi && same_phrase(key_pos(cur), p, len, lsat == kLenSat))) {
-                out_slot[ord] = (u32)slot;
-                return (u32)slot;
-            }
-            slot = (slot + 1) & mask;
+            bool hit = (cur == mine);
+            if (!hit && (cur >> kPosBits) == hi) hit = same_phrase(key_pos(cur), p, len, lsat == kLenSat);
+            if (hit) found = (u32)slot;
+            else slot = (slot + 1) & mask;
         }
-        scal[1] = 1;   // table full
-        return prim::kNoBucket;
+        if (found == prim::kNoBucket) { scal[1] = 1; return found; }   // table full
+        out_slot[ord] = found;
+        return found;
     }
 };
 struct SlotCountAdd {
@@ -766,11 +774,21 @@ class Engine {
         {
             StageTimer st(&tm.hash);
             slots.zero(); scal.zero();
-            prim::for_each_agg(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, slots.p, cap - 1, next_text.p, scal.p},
+            prim::for_each_agg(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, slots.p, cap - 1, next_text.p, scal.p, n, n_occ},
                                SlotCountAdd{slots.p}, "hash_phrases");
-            std::vector<u32> sc = scal.to_host(2);
-            if (sc[1]) throw prim::Error(-28, "phrase hash table overflow");
+            std::vector<u32> sc = scal.to_host(4);
+            if (sc[1] == 1) throw prim::Error(-28, "phrase hash table overflow");
+            if (sc[1]) throw prim::Error(-71, "phrase hashing: consistency check " + std::to_string(sc[1]) + " failed (" +
+                                                   std::to_string(sc[2]) + ", " + std::to_string(sc[3]) + ")");
             maxlen = sc[0];
+            if (getenv("GRLBWT_DEBUG_TABLE")) {
+                std::vector<Slot> hs = slots.to_host(cap);
+                u64 nk = 0, tot = 0, mx = 0;
+                for (u64 i = 0; i < cap; i++) { if (hs[i].key) { nk++; tot += hs[i].cnt; if (hs[i].cnt > mx) mx = hs[i].cnt; } }
+                fprintf(stderr, "[grlbwt] table: cap %llu keys %llu sum(cnt) %llu max(cnt) %llu n_occ %llu sizeof(Slot) %zu\n",
+                        (unsigned long long)cap, (unsigned long long)nk, (unsigned long long)tot, (unsigned long long)mx,
+                        (unsigned long long)n_occ, sizeof(Slot));
+            }
         }
         L.info.max_phrase_len = maxlen;
         wordbase.release();
@@ -786,6 +804,9 @@ class Engine {
             ph_pos.alloc(D); ph_freq.alloc(D); ph_len.alloc(D); ph_slot.alloc(D); ph_lastT.alloc(D); ph_off.alloc(D + 1);
             prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, slots.p, slot_ph.p, ph_pos.p,
                                                               ph_freq.p, ph_len.p, ph_slot.p, ph_lastT.p}, "table_compact");
+            u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dict_freq_check");
+            if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
+                                                           std::to_string(n_occ) + ")");
             u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dict_syms");
             if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
             S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dict_offsets");

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -50,6 +51,7 @@ struct Runtime {
     u64 bytes_allocated = 0, peak_bytes = 0;
     bool sync_each_launch = false;   // debug: catch faults at the launch site
     // per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
+    bool trace = false;              // GRLBWT_TRACE=1: print every launch and synchronise after it
     bool profile = false;
     struct Prof { std::string name; hipEvent_t a, b; };
     std::vector<Prof> pending;
@@ -65,6 +67,7 @@ inline void init(int device) {
     hipDeviceProp_t p;
     GRL_HIP_CHECK(hipGetDeviceProperties(&p, device));
     rt().device = device;
+    if (const char *t = getenv("GRLBWT_TRACE")) { rt().trace = t[0] == '1'; rt().sync_each_launch = rt().trace; }
     rt().num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     if (!rt().stream) GRL_HIP_CHECK(hipStreamCreateWithFlags(&rt().stream, hipStreamNonBlocking));
 }
@@ -75,6 +78,7 @@ inline void sync() {
     if (rt().profile) prof_collect();
 }
 inline void prof_begin(const std::string &name) {
+    if (rt().trace) { fprintf(stderr, "[grlbwt] launch %s\n", name.c_str()); fflush(stderr); }
     if (!rt().profile) return;
     Runtime::Prof p;
     p.name = name;
@@ -142,7 +146,17 @@ inline void pool_trim() {
     P.free_blocks.clear();
     P.cached_bytes = 0;
 }
+inline bool pool_disabled() {
+    static int d = getenv("GRLBWT_NOPOOL") ? 1 : 0;
+    return d != 0;
+}
 inline void *dev_alloc(size_t bytes) {
+    if (pool_disabled()) {
+        void *q = nullptr;
+        hipError_t e0 = hipMalloc(&q, bytes ? bytes : 16);
+        if (e0 != hipSuccess) throw Error(-12, "hipMalloc: " + std::string(hipGetErrorString(e0)));
+        return q;
+    }
     Pool &P = pool();
     size_t cap = pool_round(bytes);
     auto it = P.free_blocks.lower_bound(cap);
@@ -299,8 +313,14 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
     }
 }
 template <class F, class A>
+struct NoAggFn {
+    F f; A add;
+    GRL_DEV void operator()(u64 i) const { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
+};
+template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, const char *name = "for_each_agg") {
     if (n == 0) return;
+    if (getenv("GRLBWT_NOAGG")) { for_each(n, NoAggFn<F, A>{f, add}, name); return; }
     u64 blocks = (u64)rt().num_cus * 4;
     u64 per_block = ((n + blocks - 1) / blocks + kBlock - 1) / kBlock * kBlock;
     blocks = (n + per_block - 1) / per_block;
