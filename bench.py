@@ -113,8 +113,16 @@ def main():
         # ---- roofline leg: one more step with HIP-event timing of every kernel on the engine's stream
         ctx.profile_enable(True)
         step()
-        prof = ctx.profile()
+        prof_detail = ctx.profile()
         ctx.profile_enable(False)
+        prof = {}
+        for k, (c, ms) in prof_detail.items():      # fold the per-level tags ("name#level")
+            b = k.split("#")[0]
+            pc, pm = prof.get(b, (0, 0.0))
+            prof[b] = (pc + c, pm + ms)
+        if os.environ.get("GRLBWT_BENCH_DETAIL"):
+            for k, (c, ms) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:40]:
+                print("  %-32s %4d launches %9.3f ms" % (k, c, ms), file=sys.stderr)
         nr = 0
         rounds = []
         while True:

@@ -122,17 +122,13 @@ struct PopcIn {
 };
 
 // ------------------------------------------------- a3: phrase hashing/count
-// table slot (16 B, one memory transaction per probe): key = tag:12 | len:12 | pos+1:40
+// phrase table, struct-of-arrays: u64 keys[] (tag:12 | len:12 | pos+1:40, 0 = empty) are written once
+// and then read-mostly, so they stay cacheable; idx_t counts[] take the atomic traffic.  (An
+// array-of-structs layout was measured 4x slower: the atomics on a hot phrase's count kept
+// invalidating the line every probe of that phrase has to read.)
 static constexpr u64 kPosBits = 40;
 static constexpr u64 kPosMask = (1ull << kPosBits) - 1;
 static constexpr u64 kLenSat = 4095;               // lengths >= 4095 saturate; verified through the start bits
-struct Slot {
-    u64 key;                                       // 0 = empty
-    idx_t cnt;                                     // phrase frequency
-#if GRL_IDX_BYTES == 4
-    u32 pad;
-#endif
-};
 GRL_HD u64 key_len(u64 k) { return (k >> kPosBits) & 0xFFFull; }
 GRL_HD u64 key_pos(u64 k) { return (k & kPosMask) - 1; }
 
@@ -156,10 +152,11 @@ struct HashInsertFn {
     CellOps<cell_t, FIRST> ops;
     const u64 *startbits;
     const idx_t *wordbase;
-    Slot *slots;
+    u64 *keys;
     u64 mask;
+    u64 probe_limit;  // give up (overflow flag) after this many probes: the host retries with a larger table
     u32 *out_slot;    // [n_occ] slot of every phrase occurrence, text order
-    u32 *scal;        // [0] max phrase length, [1] error flag, [2..3] debug
+    u32 *scal;        // [1] error flag, [2..3] debug
     u64 n, n_occ;
     GRL_DEV bool same_phrase(u64 q, u64 p, u64 len, bool check_bits) const {
         if (q + len > n) { scal[1] = 3; scal[2] = (u32)q; scal[3] = (u32)len; return false; }
@@ -194,11 +191,14 @@ struct HashInsertFn {
         // the probe loop made hipcc 7.2 (gfx950) reuse the return register as a scratch under a
         // partial exec mask, so lanes that matched an existing key returned a stale value.
         u32 found = prim::kNoBucket;
-        for (u64 probes = 0; probes <= mask && found == prim::kNoBucket; probes++) {
-            u64 cur = prim::load_relaxed(&slots[slot].key);
+        for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket; probes++) {
+            // once probing gets long, look at the overflow flag (L1-bypassing load; done rarely: a coherent load of one
+            // address by every lane was measured to serialise and cost 20 ms per 10 M phrases)
+            if (probes == 16 && prim::load_relaxed(&scal[1])) return prim::kNoBucket;
+            u64 cur = prim::load_relaxed(&keys[slot]);   // L1-bypassing: a stale 0 from L1 would turn every later occurrence of a hot phrase into a CAS on one address
             if (cur == 0) {
-                u64 old = prim::atomic_cas(&slots[slot].key, 0ull, mine);
-                if (old == 0) { prim::atomic_max(&scal[0], (u32)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len)); cur = mine; }
+                u64 old = prim::atomic_cas(&keys[slot], 0ull, mine);
+                if (old == 0) cur = mine;
                 else cur = old;
             }
             bool hit = (cur == mine);
@@ -212,13 +212,13 @@ struct HashInsertFn {
     }
 };
 struct SlotCountAdd {
-    Slot *slots;
-    GRL_DEV void operator()(u32 slot, u32 c) const { prim::atomic_add(&slots[slot].cnt, (idx_t)c); }
+    idx_t *counts;
+    GRL_DEV void operator()(u32 slot, u32 c) const { prim::atomic_add(&counts[slot], (idx_t)c); }
 };
 
 struct OccIn {
-    const Slot *slots;
-    GRL_DEV u32 operator()(u64 i) const { return slots[i].key != 0 ? 1u : 0u; }
+    const u64 *keys;
+    GRL_DEV u32 operator()(u64 i) const { return keys[i] != 0 ? 1u : 0u; }
 };
 
 // ------------------------------------------------------ a5: dictionary view
@@ -227,10 +227,10 @@ struct CompactTableFn {
     const cell_t *t;
     CellOps<cell_t, FIRST> ops;
     const u64 *startbits;
-    const Slot *slots; const u32 *slot_ph;
+    const u64 *keys; const idx_t *counts; const u32 *slot_ph;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
     GRL_DEV void operator()(u64 s) const {
-        u64 k64 = slots[s].key;
+        u64 k64 = keys[s];
         if (!k64) return;
         u32 k = slot_ph[s];
         u64 pos = key_pos(k64), len = key_len(k64);
@@ -239,7 +239,7 @@ struct CompactTableFn {
             for (;;) { if (ops.isT(t[e])) break; e++; if (bit_at(startbits, e)) break; }
             len = e - pos + 1;
         }
-        ph_pos[k] = pos; ph_freq[k] = slots[s].cnt; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
+        ph_pos[k] = pos; ph_freq[k] = counts[s]; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
         ph_lastT[k] = ops.isT(t[pos + len - 1]) ? 1 : 0;
     }
 };
@@ -310,41 +310,45 @@ struct GroupStartFn {
         if (t == S - 1) gstart[gid[t] + 1] = (u32)S;
     }
 };
+// Per dictionary position q (coalesced pass): left symbol (or the BWT marker for a whole phrase)
+// and the frequency of its phrase, so that the pass over the sorted suffixes needs ONE gather.
+struct SuffixRecFn {
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq; u32 bwt_code;
+    u32 *rec_left; idx_t *rec_freq;
+    GRL_DEV void operator()(u64 q) const {
+        u32 k = dict_phr[q];
+        rec_left[q] = (q == ph_off[k]) ? bwt_code : dict_sym[q - 1];
+        rec_freq[q] = ph_freq[k];
+    }
+};
 // Per equal-suffix group: min/max of the left symbol, sum of frequencies, "contains a whole
-// phrase".  Small groups (the overwhelming majority) are folded by their head lane with plain
-// stores; only groups larger than kSmallGroup fall back to atomics (one lane per member).
-static constexpr u32 kSmallGroup = 32;
+// phrase".  Every group is cut into chunks of kGroupChunk consecutive members; the first lane
+// of a chunk folds it sequentially.  Groups of one chunk (the overwhelming majority) finish with
+// plain stores; larger groups combine their chunks with one set of atomics per chunk (32x fewer
+// same-address atomics than one per member).
+static constexpr u32 kGroupChunk = 32;
 struct GroupAccumFn {
-    const u32 *perm; const u32 *gid; const u32 *gstart; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off;
-    const idx_t *ph_freq;
+    const u32 *perm; const u32 *gid; const u32 *gstart; const u32 *rec_left; const idx_t *rec_freq;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
     GRL_DEV void operator()(u64 t) const {
         u32 g = gid[t];
-        u32 t0 = gstart[g], size = gstart[g + 1] - t0;
-        if (size <= kSmallGroup) {
-            if (t != t0) return;
-            u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
-            for (u32 j = 0; j < size; j++) {
-                u64 q = perm[t0 + j];
-                u32 k = dict_phr[q];
-                bool full = (q == ph_off[k]);
-                u32 left = full ? bwt_code : dict_sym[q - 1];
-                mn = left < mn ? left : mn; mx = left > mx ? left : mx;
-                acc += ph_freq[k];
-                fl |= full ? 1 : 0;
-            }
-            gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
-            return;
+        u32 t0 = gstart[g], t1 = gstart[g + 1];
+        if (((u32)t - t0) % kGroupChunk != 0) return;
+        u32 te = (u32)t + kGroupChunk < t1 ? (u32)t + kGroupChunk : t1;
+        u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
+        for (u32 j = (u32)t; j < te; j++) {
+            u64 q = perm[j];
+            u32 left = rec_left[q];
+            mn = left < mn ? left : mn; mx = left > mx ? left : mx;
+            acc += rec_freq[q];
+            fl |= (left == bwt_code) ? 1 : 0;
         }
-        u64 q = perm[t];
-        u32 k = dict_phr[q];
-        bool full = (q == ph_off[k]);
-        u32 left = full ? bwt_code : dict_sym[q - 1];
-        prim::atomic_min(&gmin[g], left);
-        prim::atomic_max(&gmax[g], left);
-        prim::atomic_add(&gacc[g], ph_freq[k]);
-        if (full) gfull[g] = 1;
+        if (t1 - t0 <= kGroupChunk) { gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl; return; }
+        prim::atomic_min(&gmin[g], mn);
+        prim::atomic_max(&gmax[g], mx);
+        prim::atomic_add(&gacc[g], acc);
+        if (fl) gfull[g] = 1;
     }
 };
 enum : u8 { GF_VALID = 1, GF_RANKED = 2, GF_MULTI = 4 };
@@ -436,9 +440,17 @@ struct RankBits {
     DBuf<u64> words;
     DBuf<idx_t> base;
 };
-struct SetBitFn {
-    const idx_t *pos; u64 *words;
-    GRL_DEV void operator()(u64 i) const { u64 x = pos[i]; prim::atomic_or(&words[x >> 6], 1ull << (x & 63)); }
+struct BuildBitsFn {     // one lane per 64-bit word: gather the (sorted, distinct) positions that fall into it
+    const idx_t *pos; u64 count; u64 *words;
+    GRL_DEV void operator()(u64 w) const {
+        u64 lo = w << 6, hi = lo + 64, m = 0;
+        for (u64 i = lower_bound<idx_t>(pos, count, (idx_t)lo); i < count; i++) {
+            u64 x = pos[i];
+            if (x >= hi) break;
+            m |= 1ull << (x - lo);
+        }
+        words[w] = m;
+    }
 };
 // # boundaries in [0, x)
 GRL_HD u64 rank1(const u64 *words, const idx_t *base, u64 x) {
@@ -448,8 +460,7 @@ static inline void build_rankbits(RankBits &rb, const idx_t *pos, u64 count, u64
     u64 nw = nbits / 64 + 2;
     rb.words.alloc(nw);
     rb.base.alloc(nw + 1);
-    rb.words.zero();
-    prim::for_each(count, SetBitFn{pos, rb.words.p}, name);
+    prim::for_each(nw, BuildBitsFn{pos, count, rb.words.p}, name);
     prim::exclusive_scan<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, name);
 }
 
@@ -640,7 +651,7 @@ struct CellIn {
 
 // =========================================================================
 struct RoundInfo {
-    u64 n_in = 0, D = 0, S = 0, M = 0, parse_size = 0, sigma = 0, max_phrase_len = 0, sort_iters = 0;
+    u64 n_in = 0, D = 0, S = 0, M = 0, parse_size = 0, sigma = 0, max_phrase_len = 0, sort_iters = 0, table_retries = 0;
 };
 struct LevelInfo {
     u64 R_next = 0, E = 0, P = 0, G = 0, A = 0, R = 0, n = 0;
@@ -748,6 +759,7 @@ class Engine {
     template <class cell_t, bool FIRST>
     void par_round_t(const cell_t *t, u64 n, u32 sigma, cell_t sep) {
         CellOps<cell_t, FIRST> ops{sep};
+        prim::rt().tag = (int)levels.size();
         LevelData L;
         L.sigma = sigma;
         L.info.n_in = n;
@@ -765,29 +777,65 @@ class Engine {
         if (n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "parse too large for u32 phrase ordinals");
 
         // ---- a3: hash every phrase occurrence ------------------------------
-        u64 cap = 1024;
-        while (cap < 2 * n_occ) cap <<= 1;
-        DBuf<Slot> slots(cap);
+        // table capacity: the number of distinct phrases is unknown and usually << the number of
+        // occurrences (20 k vs 30 M at level 0 of DNA reads): estimate the distinct fraction on a prefix,
+        // size the table for load <= ~0.6, and grow x4 (re-running the pass) if a lane runs out of
+        // probes because the prefix was not representative; cap_max = 2*n_occ always fits.
+        u64 cap_max = 1024;
+        while (cap_max < 2 * n_occ) cap_max <<= 1;
         DBuf<u32> next_text(n_occ);
         DBuf<u32> scal(4);
-        u32 maxlen;
+        u64 cap = cap_max;
+        double frac = 1.0;
+        {
+            // estimate the distinct fraction on a prefix of the text (first <= 2^20 cells)
+            StageTimer st(&tm.hash);
+            const u64 n_s = n < (1ull << 20) ? n : (1ull << 20);
+            if (n_s < n) {
+                u64 occ_s = (u64)wordbase.get(n_s >> 6);
+                if (occ_s < 64) occ_s = 64;
+                u64 cap_s = 1024;
+                while (cap_s < 2 * occ_s) cap_s <<= 1;
+                DBuf<u64> tk(cap_s);
+                DBuf<idx_t> tc(cap_s);
+                tk.zero(); tc.zero(); scal.zero();
+                prim::for_each_agg(n_s, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s,
+                                                                    next_text.p, scal.p, n, n_occ},
+                                   SlotCountAdd{tc.p}, true, "hash_sample");
+                u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p}, "hash_sample_count");
+                frac = (double)d_s / (double)occ_s;
+                if (frac > 1.0) frac = 1.0;
+                u64 want = (u64)(1.7 * frac * (double)n_occ) + 4096;      // target load <= ~0.6 if the prefix is representative
+                cap = 4096;
+                while (cap < want) cap <<= 1;
+                if (cap > cap_max) cap = cap_max;
+            }
+        }
+        DBuf<u64> keys;
+        DBuf<idx_t> counts;
+        u32 maxlen = 0;
+        // LDS pre-aggregation of the counts pays when few distinct phrases take most occurrences (level 0 of
+        // DNA: 20 k phrases, 30 M occurrences); with mostly-distinct phrases the cache only thrashes.
+        const bool aggregate = frac < 0.25;
         {
             StageTimer st(&tm.hash);
-            slots.zero(); scal.zero();
-            prim::for_each_agg(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, slots.p, cap - 1, next_text.p, scal.p, n, n_occ},
-                               SlotCountAdd{slots.p}, "hash_phrases");
-            std::vector<u32> sc = scal.to_host(4);
-            if (sc[1] == 1) throw prim::Error(-28, "phrase hash table overflow");
-            if (sc[1]) throw prim::Error(-71, "phrase hashing: consistency check " + std::to_string(sc[1]) + " failed (" +
-                                                   std::to_string(sc[2]) + ", " + std::to_string(sc[3]) + ")");
-            maxlen = sc[0];
-            if (getenv("GRLBWT_DEBUG_TABLE")) {
-                std::vector<Slot> hs = slots.to_host(cap);
-                u64 nk = 0, tot = 0, mx = 0;
-                for (u64 i = 0; i < cap; i++) { if (hs[i].key) { nk++; tot += hs[i].cnt; if (hs[i].cnt > mx) mx = hs[i].cnt; } }
-                fprintf(stderr, "[grlbwt] table: cap %llu keys %llu sum(cnt) %llu max(cnt) %llu n_occ %llu sizeof(Slot) %zu\n",
-                        (unsigned long long)cap, (unsigned long long)nk, (unsigned long long)tot, (unsigned long long)mx,
-                        (unsigned long long)n_occ, sizeof(Slot));
+            for (;;) {
+                keys.alloc(cap); counts.alloc(cap);
+                keys.zero(); counts.zero(); scal.zero();
+                u64 probe_limit = (cap == cap_max) ? cap : 96;
+                prim::for_each_agg(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit,
+                                                                  next_text.p, scal.p, n, n_occ},
+                                   SlotCountAdd{counts.p}, aggregate, "hash_phrases");
+                std::vector<u32> sc = scal.to_host(4);
+                if (sc[1] == 1) {
+                    if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");
+                    cap = cap * 4 > cap_max ? cap_max : cap * 4;
+                    L.info.table_retries++;
+                    continue;
+                }
+                if (sc[1]) throw prim::Error(-71, "phrase hashing: consistency check " + std::to_string(sc[1]) + " failed (" +
+                                                       std::to_string(sc[2]) + ", " + std::to_string(sc[3]) + ")");
+                break;
             }
         }
         L.info.max_phrase_len = maxlen;
@@ -800,20 +848,22 @@ class Engine {
         DBuf<u32> dict_sym, dict_phr;
         {
             StageTimer st(&tm.dict_sort);
-            D = prim::exclusive_scan<u32>(cap, OccIn{slots.p}, slot_ph.p, false, "table_compact");
+            D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "table_compact");
             ph_pos.alloc(D); ph_freq.alloc(D); ph_len.alloc(D); ph_slot.alloc(D); ph_lastT.alloc(D); ph_off.alloc(D + 1);
-            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, slots.p, slot_ph.p, ph_pos.p,
+            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts.p, slot_ph.p, ph_pos.p,
                                                               ph_freq.p, ph_len.p, ph_slot.p, ph_lastT.p}, "table_compact");
             u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dict_freq_check");
             if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
                                                            std::to_string(n_occ) + ")");
+            maxlen = prim::reduce_max<u32>(D, LenIn{ph_len.p}, "dict_maxlen");   // (an atomicMax per insert serialised on one address)
+            L.info.max_phrase_len = maxlen;
             u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dict_syms");
             if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
             S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dict_offsets");
             dict_sym.alloc(S); dict_phr.alloc(S);
             prim::for_each(S, DictBuildFn<cell_t, FIRST>{t, ops, ph_off.p, D, ph_pos.p, dict_sym.p, dict_phr.p}, "dict_build");
         }
-        slots.release(); slot_ph.release(); startbits.release();
+        keys.release(); counts.release(); slot_ph.release(); startbits.release();
         L.info.D = D; L.info.S = S;
 
         // ---- a6: sort all phrase suffixes (radix + prefix doubling) ----------
@@ -862,8 +912,13 @@ class Engine {
             StageTimer st(&tm.dict_groups);
             gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
             prim::for_each(S, GroupStartFn{gid.p, S, gstart.p}, "group_starts");
-            prim::for_each(S, GroupAccumFn{perm.p, gid.p, gstart.p, dict_sym.p, dict_phr.p, ph_off.p, ph_freq.p, bwt_code,
-                                           gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+            {
+                DBuf<u32> rec_left(S);
+                DBuf<idx_t> rec_freq(S);
+                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off.p, ph_freq.p, bwt_code, rec_left.p, rec_freq.p}, "suffix_records");
+                prim::for_each(S, GroupAccumFn{perm.p, gid.p, gstart.p, rec_left.p, rec_freq.p, bwt_code,
+                                               gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+            }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off.p, ph_lastT.p, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
             M = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
@@ -958,6 +1013,7 @@ class Engine {
     void induce_level() {
         if (bwt_level <= 0) throw prim::Error(-22, "no level left to induce");
         const int r = bwt_level - 1;
+        prim::rt().tag = r;
         LevelData &L = levels[r];
         const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
         const u64 R = bwt.R, P = L.prebwt.R;

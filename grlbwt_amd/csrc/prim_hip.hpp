@@ -53,6 +53,7 @@ struct Runtime {
     // per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
     bool trace = false;              // GRLBWT_TRACE=1: print every launch and synchronise after it
     bool profile = false;
+    int tag = -1;                    // appended to profile names as "#<tag>" (the engine sets it to the level)
     struct Prof { std::string name; hipEvent_t a, b; };
     std::vector<Prof> pending;
     std::map<std::string, std::pair<u64, double>> prof;   // name -> (launches, total ms)
@@ -81,7 +82,7 @@ inline void prof_begin(const std::string &name) {
     if (rt().trace) { fprintf(stderr, "[grlbwt] launch %s\n", name.c_str()); fflush(stderr); }
     if (!rt().profile) return;
     Runtime::Prof p;
-    p.name = name;
+    p.name = rt().tag >= 0 ? name + "#" + std::to_string(rt().tag) : name;
     GRL_HIP_CHECK(hipEventCreate(&p.a));
     GRL_HIP_CHECK(hipEventCreate(&p.b));
     GRL_HIP_CHECK(hipEventRecord(p.a, rt().stream));
@@ -226,6 +227,9 @@ GRL_DEV u64 atomic_cas(u64 *p, u64 expect, u64 desired) {
     return (u64)atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)expect,
                           (unsigned long long)desired);
 }
+GRL_DEV u32 load_relaxed(const u32 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 GRL_DEV u64 load_relaxed(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -280,11 +284,11 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char *name = "b
 // ------------------------------------------ for_each with LDS count aggregation
 // f(i) returns a bucket id (u32) or kNoBucket; every returned id must be counted once
 // in a global table through add(id, count).  Same-address global atomics serialise at
-// the memory side, so each workgroup first aggregates (id -> count) in a 4096-entry LDS
+// the memory side, so each workgroup first aggregates (id -> count) in a 2048-entry LDS
 // open-addressing cache over its CONTIGUOUS chunk of the index space and flushes one
 // atomic per distinct id at the end; ids that do not fit the cache go straight to add().
 static constexpr u32 kNoBucket = 0xFFFFFFFFu;
-static constexpr int kAggSlots = 4096;
+static constexpr int kAggSlots = 2048;
 template <class F, class A>
 __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F f, A add) {
     __shared__ u32 c_key[kAggSlots];
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
     for (u64 i = start + threadIdx.x; i < end; i += kBlock) {
         u32 s = f(i);
         if (s != kNoBucket) {
-            u32 h = (s * 2654435761u) >> 20;
+            u32 h = (s * 2654435761u) >> 21;
             bool done = false;
             for (int p = 0; p < 8 && !done; p++) {
                 u32 old = atomicCAS(&c_key[h], kNoBucket, s);
@@ -318,10 +322,10 @@ struct NoAggFn {
     GRL_DEV void operator()(u64 i) const { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
 };
 template <class F, class A>
-inline void for_each_agg(u64 n, F f, A add, const char *name = "for_each_agg") {
+inline void for_each_agg(u64 n, F f, A add, bool aggregate, const char *name = "for_each_agg") {
     if (n == 0) return;
-    if (getenv("GRLBWT_NOAGG")) { for_each(n, NoAggFn<F, A>{f, add}, name); return; }
-    u64 blocks = (u64)rt().num_cus * 4;
+    if (!aggregate || getenv("GRLBWT_NOAGG")) { for_each(n, NoAggFn<F, A>{f, add}, name); return; }
+    u64 blocks = (u64)rt().num_cus * 8;
     u64 per_block = ((n + blocks - 1) / blocks + kBlock - 1) / kBlock * kBlock;
     blocks = (n + per_block - 1) / per_block;
     prof_begin(name);
@@ -464,17 +468,19 @@ struct PtrIn {
     GRL_HD T operator()(u64 i) const { return p[i]; }
 };
 
-// out[i] = sum_{j<i} in(j) for i in [0,n); returns the grand total (host value).
-// `out` may alias the array `in` reads (each tile is read before it is written
-// and tiles are disjoint).  If out_total_slot, also stores the total at out[n].
+// Device-only exclusive scan: out[i] = sum_{j<i} in(j); if total_dev != nullptr the grand total is
+// written there (device memory).  No host synchronisation: everything is stream-ordered.
+// `out` may alias the array `in` reads (each tile is read before it is written, tiles are disjoint).
+template <class T>
+struct StoreTotalFn {
+    const T *sums; const T *last_in_dummy; T *dst;
+    GRL_DEV void operator()(u64) const { *dst = *sums; }
+};
 template <class T, class F>
-inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, const char *name = "scan") {
+inline void exclusive_scan_async(u64 n, F in, T *out, T *total_dev, const char *name = "scan") {
     if (n == 0) {
-        if (store_total_at_n) {
-            T z = 0;
-            h2d(out, &z, sizeof(T));
-        }
-        return T(0);
+        if (total_dev) dev_memset(total_dev, 0, sizeof(T));
+        return;
     }
     u64 tiles = (n + kScanTile - 1) / kScanTile;
     T *sums = (T *)dev_alloc(sizeof(T) * (tiles + 1));
@@ -482,21 +488,31 @@ inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, cons
     hipLaunchKernelGGL((k_scan_tile_sums<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, sums);
     prof_end();
     after_launch(name);
-    T total;
+    // scan the tile sums in place; their total lands in sums[tiles]
     if (tiles == 1) {
-        d2h(&total, sums, sizeof(T));
-        T z = 0;
-        h2d(sums, &z, sizeof(T));
+        d2d(sums + 1, sums, sizeof(T));
+        dev_memset(sums, 0, sizeof(T));
     } else {
-        total = exclusive_scan<T, PtrIn<T>>(tiles, PtrIn<T>{sums}, sums, false, name);
+        exclusive_scan_async<T, PtrIn<T>>(tiles, PtrIn<T>{sums}, sums, sums + tiles, name);
     }
     prof_begin(name);
     hipLaunchKernelGGL((k_scan_tiles<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, sums, out);
     prof_end();
     after_launch(name);
-    if (store_total_at_n) GRL_HIP_CHECK(hipMemcpyAsync(out + n, &total, sizeof(T), hipMemcpyHostToDevice, rt().stream));
-    sync();   // `total` on the stack is the memcpy source; sums freed below
-    dev_free(sums);
+    if (total_dev) d2d(total_dev, sums + tiles, sizeof(T));
+    dev_free(sums);      // stream-ordered reuse (pool)
+}
+
+// out[i] = sum_{j<i} in(j) for i in [0,n); returns the grand total (host value, one sync).
+// If store_total_at_n, also stores the total at out[n].
+template <class T, class F>
+inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, const char *name = "scan") {
+    T *tot = (T *)dev_alloc(sizeof(T));
+    exclusive_scan_async<T, F>(n, in, out, tot, name);
+    if (store_total_at_n) d2d(out + n, tot, sizeof(T));
+    T total;
+    d2h(&total, tot, sizeof(T));
+    dev_free(tot);
     return total;
 }
 
@@ -633,7 +649,7 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, counts, tiles);
         prof_end();
         after_launch(name);
-        exclusive_scan<u64, RsCountIn>((u64)256 * tiles, RsCountIn{counts}, offsets, false, name);
+        exclusive_scan_async<u64, RsCountIn>((u64)256 * tiles, RsCountIn{counts}, offsets, nullptr, name);
         prof_begin(std::string(name) + ".scatter");
         hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
                            shift, offsets, tiles);

@@ -41,6 +41,7 @@ struct Runtime {
     int num_cus = 1;
     bool sync_each_launch = false;
     bool profile = false;
+    int tag = -1;
     std::map<std::string, std::pair<u64, double>> prof;
 };
 inline Runtime &rt() {
@@ -69,6 +70,7 @@ inline u32 atomic_min(u32 *p, u32 v) { u32 o = *p; if (v < o) *p = v; return o; 
 inline u32 atomic_max(u32 *p, u32 v) { u32 o = *p; if (v > o) *p = v; return o; }
 inline u64 atomic_cas(u64 *p, u64 expect, u64 desired) { u64 o = *p; if (o == expect) *p = desired; return o; }
 inline u64 load_relaxed(const u64 *p) { return *p; }
+inline u32 load_relaxed(const u32 *p) { return *p; }
 
 template <class F>
 inline void for_each(u64 n, F f, const char * = "") {
@@ -86,7 +88,7 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char * = "") {
 }
 static constexpr u32 kNoBucket = 0xFFFFFFFFu;
 template <class F, class A>
-inline void for_each_agg(u64 n, F f, A add, const char * = "") {
+inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
 }
 inline void pool_trim() {}

@@ -93,3 +93,15 @@ def test_long_phrases_saturated_length(sim, oracle_mod):
     data = b"A" * 6000 + b"\n" + b"A" * 6000 + b"\n" + b"A" * 7000 + b"\n" + b"C" * 5000 + b"A" * 4999 + b"\n"
     parity.check_final(sim, data, 1)
     parity.check_stagewise(sim, data, 1, engine.FLAG_FORCE_IDX64)
+
+
+def test_table_growth_when_prefix_is_unrepresentative(sim, oracle_mod):
+    # > 2^20 repetitive cells first (the capacity estimate sees almost no distinct phrases), then diverse reads
+    rep = (b"ACGTTGCA" * 16 + b"\n") * 8500
+    data = rep + workloads.uniform_reads(3000, 100, seed=77).tobytes()
+    assert len(rep) > (1 << 20)
+    with engine.Context(0, 0, sim) as ctx:
+        ctx.upload(data, 1)
+        ctx.build()
+        got = ctx.result_bytes()
+    assert got == oracle_mod.rl_bwt(data, 1)

@@ -128,3 +128,9 @@ def test_full_size_config_properties(hip):
     assert np.array_equal(hist, got)          # the BWT is a permutation of the text
     b = parity.run_engine(hip, data, 1, engine.FLAG_FORCE_IDX64)
     assert hashlib.md5(a).hexdigest() == hashlib.md5(b).hexdigest()
+
+
+def test_table_growth_when_prefix_is_unrepresentative(hip, oracle_mod):
+    rep = (b"ACGTTGCA" * 16 + b"\n") * 8500
+    data = rep + workloads.uniform_reads(30000, 100, seed=77).tobytes()
+    parity.check_final(hip, data, 1)
