@@ -419,13 +419,17 @@ struct GrammarFn {
 };
 
 // ------------------------------------------- a9 + a10: ranks -> next text
-struct SlotValFn {
-    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *ph_slot; const u32 *rank; const u32 *grank;
-    u32 *slot_val;
+struct PhraseValFn {
+    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *rank; const u32 *grank;
+    u32 *phrase_val;
     GRL_DEV void operator()(u64 k) const {
         u32 r = grank[rank[ph_off[k]]];
-        slot_val[ph_slot[k]] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
+        phrase_val[k] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
     }
+};
+struct ScatterValFn {
+    const u32 *ph_slot; const u32 *val; u32 *slot_val;
+    GRL_DEV void operator()(u64 k) const { slot_val[ph_slot[k]] = val[k]; }
 };
 struct MapFn {
     const u32 *slot_val; u32 *text;
@@ -756,14 +760,19 @@ class Engine {
     }
 
     // ---- one parsing round (par_round, exact_par_phase.cpp:374-497) ------
+    // The round is cut in three pieces so that the collection-level multi-GPU driver can put its
+    // exchanges between them:  hash_local (a2-a5: breaks, phrase table, distinct phrases of THIS
+    // text) -> dict_stage (a5-a8 on a set of distinct phrases, local or merged over all ranks)
+    // -> emit_local (a9/a10: metasymbols back into the local parse).
+    struct LocalParse {
+        u64 n_occ = 0, D = 0, S = 0, cap = 0;
+        u32 maxlen = 0;
+        DBuf<u32> next_text;       // slot id of every phrase occurrence, then the parse itself
+        DBuf<u64> ph_pos; DBuf<idx_t> ph_freq; DBuf<u32> ph_len, ph_slot, ph_off; DBuf<u8> ph_lastT;
+    };
+
     template <class cell_t, bool FIRST>
-    void par_round_t(const cell_t *t, u64 n, u32 sigma, cell_t sep) {
-        CellOps<cell_t, FIRST> ops{sep};
-        prim::rt().tag = (int)levels.size();
-        LevelData L;
-        L.sigma = sigma;
-        L.info.n_in = n;
-        L.info.sigma = sigma;
+    void hash_local(const cell_t *t, u64 n, CellOps<cell_t, FIRST> ops, LocalParse &P, LevelData &L) {
         const u64 nwords = (n + 63) / 64;
         DBuf<u64> startbits(nwords + 1);
         DBuf<idx_t> wordbase(nwords + 1);
@@ -773,6 +782,7 @@ class Engine {
             prim::bitvector_from_pred(n, StartPred<cell_t, FIRST>{t, ops}, startbits.p, "lms_breaks");
             n_occ = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{startbits.p}, wordbase.p, true, "phrase_ordinals");
         }
+        P.n_occ = n_occ;
         L.info.parse_size = n_occ;
         if (n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "parse too large for u32 phrase ordinals");
 
@@ -783,7 +793,7 @@ class Engine {
         // probes because the prefix was not representative; cap_max = 2*n_occ always fits.
         u64 cap_max = 1024;
         while (cap_max < 2 * n_occ) cap_max <<= 1;
-        DBuf<u32> next_text(n_occ);
+        P.next_text.alloc(n_occ);
         DBuf<u32> scal(4);
         u64 cap = cap_max;
         double frac = 1.0;
@@ -800,7 +810,7 @@ class Engine {
                 DBuf<idx_t> tc(cap_s);
                 tk.zero(); tc.zero(); scal.zero();
                 prim::for_each_agg(n_s, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s,
-                                                                    next_text.p, scal.p, n, n_occ},
+                                                                    P.next_text.p, scal.p, n, n_occ},
                                    SlotCountAdd{tc.p}, true, "hash_sample");
                 u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p}, "hash_sample_count");
                 frac = (double)d_s / (double)occ_s;
@@ -813,7 +823,6 @@ class Engine {
         }
         DBuf<u64> keys;
         DBuf<idx_t> counts;
-        u32 maxlen = 0;
         // LDS pre-aggregation of the counts pays when few distinct phrases take most occurrences (level 0 of
         // DNA: 20 k phrases, 30 M occurrences); with mostly-distinct phrases the cache only thrashes.
         const bool aggregate = frac < 0.25;
@@ -824,7 +833,7 @@ class Engine {
                 keys.zero(); counts.zero(); scal.zero();
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
                 prim::for_each_agg(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit,
-                                                                  next_text.p, scal.p, n, n_occ},
+                                                                  P.next_text.p, scal.p, n, n_occ},
                                    SlotCountAdd{counts.p}, aggregate, "hash_phrases");
                 std::vector<u32> sc = scal.to_host(4);
                 if (sc[1] == 1) {
@@ -838,34 +847,39 @@ class Engine {
                 break;
             }
         }
-        L.info.max_phrase_len = maxlen;
         wordbase.release();
+        P.cap = cap;
 
-        // ---- a5: flatten the dictionary -------------------------------------
-        u64 D, S;
-        DBuf<u32> slot_ph(cap);
-        DBuf<u64> ph_pos; DBuf<idx_t> ph_freq; DBuf<u32> ph_len, ph_slot, ph_off; DBuf<u8> ph_lastT;
-        DBuf<u32> dict_sym, dict_phr;
+        // ---- a5: distinct phrases of this text --------------------------------
         {
             StageTimer st(&tm.dict_sort);
-            D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "table_compact");
-            ph_pos.alloc(D); ph_freq.alloc(D); ph_len.alloc(D); ph_slot.alloc(D); ph_lastT.alloc(D); ph_off.alloc(D + 1);
-            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts.p, slot_ph.p, ph_pos.p,
-                                                              ph_freq.p, ph_len.p, ph_slot.p, ph_lastT.p}, "table_compact");
-            u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dict_freq_check");
+            DBuf<u32> slot_ph(cap);
+            u64 D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "table_compact");
+            P.D = D;
+            P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
+            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts.p, slot_ph.p, P.ph_pos.p,
+                                                              P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p}, "table_compact");
+            u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{P.ph_freq.p}, "dict_freq_check");
             if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
                                                            std::to_string(n_occ) + ")");
-            maxlen = prim::reduce_max<u32>(D, LenIn{ph_len.p}, "dict_maxlen");   // (an atomicMax per insert serialised on one address)
-            L.info.max_phrase_len = maxlen;
-            u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dict_syms");
+            P.maxlen = prim::reduce_max<u32>(D, LenIn{P.ph_len.p}, "dict_maxlen");   // (an atomicMax per insert serialised on one address)
+            u64 S64 = prim::reduce_sum<u64>(D, LenIn{P.ph_len.p}, "dict_syms");
             if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
-            S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dict_offsets");
-            dict_sym.alloc(S); dict_phr.alloc(S);
-            prim::for_each(S, DictBuildFn<cell_t, FIRST>{t, ops, ph_off.p, D, ph_pos.p, dict_sym.p, dict_phr.p}, "dict_build");
+            P.S = prim::exclusive_scan<u32>(D, LenIn{P.ph_len.p}, P.ph_off.p, true, "dict_offsets");
         }
-        keys.release(); counts.release(); slot_ph.release(); startbits.release();
-        L.info.D = D; L.info.S = S;
+    }
 
+    // a5-a8 on D distinct phrases given as (position in t, length, frequency, ends-with-terminator);
+    // fills L (grammar, has_hocc, pre-BWT, M) and phrase_val[k] = rank<<2 | (freq>1)<<1 | lastT.
+    template <class cell_t, bool FIRST>
+    void dict_stage(const cell_t *t, CellOps<cell_t, FIRST> ops, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
+                    const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val) {
+        L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
+        DBuf<u32> dict_sym(S), dict_phr(S);
+        {
+            StageTimer st(&tm.dict_sort);
+            prim::for_each(S, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
+        }
         // ---- a6: sort all phrase suffixes (radix + prefix doubling) ----------
         DBuf<u32> perm(S), gid(S), rank(S);
         u64 G;
@@ -879,14 +893,14 @@ class Engine {
             if (K > 16) K = 16;
             u64 *kA = ka.p, *kB = kb.p;          // (kA, vA) always holds the current sorted order
             u32 *vA = va.p, *vB = vb.p;
-            prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off.p, K, b, kA, vA}, "suffix_keys0");
+            prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, kA, vA}, "suffix_keys0");
             if (prim::sort_pairs<u64, u32>(kA, vA, kB, vB, S, 0, K * b, "suffix_sort0")) { std::swap(kA, kB); std::swap(vA, vB); }
             G = prim::exclusive_scan<u32>(S, HeadKeyIn{kA}, ex.p, false, "suffix_heads");
             prim::for_each(S, RankWriteFn{kA, ex.p, vA, gid.p, rank.p}, "suffix_ranks");
             u64 Lres = (u64)K, iters = 1;
             while (Lres < maxlen) {              // prefix doubling: Lres symbols resolved so far
                 int lowbits = (int)bitlen64(G);
-                prim::for_each(S, Key1Fn{vA, rank.p, dict_phr.p, ph_off.p, Lres, lowbits, kB, vB}, "suffix_keys");
+                prim::for_each(S, Key1Fn{vA, rank.p, dict_phr.p, ph_off, Lres, lowbits, kB, vB}, "suffix_keys");
                 if (prim::sort_pairs<u64, u32>(kB, vB, kA, vA, S, 0, 2 * lowbits, "suffix_sort") == 0) {
                     std::swap(kA, kB); std::swap(vA, vB);
                 }
@@ -895,8 +909,7 @@ class Engine {
                 Lres *= 2;
                 iters++;
             }
-            const u32 *vs = vA;
-            prim::d2d(perm.p, vs, S * sizeof(u32));
+            prim::d2d(perm.p, vA, S * sizeof(u32));
             prim::sync();
             L.info.sort_iters = iters;
         }
@@ -915,11 +928,11 @@ class Engine {
             {
                 DBuf<u32> rec_left(S);
                 DBuf<idx_t> rec_freq(S);
-                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off.p, ph_freq.p, bwt_code, rec_left.p, rec_freq.p}, "suffix_records");
+                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec_left.p, rec_freq.p}, "suffix_records");
                 prim::for_each(S, GroupAccumFn{perm.p, gid.p, gstart.p, rec_left.p, rec_freq.p, bwt_code,
                                                gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
             }
-            prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off.p, ph_lastT.p, gmin.p, gmax.p, gfull.p,
+            prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
             M = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
             P0 = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
@@ -937,30 +950,52 @@ class Engine {
             // ---- a8: grammar ------------------------------------------------
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
-            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off.p, ph_lastT.p, rank.p, gflag.p, grank.p,
+            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, rank.p, gflag.p, grank.p,
                                         sigma3, MD, L.g0.p, L.g1.p}, "grammar");
+            // ---- a9: metasymbol of every phrase --------------------------------
+            phrase_val.alloc(D);
+            prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rank.p, grank.p, phrase_val.p}, "phrase_values");
         }
         L.info.M = M;
+    }
 
-        // ---- a9/a10: metasymbols -> next text ---------------------------------
-        {
-            StageTimer st(&tm.emit);
-            DBuf<u32> slot_val(cap);
-            prim::for_each(D, SlotValFn{ph_off.p, ph_freq.p, ph_lastT.p, ph_slot.p, rank.p, grank.p, slot_val.p}, "slot_values");
-            prim::for_each(n_occ, MapFn{slot_val.p, next_text.p}, "emit_parse");
-            prim::sync();
-        }
+    // a10: the local parse: slot id of every occurrence -> (rank<<2 | rep<<1 | T) of its phrase
+    void emit_local(LocalParse &P, const u32 *val_of_local_phrase) {
+        StageTimer st(&tm.emit);
+        DBuf<u32> slot_val(P.cap);
+        prim::for_each(P.D, ScatterValFn{P.ph_slot.p, val_of_local_phrase, slot_val.p}, "slot_values");
+        prim::for_each(P.n_occ, MapFn{slot_val.p, P.next_text.p}, "emit_parse");
+        prim::sync();
+    }
+
+    void finish_round(LocalParse &P, LevelData &L, u64 n_strings_for_termination, u64 n_occ_for_termination) {
         if (keep_texts) {
-            DBuf<u32> cp(n_occ);
-            prim::d2d(cp.p, next_text.p, n_occ * sizeof(u32));
+            DBuf<u32> cp(P.n_occ);
+            prim::d2d(cp.p, P.next_text.p, P.n_occ * sizeof(u32));
             prim::sync();
             kept_texts.push_back(std::move(cp));
         }
-        cur_text = std::move(next_text);
-        cur_n = n_occ;
-        cur_sigma = (u32)M;
+        cur_text = std::move(P.next_text);
+        cur_n = P.n_occ;
+        cur_sigma = L.M;
         levels.push_back(std::move(L));
-        if (n_occ == stats.n_strings) parse_done = true;      // exact_par_phase.cpp:496
+        if (n_occ_for_termination == n_strings_for_termination) parse_done = true;      // exact_par_phase.cpp:496
+    }
+
+    template <class cell_t, bool FIRST>
+    void par_round_t(const cell_t *t, u64 n, u32 sigma, cell_t sep) {
+        CellOps<cell_t, FIRST> ops{sep};
+        prim::rt().tag = (int)levels.size();
+        LevelData L;
+        L.sigma = sigma;
+        L.info.n_in = n;
+        L.info.sigma = sigma;
+        LocalParse P;
+        hash_local<cell_t, FIRST>(t, n, ops, P, L);
+        DBuf<u32> phrase_val;
+        dict_stage<cell_t, FIRST>(t, ops, P.D, P.S, P.maxlen, P.ph_pos.p, P.ph_freq.p, P.ph_off.p, P.ph_lastT.p, sigma, L, phrase_val);
+        emit_local(P, phrase_val.p);
+        finish_round(P, L, stats.n_strings, P.n_occ);
     }
 
     // returns true when the parsing phase is complete
