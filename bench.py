@@ -5,7 +5,8 @@ A "step" is one pass of the whole parse-then-induce path over the workload,
 input cells already resident in HBM, output .rl_bwt image left in HBM.
 N=1 workload: BASELINE.json configs[1] (1,000,000 x 100 bp uniform ACGT reads,
 101,000,000 bytes).  N>1: records are sharded (weak scaling: one such shard per
-GPU, different seeds), one process per GPU.
+GPU, different seeds), one process per GPU; the ranks build ONE BWT of the whole sharded collection
+(grlbwt_amd/dist.py), so value = total input bytes of the collection / time.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, algorithmic bytes
 / HIP-event time on the engine's stream) and `cpu_baseline` (the CPU oracle,
@@ -81,11 +82,21 @@ def main():
     text = torch.from_numpy(data).to(dev)
     torch.cuda.synchronize()
 
-    ctx = engine.Context(local_rank, 0, lib)
+    comm = None
+    flags = 0
+    if world > 1:
+        from grlbwt_amd import dist as gdist
+        comm = gdist.Communicator(dev)
+        if world * n_bytes >= 0xFFFFFF00:
+            flags |= engine.FLAG_FORCE_IDX64
+    ctx = engine.Context(local_rank, flags, lib)
 
     def step():
         ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
-        ctx.build()
+        if comm is None:
+            ctx.build()
+        else:
+            gdist.dist_build(ctx, comm)      # BWT of the whole collection (all shards), identical on every rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -177,7 +188,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d x %d bp uniform ACGT reads per GPU (%d bytes), sigma=5, byte alphabet; "
                                    "BASELINE configs[1]" % (args.reads, args.read_len, n_bytes),
-                       "input_resident": "HBM", "output": ".rl_bwt image in HBM", "parallelism": "records sharded x%d" % world},
+                       "input_resident": "HBM", "output": ".rl_bwt image in HBM", "parallelism": ("1 GPU" if world == 1 else "collection of %d record shards, one per GPU: local hashing/emission, RCCL all-gather "
+                                       "dictionary merge per round, induction replicated (round-1 form)" % world)},
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
             "top_kernels": top, "rounds": nr,

@@ -383,6 +383,21 @@ int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out) {
     return GRLBWT_OK;
 }
 
+int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm) {
+    if (!HAS_ENG(ctx) || !comm || !comm->allgather || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        if (ctx->e32) {
+            grl32::Engine::Comm C;
+            C.rank = comm->rank; C.size = comm->size; C.user = comm->user; C.ag = comm->allgather; C.a2a = comm->alltoallv;
+            ctx->e32->dist_build(C);
+        } else {
+            grl64::Engine::Comm C;
+            C.rank = comm->rank; C.size = comm->size; C.user = comm->user; C.ag = comm->allgather; C.a2a = comm->alltoallv;
+            ctx->e64->dist_build(C);
+        }
+    });
+}
+
 int grlbwt_profile_enable(grlbwt_ctx *ctx, int on) {
     if (!ctx) return GRLBWT_EINVAL;
     return guarded(ctx, [&] {

@@ -653,6 +653,85 @@ struct CellIn {
     GRL_DEV u64 operator()(u64 i) const { return (u64)t[i]; }
 };
 
+// ------------------------------------------- collection-level multi-GPU pieces
+// exchange format of a phrase cell on every level: u32  sym<<2 | rep<<1 | is_terminator
+template <class cell_t, bool FIRST>
+struct ExportCellsFn {
+    const cell_t *t; CellOps<cell_t, FIRST> ops; const u32 *ph_off; u64 D; const u64 *ph_pos;
+    u32 *out;
+    GRL_DEV void operator()(u64 q) const {
+        u64 k = upper_bound<u32>(ph_off, D, (u32)q) - 1;
+        cell_t c = t[ph_pos[k] + (q - ph_off[k])];
+        out[q] = (ops.sym(c) << 2) | (ops.rep(c) ? 2u : 0u) | (ops.isT(c) ? 1u : 0u);
+    }
+};
+struct WidenFn {          // idx_t -> u64
+    const idx_t *a; u64 *b;
+    GRL_DEV void operator()(u64 i) const { b[i] = (u64)a[i]; }
+};
+template <class T>
+struct UnpadFn {          // dense[i] = padded[g*stride + (i - base[g])], g = rank owning i
+    const T *padded; const u64 *base; int size; u64 stride; T *dense;
+    GRL_DEV void operator()(u64 i) const {
+        int g = 0;
+        while (g + 1 < size && base[g + 1] <= i) g++;
+        dense[i] = padded[(u64)g * stride + (i - base[g])];
+    }
+};
+// phrases given as a list (offset, length, weight) over a cell buffer: the merged dictionary
+struct ListInsertFn {
+    const u32 *cells; const u64 *off; const u32 *len; const u64 *weight;
+    u64 *keys; idx_t *counts; u64 mask;      // key = tag:24 | (list index + 1):40
+    u32 *list_slot; u32 *scal;
+    GRL_DEV void operator()(u64 i) const {
+        u64 o = off[i], l = len[i];
+        u64 h = 0x243F6A8885A308D3ull;
+        for (u64 j = 0; j < l; j++) h = hash_mix(h, (u64)(cells[o + j] >> 2));
+        h = hash_fin(h, l);
+        u64 tag = h >> kPosBits;
+        u64 mine = (tag << kPosBits) | (i + 1);
+        u64 slot = h & mask;
+        u32 found = prim::kNoBucket;
+        for (u64 probes = 0; probes <= mask && found == prim::kNoBucket; probes++) {
+            u64 cur = prim::load_relaxed(&keys[slot]);
+            if (cur == 0) {
+                u64 old = prim::atomic_cas(&keys[slot], 0ull, mine);
+                cur = (old == 0) ? mine : old;
+            }
+            bool hit = (cur == mine);
+            if (!hit && (cur >> kPosBits) == tag) {
+                u64 i2 = (cur & kPosMask) - 1;
+                if (len[i2] == l) {
+                    u64 o2 = off[i2];
+                    hit = true;
+                    for (u64 j = 0; j < l; j++) if (cells[o2 + j] != cells[o + j]) { hit = false; break; }
+                }
+            }
+            if (hit) found = (u32)slot; else slot = (slot + 1) & mask;
+        }
+        if (found == prim::kNoBucket) { scal[1] = 1; return; }
+        prim::atomic_add(&counts[found], (idx_t)weight[i]);
+        list_slot[i] = found;
+    }
+};
+struct ListCompactFn {
+    const u32 *cells; const u64 *off; const u32 *len;
+    const u64 *keys; const idx_t *counts; const u32 *slot_ph;
+    u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u8 *ph_lastT;
+    GRL_DEV void operator()(u64 s) const {
+        u64 k64 = keys[s];
+        if (!k64) return;
+        u32 k = slot_ph[s];
+        u64 i = (k64 & kPosMask) - 1;
+        ph_pos[k] = off[i]; ph_freq[k] = counts[s]; ph_len[k] = len[i];
+        ph_lastT[k] = (u8)(cells[off[i] + len[i] - 1] & 1u);
+    }
+};
+struct LocalValFn {       // metasymbol of my k-th local phrase through the merged dictionary
+    const u32 *list_slot; const u32 *slot_ph; const u32 *gval; u64 my_first; u32 *val;
+    GRL_DEV void operator()(u64 k) const { val[k] = gval[slot_ph[list_slot[my_first + k]]]; }
+};
+
 // =========================================================================
 struct RoundInfo {
     u64 n_in = 0, D = 0, S = 0, M = 0, parse_size = 0, sigma = 0, max_phrase_len = 0, sort_iters = 0, table_retries = 0;
@@ -1157,6 +1236,176 @@ class Engine {
         prim::h2d(image.p, hdr, 16);
         prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, bwt.len.p, sb, fb, image.p}, "pack_rl_bwt");
     }
+    // =====================================================================
+    // collection-level multi-GPU: this engine holds one record shard
+    // =====================================================================
+    struct Comm {
+        int rank = 0, size = 1;
+        void *user = nullptr;
+        int (*ag)(void *, const void *, void *, u64) = nullptr;
+        int (*a2a)(void *, const void *, const u64 *, void *, const u64 *) = nullptr;
+        void allgather(const void *send, void *recv, u64 bytes) const {
+            prim::sync();
+            if (ag(user, send, recv, bytes) != 0) throw prim::Error(-5, "allgather callback failed");
+        }
+        std::vector<u64> allgather_u64(const std::vector<u64> &mine) const {
+            u64 c = mine.size();
+            DBuf<u64> s(c), r(c * size);
+            prim::h2d(s.p, mine.data(), c * 8);
+            allgather(s.p, r.p, c * 8);
+            return r.to_host(c * size);
+        }
+        // variable-length all-gather of a typed device array -> dense concatenation in rank order
+        template <class T>
+        DBuf<T> allgather_v(const T *send, u64 count, std::vector<u64> &base) const {
+            std::vector<u64> cnt = allgather_u64({count});
+            base.assign(size + 1, 0);
+            u64 mx = 1;
+            for (int g = 0; g < size; g++) { base[g + 1] = base[g] + cnt[g]; if (cnt[g] > mx) mx = cnt[g]; }
+            DBuf<T> sp(mx), rp(mx * size);
+            prim::dev_memset(sp.p, 0, mx * sizeof(T));
+            prim::d2d(sp.p, send, count * sizeof(T));
+            allgather(sp.p, rp.p, mx * sizeof(T));
+            DBuf<T> dense(base[size]);
+            DBuf<u64> dbase(size + 1);
+            prim::h2d(dbase.p, base.data(), (size + 1) * 8);
+            prim::for_each(base[size], UnpadFn<T>{rp.p, dbase.p, size, mx, dense.p}, "dist.unpad");
+            prim::sync();
+            return dense;
+        }
+    };
+
+    u64 g_n_strings = 0, g_n_syms = 0;      // collection-wide totals (distributed mode)
+
+    // collection_stats over all shards: separator, alphabet, header widths
+    void dist_stats(const Comm &C) {
+        std::vector<u64> mine(8 + 256, 0);
+        mine[0] = stats.n_syms; mine[1] = stats.n_strings; mine[2] = stats.min_sym; mine[3] = stats.max_sym;
+        if (cell_bytes == 1) {
+            u64 h[256];
+            prim::byte_histogram((const u8 *)text0, n0, h);
+            for (int i = 0; i < 256; i++) mine[8 + i] = h[i];
+        }
+        std::vector<u64> all = C.allgather_u64(mine);
+        const u64 w = mine.size();
+        u64 n = 0, ns = 0, mn = ~0ull, mx = 0;
+        std::vector<u64> hist(256, 0);
+        for (int g = 0; g < C.size; g++) {
+            n += all[g * w]; ns += all[g * w + 1];
+            if (all[g * w + 2] < mn) mn = all[g * w + 2];
+            if (all[g * w + 3] > mx) mx = all[g * w + 3];
+            for (int i = 0; i < 256; i++) hist[i] += all[g * w + 8 + i];
+        }
+        // every shard ends with the separator == its own minimum; it must be the global minimum too
+        // (decided from the gathered values so that every rank takes the same branch)
+        for (int g = 0; g < C.size; g++)
+            if (all[g * w + 2] != mn) throw prim::Error(-84, "Error: the file is ill formed");
+        u64 F = n;
+        if (cell_bytes == 1) { F = 0; for (int i = 0; i < 256; i++) if (hist[i] > F) F = hist[i]; }
+        if (sizeof(idx_t) == 4 && n >= 0xFFFFFF00ull) throw prim::Error(-75, "collection too large for the 32-bit index build");
+        g_n_strings = ns; g_n_syms = n;
+        stats.max_sym = mx; stats.max_sym_freq = F;
+        stats.sb = (bitlen64(mx + 4) + 7) / 8;
+        stats.fb = (bitlen64(F) + 7) / 8;
+        cur_sigma = (u32)(mx + 1);
+    }
+
+    template <class cell_t, bool FIRST>
+    void dist_round_t(const Comm &C, const cell_t *t, u64 n, u32 sigma, cell_t sep) {
+        CellOps<cell_t, FIRST> ops{sep};
+        prim::rt().tag = (int)levels.size();
+        LevelData L;
+        L.sigma = sigma;
+        L.info.sigma = sigma;
+        LocalParse P;
+        hash_local<cell_t, FIRST>(t, n, ops, P, L);
+        // ---- exchange: distinct phrases of every shard (cells, lengths, frequencies) -------------
+        DBuf<u32> lcells(P.S);
+        DBuf<u64> lfreq(P.D);
+        prim::for_each(P.S, ExportCellsFn<cell_t, FIRST>{t, ops, P.ph_off.p, P.D, P.ph_pos.p, lcells.p}, "dist.export_cells");
+        prim::for_each(P.D, WidenFn{P.ph_freq.p, lfreq.p}, "dist.export_freq");
+        std::vector<u64> sbase, dbase, dbase2;
+        DBuf<u32> gcells = C.allgather_v<u32>(lcells.p, P.S, sbase);
+        DBuf<u32> glen = C.allgather_v<u32>(P.ph_len.p, P.D, dbase);
+        DBuf<u64> gfreq = C.allgather_v<u64>(lfreq.p, P.D, dbase2);
+        lcells.release(); lfreq.release();
+        const u64 Dl = dbase[C.size], Sl = sbase[C.size];
+        std::vector<u64> tot = C.allgather_u64({P.n_occ, n});
+        u64 occ_total = 0, n_total = 0;
+        for (int g = 0; g < C.size; g++) { occ_total += tot[2 * g]; n_total += tot[2 * g + 1]; }
+        L.info.n_in = n_total;
+        L.info.parse_size = occ_total;
+        // ---- merge: one table over the concatenated lists (join_thread_phrases, parsing_strategies.h:277-386) ----
+        DBuf<u64> goff(Dl + 1);
+        {
+            u64 chk = prim::exclusive_scan<u64>(Dl, LenIn{glen.p}, goff.p, true, "dist.list_offsets");
+            if (chk != Sl) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
+        }
+        u64 cap = 1024;
+        while (cap < 2 * Dl) cap <<= 1;
+        DBuf<u64> keys(cap);
+        DBuf<idx_t> counts(cap);
+        DBuf<u32> list_slot(Dl), scal(4), slot_ph(cap);
+        keys.zero(); counts.zero(); scal.zero();
+        prim::for_each(Dl, ListInsertFn{gcells.p, goff.p, glen.p, gfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p}, "dist.merge_phrases");
+        if (scal.to_host(2)[1]) throw prim::Error(-28, "merged phrase table overflow");
+        u64 D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "dist.merge_compact");
+        DBuf<u64> ph_pos(D); DBuf<idx_t> ph_freq(D); DBuf<u32> ph_len(D), ph_off(D + 1); DBuf<u8> ph_lastT(D);
+        prim::for_each(cap, ListCompactFn{gcells.p, goff.p, glen.p, keys.p, counts.p, slot_ph.p, ph_pos.p, ph_freq.p, ph_len.p, ph_lastT.p},
+                       "dist.merge_compact");
+        u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dist.freq_check");
+        if (fsum != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
+        u32 maxlen = prim::reduce_max<u32>(D, LenIn{ph_len.p}, "dist.maxlen");
+        u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dist.dict_syms");
+        if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
+        u64 S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dist.dict_offsets");
+        // ---- the dictionary stage runs replicated on every rank (its result is canonical) -------
+        DBuf<u32> gval;
+        dict_stage<u32, false>(gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p, ph_off.p, ph_lastT.p, sigma, L, gval);
+        // ---- back to the local parse ---------------------------------------------------------
+        DBuf<u32> lval(P.D);
+        prim::for_each(P.D, LocalValFn{list_slot.p, slot_ph.p, gval.p, dbase[C.rank], lval.p}, "dist.local_values");
+        emit_local(P, lval.p);
+        finish_round(P, L, g_n_strings, occ_total);
+    }
+
+    bool dist_parse_round(const Comm &C) {
+        if (parse_done) return true;
+        if (levels.empty()) {
+            switch (cell_bytes) {
+                case 1: dist_round_t<u8, true>(C, (const u8 *)text0, n0, cur_sigma, (u8)stats.min_sym); break;
+                case 2: dist_round_t<u16, true>(C, (const u16 *)text0, n0, cur_sigma, (u16)stats.min_sym); break;
+                case 4: dist_round_t<u32, true>(C, (const u32 *)text0, n0, cur_sigma, (u32)stats.min_sym); break;
+                default: dist_round_t<u64, true>(C, (const u64 *)text0, n0, cur_sigma, (u64)stats.min_sym); break;
+            }
+        } else {
+            DBuf<u32> t = std::move(cur_text);
+            dist_round_t<u32, false>(C, t.p, cur_n, cur_sigma, 0u);
+        }
+        if (levels.size() > 64) throw prim::Error(-75, "too many parsing rounds");
+        return parse_done;
+    }
+
+    // Induction, round-1 form: the deepest parse (one cell per string, a few bytes per record) is
+    // all-gathered and every rank induces the whole collection's BWT from the replicated grammar.
+    void dist_induce_replicated(const Comm &C) {
+        std::vector<u64> base;
+        DBuf<u32> all = C.allgather_v<u32>(cur_text.p, cur_n, base);
+        cur_n = base[C.size];
+        if (cur_n != g_n_strings) throw prim::Error(-71, "deepest parse does not have one cell per string");
+        cur_text = std::move(all);
+        stats.n_strings = g_n_strings;
+        stats.n_syms = g_n_syms;
+        induce_phase();
+        finish();
+    }
+
+    void dist_build(const Comm &C) {
+        dist_stats(C);
+        while (!dist_parse_round(C)) {}
+        dist_induce_replicated(C);
+    }
+
     void run_all() {
         parse_phase();
         induce_phase();

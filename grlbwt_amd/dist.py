@@ -1,0 +1,126 @@
+"""Collection-level multi-GPU driver: one process per GPU, torch.distributed transport.
+
+The collection is sharded by record (contiguous ranges of whole strings, rank order =
+collection order).  All orchestration lives in the C++ engine (grlbwt_dist_build); this
+module only provides the two collectives the engine calls back for, implemented with
+torch.distributed -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine
+
+_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class CommStruct(C.Structure):
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", C.c_void_p), ("allgather", _AG), ("alltoallv", _A2A)]
+
+
+class _DevView:
+    """Zero-copy view of engine-owned device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _view(ptr, nbytes, device):
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    if device.type == "cuda":
+        return torch.as_tensor(_DevView(ptr, nbytes), device=device)
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+
+
+class Communicator:
+    """Callbacks handed to the engine (must stay alive while the engine uses them)."""
+
+    def __init__(self, device, group=None):
+        self.device = torch.device(device)
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.bytes_moved = 0
+        self._ag = _AG(self._allgather)
+        self._a2a = _A2A(self._alltoallv)
+        self.struct = CommStruct(self.rank, self.size, None, self._ag, self._a2a)
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def _allgather(self, user, send, recv, nbytes):
+        try:
+            s = _view(send, nbytes, self.device)
+            r = _view(recv, nbytes * self.size, self.device)
+            if self.size == 1:
+                r.copy_(s)
+            else:
+                dist.all_gather_into_tensor(r, s, group=self.group)
+            self._sync()
+            self.bytes_moved += nbytes * self.size
+            return 0
+        except Exception as e:          # never let an exception cross the C boundary
+            print("grlbwt allgather callback failed:", repr(e), flush=True)
+            return 1
+
+    def _alltoallv(self, user, send, send_bytes, recv, recv_bytes):
+        try:
+            sb = [int(send_bytes[i]) for i in range(self.size)]
+            rb = [int(recv_bytes[i]) for i in range(self.size)]
+            s = _view(send, sum(sb), self.device)
+            r = _view(recv, sum(rb), self.device)
+            if self.size == 1:
+                r.copy_(s)
+            else:
+                dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+            self._sync()
+            self.bytes_moved += sum(sb)
+            return 0
+        except Exception as e:
+            print("grlbwt alltoallv callback failed:", repr(e), flush=True)
+            return 1
+
+
+def shard_records(cells, rank, size, sep=None):
+    """Contiguous record range of `cells` (numpy array of whole strings) for `rank`: the reference's
+    thread_ranges split (parsing_strategies.h:208-214), by string count."""
+    cells = np.asarray(cells)
+    sep = cells[-1] if sep is None else sep
+    ends = np.flatnonzero(cells == sep)
+    n_str = len(ends)
+    lo_s = (n_str * rank) // size
+    hi_s = (n_str * (rank + 1)) // size
+    lo = 0 if lo_s == 0 else int(ends[lo_s - 1]) + 1
+    hi = int(ends[hi_s - 1]) + 1 if hi_s > 0 else 0
+    return cells[lo:hi]
+
+
+def dist_build(ctx, comm):
+    """Run the collection-level build on a context that already holds this rank's shard."""
+    L = ctx.L
+    L.grlbwt_dist_build.argtypes = [C.c_void_p, C.POINTER(CommStruct)]
+    ctx._ck(L.grlbwt_dist_build(ctx._h, C.byref(comm.struct)))
+
+
+def grl_bwt_algo_sharded(shard, cell_bytes=1, device="cpu", lib=None, flags=0, group=None):
+    """BCR BWT (.rl_bwt bytes) of the whole collection whose rank-th record shard is `shard`.
+    Every rank returns the same bytes."""
+    dev = torch.device(device)
+    comm = Communicator(dev, group)
+    n_local = torch.tensor([len(shard) // cell_bytes if isinstance(shard, (bytes, bytearray)) else int(np.asarray(shard).size)],
+                           dtype=torch.int64, device=dev)
+    if comm.size > 1:
+        dist.all_reduce(n_local, group=group)
+    if int(n_local.item()) >= 0xFFFFFF00:
+        flags |= engine.FLAG_FORCE_IDX64           # collection-wide positions/frequencies need 64 bits
+    index = dev.index if dev.type == "cuda" and dev.index is not None else 0
+    with engine.Context(index, flags, lib) as ctx:
+        ctx.upload(shard, cell_bytes)
+        dist_build(ctx, comm)
+        return ctx.result_bytes()

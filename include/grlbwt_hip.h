@@ -141,6 +141,26 @@ int grlbwt_level_bwt_download(const grlbwt_ctx *ctx, int level, uint64_t *sym_ou
 
 int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out);
 
+/* ---- collection-level multi-GPU ------------------------
+ * One context per GPU/process; the collection is sharded by record: rank g loads (text_upload /
+ * text_attach_device) a contiguous range of whole strings, ranks in collection order.  The engine
+ * calls back into the host for the exchanges (the host implements them with torch.distributed:
+ * RCCL over xGMI on GPUs, gloo in the CPU tests); all pointers are device pointers of this
+ * engine's device.  Replaces the thread-range strategy of mt_parse_strat_t
+ * (include/parsing_strategies.h:200-275,277-386): hashing and parse emission stay local to the
+ * shard, the per-thread table merge (join_thread_phrases) becomes an all-gather + device merge.
+ * The output is the BWT of the WHOLE collection, identical on every rank and for every N.   */
+typedef struct grlbwt_comm {
+    int rank, size;
+    void *user;
+    /* every rank contributes `bytes` bytes at `send`; `recv` gets size*bytes in rank order; 0 = ok */
+    int (*allgather)(void *user, const void *send, void *recv, uint64_t bytes);
+    /* variable all-to-all: send_bytes[size]/recv_bytes[size] (host arrays), blocks contiguous in rank order */
+    int (*alltoallv)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+} grlbwt_comm;
+/* grl_bwt_algo over the sharded collection: par_phase with a dictionary merge per round, ind_phase, image */
+int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm);
+
 /* per-kernel timing with HIP events on the engine's stream (bench.py's roofline leg).
  * enable(1) clears the table and starts recording; dump writes one line per kernel name:
  * "<name> <launches> <total_ms>\n" (NUL terminated, truncated to capacity). */

@@ -1,0 +1,57 @@
+"""Worker for the world_size>1 tests (gloo on CPU over the serial test stand-in of the
+device primitives; nccl/RCCL with the HIP library on a GPU box)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from grlbwt_amd import dist as gdist
+    from grlbwt_amd import engine, workloads
+    lib, backend, case, out_dir = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        device = "cuda:%d" % torch.cuda.current_device()
+    else:
+        dist.init_process_group("gloo")
+        device = "cpu"
+    w = 1
+    if case == "reads":
+        data = workloads.sampled_reads(3001, 100, 20000, seed=11)
+    elif case == "uniform":
+        data = workloads.uniform_reads(2000, 100, seed=5)
+    elif case == "repetitive":
+        data = workloads.repetitive_copies(31, 8000, seed=3)
+    elif case == "tokens":
+        data = workloads.zipf_tokens(30000, doc_len=100, vocab=3000)
+        w = 2
+    elif case == "tiny":
+        data = np.frombuffer(b"A\n\nA\nGATTACA\nGATTACA\nT\n", dtype=np.uint8)
+    else:
+        raise SystemExit("unknown case " + case)
+    shard = gdist.shard_records(data, rank, world)
+    flags = engine.FLAG_FORCE_IDX64 if case == "repetitive" else 0
+    out = gdist.grl_bwt_algo_sharded(shard.tobytes(), w, device, lib, flags)
+    with open(os.path.join(out_dir, "%s.rank%d.md5" % (case, rank)), "w") as f:
+        f.write(hashlib.md5(out).hexdigest())
+    if rank == 0:
+        with open(os.path.join(out_dir, case + ".rl_bwt"), "wb") as f:
+            f.write(out)
+        with open(os.path.join(out_dir, case + ".input"), "wb") as f:
+            f.write(data.tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,3 +134,19 @@ def test_table_growth_when_prefix_is_unrepresentative(hip, oracle_mod):
     rep = (b"ACGTTGCA" * 16 + b"\n") * 8500
     data = rep + workloads.uniform_reads(30000, 100, seed=77).tobytes()
     parity.check_final(hip, data, 1)
+
+
+def test_dist_path_single_rank_rccl(hip, oracle_mod, tmp_path):
+    """The collection-level path over torch.distributed/RCCL (world_size 1 on this box): exercises the
+    device-pointer callbacks (CUDA array interface views) and the merged-dictionary kernels on the GPU."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for case, w in (("reads", 1), ("tokens", 2)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+               "--master-addr", "127.0.0.1", "--master-port", "29611",
+               os.path.join(here, "dist_worker.py"), hip, "nccl", case, str(tmp_path)]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+        data = open(tmp_path / (case + ".input"), "rb").read()
+        assert open(tmp_path / (case + ".rl_bwt"), "rb").read() == oracle_mod.rl_bwt(data, w)
