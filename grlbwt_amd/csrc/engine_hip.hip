@@ -5,6 +5,7 @@
 #include <type_traits>
 #include <utility>
 #include <vector>
+#include <algorithm>
 #include <string>
 
 #include "prim_hip.hpp"

@@ -732,6 +732,140 @@ struct LocalValFn {       // metasymbol of my k-th local phrase through the merg
     GRL_DEV void operator()(u64 k) const { val[k] = gval[slot_ph[list_slot[my_first + k]]]; }
 };
 
+// ---- distributed induction functors -------------------------------------------------
+struct BucketSumFn {      // per bucket u: my cells' symbol count, my TAKE symbol count, my first cell
+    const u32 *skey; u64 E; const idx_t *lH; const idx_t *lT;
+    u64 *cntpair /*[2M]*/; idx_t *lfirst;
+    GRL_DEV void operator()(u64 u) const {
+        u64 a = lower_bound<u32>(skey, E, (u32)u), b = lower_bound<u32>(skey, E, (u32)u + 1);
+        cntpair[2 * u] = (u64)lH[b] - (u64)lH[a];
+        cntpair[2 * u + 1] = (u64)lT[b] - (u64)lT[a];
+        lfirst[u] = (idx_t)a;
+    }
+};
+struct BucketPrefixFn {   // totals over all ranks and the part held by ranks before me
+    const u64 *all /*[size][2M]*/; int size, me; u64 M;
+    idx_t *tot, *before, *totT, *beforeT;
+    GRL_DEV void operator()(u64 u) const {
+        u64 t = 0, b = 0, tT = 0, bT = 0;
+        for (int g = 0; g < size; g++) {
+            u64 c = all[(u64)g * 2 * M + 2 * u], cT = all[(u64)g * 2 * M + 2 * u + 1];
+            if (g < me) { b += c; bT += cT; }
+            t += c; tT += cT;
+        }
+        tot[u] = (idx_t)t; before[u] = (idx_t)b; totT[u] = (idx_t)tT; beforeT[u] = (idx_t)bT;
+    }
+};
+struct PreClipFlagIn {    // 1 if the (non-HOCC) pre-BWT run overlaps my output range
+    const u32 *psym; const idx_t *Ppos; u32 hocc_code; u64 lo, hi;
+    GRL_DEV u32 operator()(u64 j) const {
+        if (psym[j] == hocc_code) return 0u;
+        u64 a = Ppos[j] > lo ? (u64)Ppos[j] : lo, b = Ppos[j + 1] < hi ? (u64)Ppos[j + 1] : hi;
+        return a < b ? 1u : 0u;
+    }
+};
+struct DistSegPreFn {
+    const u32 *psym; const idx_t *plen; const idx_t *Ppos; const idx_t *PB; const u32 *u_to_p; const idx_t *th_base;
+    const u32 *pidx; u64 M, lo, hi; u32 bwt_code, hocc_code, take_code;
+    u64 *seg_out; u32 *seg_sym; idx_t *seg_len; idx_t *seg_toff;
+    GRL_DEV void operator()(u64 j) const {
+        u32 s = psym[j];
+        if (s == hocc_code) return;
+        u64 a = Ppos[j] > lo ? (u64)Ppos[j] : lo, b = Ppos[j + 1] < hi ? (u64)Ppos[j + 1] : hi;
+        if (a >= b) return;
+        u64 g = pidx[j];
+        seg_out[g] = a; seg_len[g] = (idx_t)(b - a);
+        if (s == bwt_code) {
+            u64 ustar = lower_bound<u32>(u_to_p, M, (u32)j);       // buckets of earlier pre-BWT runs
+            seg_sym[g] = take_code;
+            seg_toff[g] = (idx_t)((u64)PB[j] + (u64)th_base[ustar] + (a - (u64)Ppos[j]));
+        } else { seg_sym[g] = s; seg_toff[g] = 0; }
+    }
+};
+struct DistSegCellFn {
+    const u32 *skey; const u32 *ssym; const idx_t *slen; const idx_t *lH; const idx_t *lT; const idx_t *lfirst;
+    const u32 *u_to_p; const idx_t *Ppos; const idx_t *PH; const idx_t *PB;
+    const idx_t *bucket_base; const idx_t *before; const idx_t *th_base; const idx_t *beforeT;
+    u64 seg0; u32 take_code;
+    u64 *seg_out; u32 *seg_sym; idx_t *seg_len; idx_t *seg_toff;
+    GRL_DEV void operator()(u64 t) const {
+        u32 u = skey[t];
+        u64 j = u_to_p[u], f = lfirst[u];
+        u64 hglob = (u64)bucket_base[u] + (u64)before[u] + ((u64)lH[t] - (u64)lH[f]);
+        u64 g = seg0 + t;
+        seg_out[g] = (u64)Ppos[j] + (hglob - (u64)PH[j]);
+        seg_sym[g] = ssym[t];
+        seg_len[g] = slen[t];
+        seg_toff[g] = (ssym[t] == take_code) ? (idx_t)((u64)PB[j] + (u64)th_base[u] + (u64)beforeT[u] + ((u64)lT[t] - (u64)lT[f])) : (idx_t)0;
+    }
+};
+struct DistAtomCountIn {
+    const u32 *seg_sym; const idx_t *seg_len; const idx_t *seg_toff; const u64 *tw; const idx_t *tb; u32 take_code;
+    GRL_DEV idx_t operator()(u64 g) const {
+        if (seg_sym[g] != take_code) return 1;
+        u64 a = seg_toff[g], b = a + seg_len[g];
+        return (idx_t)(rank1(tw, tb, b) - rank1(tw, tb, a + 1) + 1);
+    }
+};
+struct DistAtomFn {       // atoms with explicit global output positions
+    const u64 *seg_out; const u32 *seg_sym; const idx_t *seg_len; const idx_t *seg_toff; const idx_t *Tpos; const u32 *Tsym;
+    const idx_t *abase; const u64 *tw; const idx_t *tb; const u64 *aw; const idx_t *ab; u32 take_code;
+    u64 *a_out; u32 *a_sym; u64 *a_len;
+    GRL_DEV void operator()(u64 x) const {
+        u64 g = rank1(aw, ab, x + 1) - 1;
+        if (seg_sym[g] != take_code) { a_out[x] = seg_out[g]; a_sym[x] = seg_sym[g]; a_len[x] = seg_len[g]; return; }
+        u64 a = seg_toff[g], b = a + seg_len[g];
+        u64 kf = rank1(tw, tb, a + 1) - 1;
+        u64 k = kf + (x - abase[g]);
+        u64 s = Tpos[k] > a ? (u64)Tpos[k] : a;
+        u64 e = Tpos[k + 1] < b ? (u64)Tpos[k + 1] : b;
+        a_out[x] = seg_out[g] + (s - a); a_sym[x] = Tsym[k]; a_len[x] = e - s;
+    }
+};
+struct PieceCountIn {     // an atom is cut at the output-range boundaries of the ranks
+    const u64 *a_out; const u64 *a_len; u64 chunk;
+    GRL_DEV idx_t operator()(u64 x) const { return (idx_t)((a_out[x] + a_len[x] - 1) / chunk - a_out[x] / chunk + 1); }
+};
+struct PieceFn {
+    const u64 *a_out; const u32 *a_sym; const u64 *a_len; const idx_t *pbase; const u64 *pw; const idx_t *pb; u64 chunk;
+    u32 *p_owner; idx_t *p_idx; u64 *p_out; u32 *p_sym; u64 *p_len;
+    GRL_DEV void operator()(u64 y) const {
+        u64 x = rank1(pw, pb, y + 1) - 1;
+        u64 o = a_out[x], l = a_len[x];
+        u64 d = o / chunk + (y - pbase[x]);
+        u64 s = d * chunk > o ? d * chunk : o;
+        u64 e = (d + 1) * chunk < o + l ? (d + 1) * chunk : o + l;
+        p_owner[y] = (u32)d; p_idx[y] = (idx_t)y; p_out[y] = s; p_sym[y] = a_sym[x]; p_len[y] = e - s;
+    }
+};
+struct PermuteAtomsFn {
+    const idx_t *perm; const u64 *o; const u32 *s; const u64 *l; u64 *o2; u32 *s2; u64 *l2;
+    GRL_DEV void operator()(u64 i) const { u64 y = perm[i]; o2[i] = o[y]; s2[i] = s[y]; l2[i] = l[y]; }
+};
+struct RecvKeyFn {
+    const u64 *o; u64 lo; u64 *key; idx_t *idx;
+    GRL_DEV void operator()(u64 i) const { key[i] = o[i] - lo; idx[i] = (idx_t)i; }
+};
+struct GatherRecvFn {
+    const idx_t *perm; const u32 *s; const u64 *l; u32 *os; idx_t *ol;
+    GRL_DEV void operator()(u64 i) const { u64 y = perm[i]; os[i] = s[y]; ol[i] = (idx_t)l[y]; }
+};
+struct CheckSortedAtomsFn {   // every received atom must start where the previous one ended
+    const u64 *key; const idx_t *perm; const u64 *l; u64 n; u32 *bad;
+    GRL_DEV void operator()(u64 i) const {
+        u64 expect = (i == 0) ? 0 : key[i - 1] + l[perm[i - 1]];
+        if (key[i] != expect) *bad = 1;
+    }
+};
+struct OwnerBoundFn {     // first routed atom of every destination rank
+    const u32 *k; u64 n; idx_t *out;
+    GRL_DEV void operator()(u64 d) const { out[d] = (idx_t)lower_bound<u32>(k, n, (u32)d); }
+};
+struct NarrowFn {
+    const u64 *a; idx_t *b;
+    GRL_DEV void operator()(u64 i) const { b[i] = (idx_t)a[i]; }
+};
+
 // =========================================================================
 struct RoundInfo {
     u64 n_in = 0, D = 0, S = 0, M = 0, parse_size = 0, sigma = 0, max_phrase_len = 0, sort_iters = 0, table_retries = 0;
@@ -1386,8 +1520,190 @@ class Engine {
         return parse_done;
     }
 
-    // Induction, round-1 form: the deepest parse (one cell per string, a few bytes per record) is
-    // all-gathered and every rank induces the whole collection's BWT from the replicated grammar.
+    // ---- distributed induction --------------------------------------------------------------
+    // Invariant: every rank holds a contiguous slice of BWT_{level} (runs), slices in rank order.
+    // Per level: (1) local chain expansion + stable bucket split of the slice (same kernels as the
+    // single-GPU path); (2) the rewritten run symbols of BWT_{r+1} are all-gathered (every rank can
+    // then resolve its own TAKE cells); (3) per-bucket symbol counts are exchanged ("rank counts":
+    // totals give the bucket starts, the part of earlier ranks the offset of my cells inside each
+    // bucket); (4) every rank turns its cells, and the part of the replicated pre-BWT that falls in
+    // its own output range, into atoms with explicit output positions; (5) atoms are routed to the
+    // rank that owns their output range (all-to-all), sorted by position and merged into runs.
+    void dist_first_bwt() {
+        first_bwt();     // local: my strings' final symbols, in collection order
+    }
+
+    void dist_induce_level(const Comm &C) {
+        if (bwt_level <= 0) throw prim::Error(-22, "no level left to induce");
+        const int r = bwt_level - 1;
+        prim::rt().tag = r;
+        LevelData &L = levels[r];
+        const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
+        const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
+        LevelInfo &I = linfo[r];
+        I.R_next = R; I.P = P;
+        // (1) local expansion and stable split by bucket
+        DBuf<idx_t> eoff(R + 1);
+        DBuf<u32> term(R);
+        u64 E;
+        {
+            StageTimer st(&tm.ind_expand);
+            E = (u64)prim::exclusive_scan<idx_t>(R, ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p, true, "induce_count");
+        }
+        I.E = E;
+        DBuf<u32> skey, ssym(E);
+        DBuf<idx_t> slen(E);
+        {
+            DBuf<u32> ekey(E), ekey2(E), esym(E);
+            DBuf<idx_t> eidx(E), eidx2(E), elen(E);
+            {
+                StageTimer st(&tm.ind_expand);
+                prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                                                       ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
+            }
+            StageTimer st(&tm.ind_sort);
+            int bits = (int)bitlen64(M > 0 ? M - 1 : 0);
+            if (bits < 1) bits = 1;
+            int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
+            prim::for_each(E, GatherCellFn{res ? eidx2.p : eidx.p, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
+            skey = std::move(res ? ekey2 : ekey);
+            prim::sync();
+        }
+        eoff.release();
+        StageTimer st(&tm.ind_assemble);
+        // (2) replicate the rewritten BWT_{r+1} (run symbols + lengths)
+        std::vector<u64> rbase, rbase2;
+        DBuf<u32> Tsym = C.allgather_v<u32>(term.p, R, rbase);
+        DBuf<idx_t> Tlen = C.allgather_v<idx_t>(bwt.len.p, R, rbase2);
+        const u64 Rt = rbase[C.size];
+        DBuf<idx_t> Tpos(Rt + 1);
+        u64 Tsum = (u64)prim::exclusive_scan<idx_t>(Rt, IdxIn<idx_t>{Tlen.p}, Tpos.p, true, "dist.Tpos");
+        term.release(); Tlen.release();
+        // (3) per-bucket rank counts
+        DBuf<idx_t> lH(E + 1), lT(E + 1), lfirst(M + 1);
+        prim::exclusive_scan<idx_t>(E, IdxIn<idx_t>{slen.p}, lH.p, true, "dist.lH");
+        prim::exclusive_scan<idx_t>(E, CondLenIn{ssym.p, slen.p, take_code}, lT.p, true, "dist.lT");
+        DBuf<u64> cntpair(2 * M + 2), allcnt((2 * M + 2) * (u64)C.size);
+        prim::for_each(M, BucketSumFn{skey.p, E, lH.p, lT.p, cntpair.p, lfirst.p}, "dist.bucket_counts");
+        C.allgather(cntpair.p, allcnt.p, (2 * M + 2) * 8);
+        DBuf<idx_t> tot(M + 1), before(M + 1), totT(M + 1), beforeT(M + 1), bucket_base(M + 1), th_base(M + 1);
+        // note: rows of allcnt have stride 2M+2; BucketPrefixFn is told that stride through M' = M+1
+        prim::for_each(M, BucketPrefixFn{allcnt.p, C.size, C.rank, M + 1, tot.p, before.p, totT.p, beforeT.p}, "dist.bucket_prefix");
+        u64 Hsum = (u64)prim::exclusive_scan<idx_t>(M, IdxIn<idx_t>{tot.p}, bucket_base.p, true, "dist.bucket_base");
+        u64 THsum = (u64)prim::exclusive_scan<idx_t>(M, IdxIn<idx_t>{totT.p}, th_base.p, true, "dist.th_base");
+        allcnt.release(); cntpair.release();
+        // replicated pre-BWT coordinates
+        DBuf<idx_t> PH(P + 1), PB(P + 1), Ppos(P + 1);
+        u64 PHsum = (u64)prim::exclusive_scan<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code}, PH.p, true, "dist.PH");
+        u64 PBsum = (u64)prim::exclusive_scan<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, bwt_code}, PB.p, true, "dist.PB");
+        u64 n_r = (u64)prim::exclusive_scan<idx_t>(P, IdxIn<idx_t>{L.prebwt.len.p}, Ppos.p, true, "dist.Ppos");
+        if (Hsum != PHsum) throw prim::Error(-71, "dist induction: induced symbols do not match the pre-BWT (level " + std::to_string(r) + ")");
+        if (PBsum + THsum != Tsum) throw prim::Error(-71, "dist induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ")");
+        // (4) my output range and my segments
+        const u64 chunk = (n_r + C.size - 1) / C.size > 0 ? (n_r + C.size - 1) / C.size : 1;
+        const u64 lo = std::min<u64>(n_r, (u64)C.rank * chunk), hi = std::min<u64>(n_r, lo + chunk);
+        DBuf<u32> pidx(P + 1);
+        u64 Pc = prim::exclusive_scan<u32>(P, PreClipFlagIn{L.prebwt.sym.p, Ppos.p, hocc_code, lo, hi}, pidx.p, false, "dist.clip");
+        const u64 G = Pc + E;
+        I.G = G;
+        DBuf<u64> seg_out(G);
+        DBuf<u32> seg_sym(G);
+        DBuf<idx_t> seg_len(G), seg_toff(G), abase(G + 1);
+        prim::for_each(P, DistSegPreFn{L.prebwt.sym.p, L.prebwt.len.p, Ppos.p, PB.p, L.u_to_p.p, th_base.p, pidx.p, M, lo, hi,
+                                       bwt_code, hocc_code, take_code, seg_out.p, seg_sym.p, seg_len.p, seg_toff.p}, "dist.seg_pre");
+        prim::for_each(E, DistSegCellFn{skey.p, ssym.p, slen.p, lH.p, lT.p, lfirst.p, L.u_to_p.p, Ppos.p, PH.p, PB.p, bucket_base.p,
+                                        before.p, th_base.p, beforeT.p, Pc, take_code, seg_out.p, seg_sym.p, seg_len.p, seg_toff.p},
+                       "dist.seg_cell");
+        skey.release(); ssym.release(); slen.release(); lH.release(); lT.release();
+        RankBits tbits, abits, pbits;
+        build_rankbits(tbits, Tpos.p, Rt, Tsum + 1, "dist.tbits");
+        u64 A = (u64)prim::exclusive_scan<idx_t>(G, DistAtomCountIn{seg_sym.p, seg_len.p, seg_toff.p, tbits.words.p, tbits.base.p, take_code},
+                                                 abase.p, true, "dist.atom_count");
+        I.A = A;
+        build_rankbits(abits, abase.p, G, A + 1, "dist.abits");
+        DBuf<u64> a_out(A), a_len(A);
+        DBuf<u32> a_sym(A);
+        prim::for_each(A, DistAtomFn{seg_out.p, seg_sym.p, seg_len.p, seg_toff.p, Tpos.p, Tsym.p, abase.p, tbits.words.p, tbits.base.p,
+                                     abits.words.p, abits.base.p, take_code, a_out.p, a_sym.p, a_len.p}, "dist.atoms");
+        seg_out.release(); seg_sym.release(); seg_len.release(); seg_toff.release(); Tsym.release(); Tpos.release();
+        // (5) route the atoms to the owners of their output ranges
+        DBuf<idx_t> pbase(A + 1);
+        u64 Np = (u64)prim::exclusive_scan<idx_t>(A, PieceCountIn{a_out.p, a_len.p, chunk}, pbase.p, true, "dist.piece_count");
+        build_rankbits(pbits, pbase.p, A, Np + 1, "dist.pbits");
+        DBuf<u32> p_owner(Np), p_owner2(Np), p_sym(Np), s_sym(Np);
+        DBuf<idx_t> p_idx(Np), p_idx2(Np);
+        DBuf<u64> p_out(Np), p_len(Np), s_out(Np), s_len(Np);
+        prim::for_each(Np, PieceFn{a_out.p, a_sym.p, a_len.p, pbase.p, pbits.words.p, pbits.base.p, chunk, p_owner.p, p_idx.p, p_out.p,
+                                   p_sym.p, p_len.p}, "dist.pieces");
+        int obits = (int)bitlen64((u64)C.size - 1);
+        if (obits < 1) obits = 1;
+        int res = prim::sort_pairs<u32, idx_t>(p_owner.p, p_idx.p, p_owner2.p, p_idx2.p, Np, 0, obits, "dist.route_sort");
+        const u32 *okey = res ? p_owner2.p : p_owner.p;
+        prim::for_each(Np, PermuteAtomsFn{res ? p_idx2.p : p_idx.p, p_out.p, p_sym.p, p_len.p, s_out.p, s_sym.p, s_len.p}, "dist.route_pack");
+        std::vector<u64> send_cnt(C.size, 0);
+        {
+            // counts per owner from the sorted owner keys (binary search on the host copy of a small prefix array)
+            DBuf<idx_t> ocount(C.size + 1);
+            prim::for_each((u64)C.size + 1, OwnerBoundFn{okey, Np, ocount.p}, "dist.route_counts");
+            std::vector<idx_t> oc = ocount.to_host(C.size + 1);
+            for (int d = 0; d < C.size; d++) send_cnt[d] = (u64)oc[d + 1] - (u64)oc[d];
+        }
+        std::vector<u64> mat = C.allgather_u64(send_cnt);       // mat[g*size + d] = atoms g sends to d
+        std::vector<u64> recv_cnt(C.size);
+        u64 Nr = 0;
+        for (int g = 0; g < C.size; g++) { recv_cnt[g] = mat[(u64)g * C.size + C.rank]; Nr += recv_cnt[g]; }
+        DBuf<u64> r_out(Nr), r_len(Nr);
+        DBuf<u32> r_sym(Nr);
+        auto a2a = [&](const void *sp, void *rp, u64 elem) {
+            std::vector<u64> sb(C.size), rb(C.size);
+            for (int g = 0; g < C.size; g++) { sb[g] = send_cnt[g] * elem; rb[g] = recv_cnt[g] * elem; }
+            prim::sync();
+            if (C.a2a(C.user, sp, sb.data(), rp, rb.data()) != 0) throw prim::Error(-5, "alltoallv callback failed");
+        };
+        a2a(s_out.p, r_out.p, 8); a2a(s_len.p, r_len.p, 8); a2a(s_sym.p, r_sym.p, 4);
+        // sort what I received by output position and merge into runs: my slice of BWT_r
+        DBuf<u64> rk(Nr), rk2(Nr);
+        DBuf<idx_t> ri(Nr), ri2(Nr);
+        prim::for_each(Nr, RecvKeyFn{r_out.p, lo, rk.p, ri.p}, "dist.recv_keys");
+        int kb = (int)bitlen64(chunk);
+        if (kb < 1) kb = 1;
+        int res2 = prim::sort_pairs<u64, idx_t>(rk.p, ri.p, rk2.p, ri2.p, Nr, 0, kb, "dist.recv_sort");
+        const u64 *sk = res2 ? rk2.p : rk.p;
+        const idx_t *sp = res2 ? ri2.p : ri.p;
+        DBuf<u32> bad(1);
+        bad.zero();
+        prim::for_each(Nr, CheckSortedAtomsFn{sk, sp, r_len.p, Nr, bad.p}, "dist.recv_check");
+        DBuf<u32> osym(Nr);
+        DBuf<idx_t> olen(Nr);
+        prim::for_each(Nr, GatherRecvFn{sp, r_sym.p, r_len.p, osym.p, olen.p}, "dist.recv_gather");
+        if (bad.get(0)) throw prim::Error(-71, "dist induction: received atoms do not tile my output range (level " + std::to_string(r) + ")");
+        bwt = merge_runs(osym.p, olen.p, Nr);
+        u64 got = prim::reduce_sum<u64>(bwt.R, IdxIn<idx_t>{bwt.len.p}, "dist.slice_check");
+        if (got != hi - lo) throw prim::Error(-71, "dist induction: slice size mismatch (level " + std::to_string(r) + ")");
+        bwt_level = r;
+        I.R = bwt.R; I.n = n_r;
+        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+    }
+
+    // gather the slices of BWT_0, restore maximal runs across rank boundaries, build the image
+    void dist_finish(const Comm &C) {
+        std::vector<u64> b1, b2;
+        DBuf<u32> gs = C.allgather_v<u32>(bwt.sym.p, bwt.R, b1);
+        DBuf<idx_t> gl = C.allgather_v<idx_t>(bwt.len.p, bwt.R, b2);
+        bwt = merge_runs(gs.p, gl.p, b1[C.size]);
+        stats.n_strings = g_n_strings;
+        stats.n_syms = g_n_syms;
+        finish();
+    }
+
+    void dist_induce(const Comm &C) {
+        dist_first_bwt();
+        while (bwt_level > 0) dist_induce_level(C);
+        dist_finish(C);
+    }
+
+    // Fallback kept for comparison: the deepest parse (one cell per string) is all-gathered and
+    // every rank induces the whole collection's BWT from the replicated grammar.
     void dist_induce_replicated(const Comm &C) {
         std::vector<u64> base;
         DBuf<u32> all = C.allgather_v<u32>(cur_text.p, cur_n, base);
@@ -1403,7 +1719,8 @@ class Engine {
     void dist_build(const Comm &C) {
         dist_stats(C);
         while (!dist_parse_round(C)) {}
-        dist_induce_replicated(C);
+        if (getenv("GRLBWT_DIST_REPLICATED_INDUCTION") || !C.a2a) dist_induce_replicated(C);
+        else dist_induce(C);
     }
 
     void run_all() {

@@ -46,6 +46,8 @@ class Communicator:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.bytes_moved = 0
+        self.n_allgather = 0
+        self.n_alltoall = 0
         self._ag = _AG(self._allgather)
         self._a2a = _A2A(self._alltoallv)
         self.struct = CommStruct(self.rank, self.size, None, self._ag, self._a2a)
@@ -58,12 +60,10 @@ class Communicator:
         try:
             s = _view(send, nbytes, self.device)
             r = _view(recv, nbytes * self.size, self.device)
-            if self.size == 1:
-                r.copy_(s)
-            else:
-                dist.all_gather_into_tensor(r, s, group=self.group)
+            dist.all_gather_into_tensor(r, s, group=self.group)      # also at size 1: same code path as N > 1
             self._sync()
             self.bytes_moved += nbytes * self.size
+            self.n_allgather += 1
             return 0
         except Exception as e:          # never let an exception cross the C boundary
             print("grlbwt allgather callback failed:", repr(e), flush=True)
@@ -75,12 +75,10 @@ class Communicator:
             rb = [int(recv_bytes[i]) for i in range(self.size)]
             s = _view(send, sum(sb), self.device)
             r = _view(recv, sum(rb), self.device)
-            if self.size == 1:
-                r.copy_(s)
-            else:
-                dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+            dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
             self._sync()
             self.bytes_moved += sum(sb)
+            self.n_alltoall += 1
             return 0
         except Exception as e:
             print("grlbwt alltoallv callback failed:", repr(e), flush=True)
@@ -108,11 +106,13 @@ def dist_build(ctx, comm):
     ctx._ck(L.grlbwt_dist_build(ctx._h, C.byref(comm.struct)))
 
 
-def grl_bwt_algo_sharded(shard, cell_bytes=1, device="cpu", lib=None, flags=0, group=None):
+def grl_bwt_algo_sharded(shard, cell_bytes=1, device="cpu", lib=None, flags=0, group=None, comm_out=None):
     """BCR BWT (.rl_bwt bytes) of the whole collection whose rank-th record shard is `shard`.
     Every rank returns the same bytes."""
     dev = torch.device(device)
     comm = Communicator(dev, group)
+    if comm_out is not None:
+        comm_out.append(comm)
     n_local = torch.tensor([len(shard) // cell_bytes if isinstance(shard, (bytes, bytearray)) else int(np.asarray(shard).size)],
                            dtype=torch.int64, device=dev)
     if comm.size > 1:

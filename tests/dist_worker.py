@@ -41,9 +41,12 @@ def main():
         raise SystemExit("unknown case " + case)
     shard = gdist.shard_records(data, rank, world)
     flags = engine.FLAG_FORCE_IDX64 if case == "repetitive" else 0
-    out = gdist.grl_bwt_algo_sharded(shard.tobytes(), w, device, lib, flags)
+    comms = []
+    out = gdist.grl_bwt_algo_sharded(shard.tobytes(), w, device, lib, flags, comm_out=comms)
     with open(os.path.join(out_dir, "%s.rank%d.md5" % (case, rank)), "w") as f:
         f.write(hashlib.md5(out).hexdigest())
+    with open(os.path.join(out_dir, "%s.rank%d.comm" % (case, rank)), "w") as f:
+        f.write("%d %d %d" % (comms[0].n_allgather, comms[0].n_alltoall, comms[0].bytes_moved))
     if rank == 0:
         with open(os.path.join(out_dir, case + ".rl_bwt"), "wb") as f:
             f.write(out)

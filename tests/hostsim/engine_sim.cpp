@@ -7,6 +7,7 @@
 #include <type_traits>
 #include <utility>
 #include <vector>
+#include <algorithm>
 #include <string>
 
 #include "prim_sim.hpp"

@@ -39,3 +39,16 @@ def test_sharded_collection_matches_oracle(sim, oracle_mod, tmp_path, world, cas
     assert out == oracle_mod.rl_bwt(data, w)
     md5s = {open(tmp_path / ("%s.rank%d.md5" % (case, r))).read() for r in range(world)}
     assert md5s == {hashlib.md5(out).hexdigest()}
+    # the exchanges really happened: dictionary/run all-gathers and the per-level atom routing (all-to-all)
+    for r in range(world):
+        n_ag, n_a2a, nbytes = map(int, open(tmp_path / ("%s.rank%d.comm" % (case, r))).read().split())
+        assert n_ag > 0 and n_a2a > 0 and nbytes > 0
+
+
+def test_replicated_induction_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
+    monkeypatch.setenv("GRLBWT_DIST_REPLICATED_INDUCTION", "1")
+    _run(2, sim, "reads", tmp_path, 29590)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+    n_ag, n_a2a, _ = map(int, open(tmp_path / "reads.rank0.comm").read().split())
+    assert n_ag > 0 and n_a2a == 0
