@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1000000)
     ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--cpu-sample-reads", type=int, default=40000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -77,9 +77,9 @@ def main():
 
     lib = g.build_hip()
     # shard of this rank: the named workload (rank 0) / same shape with another seed (other ranks)
-    data = workloads.uniform_reads(args.reads, args.read_len, seed=20260001 + rank)
-    n_bytes = int(data.size)
-    text = torch.from_numpy(data).to(dev)
+    # generated on the device (bit-identical to workloads.uniform_reads on the host; tests/test_gpu_parity.py)
+    text = workloads.uniform_reads_torch(args.reads, args.read_len, seed=20260001 + rank, device=dev)
+    n_bytes = int(text.numel())
     torch.cuda.synchronize()
 
     comm = None
@@ -171,7 +171,7 @@ def main():
             from oracle import oracle
             oracle.build()
             m = min(args.cpu_sample_reads, args.reads)
-            sample = data[: m * (args.read_len + 1)]
+            sample = text[: m * (args.read_len + 1)].cpu().numpy()
             with tempfile.TemporaryDirectory() as td:
                 fi, fo = os.path.join(td, "in.txt"), os.path.join(td, "out.rl_bwt")
                 sample.tofile(fi)

@@ -288,17 +288,60 @@ struct RankWriteFn {   // gid[t] = (#heads before t) + head(t) - 1 ; rank[perm[t
         rank[perm[t]] = g;
     }
 };
-struct Key1Fn {        // (rank[q], rank[q+h] or +inf)
-    const u32 *perm_in; const u32 *rank; const u32 *dict_phr; const u32 *ph_off;
-    u64 h; int lowbits;
-    u64 *keys; u32 *vals;
+// prefix doubling with filtering: after every pass only the suffixes that sit in a group of equal
+// keys whose key did not yet reach the phrase end ("unresolved") are re-sorted, by
+// (group id, rank of the suffix h symbols further or +inf).
+struct HeadFlagFn {       // hflag[t] = 1 where the sorted key changes
+    const u64 *k; u8 *hflag;
+    GRL_DEV void operator()(u64 t) const { hflag[t] = (t == 0 || k[t] != k[t - 1]) ? 1 : 0; }
+};
+struct ByteIn {
+    const u8 *f;
+    GRL_DEV u32 operator()(u64 i) const { return f[i]; }
+};
+struct RankFromFlagsFn {  // gid[t] = (#heads before t) + head(t) - 1 ; rank[perm[t]] = gid[t] ; gstart[gid] = t at heads
+    const u8 *hflag; const u32 *ex; const u32 *perm; u64 S; u32 *gid; u32 *rank; u32 *gstart;
     GRL_DEV void operator()(u64 t) const {
-        u64 q = perm_in[t];
+        u32 g = ex[t] + hflag[t] - 1;
+        gid[t] = g;
+        rank[perm[t]] = g;
+        if (hflag[t]) gstart[g] = (u32)t;
+        if (t == S - 1) gstart[g + 1] = (u32)S;
+    }
+};
+struct UnresolvedIn {     // member of a group of >1 suffixes that are all longer than the resolved prefix
+    const u32 *gid; const u32 *gstart; const u32 *perm; const u32 *dict_phr; const u32 *ph_off; u64 Lres;
+    GRL_DEV u32 operator()(u64 t) const {
+        u32 g = gid[t];
+        if (gstart[g + 1] - gstart[g] < 2) return 0u;
+        u64 q = perm[t];
+        return ((u64)ph_off[dict_phr[q] + 1] - q >= Lres) ? 1u : 0u;
+    }
+};
+struct UnresolvedKeyFn {  // compact the unresolved slots and build their refinement keys
+    const u32 *gid; const u32 *gstart; const u32 *perm; const u32 *rank; const u32 *dict_phr; const u32 *ph_off; const u32 *uex;
+    u64 h; int lowbits;
+    u64 *keys; u32 *vals; u32 *uslot;
+    GRL_DEV void operator()(u64 t) const {
+        u32 g = gid[t];
+        if (gstart[g + 1] - gstart[g] < 2) return;
+        u64 q = perm[t];
         u64 end = ph_off[dict_phr[q] + 1];
+        if (end - q < h) return;
         u64 sent = (1ull << lowbits) - 1;
         u64 low = (q + h < end) ? (u64)rank[q + h] : sent;
-        keys[t] = ((u64)rank[q] << lowbits) | low;
-        vals[t] = (u32)q;
+        u32 i = uex[t];
+        keys[i] = ((u64)g << lowbits) | low;
+        vals[i] = (u32)q;
+        uslot[i] = (u32)t;
+    }
+};
+struct RefineWriteFn {    // sorted unresolved suffixes go back into their slots; new heads where the key changes
+    const u64 *k; const u32 *v; const u32 *uslot; u32 *perm; u8 *hflag;
+    GRL_DEV void operator()(u64 i) const {
+        u32 t = uslot[i];
+        perm[t] = v[i];
+        if (i > 0 && k[i] != k[i - 1]) hflag[t] = 1;
     }
 };
 
@@ -1093,43 +1136,56 @@ class Engine {
             StageTimer st(&tm.dict_sort);
             prim::for_each(S, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
         }
-        // ---- a6: sort all phrase suffixes (radix + prefix doubling) ----------
-        DBuf<u32> perm(S), gid(S), rank(S);
+        // ---- a6: sort all phrase suffixes (radix + filtered prefix doubling) ----------
+        DBuf<u32> perm(S), gid(S), rank(S), gstart(S + 1);
         u64 G;
         {
             StageTimer st(&tm.dict_sort);
-            DBuf<u64> ka(S), kb(S);
-            DBuf<u32> va(S), vb(S), ex(S + 1);
+            DBuf<u8> hflag(S);
+            DBuf<u32> ex(S + 1);
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
-            int K = 64 / b;
+            int K = 48 / b;                      // first pass: <= 48 key bits (6 radix passes over all suffixes)
+            if (K < 1) K = 1;
             if (K > 16) K = 16;
-            u64 *kA = ka.p, *kB = kb.p;          // (kA, vA) always holds the current sorted order
-            u32 *vA = va.p, *vB = vb.p;
-            prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, kA, vA}, "suffix_keys0");
-            if (prim::sort_pairs<u64, u32>(kA, vA, kB, vB, S, 0, K * b, "suffix_sort0")) { std::swap(kA, kB); std::swap(vA, vB); }
-            G = prim::exclusive_scan<u32>(S, HeadKeyIn{kA}, ex.p, false, "suffix_heads");
-            prim::for_each(S, RankWriteFn{kA, ex.p, vA, gid.p, rank.p}, "suffix_ranks");
-            u64 Lres = (u64)K, iters = 1;
-            while (Lres < maxlen) {              // prefix doubling: Lres symbols resolved so far
-                int lowbits = (int)bitlen64(G);
-                prim::for_each(S, Key1Fn{vA, rank.p, dict_phr.p, ph_off, Lres, lowbits, kB, vB}, "suffix_keys");
-                if (prim::sort_pairs<u64, u32>(kB, vB, kA, vA, S, 0, 2 * lowbits, "suffix_sort") == 0) {
-                    std::swap(kA, kB); std::swap(vA, vB);
+            if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
+            {
+                DBuf<u64> ka(S), kb(S);
+                DBuf<u32> vb(S);
+                prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, ka.p, perm.p}, "suffix_keys0");
+                const u64 *ks = ka.p;
+                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, S, 0, K * b, "suffix_sort0")) {
+                    prim::d2d(perm.p, vb.p, S * sizeof(u32));
+                    ks = kb.p;
                 }
-                G = prim::exclusive_scan<u32>(S, HeadKeyIn{kA}, ex.p, false, "suffix_heads");
-                prim::for_each(S, RankWriteFn{kA, ex.p, vA, gid.p, rank.p}, "suffix_ranks");
+                prim::for_each(S, HeadFlagFn{ks, hflag.p}, "suffix_heads");
+                prim::sync();
+            }
+            G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+            prim::for_each(S, RankFromFlagsFn{hflag.p, ex.p, perm.p, S, gid.p, rank.p, gstart.p}, "suffix_ranks");
+            u64 Lres = (u64)K, iters = 1;
+            while (Lres < maxlen) {              // Lres symbols (incl. a possible sentinel) resolved so far
+                u64 U = prim::exclusive_scan<u32>(S, UnresolvedIn{gid.p, gstart.p, perm.p, dict_phr.p, ph_off, Lres}, ex.p, false, "suffix_unresolved");
+                if (U == 0) break;
+                int lowbits = (int)bitlen64(G);
+                DBuf<u64> ka(U), kb(U);
+                DBuf<u32> va(U), vb(U), uslot(U);
+                prim::for_each(S, UnresolvedKeyFn{gid.p, gstart.p, perm.p, rank.p, dict_phr.p, ph_off, ex.p, Lres, lowbits, ka.p, va.p, uslot.p},
+                               "suffix_keys");
+                int res = prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort");
+                prim::for_each(U, RefineWriteFn{res ? kb.p : ka.p, res ? vb.p : va.p, uslot.p, perm.p, hflag.p}, "suffix_refine");
+                G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+                prim::for_each(S, RankFromFlagsFn{hflag.p, ex.p, perm.p, S, gid.p, rank.p, gstart.p}, "suffix_ranks");
                 Lres *= 2;
                 iters++;
             }
-            prim::d2d(perm.p, vA, S * sizeof(u32));
             prim::sync();
             L.info.sort_iters = iters;
         }
 
         // ---- a7: equal-suffix groups -> pre-BWT, ranks -----------------------
         const u32 bwt_code = sigma + 1, hocc_code = sigma + 2, sigma3 = sigma + 3;
-        DBuf<u32> gstart(G + 1), grank(G + 1), pidx(G + 1), gmin(G), gmax(G);
+        DBuf<u32> grank(G + 1), pidx(G + 1), gmin(G), gmax(G);
         DBuf<idx_t> gacc(G);
         DBuf<u8> gfull(G), gflag(G);
         DBuf<u32> repq;
@@ -1137,7 +1193,6 @@ class Engine {
         {
             StageTimer st(&tm.dict_groups);
             gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
-            prim::for_each(S, GroupStartFn{gid.p, S, gstart.p}, "group_starts");
             {
                 DBuf<u32> rec_left(S);
                 DBuf<idx_t> rec_freq(S);

@@ -89,3 +89,28 @@ def zipf_tokens(n_cells, doc_len=1000, vocab=65000, s=1.1, seed=20260005):
     out = np.zeros((n_docs, doc_len + 1), dtype=np.uint16)
     out[:, :doc_len] = tok
     return out.reshape(-1)
+
+
+def uniform_reads_torch(n_reads, read_len, seed=20260001, device="cuda", chunk_reads=4_000_000):
+    """Same bytes as uniform_reads(), generated on `device` with torch (for multi-GB inputs that
+    should never exist on the host).  int64 arithmetic wraps like uint64; shifts are masked to be logical."""
+    import torch
+    out = torch.empty(n_reads * (read_len + 1), dtype=torch.uint8, device=device)
+    view = out.view(n_reads, read_len + 1)
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    golden = -7046029254386353131          # 0x9E3779B97F4A7C15 as int64
+    m1 = -4658895280553007687              # 0xBF58476D1CE4E5B9
+    m2 = -7723592293110705685              # 0x94D049BB133111EB
+    s0 = seed if seed < (1 << 63) else seed - (1 << 64)
+    for r0 in range(0, n_reads, chunk_reads):
+        r1 = min(n_reads, r0 + chunk_reads)
+        idx = torch.arange(r0 * read_len + 1, r1 * read_len + 1, dtype=torch.int64, device=device)
+        z = s0 + idx * golden
+        z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * m1
+        z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * m2
+        z = z ^ ((z >> 31) & ((1 << 33) - 1))
+        base = acgt[((z >> 62) & 3)]
+        view[r0:r1, :read_len] = base.view(r1 - r0, read_len)
+        view[r0:r1, read_len] = 10
+        del idx, z, base
+    return out

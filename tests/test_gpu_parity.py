@@ -150,3 +150,10 @@ def test_dist_path_single_rank_rccl(hip, oracle_mod, tmp_path):
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
         data = open(tmp_path / (case + ".input"), "rb").read()
         assert open(tmp_path / (case + ".rl_bwt"), "rb").read() == oracle_mod.rl_bwt(data, w)
+
+
+def test_device_side_generator_matches_host(hip):
+    import torch
+    a = workloads.uniform_reads(5000, 100, seed=20260001)
+    b = workloads.uniform_reads_torch(5000, 100, seed=20260001, device="cuda:0", chunk_reads=1300).cpu().numpy()
+    assert np.array_equal(a, b)
