@@ -299,39 +299,43 @@ struct ByteIn {
     const u8 *f;
     GRL_DEV u32 operator()(u64 i) const { return f[i]; }
 };
-struct RankFromFlagsFn {  // gid[t] = (#heads before t) + head(t) - 1 ; rank[perm[t]] = gid[t] ; gstart[gid] = t at heads
-    const u8 *hflag; const u32 *ex; const u32 *perm; u64 S; u32 *gid; u32 *rank; u32 *gstart;
+// Ranks are POSITIONAL: rank[q] = first slot of q's group in the sorted order, so refining one
+// group never renumbers the others and only the re-sorted suffixes get their rank rewritten.
+struct SufLenFn {         // suffix length of every dictionary position (coalesced)
+    const u32 *dict_phr; const u32 *ph_off; u32 *suflen;
+    GRL_DEV void operator()(u64 q) const { suflen[q] = ph_off[dict_phr[q] + 1] - (u32)q; }
+};
+struct GroupStartsFn {    // gstart[dense group id] = head slot ; gstart[G] = S
+    const u8 *hflag; const u32 *ex; u64 S; u32 *gstart;
     GRL_DEV void operator()(u64 t) const {
-        u32 g = ex[t] + hflag[t] - 1;
-        gid[t] = g;
-        rank[perm[t]] = g;
-        if (hflag[t]) gstart[g] = (u32)t;
-        if (t == S - 1) gstart[g + 1] = (u32)S;
+        if (hflag[t]) gstart[ex[t]] = (u32)t;
+        if (t == S - 1) gstart[ex[t] + hflag[t]] = (u32)S;
     }
 };
-struct UnresolvedIn {     // member of a group of >1 suffixes that are all longer than the resolved prefix
-    const u32 *gid; const u32 *gstart; const u32 *perm; const u32 *dict_phr; const u32 *ph_off; u64 Lres;
-    GRL_DEV u32 operator()(u64 t) const {
-        u32 g = gid[t];
-        if (gstart[g + 1] - gstart[g] < 2) return 0u;
-        u64 q = perm[t];
-        return ((u64)ph_off[dict_phr[q] + 1] - q >= Lres) ? 1u : 0u;
+struct RankAllFn {        // rank of every suffix after the first pass
+    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 *rank;
+    GRL_DEV void operator()(u64 t) const { rank[perm[t]] = gstart[ex[t] + hflag[t] - 1]; }
+};
+struct UnresolvedFlagFn { // member of a group of >1 suffixes that are all at least as long as the resolved prefix
+    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; const u32 *suflen; u64 Lres; u8 *uflag;
+    GRL_DEV void operator()(u64 t) const {
+        u32 g = ex[t] + hflag[t] - 1;
+        u8 f = 0;
+        if (gstart[g + 1] - gstart[g] >= 2) f = (suflen[perm[t]] >= Lres) ? 1 : 0;
+        uflag[t] = f;
     }
 };
 struct UnresolvedKeyFn {  // compact the unresolved slots and build their refinement keys
-    const u32 *gid; const u32 *gstart; const u32 *perm; const u32 *rank; const u32 *dict_phr; const u32 *ph_off; const u32 *uex;
+    const u8 *uflag; const u32 *uex; const u32 *perm; const u32 *rank; const u32 *suflen;
     u64 h; int lowbits;
     u64 *keys; u32 *vals; u32 *uslot;
     GRL_DEV void operator()(u64 t) const {
-        u32 g = gid[t];
-        if (gstart[g + 1] - gstart[g] < 2) return;
+        if (!uflag[t]) return;
         u64 q = perm[t];
-        u64 end = ph_off[dict_phr[q] + 1];
-        if (end - q < h) return;
         u64 sent = (1ull << lowbits) - 1;
-        u64 low = (q + h < end) ? (u64)rank[q + h] : sent;
+        u64 low = (h < suflen[q]) ? (u64)rank[q + h] : sent;
         u32 i = uex[t];
-        keys[i] = ((u64)g << lowbits) | low;
+        keys[i] = ((u64)rank[q] << lowbits) | low;
         vals[i] = (u32)q;
         uslot[i] = (u32)t;
     }
@@ -343,6 +347,17 @@ struct RefineWriteFn {    // sorted unresolved suffixes go back into their slots
         perm[t] = v[i];
         if (i > 0 && k[i] != k[i - 1]) hflag[t] = 1;
     }
+};
+struct RankRefinedFn {    // new positional rank of the re-sorted suffixes only
+    const u32 *uslot; const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 *rank;
+    GRL_DEV void operator()(u64 i) const {
+        u32 t = uslot[i];
+        rank[perm[t]] = gstart[ex[t] + hflag[t] - 1];
+    }
+};
+struct DenseGidFn {       // final dense group id of every slot
+    const u8 *hflag; const u32 *ex; u32 *gid;
+    GRL_DEV void operator()(u64 t) const { gid[t] = ex[t] + hflag[t] - 1; }
 };
 
 // -------------------------------------------- a7: groups -> pre-BWT + ranks
@@ -442,7 +457,7 @@ struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
 // ------------------------------------------------------------- a8: grammar
 struct GrammarFn {
     const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
-    const u32 *rank; const u8 *gflag; const u32 *grank;
+    const u32 *rank; const u32 *gid; const u8 *gflag; const u32 *grank;
     u32 sigma3, MD;
     u32 *g0; u32 *g1;
     GRL_DEV void operator()(u64 u) const {
@@ -452,7 +467,7 @@ struct GrammarFn {
         if (q == e) { g0[u] = MD; g1[u] = dict_sym[q]; return; }                    // :38-41
         u64 x = q + 1;
         for (;;) {
-            u32 gx = rank[x];
+            u32 gx = gid[rank[x]];     // positional rank -> slot of the group head -> dense group id
             bool marked = (gflag[gx] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI);
             if (marked) { g0[u] = dict_sym[x - 1]; g1[u] = grank[gx] + sigma3; return; }   // :49-80
             if (x == e) { g0[u] = MD; g1[u] = ph_lastT[k] ? dict_sym[e] : dict_sym[e - 1]; return; }   // :81-85
@@ -463,10 +478,10 @@ struct GrammarFn {
 
 // ------------------------------------------- a9 + a10: ranks -> next text
 struct PhraseValFn {
-    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *rank; const u32 *grank;
+    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *rank; const u32 *gid; const u32 *grank;
     u32 *phrase_val;
     GRL_DEV void operator()(u64 k) const {
-        u32 r = grank[rank[ph_off[k]]];
+        u32 r = grank[gid[rank[ph_off[k]]]];
         phrase_val[k] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
     }
 };
@@ -1141,8 +1156,9 @@ class Engine {
         u64 G;
         {
             StageTimer st(&tm.dict_sort);
-            DBuf<u8> hflag(S);
-            DBuf<u32> ex(S + 1);
+            DBuf<u8> hflag(S), uflag(S);
+            DBuf<u32> ex(S + 1), suflen(S);
+            prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
             int K = 48 / b;                      // first pass: <= 48 key bits (6 radix passes over all suffixes)
@@ -1162,23 +1178,27 @@ class Engine {
                 prim::sync();
             }
             G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-            prim::for_each(S, RankFromFlagsFn{hflag.p, ex.p, perm.p, S, gid.p, rank.p, gstart.p}, "suffix_ranks");
+            prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
+            prim::for_each(S, RankAllFn{hflag.p, ex.p, gstart.p, perm.p, rank.p}, "suffix_ranks");
+            const int lowbits = (int)bitlen64(S);
             u64 Lres = (u64)K, iters = 1;
             while (Lres < maxlen) {              // Lres symbols (incl. a possible sentinel) resolved so far
-                u64 U = prim::exclusive_scan<u32>(S, UnresolvedIn{gid.p, gstart.p, perm.p, dict_phr.p, ph_off, Lres}, ex.p, false, "suffix_unresolved");
+                prim::for_each(S, UnresolvedFlagFn{hflag.p, ex.p, gstart.p, perm.p, suflen.p, Lres, uflag.p}, "suffix_unresolved");
+                DBuf<u32> uex(S + 1);
+                u64 U = prim::exclusive_scan<u32>(S, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
                 if (U == 0) break;
-                int lowbits = (int)bitlen64(G);
                 DBuf<u64> ka(U), kb(U);
                 DBuf<u32> va(U), vb(U), uslot(U);
-                prim::for_each(S, UnresolvedKeyFn{gid.p, gstart.p, perm.p, rank.p, dict_phr.p, ph_off, ex.p, Lres, lowbits, ka.p, va.p, uslot.p},
-                               "suffix_keys");
+                prim::for_each(S, UnresolvedKeyFn{uflag.p, uex.p, perm.p, rank.p, suflen.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
                 int res = prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort");
                 prim::for_each(U, RefineWriteFn{res ? kb.p : ka.p, res ? vb.p : va.p, uslot.p, perm.p, hflag.p}, "suffix_refine");
                 G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-                prim::for_each(S, RankFromFlagsFn{hflag.p, ex.p, perm.p, S, gid.p, rank.p, gstart.p}, "suffix_ranks");
+                prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
+                prim::for_each(U, RankRefinedFn{uslot.p, hflag.p, ex.p, gstart.p, perm.p, rank.p}, "suffix_ranks");
                 Lres *= 2;
                 iters++;
             }
+            prim::for_each(S, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
             prim::sync();
             L.info.sort_iters = iters;
         }
@@ -1218,11 +1238,11 @@ class Engine {
             // ---- a8: grammar ------------------------------------------------
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
-            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, rank.p, gflag.p, grank.p,
+            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, rank.p, gid.p, gflag.p, grank.p,
                                         sigma3, MD, L.g0.p, L.g1.p}, "grammar");
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
-            prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rank.p, grank.p, phrase_val.p}, "phrase_values");
+            prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rank.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
         }
         L.info.M = M;
     }

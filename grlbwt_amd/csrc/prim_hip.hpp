@@ -115,75 +115,96 @@ inline void after_launch(const char *name) {
     }
 }
 
-// Caching device allocator: the engine allocates and frees hundreds of scratch arrays per
-// build; hipMalloc/hipFree each cost tens of microseconds and synchronise the device.
-// Freed blocks are kept in size-class free lists (powers of two up to 1 MiB, then 1 MiB
-// granules, exact-size match) and reused; everything is stream-ordered on one stream, so
-// a block freed by the host after its last launch was enqueued may be handed out again
-// to a later launch on the same stream.
+// Slab allocator.  The engine allocates and frees hundreds of scratch arrays per build, from
+// bytes to tens of GB; hipMalloc/hipFree cost tens of microseconds for small blocks and tens of
+// milliseconds for multi-GB ones, and synchronise the device.  Device memory is therefore taken
+// from the runtime in a few large slabs (1 GiB, doubling) and carved up here: first-fit over an
+// offset-ordered free list with coalescing (the engine's allocation pattern is close to a stack,
+// so fragmentation stays low).  Everything is stream-ordered on ONE stream: a block freed by the
+// host right after its last kernel was enqueued may be handed to a later launch on that stream.
+struct Slab {
+    char *base = nullptr;
+    size_t size = 0;
+    std::map<size_t, size_t> free_list;      // offset -> length
+};
 struct Pool {
-    std::multimap<size_t, void *> free_blocks;   // capacity -> ptr
-    std::map<void *, size_t> live;                // ptr -> capacity
-    size_t cached_bytes = 0, live_bytes = 0, peak_bytes = 0;
-    size_t cache_limit = (size_t)64 << 30;        // keep at most this much idle memory
+    std::vector<Slab> slabs;
+    std::map<void *, std::pair<int, size_t>> live;   // ptr -> (slab, length)
+    size_t live_bytes = 0, peak_bytes = 0, slab_bytes = 0, next_slab = (size_t)1 << 30;
 };
 inline Pool &pool() {
     static Pool p;
     return p;
 }
-inline size_t pool_round(size_t bytes) {
-    if (bytes < 256) return 256;
-    if (bytes <= ((size_t)1 << 20)) {
-        size_t c = 256;
-        while (c < bytes) c <<= 1;
-        return c;
-    }
-    const size_t g = (size_t)1 << 20;
-    return (bytes + g - 1) / g * g;
-}
-inline void pool_trim() {
-    Pool &P = pool();
-    for (auto &kv : P.free_blocks) (void)hipFree(kv.second);
-    P.free_blocks.clear();
-    P.cached_bytes = 0;
-}
 inline bool pool_disabled() {
     static int d = getenv("GRLBWT_NOPOOL") ? 1 : 0;
     return d != 0;
 }
+inline void pool_trim() {                    // give every fully free slab back to the runtime
+    Pool &P = pool();
+    for (auto &sl : P.slabs) {
+        if (sl.base && sl.free_list.size() == 1 && sl.free_list.begin()->second == sl.size) {
+            (void)hipFree(sl.base);
+            P.slab_bytes -= sl.size;
+            sl.base = nullptr; sl.size = 0; sl.free_list.clear();
+        }
+    }
+    bool any = false;
+    for (auto &sl : P.slabs) any = any || sl.base;
+    if (!any) { P.slabs.clear(); P.next_slab = (size_t)1 << 30; }
+}
+inline void *slab_take(Pool &P, int si, size_t need) {
+    Slab &sl = P.slabs[si];
+    for (auto it = sl.free_list.begin(); it != sl.free_list.end(); ++it) {
+        if (it->second >= need) {
+            size_t off = it->first, len = it->second;
+            sl.free_list.erase(it);
+            if (len > need) sl.free_list.emplace(off + need, len - need);
+            void *p = sl.base + off;
+            P.live[p] = {si, need};
+            P.live_bytes += need;
+            if (P.live_bytes > P.peak_bytes) P.peak_bytes = P.live_bytes;
+            return p;
+        }
+    }
+    return nullptr;
+}
 inline void *dev_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 16;
     if (pool_disabled()) {
         void *q = nullptr;
-        hipError_t e0 = hipMalloc(&q, bytes ? bytes : 16);
+        hipError_t e0 = hipMalloc(&q, bytes);
         if (e0 != hipSuccess) throw Error(-12, "hipMalloc: " + std::string(hipGetErrorString(e0)));
         return q;
     }
     Pool &P = pool();
-    size_t cap = pool_round(bytes);
-    auto it = P.free_blocks.lower_bound(cap);
-    // accept a cached block up to 25 % larger than requested
-    if (it != P.free_blocks.end() && it->first <= cap + cap / 4) {
-        void *p = it->second;
-        size_t c = it->first;
-        P.free_blocks.erase(it);
-        P.cached_bytes -= c;
-        P.live[p] = c;
-        P.live_bytes += c;
-        if (P.live_bytes > P.peak_bytes) P.peak_bytes = P.live_bytes;
-        return p;
-    }
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, cap);
-    if (e != hipSuccess) {      // give the cache back and retry once
+    size_t need = (bytes + 255) & ~(size_t)255;
+    for (int si = 0; si < (int)P.slabs.size(); si++)
+        if (P.slabs[si].base) if (void *p = slab_take(P, si, need)) return p;
+    // new slab: at least the request, otherwise the doubling schedule, never more than what is free
+    size_t fr = 0, tot = 0;
+    (void)hipMemGetInfo(&fr, &tot);
+    size_t want = P.next_slab > need ? P.next_slab : need + need / 8;
+    size_t cap = fr > ((size_t)1 << 30) ? fr - ((size_t)512 << 20) : fr;
+    if (want > cap) want = cap;
+    if (want < need) want = need;
+    void *base = nullptr;
+    hipError_t e = hipMalloc(&base, want);
+    if (e != hipSuccess && want > need) { (void)hipGetLastError(); want = need; e = hipMalloc(&base, want); }
+    if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(rt().stream);
         pool_trim();
-        e = hipMalloc(&p, cap);
+        e = hipMalloc(&base, want);
     }
-    if (e != hipSuccess) throw Error(-12, "hipMalloc(" + std::to_string(cap) + "): " + hipGetErrorString(e));
-    P.live[p] = cap;
-    P.live_bytes += cap;
-    if (P.live_bytes > P.peak_bytes) P.peak_bytes = P.live_bytes;
+    if (e != hipSuccess) throw Error(-12, "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
+    Slab sl;
+    sl.base = (char *)base; sl.size = want; sl.free_list.emplace(0, want);
+    P.slabs.push_back(sl);
+    P.slab_bytes += want;
+    if (P.next_slab < ((size_t)64 << 30)) P.next_slab *= 2;
+    void *p = slab_take(P, (int)P.slabs.size() - 1, need);
+    if (!p) throw Error(-12, "slab allocator: internal error");
     return p;
 }
 inline void dev_free(void *p) {
@@ -191,12 +212,19 @@ inline void dev_free(void *p) {
     Pool &P = pool();
     auto it = P.live.find(p);
     if (it == P.live.end()) { (void)hipFree(p); return; }
-    size_t c = it->second;
+    int si = it->second.first;
+    size_t len = it->second.second;
     P.live.erase(it);
-    P.live_bytes -= c;
-    if (P.cached_bytes + c > P.cache_limit) { (void)hipStreamSynchronize(rt().stream); (void)hipFree(p); return; }
-    P.free_blocks.emplace(c, p);
-    P.cached_bytes += c;
+    P.live_bytes -= len;
+    Slab &sl = P.slabs[si];
+    size_t off = (size_t)((char *)p - sl.base);
+    auto nx = sl.free_list.lower_bound(off);
+    if (nx != sl.free_list.end() && off + len == nx->first) { len += nx->second; nx = sl.free_list.erase(nx); }
+    if (nx != sl.free_list.begin()) {
+        auto pv = std::prev(nx);
+        if (pv->first + pv->second == off) { pv->second += len; return; }
+    }
+    sl.free_list.emplace(off, len);
 }
 inline void h2d(void *d, const void *h, size_t n) {
     if (n) GRL_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().stream));
