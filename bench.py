@@ -132,7 +132,7 @@ def main():
             pc, pm = prof.get(b, (0, 0.0))
             prof[b] = (pc + c, pm + ms)
         if os.environ.get("GRLBWT_BENCH_DETAIL"):
-            for k, (c, ms) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:40]:
+            for k, (c, ms) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:90]:
                 print("  %-32s %4d launches %9.3f ms" % (k, c, ms), file=sys.stderr)
         nr = 0
         rounds = []

@@ -383,6 +383,13 @@ int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out) {
     return GRLBWT_OK;
 }
 
+int grlbwt_memory_usage(const grlbwt_ctx *ctx, uint64_t *peak_live_bytes, uint64_t *reserved_bytes) {
+    if (!ctx) return GRLBWT_EINVAL;
+    if (peak_live_bytes) *peak_live_bytes = prim::pool_peak_bytes();
+    if (reserved_bytes) *reserved_bytes = prim::pool_reserved_bytes();
+    return GRLBWT_OK;
+}
+
 int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm) {
     if (!HAS_ENG(ctx) || !comm || !comm->allgather || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size) return GRLBWT_EINVAL;
     return guarded(ctx, [&] {

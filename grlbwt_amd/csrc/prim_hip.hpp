@@ -136,6 +136,8 @@ inline Pool &pool() {
     static Pool p;
     return p;
 }
+inline u64 pool_peak_bytes() { return pool().peak_bytes; }
+inline u64 pool_reserved_bytes() { return pool().slab_bytes; }
 inline bool pool_disabled() {
     static int d = getenv("GRLBWT_NOPOOL") ? 1 : 0;
     return d != 0;

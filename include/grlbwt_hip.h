@@ -140,6 +140,8 @@ int grlbwt_level_bwt_size(const grlbwt_ctx *ctx, int level, uint64_t *n_runs);
 int grlbwt_level_bwt_download(const grlbwt_ctx *ctx, int level, uint64_t *sym_out, uint64_t *len_out);
 
 int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out);
+/* device memory taken by the engine's slab allocator: peak bytes in use, bytes reserved from the runtime */
+int grlbwt_memory_usage(const grlbwt_ctx *ctx, uint64_t *peak_live_bytes, uint64_t *reserved_bytes);
 
 /* ---- collection-level multi-GPU ------------------------
  * One context per GPU/process; the collection is sharded by record: rank g loads (text_upload /

@@ -92,6 +92,8 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
 }
 inline void pool_trim() {}
+inline u64 pool_peak_bytes() { return 0; }
+inline u64 pool_reserved_bytes() { return 0; }
 template <class T, class F>
 inline T reduce_sum(u64 n, F f, const char * = "") { T r = 0; for (u64 i = 0; i < n; i++) r += (T)f(i); return r; }
 template <class T, class F>
