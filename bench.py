@@ -46,6 +46,27 @@ def algorithmic_bytes(name, rounds, levels, cell_bytes, idx_bytes):
     return None
 
 
+def pmc_traffic_per_launch(kernel_substr, n_launches):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/<round>/pmc_traffic.json, collected with separate --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command; FETCH_SIZE doubled per the gfx950 correction).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        tot = 0.0
+        launches = 0
+        for name, e in d["kernels"].items():
+            if kernel_substr in name:
+                tot += 2.0 * e.get("fetch_kib_total", 0.0) * 1024 + e.get("write_kib_total", 0.0) * 1024
+                launches += max(e.get("fetch_launches", 0), e.get("write_launches", 0))
+        return round(tot / launches) if launches else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +180,8 @@ def main():
             achieved = ab / (ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": name, "launches": launches,
                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": pmc_traffic_per_launch({"hash_phrases": "HashInsertFn"}.get(name, name), launches),
                         "algorithmic_bytes": ab, "kernel_ms_total": round(ms, 4),
                         "avg_launch_ms": round(ms / max(launches, 1), 5),
                         "share_of_kernel_time": round(ms / max(total_kernel_ms, 1e-9), 4)}

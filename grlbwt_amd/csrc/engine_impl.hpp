@@ -183,11 +183,17 @@ struct HashInsertFn {
         if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; return prim::kNoBucket; }
         u64 len = e - p + 1;
         h = hash_fin(h, len);
+        u32 found = find_or_insert(p, len, h);
+        if (found != prim::kNoBucket) out_slot[ord] = found;
+        return found;
+    }
+    // claim or find the table slot of the phrase t[p .. p+len) whose (finalised) hash is h
+    GRL_DEV u32 find_or_insert(u64 p, u64 len, u64 h) const {
         u64 lsat = len < kLenSat ? len : kLenSat;
         u64 hi = ((h >> 52) << 12) | lsat;          // tag:12 | len:12
         u64 mine = (hi << kPosBits) | (p + 1);
         u64 slot = h & mask;
-        // NOTE: the result is carried in `found` and written after the loop.  Returning from inside
+        // NOTE: the result is carried in `found` and returned after the loop.  Returning from inside
         // the probe loop made hipcc 7.2 (gfx950) reuse the return register as a scratch under a
         // partial exec mask, so lanes that matched an existing key returned a stale value.
         u32 found = prim::kNoBucket;
@@ -206,8 +212,7 @@ struct HashInsertFn {
             if (hit) found = (u32)slot;
             else slot = (slot + 1) & mask;
         }
-        if (found == prim::kNoBucket) { scal[1] = 1; return found; }   // table full
-        out_slot[ord] = found;
+        if (found == prim::kNoBucket) scal[1] = 1;   // table full / out of probes
         return found;
     }
 };
@@ -455,9 +460,15 @@ struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
 };
 
 // ------------------------------------------------------------- a8: grammar
+struct MarkPosFn {        // mark[q] = 1 iff q's suffix group is ranked and has > 1 member (phr_marks, exact_par_phase.cpp:203-205)
+    const u32 *perm; const u32 *gid; const u8 *gflag; u8 *mark;
+    GRL_DEV void operator()(u64 t) const {
+        mark[perm[t]] = ((gflag[gid[t]] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1 : 0;
+    }
+};
 struct GrammarFn {
     const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
-    const u32 *rank; const u32 *gid; const u8 *gflag; const u32 *grank;
+    const u32 *rank; const u32 *gid; const u8 *mark; const u32 *grank;
     u32 sigma3, MD;
     u32 *g0; u32 *g1;
     GRL_DEV void operator()(u64 u) const {
@@ -467,9 +478,9 @@ struct GrammarFn {
         if (q == e) { g0[u] = MD; g1[u] = dict_sym[q]; return; }                    // :38-41
         u64 x = q + 1;
         for (;;) {
-            u32 gx = gid[rank[x]];     // positional rank -> slot of the group head -> dense group id
-            bool marked = (gflag[gx] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI);
-            if (marked) { g0[u] = dict_sym[x - 1]; g1[u] = grank[gx] + sigma3; return; }   // :49-80
+            if (mark[x]) {             // positional rank -> slot of the group head -> dense group id -> metasymbol
+                g0[u] = dict_sym[x - 1]; g1[u] = grank[gid[rank[x]]] + sigma3; return;       // :49-80
+            }
             if (x == e) { g0[u] = MD; g1[u] = ph_lastT[k] ? dict_sym[e] : dict_sym[e - 1]; return; }   // :81-85
             x++;
         }
@@ -584,6 +595,12 @@ static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merg
 struct CellSymFn {
     const u32 *t; u32 *sym; idx_t *len;
     GRL_DEV void operator()(u64 i) const { sym[i] = t[i] >> 2; len[i] = 1; }
+};
+
+template <class F>
+struct StoreFn {          // out[i] = f(i): materialise an expensive scan input once
+    F f; idx_t *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = f(i); }
 };
 
 // ----------------------------------------------------- a13/a14: induction
@@ -1042,6 +1059,14 @@ class Engine {
         DBuf<u64> ph_pos; DBuf<idx_t> ph_freq; DBuf<u32> ph_len, ph_slot, ph_off; DBuf<u8> ph_lastT;
     };
 
+    // phrase hashing launch: one lane per text position, counts pre-aggregated in LDS when few phrases dominate
+    // (a tiled variant -- 64 positions per lane, text staged in LDS, per-tile de-duplication of <= 7-byte phrases --
+    // was built and measured at 1.9-3.2 ms vs 2.2 ms for this form on 101 MB of reads, and dropped)
+    template <class cell_t, bool FIRST>
+    void launch_hash(HashInsertFn<cell_t, FIRST> f, idx_t *counts, u64 n, bool aggregate) {
+        prim::for_each_agg(n, f, SlotCountAdd{counts}, aggregate, "hash_phrases");
+    }
+
     template <class cell_t, bool FIRST>
     void hash_local(const cell_t *t, u64 n, CellOps<cell_t, FIRST> ops, LocalParse &P, LevelData &L) {
         const u64 nwords = (n + 63) / 64;
@@ -1103,9 +1128,8 @@ class Engine {
                 keys.alloc(cap); counts.alloc(cap);
                 keys.zero(); counts.zero(); scal.zero();
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
-                prim::for_each_agg(n, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit,
-                                                                  P.next_text.p, scal.p, n, n_occ},
-                                   SlotCountAdd{counts.p}, aggregate, "hash_phrases");
+                launch_hash<cell_t, FIRST>(HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit,
+                                                                     P.next_text.p, scal.p, n, n_occ}, counts.p, n, aggregate);
                 std::vector<u32> sc = scal.to_host(4);
                 if (sc[1] == 1) {
                     if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");
@@ -1238,7 +1262,9 @@ class Engine {
             // ---- a8: grammar ------------------------------------------------
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
-            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, rank.p, gid.p, gflag.p, grank.p,
+            DBuf<u8> mark(S);
+            prim::for_each(S, MarkPosFn{perm.p, gid.p, gflag.p, mark.p}, "grammar_marks");
+            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, rank.p, gid.p, mark.p, grank.p,
                                         sigma3, MD, L.g0.p, L.g1.p}, "grammar");
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
@@ -1349,8 +1375,8 @@ class Engine {
         u64 E;
         {
             StageTimer st(&tm.ind_expand);
-            E = (u64)prim::exclusive_scan<idx_t>(R, ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p, true,
-                                                 "induce_count");
+            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p}, "induce_count");
+            E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
         }
         I.E = E;
         DBuf<u32> skey;                         // bucket of every induced cell, bucket-major order
@@ -1411,8 +1437,9 @@ class Engine {
                                                            ": " + std::to_string(Tused) + " vs " + std::to_string(Tsum) + ")");
             RankBits tbits, abits;
             build_rankbits(tbits, Tpos.p, R, Tsum + 1, "asm.tbits");        // run boundaries of BWT_{r+1} on the T axis
-            u64 A = (u64)prim::exclusive_scan<idx_t>(G, AtomCountIn{seg_sym.p, seg_len.p, Toff.p, tbits.words.p, tbits.base.p, take_code},
-                                                     abase.p, true, "asm.atom_count");
+            prim::for_each(G, StoreFn<AtomCountIn>{AtomCountIn{seg_sym.p, seg_len.p, Toff.p, tbits.words.p, tbits.base.p, take_code}, abase.p},
+                           "asm.atom_count");
+            u64 A = (u64)prim::exclusive_scan<idx_t>(G, IdxIn<idx_t>{abase.p}, abase.p, true, "asm.atom_scan");
             I.A = A;
             build_rankbits(abits, abase.p, G, A + 1, "asm.abits");          // first atom of every segment on the atom axis
             DBuf<u32> osym(A);
@@ -1623,7 +1650,8 @@ class Engine {
         u64 E;
         {
             StageTimer st(&tm.ind_expand);
-            E = (u64)prim::exclusive_scan<idx_t>(R, ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p, true, "induce_count");
+            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p}, "induce_count");
+            E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
         }
         I.E = E;
         DBuf<u32> skey, ssym(E);

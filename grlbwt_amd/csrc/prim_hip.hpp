@@ -591,8 +591,8 @@ inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
 //   pass = k_rs_hist (per-tile digit histogram in LDS)  -> counts[digit][tile]
 //        + exclusive_scan over counts (digit-major = global digit offsets)
 //        + k_rs_scatter (in-tile stable ranking with wave64 ballots)
-static constexpr int kRsItems = 16;                 // rounds of 256 keys per tile
-static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup
+static constexpr int kRsItems = 32;                 // rounds of 256 keys per tile
+static constexpr int kRsTile = kBlock * kRsItems;   // 8192 keys per workgroup
 
 template <class K>
 __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 *counts, u32 tiles) {
