@@ -383,6 +383,17 @@ int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out) {
     return GRLBWT_OK;
 }
 
+int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int cell_bytes,
+                        void *dev_text_out, uint64_t capacity_cells, uint64_t *n_cells_out) {
+    if (!ctx || !dev_image || !dev_text_out) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        bool big = capacity_cells >= 0xFFFFFF00ull || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+        uint64_t n = big ? grl64::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells)
+                         : grl32::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells);
+        if (n_cells_out) *n_cells_out = n;
+    });
+}
+
 int grlbwt_memory_usage(const grlbwt_ctx *ctx, uint64_t *peak_live_bytes, uint64_t *reserved_bytes) {
     if (!ctx) return GRLBWT_EINVAL;
     if (peak_live_bytes) *peak_live_bytes = prim::pool_peak_bytes();

@@ -941,6 +941,51 @@ struct NarrowFn {
     GRL_DEV void operator()(u64 i) const { b[i] = (idx_t)a[i]; }
 };
 
+// ---- .rl_bwt consumers (scripts/grl2plain.cpp, scripts/reverse_bwt.cpp + fm_index.h:79-83) ------
+struct PtrU32In {
+    const u32 *p;
+    GRL_DEV u32 operator()(u64 i) const { return p[i]; }
+};
+struct SepLenIn {         // total length of the runs of one symbol
+    const u32 *sym; const idx_t *len; u32 code;
+    GRL_DEV u64 operator()(u64 i) const { return sym[i] == code ? (u64)len[i] : 0ull; }
+};
+struct UnpackRunsFn {     // (sym: sb bytes LE, len: fb bytes LE) records -> arrays
+    const u8 *img; u32 sb, fb; u32 *sym; idx_t *len;
+    GRL_DEV void operator()(u64 i) const {
+        const u8 *p = img + 16 + i * (u64)(sb + fb);
+        u64 s = 0, l = 0;
+        for (u32 b = 0; b < sb; b++) s |= (u64)p[b] << (8 * b);
+        for (u32 b = 0; b < fb; b++) l |= (u64)p[sb + b] << (8 * b);
+        sym[i] = (u32)s; len[i] = (idx_t)l;
+    }
+};
+struct ExpandRunsFn {     // grl2plain: symbol of every BWT position through the run-start bitmap
+    const u32 *rsym; const u64 *rw; const idx_t *rb; u32 *out; idx_t *idx;
+    GRL_DEV void operator()(u64 i) const { out[i] = rsym[rank1(rw, rb, i + 1) - 1]; idx[i] = (idx_t)i; }
+};
+struct LfScatterFn {      // LF[order[j]] = j  (order = stable sort of positions by symbol)
+    const idx_t *order; idx_t *lf;
+    GRL_DEV void operator()(u64 j) const { lf[order[j]] = (idx_t)j; }
+};
+struct InvertLenFn {      // string i: backward LF walk from row i until its own terminator comes back
+    const u32 *bwt; const idx_t *lf; u32 sep; idx_t *slen;
+    GRL_DEV void operator()(u64 i) const {
+        u64 row = i, l = 1;
+        for (u32 c = bwt[row]; c != sep; c = bwt[row]) { l++; row = lf[row]; }
+        slen[i] = (idx_t)l;
+    }
+};
+template <class cell_t>
+struct InvertWriteFn {
+    const u32 *bwt; const idx_t *lf; const idx_t *off; u32 sep; cell_t *text;
+    GRL_DEV void operator()(u64 i) const {
+        u64 end = off[i + 1] - 1, row = i;
+        text[end] = (cell_t)sep;
+        for (u32 c = bwt[row]; c != sep; c = bwt[row]) { text[--end] = (cell_t)c; row = lf[row]; }
+    }
+};
+
 // =========================================================================
 struct RoundInfo {
     u64 n_in = 0, D = 0, S = 0, M = 0, parse_size = 0, sigma = 0, max_phrase_len = 0, sort_iters = 0, table_retries = 0;
@@ -1824,6 +1869,61 @@ class Engine {
         while (!dist_parse_round(C)) {}
         if (getenv("GRLBWT_DIST_REPLICATED_INDUCTION") || !C.a2a) dist_induce_replicated(C);
         else dist_induce(C);
+    }
+
+    // ---- consumers of the .rl_bwt image (validation): grl2plain + reverse_bwt on the device ----------
+    // Rebuilds the collection (strings in input order) from an image in device memory.
+    template <class cell_t>
+    static u64 invert_t(const u8 *img, u64 R, u32 sb, u32 fb, cell_t *text_out, u64 capacity) {
+        DBuf<u32> rsym(R);
+        DBuf<idx_t> rlen(R), rpos(R + 1);
+        prim::for_each(R, UnpackRunsFn{img, sb, fb, rsym.p, rlen.p}, "inv.unpack");
+        u64 n = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{rlen.p}, rpos.p, true, "inv.positions");
+        if (n > capacity) throw prim::Error(-22, "inversion: output buffer too small");
+        u32 sep = prim::reduce_min<u32>(R, PtrU32In{rsym.p}, "inv.sep");
+        u32 mx = prim::reduce_max<u32>(R, PtrU32In{rsym.p}, "inv.max");
+        RankBits rb;
+        build_rankbits(rb, rpos.p, R, n + 1, "inv.runbits");
+        DBuf<u32> bwt(n), k2(n);
+        DBuf<idx_t> ia(n), ib(n), lf(n);
+        prim::for_each(n, ExpandRunsFn{rsym.p, rb.words.p, rb.base.p, bwt.p, ia.p}, "inv.expand");          // grl2plain
+        d2d_copy(k2.p, bwt.p, n);
+        DBuf<u32> k3(n);
+        int bits = (int)bitlen64(mx);
+        if (bits < 1) bits = 1;
+        int res = prim::sort_pairs<u32, idx_t>(k2.p, ia.p, k3.p, ib.p, n, 0, bits, "inv.lf_sort");
+        prim::for_each(n, LfScatterFn{res ? ib.p : ia.p, lf.p}, "inv.lf");
+        k2.release(); k3.release();
+        u64 k = 0;                       // number of strings = occurrences of the separator
+        {
+            k = prim::reduce_sum<u64>(R, SepLenIn{rsym.p, rlen.p, sep}, "inv.nstrings");
+        }
+        DBuf<idx_t> slen(k + 1);
+        prim::for_each(k, InvertLenFn{bwt.p, lf.p, sep, slen.p}, "inv.lengths");
+        u64 tot = (u64)prim::exclusive_scan<idx_t>(k, IdxIn<idx_t>{slen.p}, slen.p, true, "inv.offsets");
+        if (tot != n) throw prim::Error(-71, "inversion: string lengths do not add up to the BWT length");
+        prim::for_each(k, InvertWriteFn<cell_t>{bwt.p, lf.p, slen.p, sep, text_out}, "inv.write");
+        prim::sync();
+        return n;
+    }
+    template <class T>
+    static void d2d_copy(T *dst, const T *src, u64 n) { prim::d2d(dst, src, n * sizeof(T)); }
+
+    static u64 invert_image(const void *dev_image, u64 image_bytes, int cell_bytes, void *dev_text_out, u64 capacity_cells) {
+        if (image_bytes < 16) throw prim::Error(-22, "not an .rl_bwt image");
+        u64 hdr[2];
+        prim::d2h(hdr, dev_image, 16);
+        u64 sb = hdr[0], fb = hdr[1];
+        if (sb == 0 || sb > 8 || fb == 0 || fb > 8 || (image_bytes - 16) % (sb + fb)) throw prim::Error(-22, "bad .rl_bwt header");
+        u64 R = (image_bytes - 16) / (sb + fb);
+        const u8 *img = (const u8 *)dev_image;
+        switch (cell_bytes) {
+            case 1: return invert_t<u8>(img, R, (u32)sb, (u32)fb, (u8 *)dev_text_out, capacity_cells);
+            case 2: return invert_t<u16>(img, R, (u32)sb, (u32)fb, (u16 *)dev_text_out, capacity_cells);
+            case 4: return invert_t<u32>(img, R, (u32)sb, (u32)fb, (u32 *)dev_text_out, capacity_cells);
+            case 8: return invert_t<u64>(img, R, (u32)sb, (u32)fb, (u64 *)dev_text_out, capacity_cells);
+            default: throw prim::Error(-22, "bad cell width");
+        }
     }
 
     void run_all() {

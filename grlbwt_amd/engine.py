@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
     "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
     "grlbwt_level_text_download", "grlbwt_level_bwt_size", "grlbwt_level_bwt_download", "grlbwt_get_counters",
-    "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump", "grlbwt_dist_build", "grlbwt_memory_usage",
+    "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump", "grlbwt_dist_build", "grlbwt_memory_usage", "grlbwt_invert_image",
 ]
 
 
@@ -109,6 +109,7 @@ def load_library(path=None):
     L.grlbwt_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.grlbwt_selftest.argtypes = [vp, u64, u64]
     L.grlbwt_memory_usage.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.grlbwt_invert_image.argtypes = [vp, vp, u64, i32, vp, u64, C.POINTER(u64)]
     L.grlbwt_profile_enable.argtypes = [vp, i32]
     L.grlbwt_profile_dump.argtypes = [vp, C.c_char_p, u64]
     _libs[path] = L
@@ -251,6 +252,13 @@ class Context:
         c = Counters()
         self._ck(self.L.grlbwt_get_counters(self._h, C.byref(c)))
         return _as_dict(c)
+
+    def invert_image(self, dev_image_ptr, image_bytes, cell_bytes, dev_out_ptr, capacity_cells):
+        """reverse_bwt on the device: .rl_bwt image (device) -> the collection's cells (device); returns #cells."""
+        n = C.c_uint64()
+        self._ck(self.L.grlbwt_invert_image(self._h, C.c_void_p(dev_image_ptr), image_bytes, cell_bytes,
+                                            C.c_void_p(dev_out_ptr), capacity_cells, C.byref(n)))
+        return n.value
 
     def memory_usage(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -132,6 +132,14 @@ int grlbwt_result_device_ptr(const grlbwt_ctx *ctx, const void **dev_ptr);
 int grlbwt_result_download(const grlbwt_ctx *ctx, void *host_out, uint64_t capacity);
 int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path);
 
+/* ---- .rl_bwt consumers: scripts/grl2plain.cpp (expand the runs) + scripts/reverse_bwt.cpp with
+ * scripts/fm_index.h:79-83 (LF walk), on the device.  Rebuilds the collection (strings in input order,
+ * cell_bytes-wide cells) from an .rl_bwt image in device memory into dev_text_out; used as the
+ * encode -> decode round-trip check at full benchmark sizes.  64-bit positions are used when
+ * the image describes >= 2^32 - 256 symbols (pass n_hint = 0 if unknown: decided from the file size). */
+int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int cell_bytes,
+                        void *dev_text_out, uint64_t capacity_cells, uint64_t *n_cells_out);
+
 /* ---- inspection (parity tests; need GRLBWT_FLAG_KEEP_LEVELS) --------------- */
 /* text of level >= 1 as (rank<<1 | rep) cells, the reference's on-disk parse format */
 int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells);

@@ -105,3 +105,22 @@ def test_table_growth_when_prefix_is_unrepresentative(sim, oracle_mod):
         ctx.build()
         got = ctx.result_bytes()
     assert got == oracle_mod.rl_bwt(data, 1)
+
+
+@pytest.mark.parametrize("kind,w", [("reads", 1), ("tokens", 2), ("dups", 1)])
+def test_invert_image_round_trip(sim, kind, w):
+    """reverse_bwt / grl2plain on the (stand-in) device: the image decodes back to the collection."""
+    if kind == "reads":
+        data = workloads.sampled_reads(3000, 100, 20000, seed=4)
+    elif kind == "tokens":
+        data = workloads.zipf_tokens(20000, doc_len=100, vocab=2000)
+    else:
+        data = np.frombuffer(b"A\n\nA\nGATTACA\nGATTACA\nT\n\n", dtype=np.uint8)
+    for flags in (0, engine.FLAG_FORCE_IDX64):
+        with engine.Context(0, flags, sim) as ctx:
+            ctx.upload(data.tobytes(), w)
+            ctx.build()
+            nb, _ = ctx.result_size()
+            out = np.zeros(data.size, dtype=data.dtype)
+            n = ctx.invert_image(ctx.result_device_ptr(), nb, w, out.ctypes.data, data.size)   # stand-in: device == host
+            assert n == data.size and np.array_equal(out, data)

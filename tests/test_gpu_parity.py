@@ -157,3 +157,34 @@ def test_device_side_generator_matches_host(hip):
     a = workloads.uniform_reads(5000, 100, seed=20260001)
     b = workloads.uniform_reads_torch(5000, 100, seed=20260001, device="cuda:0", chunk_reads=1300).cpu().numpy()
     assert np.array_equal(a, b)
+
+
+def test_full_size_encode_decode_round_trip(hip):
+    """BASELINE config[1] at full size (101 MB): build the BWT, invert the image on the device
+    (grl2plain + reverse_bwt kernels), compare with the input byte for byte."""
+    import torch
+    text = workloads.uniform_reads_torch(1000000, 100, device="cuda:0")
+    out = torch.zeros_like(text)
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+        nb, _ = ctx.result_size()
+        n = ctx.invert_image(ctx.result_device_ptr(), nb, 1, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    assert n == text.numel() and torch.equal(out, text)
+
+
+def test_round_trip_u16_and_long_strings(hip):
+    import torch
+    for data, w in ((workloads.zipf_tokens(2000000, doc_len=1000, vocab=30000), 2),
+                    (workloads.repetitive_copies(20, 300000, seed=9), 1)):
+        t = torch.from_numpy(data.view(np.int16) if w == 2 else data).to("cuda:0")
+        out = torch.zeros_like(t)
+        with engine.Context(0, 0, hip) as ctx:
+            ctx.attach_device(t.data_ptr(), data.size, w, keepalive=t)
+            ctx.build()
+            nb, _ = ctx.result_size()
+            n = ctx.invert_image(ctx.result_device_ptr(), nb, w, out.data_ptr(), data.size)
+        torch.cuda.synchronize()
+        assert n == data.size and torch.equal(out, t)
