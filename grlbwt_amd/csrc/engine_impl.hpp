@@ -513,16 +513,17 @@ struct RankBits {
     DBuf<u64> words;
     DBuf<idx_t> base;
 };
-struct BuildBitsFn {     // one lane per 64-bit word: gather the (sorted, distinct) positions that fall into it
+struct BuildBitsFn {      // one lane per 16 consecutive (sorted, distinct) positions: OR them into their words
     const idx_t *pos; u64 count; u64 *words;
-    GRL_DEV void operator()(u64 w) const {
-        u64 lo = w << 6, hi = lo + 64, m = 0;
-        for (u64 i = lower_bound<idx_t>(pos, count, (idx_t)lo); i < count; i++) {
-            u64 x = pos[i];
-            if (x >= hi) break;
-            m |= 1ull << (x - lo);
+    GRL_DEV void operator()(u64 j) const {
+        u64 i0 = j * 16, i1 = i0 + 16 < count ? i0 + 16 : count;
+        u64 cur = (u64)pos[i0] >> 6, m = 0;
+        for (u64 i = i0; i < i1; i++) {
+            u64 x = pos[i], w = x >> 6;
+            if (w != cur) { prim::atomic_or(&words[cur], m); m = 0; cur = w; }
+            m |= 1ull << (x & 63);
         }
-        words[w] = m;
+        prim::atomic_or(&words[cur], m);
     }
 };
 // # boundaries in [0, x)
@@ -533,7 +534,8 @@ static inline void build_rankbits(RankBits &rb, const idx_t *pos, u64 count, u64
     u64 nw = nbits / 64 + 2;
     rb.words.alloc(nw);
     rb.base.alloc(nw + 1);
-    prim::for_each(nw, BuildBitsFn{pos, count, rb.words.p}, name);
+    rb.words.zero();
+    prim::for_each((count + 15) / 16, BuildBitsFn{pos, count, rb.words.p}, name);
     prim::exclusive_scan<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, name);
 }
 

@@ -471,8 +471,10 @@ __global__ void __launch_bounds__(kBlock) k_scan_tile_sums(u64 n, F in, T *tile_
     __syncthreads();
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
+// tile_offsets == nullptr: single tile, offset 0.  The thread holding element n-1 stores the grand
+// total to total_a / total_b when they are non-null (no separate copy kernels for scalars).
 template <class T, class F>
-__global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *tile_offsets, T *out) {
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *tile_offsets, T *out, T *total_a, T *total_b) {
     __shared__ T s_w[4];
     u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanItems;
     T v[kScanItems];
@@ -484,12 +486,19 @@ __global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *til
         acc += v[j];
     }
     T tot;
-    T ex = block_excl_scan<T>(acc, s_w, &tot) + tile_offsets[blockIdx.x];
+    T ex = block_excl_scan<T>(acc, s_w, &tot) + (tile_offsets ? tile_offsets[blockIdx.x] : T(0));
 #pragma unroll
     for (int j = 0; j < kScanItems; j++) {
         u64 i = base + j;
-        if (i < n) out[i] = ex;
-        ex += v[j];
+        T nx = ex + v[j];
+        if (i < n) {
+            if (i == n - 1) {
+                if (total_a) *total_a = nx;
+                if (total_b) *total_b = nx;
+            }
+            out[i] = ex;
+        }
+        ex = nx;
     }
 }
 template <class T>
@@ -498,38 +507,36 @@ struct PtrIn {
     GRL_HD T operator()(u64 i) const { return p[i]; }
 };
 
-// Device-only exclusive scan: out[i] = sum_{j<i} in(j); if total_dev != nullptr the grand total is
-// written there (device memory).  No host synchronisation: everything is stream-ordered.
-// `out` may alias the array `in` reads (each tile is read before it is written, tiles are disjoint).
-template <class T>
-struct StoreTotalFn {
-    const T *sums; const T *last_in_dummy; T *dst;
-    GRL_DEV void operator()(u64) const { *dst = *sums; }
-};
+// Device-only exclusive scan: out[i] = sum_{j<i} in(j); the grand total is written to total_a and
+// total_b when non-null (device memory; total_a may be out + n).  No host synchronisation and no
+// scalar copies: everything is stream-ordered kernels.  `out` may alias the array `in` reads (each
+// tile is read before it is written, tiles are disjoint) -- but then total_a/total_b must not
+// alias an element `in` still reads.
 template <class T, class F>
-inline void exclusive_scan_async(u64 n, F in, T *out, T *total_dev, const char *name = "scan") {
+inline void exclusive_scan_async(u64 n, F in, T *out, T *total_a, T *total_b = nullptr, const char *name = "scan") {
     if (n == 0) {
-        if (total_dev) dev_memset(total_dev, 0, sizeof(T));
+        if (total_a) dev_memset(total_a, 0, sizeof(T));
+        if (total_b) dev_memset(total_b, 0, sizeof(T));
         return;
     }
     u64 tiles = (n + kScanTile - 1) / kScanTile;
+    if (tiles == 1) {
+        prof_begin(name);
+        hipLaunchKernelGGL((k_scan_tiles<T, F>), dim3(1), dim3(kBlock), 0, rt().stream, n, in, (const T *)nullptr, out, total_a, total_b);
+        prof_end();
+        after_launch(name);
+        return;
+    }
     T *sums = (T *)dev_alloc(sizeof(T) * (tiles + 1));
     prof_begin(name);
     hipLaunchKernelGGL((k_scan_tile_sums<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, sums);
     prof_end();
     after_launch(name);
-    // scan the tile sums in place; their total lands in sums[tiles]
-    if (tiles == 1) {
-        d2d(sums + 1, sums, sizeof(T));
-        dev_memset(sums, 0, sizeof(T));
-    } else {
-        exclusive_scan_async<T, PtrIn<T>>(tiles, PtrIn<T>{sums}, sums, sums + tiles, name);
-    }
+    exclusive_scan_async<T, PtrIn<T>>(tiles, PtrIn<T>{sums}, sums, nullptr, nullptr, name);
     prof_begin(name);
-    hipLaunchKernelGGL((k_scan_tiles<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, sums, out);
+    hipLaunchKernelGGL((k_scan_tiles<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, (const T *)sums, out, total_a, total_b);
     prof_end();
     after_launch(name);
-    if (total_dev) d2d(total_dev, sums + tiles, sizeof(T));
     dev_free(sums);      // stream-ordered reuse (pool)
 }
 
@@ -538,8 +545,7 @@ inline void exclusive_scan_async(u64 n, F in, T *out, T *total_dev, const char *
 template <class T, class F>
 inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, const char *name = "scan") {
     T *tot = (T *)dev_alloc(sizeof(T));
-    exclusive_scan_async<T, F>(n, in, out, tot, name);
-    if (store_total_at_n) d2d(out + n, tot, sizeof(T));
+    exclusive_scan_async<T, F>(n, in, out, tot, store_total_at_n ? out + n : nullptr, name);
     T total;
     d2h(&total, tot, sizeof(T));
     dev_free(tot);
@@ -679,7 +685,7 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, counts, tiles);
         prof_end();
         after_launch(name);
-        exclusive_scan_async<u64, RsCountIn>((u64)256 * tiles, RsCountIn{counts}, offsets, nullptr, name);
+        exclusive_scan_async<u64, RsCountIn>((u64)256 * tiles, RsCountIn{counts}, offsets, nullptr, nullptr, name);
         prof_begin(std::string(name) + ".scatter");
         hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
                            shift, offsets, tiles);
