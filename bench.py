@@ -140,11 +140,14 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n_bytes * args.steps / dt / 1e6
 
+    # ---- roofline leg: one more step with HIP-event timing of every kernel on the engine's stream.
+    # Every rank takes the step (for N > 1 it contains collectives); only rank 0 records and reports.
+    if rank == 0:
+        ctx.profile_enable(True)
+    step()
+    barrier()
     out = None
     if rank == 0:
-        # ---- roofline leg: one more step with HIP-event timing of every kernel on the engine's stream
-        ctx.profile_enable(True)
-        step()
         prof_detail = ctx.profile()
         ctx.profile_enable(False)
         prof = {}

@@ -48,6 +48,8 @@ class Communicator:
         self.bytes_moved = 0
         self.n_allgather = 0
         self.n_alltoall = 0
+        # gloo transport with device-resident engine buffers (tests on a single-GPU box): stage through the host
+        self.stage = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
         self._ag = _AG(self._allgather)
         self._a2a = _A2A(self._alltoallv)
         self.struct = CommStruct(self.rank, self.size, None, self._ag, self._a2a)
@@ -60,7 +62,12 @@ class Communicator:
         try:
             s = _view(send, nbytes, self.device)
             r = _view(recv, nbytes * self.size, self.device)
-            dist.all_gather_into_tensor(r, s, group=self.group)      # also at size 1: same code path as N > 1
+            if self.stage:
+                hs, hr = s.cpu(), torch.empty(nbytes * self.size, dtype=torch.uint8)
+                dist.all_gather_into_tensor(hr, hs, group=self.group)
+                r.copy_(hr)
+            else:
+                dist.all_gather_into_tensor(r, s, group=self.group)      # also at size 1: same code path as N > 1
             self._sync()
             self.bytes_moved += nbytes * self.size
             self.n_allgather += 1
@@ -75,7 +82,12 @@ class Communicator:
             rb = [int(recv_bytes[i]) for i in range(self.size)]
             s = _view(send, sum(sb), self.device)
             r = _view(recv, sum(rb), self.device)
-            dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+            if self.stage:
+                hs, hr = s.cpu(), torch.empty(sum(rb), dtype=torch.uint8)
+                dist.all_to_all_single(hr, hs, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+                r.copy_(hr)
+            else:
+                dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
             self._sync()
             self.bytes_moved += sum(sb)
             self.n_alltoall += 1

@@ -22,6 +22,9 @@ def main():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         device = "cuda:%d" % torch.cuda.current_device()
+    elif backend == "gloo-cuda":       # two ranks sharing one GPU, gloo transport staged through the host
+        dist.init_process_group("gloo")
+        device = "cuda:0"
     else:
         dist.init_process_group("gloo")
         device = "cpu"
@@ -35,6 +38,8 @@ def main():
     elif case == "tokens":
         data = workloads.zipf_tokens(30000, doc_len=100, vocab=3000)
         w = 2
+    elif case == "reads_big":
+        data = workloads.sampled_reads(60001, 100, 400000, seed=13)
     elif case == "tiny":
         data = np.frombuffer(b"A\n\nA\nGATTACA\nGATTACA\nT\n", dtype=np.uint8)
     else:
