@@ -114,3 +114,52 @@ def uniform_reads_torch(n_reads, read_len, seed=20260001, device="cuda", chunk_r
         view[r0:r1, read_len] = 10
         del idx, z, base
     return out
+
+
+def _splitmix64_torch(seed, i0, i1, device):
+    """splitmix64 outputs number i0+1 .. i1 for `seed` as int64 (bit pattern of the uint64 value)."""
+    import torch
+    golden, m1, m2 = -7046029254386353131, -4658895280553007687, -7723592293110705685
+    s0 = seed if seed < (1 << 63) else seed - (1 << 64)
+    idx = torch.arange(i0 + 1, i1 + 1, dtype=torch.int64, device=device)
+    z = s0 + idx * golden
+    z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * m1
+    z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * m2
+    return z ^ ((z >> 31) & ((1 << 33) - 1))
+
+
+def sampled_reads_torch(n_reads, read_len, genome_len, seed=20260003, err=0.005, device="cuda", chunk_reads=2_000_000):
+    """Same bytes as sampled_reads() (config 4: Illumina-style reads from a random genome, substitution errors),
+    generated on `device`."""
+    import torch
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    g = torch.empty(genome_len, dtype=torch.uint8, device=device)
+    for a in range(0, genome_len, 1 << 26):
+        b = min(genome_len, a + (1 << 26))
+        g[a:b] = acgt[(_splitmix64_torch(seed, a, b, device) >> 62) & 3]
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    code[acgt.long()] = torch.arange(4, device=device)
+    out = torch.empty(n_reads * (read_len + 1), dtype=torch.uint8, device=device)
+    view = out.view(n_reads, read_len + 1)
+    ar = torch.arange(read_len, dtype=torch.int64, device=device)
+    span = genome_len - read_len
+    for r0 in range(0, n_reads, chunk_reads):
+        r1 = min(n_reads, r0 + chunk_reads)
+        z = _splitmix64_torch(seed + 1, r0, r1, device)
+        # uint64 modulo on int64 bit patterns: split off the sign bit
+        hi = (z >> 63) & 1
+        lo = z & ((1 << 63) - 1)
+        starts = (lo % span + hi * (pow(2, 63, span))) % span
+        bases = g[starts[:, None] + ar[None, :]]
+        if err > 0:
+            e = _splitmix64_torch(seed + 2, r0 * read_len, r1 * read_len, device).view(r1 - r0, read_len)
+            u = ((e >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / (1 << 53))
+            hit = u < err
+            shift = (e & 3) % 3 + 1
+            sub = acgt[(code[bases.long()] + shift) % 4]
+            bases = torch.where(hit, sub, bases)
+            del e, u, hit, shift, sub
+        view[r0:r1, :read_len] = bases
+        view[r0:r1, read_len] = 10
+        del z, hi, lo, starts, bases
+    return out
