@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1000000)
     ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--workload", default="uniform", choices=["uniform", "illumina"],
+                    help="uniform: BASELINE configs[1] shape (i.i.d. ACGT reads); illumina: configs[3] shape "
+                         "(--reads x 150 bp sampled from a --genome bp random genome, 0.5 %% substitutions)")
+    ap.add_argument("--genome", type=int, default=330000000)
     ap.add_argument("--cpu-sample-reads", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -103,7 +107,11 @@ def main():
     lib = g.build_hip()
     # shard of this rank: the named workload (rank 0) / same shape with another seed (other ranks)
     # generated on the device (bit-identical to workloads.uniform_reads on the host; tests/test_gpu_parity.py)
-    text = workloads.uniform_reads_torch(args.reads, args.read_len, seed=20260001 + rank, device=dev)
+    if args.workload == "illumina":
+        args.read_len = 150
+        text = workloads.sampled_reads_torch(args.reads, 150, args.genome, seed=20260003 + 10 * rank, device=dev)
+    else:
+        text = workloads.uniform_reads_torch(args.reads, args.read_len, seed=20260001 + rank, device=dev)
     n_bytes = int(text.numel())
     torch.cuda.synchronize()
 
@@ -215,8 +223,10 @@ def main():
             "metric": "input MB/s building BCR BWT (.rl_bwt) of DNA reads", "value": round(value, 3), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d x %d bp uniform ACGT reads per GPU (%d bytes), sigma=5, byte alphabet; "
-                                   "BASELINE configs[1]" % (args.reads, args.read_len, n_bytes),
+            "config": {"workload": ("%d x %d bp uniform ACGT reads per GPU (%d bytes), sigma=5, byte alphabet; BASELINE configs[1]"
+                                    % (args.reads, args.read_len, n_bytes)) if args.workload == "uniform" else
+                                   ("%d x 150 bp Illumina-style reads per GPU (%d bytes) from a %d bp genome, 0.5%% substitutions; "
+                                    "BASELINE configs[3] shape" % (args.reads, n_bytes, args.genome)),
                        "input_resident": "HBM", "output": ".rl_bwt image in HBM", "parallelism": ("1 GPU" if world == 1 else "collection of %d record shards, one per GPU: local hashing/emission, RCCL all-gather "
                                        "dictionary merge per round, induction replicated (round-1 form)" % world)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -1076,6 +1076,8 @@ class Engine {
         if (sizeof(idx_t) == 4 && n >= 0xFFFFFF00ull) throw prim::Error(-75, "input too large for the 32-bit index build");
         if (n >= kPosMask) throw prim::Error(-75, "input too large");
         cell_bytes = w; text0 = dev_cells; n0 = n;
+        // scratch for the whole build in one slab: ~22x the input for the 32-bit index build, ~30x for the 64-bit one
+        prim::pool_reserve((size_t)(n * (u64)w) * (sizeof(idx_t) == 4 ? 22 : 30));
         levels.clear(); linfo.clear(); kept_texts.clear(); kept_bwts.clear();
         parse_done = false; bwt_level = -1; image_bytes = 0;
         tm = Timers();

@@ -171,6 +171,27 @@ inline void *slab_take(Pool &P, int si, size_t need) {
     }
     return nullptr;
 }
+// Make sure one slab of at least `bytes` exists (capped to what the device has free): a build of a
+// multi-GB input then lives in ONE slab, so large blocks never fail for cross-slab fragmentation.
+inline void pool_reserve(size_t bytes) {
+    if (pool_disabled()) return;
+    Pool &P = pool();
+    for (auto &sl : P.slabs) if (sl.base && sl.size >= bytes) return;
+    size_t fr = 0, tot = 0;
+    (void)hipMemGetInfo(&fr, &tot);
+    size_t cap = fr > ((size_t)4 << 30) ? fr - ((size_t)2 << 30) : fr / 2;
+    if (bytes > cap) bytes = cap;
+    if (bytes < ((size_t)1 << 30)) return;          // the doubling schedule covers small builds
+    pool_trim();                                     // give idle slabs back first
+    void *base = nullptr;
+    if (hipMalloc(&base, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+    Slab sl;
+    sl.base = (char *)base; sl.size = bytes; sl.free_list.emplace(0, bytes);
+    P.slabs.insert(P.slabs.begin(), sl);             // first-fit looks here first
+    // slab indices of live blocks shift by one
+    for (auto &kv : P.live) kv.second.first += 1;
+    P.slab_bytes += bytes;
+}
 inline void *dev_alloc(size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (pool_disabled()) {

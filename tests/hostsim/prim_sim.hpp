@@ -92,6 +92,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
 }
 inline void pool_trim() {}
+inline void pool_reserve(size_t) {}
 inline u64 pool_peak_bytes() { return 0; }
 inline u64 pool_reserved_bytes() { return 0; }
 template <class T, class F>
