@@ -132,17 +132,23 @@ static constexpr u64 kLenSat = 4095;               // lengths >= 4095 saturate; 
 GRL_HD u64 key_len(u64 k) { return (k >> kPosBits) & 0xFFFull; }
 GRL_HD u64 key_pos(u64 k) { return (k & kPosMask) - 1; }
 
-GRL_HD u64 hash_mix(u64 h, u64 v) {
-    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-    h *= 0xFF51AFD7ED558CCDull;
-    h ^= h >> 32;
-    return h;
-}
-GRL_HD u64 hash_fin(u64 h, u64 len) {
-    h ^= len * 0xC2B2AE3D27D4EB4Full;
-    h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
-    return h;
-}
+// Phrase hash: two 32-bit multiplicative lanes per symbol (the walk is instruction-bound: a 64-bit
+// multiply per byte cost ~4x the ALU work), folded into 64 bits and finalised once per phrase.
+struct PhraseHash {
+    u32 a, b;
+    GRL_HD static PhraseHash init() { return PhraseHash{0x85A308D3u, 0x243F6A88u}; }
+    GRL_HD void add(u32 v) {
+        a = (a ^ v) * 0x9E3779B1u;
+        b = (b + v) * 0x85EBCA6Bu;
+        b ^= b >> 15;
+    }
+    GRL_HD u64 finish(u64 len) const {
+        u64 h = ((u64)a << 32) | (u64)b;
+        h ^= len * 0xC2B2AE3D27D4EB4Full;
+        h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+        return h;
+    }
+};
 
 // One lane per text position; lanes on a phrase start hash the phrase, find/claim its
 // slot and return the slot id (the caller counts it: prim::for_each_agg).
@@ -166,24 +172,27 @@ struct HashInsertFn {
         }
         return true;
     }
-    GRL_DEV u32 operator()(u64 p) const {
+    GRL_DEV bool is_start(u64 p) const { return (startbits[p >> 6] >> (p & 63)) & 1ull; }
+    GRL_DEV u32 operator()(u64 p) const { return is_start(p) ? process(p) : prim::kNoBucket; }
+    // p is a phrase start: hash the phrase, find/claim its slot, record it for this occurrence
+    GRL_DEV u32 process(u64 p) const {
         u64 w = startbits[p >> 6];
-        if (!((w >> (p & 63)) & 1ull)) return prim::kNoBucket;
         u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
-        u64 h = 0x243F6A8885A308D3ull, e = p;
+        PhraseHash ph = PhraseHash::init();
+        u64 e = p, wi = p >> 6, wcur = w;       // start-bit word of the current position stays in a register
         cell_t c = t[p];
         for (;;) {
-            h = hash_mix(h, (u64)ops.sym(c));
+            ph.add(ops.sym(c));
             if (ops.isT(c)) break;
             e++;
             if (e >= n) { scal[1] = 4; scal[2] = (u32)p; return prim::kNoBucket; }
             c = t[e];
-            if (bit_at(startbits, e)) { h = hash_mix(h, (u64)ops.sym(c)); break; }
+            if ((e >> 6) != wi) { wi = e >> 6; wcur = startbits[wi]; }
+            if ((wcur >> (e & 63)) & 1ull) { ph.add(ops.sym(c)); break; }
         }
         if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; return prim::kNoBucket; }
         u64 len = e - p + 1;
-        h = hash_fin(h, len);
-        u32 found = find_or_insert(p, len, h);
+        u32 found = find_or_insert(p, len, ph.finish(len));
         if (found != prim::kNoBucket) out_slot[ord] = found;
         return found;
     }
@@ -762,9 +771,9 @@ struct ListInsertFn {
     u32 *list_slot; u32 *scal;
     GRL_DEV void operator()(u64 i) const {
         u64 o = off[i], l = len[i];
-        u64 h = 0x243F6A8885A308D3ull;
-        for (u64 j = 0; j < l; j++) h = hash_mix(h, (u64)(cells[o + j] >> 2));
-        h = hash_fin(h, l);
+        PhraseHash ph = PhraseHash::init();
+        for (u64 j = 0; j < l; j++) ph.add(cells[o + j] >> 2);
+        u64 h = ph.finish(l);
         u64 tag = h >> kPosBits;
         u64 mine = (tag << kPosBits) | (i + 1);
         u64 slot = h & mask;
@@ -1434,7 +1443,11 @@ class Engine {
             DBuf<u32> ekey(E), ekey2(E);
             int bits = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
             if (bits < 1) bits = 1;
-            if (sizeof(idx_t) == 4) {           // payload (sym, len) rides through the split as one u64
+            // payload (sym, len) rides through the split as one u64 whenever every run length fits 32 bits
+            // (always in the 32-bit index build; in the 64-bit build unless a single run is >= 2^32 symbols long)
+            bool packed = sizeof(idx_t) == 4;
+            if (!packed) packed = prim::reduce_max<u64>(R, IdxIn<idx_t>{bwt.len.p}, "induce_maxrun") < 0xFFFFFFFFull;
+            if (packed) {
                 DBuf<u64> ep(E), ep2(E);
                 {
                     StageTimer st(&tm.ind_expand);

@@ -339,32 +339,62 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char *name = "b
 // open-addressing cache over its CONTIGUOUS chunk of the index space and flushes one
 // atomic per distinct id at the end; ids that do not fit the cache go straight to add().
 static constexpr u32 kNoBucket = 0xFFFFFFFFu;
-static constexpr int kAggSlots = 2048;
-template <class F, class A>
+// f.is_start(i): cheap test (is i a work item?);  f.process(i): the expensive, divergent part.
+// The measured kernel was instruction-issue bound by divergence (30 % of the lanes carry a phrase
+// at DNA phrase lengths; 577 SALU + 266 VALU instructions per wave iteration, mostly exec-mask
+// bookkeeping), so every workgroup first COMPACTS the work items of a 2048-position chunk into an
+// LDS queue (wave ballot + one LDS atomic per wave) and then runs process() with all lanes busy.
+static constexpr int kAggChunk = 2048;
+template <int SLOTS, bool AGG, class F, class A>
 __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F f, A add) {
-    __shared__ u32 c_key[kAggSlots];
-    __shared__ u32 c_cnt[kAggSlots];
-    for (int i = threadIdx.x; i < kAggSlots; i += kBlock) { c_key[i] = kNoBucket; c_cnt[i] = 0; }
-    __syncthreads();
+    __shared__ u32 c_key[AGG ? SLOTS : 1];
+    __shared__ u32 c_cnt[AGG ? SLOTS : 1];
+    __shared__ u32 s_queue[kAggChunk];
+    __shared__ u32 s_qn;
+    if (AGG) {
+        for (int i = threadIdx.x; i < SLOTS; i += kBlock) { c_key[i] = kNoBucket; c_cnt[i] = 0; }
+    }
+    const int lane = threadIdx.x & 63;
     u64 start = (u64)blockIdx.x * per_block;
     u64 end = start + per_block < n ? start + per_block : n;
-    for (u64 i = start + threadIdx.x; i < end; i += kBlock) {
-        u32 s = f(i);
-        if (s != kNoBucket) {
-            u32 h = (s * 2654435761u) >> 21;
-            bool done = false;
-            for (int p = 0; p < 8 && !done; p++) {
-                u32 old = atomicCAS(&c_key[h], kNoBucket, s);
-                if (old == kNoBucket || old == s) { atomicAdd(&c_cnt[h], 1u); done = true; }
-                else h = (h + 1) & (kAggSlots - 1);
+    for (u64 base = start; base < end; base += kAggChunk) {
+        __syncthreads();                      // queue consumed (and cache initialised on the first trip)
+        if (threadIdx.x == 0) s_qn = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kAggChunk / kBlock; k++) {
+            u64 i = base + (u64)k * kBlock + threadIdx.x;
+            bool st = (i < end) && f.is_start(i);
+            unsigned long long m = __ballot(st);
+            u32 wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&s_qn, (u32)__popcll(m));
+            wbase = __shfl(wbase, 0, 64);
+            if (st) s_queue[wbase + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)(i - base);
+        }
+        __syncthreads();
+        const u32 qn = s_qn;
+        for (u32 q = threadIdx.x; q < qn; q += kBlock) {
+            u32 s = f.process(base + s_queue[q]);
+            if (s != kNoBucket) {
+                if (AGG) {
+                    u32 h = (s * 2654435761u) >> (32 - __builtin_ctz(SLOTS));
+                    bool done = false;
+                    for (int p = 0; p < 4 && !done; p++) {
+                        u32 old = atomicCAS(&c_key[h], kNoBucket, s);
+                        if (old == kNoBucket || old == s) { atomicAdd(&c_cnt[h], 1u); done = true; }
+                        else h = (h + 1) & (SLOTS - 1);
+                    }
+                    if (!done) add(s, 1u);
+                } else add(s, 1u);
             }
-            if (!done) add(s, 1u);
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kAggSlots; i += kBlock) {
-        u32 c = c_cnt[i];
-        if (c) add(c_key[i], c);
+    if (AGG) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < SLOTS; i += kBlock) {
+            u32 c = c_cnt[i];
+            if (c) add(c_key[i], c);
+        }
     }
 }
 template <class F, class A>
@@ -375,12 +405,13 @@ struct NoAggFn {
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool aggregate, const char *name = "for_each_agg") {
     if (n == 0) return;
-    if (!aggregate || getenv("GRLBWT_NOAGG")) { for_each(n, NoAggFn<F, A>{f, add}, name); return; }
+    if (getenv("GRLBWT_NOAGG")) { for_each(n, NoAggFn<F, A>{f, add}, name); return; }
     u64 blocks = (u64)rt().num_cus * 8;
-    u64 per_block = ((n + blocks - 1) / blocks + kBlock - 1) / kBlock * kBlock;
+    u64 per_block = ((n + blocks - 1) / blocks + kAggChunk - 1) / kAggChunk * kAggChunk;
     blocks = (n + per_block - 1) / per_block;
     prof_begin(name);
-    hipLaunchKernelGGL((k_for_each_agg<F, A>), dim3((unsigned)blocks), dim3(kBlock), 0, rt().stream, n, per_block, f, add);
+    if (aggregate) hipLaunchKernelGGL((k_for_each_agg<2048, true, F, A>), dim3((unsigned)blocks), dim3(kBlock), 0, rt().stream, n, per_block, f, add);
+    else hipLaunchKernelGGL((k_for_each_agg<2048, false, F, A>), dim3((unsigned)blocks), dim3(kBlock), 0, rt().stream, n, per_block, f, add);
     prof_end();
     after_launch(name);
 }
