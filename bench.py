@@ -204,7 +204,7 @@ def main():
 
         # ---- CPU baseline leg (reported, not the target): the oracle ("port"), 1 core, bounded sample
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             from oracle import oracle
             oracle.build()
             m = min(args.cpu_sample_reads, args.reads)

@@ -558,12 +558,18 @@ struct IdxIn {
     const L *p;
     GRL_DEV idx_t operator()(u64 i) const { return (idx_t)p[i]; }
 };
+typedef prim::Pair<idx_t, idx_t> HeadLen;      // (#run heads, #symbols) scanned together
+struct HeadLenIn {
+    const u32 *s; const idx_t *len;
+    GRL_DEV HeadLen operator()(u64 t) const { return HeadLen((t == 0 || s[t] != s[t - 1]) ? (idx_t)1 : (idx_t)0, len[t]); }
+};
 struct MergeHeadsFn {
-    const u32 *sym; const idx_t *cum; const idx_t *ex; u64 n;
+    const u32 *sym; const HeadLen *ps; u64 n;
     u32 *osym; idx_t *ostart;
     GRL_DEV void operator()(u64 t) const {
-        if (t == 0 || sym[t] != sym[t - 1]) { idx_t r = ex[t]; osym[r] = sym[t]; ostart[r] = cum[t]; }
-        if (t == n - 1) ostart[ex[t] + ((t == 0 || sym[t] != sym[t - 1]) ? 1 : 0)] = cum[n];
+        bool head = (t == 0 || sym[t] != sym[t - 1]);
+        if (head) { idx_t r = ps[t].a; osym[r] = sym[t]; ostart[r] = ps[t].b; }
+        if (t == n - 1) ostart[ps[n].a] = ps[n].b;
     }
 };
 struct DiffFn {
@@ -582,22 +588,23 @@ struct Runs {
 };
 
 struct MergedIndexFn {   // merged run index of every input run
-    const u32 *sym; const idx_t *ex; u32 *map;
-    GRL_DEV void operator()(u64 t) const { map[t] = (u32)(ex[t] + ((t == 0 || sym[t] != sym[t - 1]) ? 1 : 0) - 1); }
+    const u32 *sym; const HeadLen *ps; u32 *map;
+    GRL_DEV void operator()(u64 t) const { map[t] = (u32)(ps[t].a + ((t == 0 || sym[t] != sym[t - 1]) ? 1 : 0) - 1); }
 };
-// merge adjacent equal symbols (bwt_io.h push_back/inc_freq_last idiom): -> maximal runs
+// merge adjacent equal symbols (bwt_io.h push_back/inc_freq_last idiom): -> maximal runs.
+// One fused scan gives every input run its output run index and its symbol offset.
 static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merged_index = nullptr) {
     Runs out;
     if (n == 0) { out.sym.alloc(0); out.len.alloc(0); return out; }
-    DBuf<idx_t> cum(n + 1), ex(n + 1);
-    prim::exclusive_scan<idx_t>(n, IdxIn<idx_t>{len}, cum.p, true, "merge_runs.cum");
-    u64 R = (u64)prim::exclusive_scan<idx_t>(n, SymHeadIdxIn{sym}, ex.p, false, "merge_runs.heads");
+    DBuf<HeadLen> ps(n + 1);
+    HeadLen tot = prim::exclusive_scan<HeadLen>(n, HeadLenIn{sym, len}, ps.p, true, "merge_runs.scan");
+    u64 R = (u64)tot.a;
     out.sym.alloc(R);
     out.len.alloc(R);
     DBuf<idx_t> ostart(R + 1);
-    prim::for_each(n, MergeHeadsFn{sym, cum.p, ex.p, n, out.sym.p, ostart.p}, "merge_runs.heads");
+    prim::for_each(n, MergeHeadsFn{sym, ps.p, n, out.sym.p, ostart.p}, "merge_runs.heads");
     prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
-    if (merged_index) prim::for_each(n, MergedIndexFn{sym, ex.p, merged_index}, "merge_runs.index");
+    if (merged_index) prim::for_each(n, MergedIndexFn{sym, ps.p, merged_index}, "merge_runs.index");
     out.R = R;
     return out;
 }

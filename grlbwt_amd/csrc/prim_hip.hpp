@@ -426,14 +426,34 @@ GRL_HD T op_identity() {
 }
 template <class T, Op OP>
 GRL_HD T op_apply(T a, T b) {
-    if (OP == Op::Sum) return a + b;
-    if (OP == Op::Min) return a < b ? a : b;
-    return a > b ? a : b;
+    if constexpr (OP == Op::Sum) return a + b;
+    else if constexpr (OP == Op::Min) return a < b ? a : b;
+    else return a > b ? a : b;
 }
+// two-component value for fused scans (e.g. run heads + run lengths in one pass)
+template <class A, class B>
+struct Pair {
+    A a; B b;
+    Pair() = default;                     // trivial: usable in __shared__ arrays
+    GRL_HD Pair(int) : a(0), b(0) {}
+    GRL_HD Pair(A a_, B b_) : a(a_), b(b_) {}
+    GRL_HD Pair &operator+=(const Pair &o) { a += o.a; b += o.b; return *this; }
+    GRL_HD Pair operator+(const Pair &o) const { return Pair(a + o.a, b + o.b); }
+    GRL_HD Pair operator-(const Pair &o) const { return Pair(a - o.a, b - o.b); }
+};
+template <class T>
+GRL_DEV T shfl_down_any(T v, int off) { return __shfl_down(v, off, 64); }
+template <class T>
+GRL_DEV T shfl_up_any(T v, int off) { return __shfl_up(v, off, 64); }
+template <class A, class B>
+GRL_DEV Pair<A, B> shfl_down_any(Pair<A, B> v, int off) { return Pair<A, B>(__shfl_down(v.a, off, 64), __shfl_down(v.b, off, 64)); }
+template <class A, class B>
+GRL_DEV Pair<A, B> shfl_up_any(Pair<A, B> v, int off) { return Pair<A, B>(__shfl_up(v.a, off, 64), __shfl_up(v.b, off, 64)); }
+
 template <class T, Op OP>
 GRL_DEV T wave_reduce(T v) {
     for (int off = 32; off > 0; off >>= 1) {
-        T o = __shfl_down(v, off, 64);
+        T o = shfl_down_any(v, off);
         v = op_apply<T, OP>(v, o);
     }
     return v;
@@ -485,7 +505,7 @@ template <class T>
 GRL_DEV T wave_incl_scan(T v) {
     int lane = threadIdx.x & 63;
     for (int off = 1; off < 64; off <<= 1) {
-        T o = __shfl_up(v, off, 64);
+        T o = shfl_up_any(v, off);
         if (lane >= off) v += o;
     }
     return v;

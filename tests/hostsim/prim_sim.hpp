@@ -102,6 +102,16 @@ inline T reduce_min(u64 n, F f, const char * = "") { T r = ~T(0); for (u64 i = 0
 template <class T, class F>
 inline T reduce_max(u64 n, F f, const char * = "") { T r = 0; for (u64 i = 0; i < n; i++) { T v = (T)f(i); if (v > r) r = v; } return r; }
 
+template <class A, class B>
+struct Pair {
+    A a; B b;
+    Pair() = default;
+    Pair(int) : a(0), b(0) {}
+    Pair(A a_, B b_) : a(a_), b(b_) {}
+    Pair &operator+=(const Pair &o) { a += o.a; b += o.b; return *this; }
+    Pair operator+(const Pair &o) const { return Pair(a + o.a, b + o.b); }
+    Pair operator-(const Pair &o) const { return Pair(a - o.a, b - o.b); }
+};
 template <class T>
 struct PtrIn {
     const T *p;
