@@ -1726,20 +1726,37 @@ class Engine {
         DBuf<u32> skey, ssym(E);
         DBuf<idx_t> slen(E);
         {
-            DBuf<u32> ekey(E), ekey2(E), esym(E);
-            DBuf<idx_t> eidx(E), eidx2(E), elen(E);
-            {
-                StageTimer st(&tm.ind_expand);
-                prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
-                                                       ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
-            }
-            StageTimer st(&tm.ind_sort);
+            DBuf<u32> ekey(E), ekey2(E);
             int bits = (int)bitlen64(M > 0 ? M - 1 : 0);
             if (bits < 1) bits = 1;
-            int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
-            prim::for_each(E, GatherCellFn{res ? eidx2.p : eidx.p, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
-            skey = std::move(res ? ekey2 : ekey);
-            prim::sync();
+            bool packed = sizeof(idx_t) == 4;
+            if (!packed) packed = prim::reduce_max<u64>(R, IdxIn<idx_t>{bwt.len.p}, "induce_maxrun") < 0xFFFFFFFFull;
+            if (packed) {
+                DBuf<u64> ep(E), ep2(E);
+                {
+                    StageTimer st(&tm.ind_expand);
+                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                                                          ekey.p, nullptr, nullptr, nullptr, ep.p, term.p}, "induce_expand");
+                }
+                StageTimer st(&tm.ind_sort);
+                int res = prim::sort_pairs<u32, u64>(ekey.p, ep.p, ekey2.p, ep2.p, E, 0, bits, "induce_split");
+                prim::for_each(E, UnpackCellFn{res ? ep2.p : ep.p, ssym.p, slen.p}, "induce_unpack");
+                skey = std::move(res ? ekey2 : ekey);
+                prim::sync();
+            } else {
+                DBuf<u32> esym(E);
+                DBuf<idx_t> eidx(E), eidx2(E), elen(E);
+                {
+                    StageTimer st(&tm.ind_expand);
+                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                                                           ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
+                }
+                StageTimer st(&tm.ind_sort);
+                int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
+                prim::for_each(E, GatherCellFn{res ? eidx2.p : eidx.p, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
+                skey = std::move(res ? ekey2 : ekey);
+                prim::sync();
+            }
         }
         eoff.release();
         StageTimer st(&tm.ind_assemble);
