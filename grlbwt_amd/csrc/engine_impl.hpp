@@ -262,15 +262,20 @@ struct LenIn {
     GRL_DEV u32 operator()(u64 i) const { return l[i]; }
 };
 template <class cell_t, bool FIRST>
-struct DictBuildFn {
+struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: one phrase search, then a forward walk
     const cell_t *t;
     CellOps<cell_t, FIRST> ops;
-    const u32 *ph_off; u64 D; const u64 *ph_pos;
+    const u32 *ph_off; u64 D; u64 S; const u64 *ph_pos;
     u32 *dict_sym; u32 *dict_phr;
-    GRL_DEV void operator()(u64 q) const {
-        u64 k = upper_bound<u32>(ph_off, D, (u32)q) - 1;
-        dict_phr[q] = (u32)k;
-        dict_sym[q] = ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
+    GRL_DEV void operator()(u64 c) const {
+        u64 q0 = c * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
+        u64 k = upper_bound<u32>(ph_off, D, (u32)q0) - 1;
+        u64 nxt = ph_off[k + 1];
+        for (u64 q = q0; q < q1; q++) {
+            while (q >= nxt) { k++; nxt = ph_off[k + 1]; }
+            dict_phr[q] = (u32)k;
+            dict_sym[q] = ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
+        }
     }
 };
 
@@ -394,19 +399,37 @@ struct SuffixRecFn {
     }
 };
 // Per equal-suffix group: min/max of the left symbol, sum of frequencies, "contains a whole
-// phrase".  Every group is cut into chunks of kGroupChunk consecutive members; the first lane
-// of a chunk folds it sequentially.  Groups of one chunk (the overwhelming majority) finish with
-// plain stores; larger groups combine their chunks with one set of atomics per chunk (32x fewer
-// same-address atomics than one per member).
+// phrase".  Groups of <= kGroupChunk members (the overwhelming majority) are folded by ONE LANE
+// PER GROUP with plain stores (GroupAccumSmallFn, every lane busy); larger groups are cut into chunks
+// of kGroupChunk consecutive members, each folded by its first lane and combined with one set of
+// atomics per chunk (GroupAccumLargeFn; 32x fewer same-address atomics than one per member).
 static constexpr u32 kGroupChunk = 32;
-struct GroupAccumFn {
+struct GroupAccumSmallFn {
+    const u32 *perm; const u32 *gstart; const u32 *rec_left; const idx_t *rec_freq;
+    u32 bwt_code;
+    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
+    GRL_DEV void operator()(u64 g) const {
+        u32 t0 = gstart[g], t1 = gstart[g + 1];
+        if (t1 - t0 > kGroupChunk) return;
+        u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
+        for (u32 j = t0; j < t1; j++) {
+            u64 q = perm[j];
+            u32 left = rec_left[q];
+            mn = left < mn ? left : mn; mx = left > mx ? left : mx;
+            acc += rec_freq[q];
+            fl |= (left == bwt_code) ? 1 : 0;
+        }
+        gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
+    }
+};
+struct GroupAccumLargeFn {
     const u32 *perm; const u32 *gid; const u32 *gstart; const u32 *rec_left; const idx_t *rec_freq;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
     GRL_DEV void operator()(u64 t) const {
         u32 g = gid[t];
         u32 t0 = gstart[g], t1 = gstart[g + 1];
-        if (((u32)t - t0) % kGroupChunk != 0) return;
+        if (t1 - t0 <= kGroupChunk || ((u32)t - t0) % kGroupChunk != 0) return;
         u32 te = (u32)t + kGroupChunk < t1 ? (u32)t + kGroupChunk : t1;
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = (u32)t; j < te; j++) {
@@ -416,7 +439,6 @@ struct GroupAccumFn {
             acc += rec_freq[q];
             fl |= (left == bwt_code) ? 1 : 0;
         }
-        if (t1 - t0 <= kGroupChunk) { gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl; return; }
         prim::atomic_min(&gmin[g], mn);
         prim::atomic_max(&gmax[g], mx);
         prim::atomic_add(&gacc[g], acc);
@@ -1238,7 +1260,7 @@ class Engine {
         DBuf<u32> dict_sym(S), dict_phr(S);
         {
             StageTimer st(&tm.dict_sort);
-            prim::for_each(S, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
+            prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
         }
         // ---- a6: sort all phrase suffixes (radix + filtered prefix doubling) ----------
         DBuf<u32> perm(S), gid(S), rank(S), gstart(S + 1);
@@ -1306,8 +1328,10 @@ class Engine {
                 DBuf<u32> rec_left(S);
                 DBuf<idx_t> rec_freq(S);
                 prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec_left.p, rec_freq.p}, "suffix_records");
-                prim::for_each(S, GroupAccumFn{perm.p, gid.p, gstart.p, rec_left.p, rec_freq.p, bwt_code,
-                                               gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+                prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec_left.p, rec_freq.p, bwt_code,
+                                                    gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+                prim::for_each(S, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec_left.p, rec_freq.p, bwt_code,
+                                                    gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum_large");
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
