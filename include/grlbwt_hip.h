@@ -18,6 +18,11 @@
  *
  * There is no CPU fallback: without a usable HIP device grlbwt_ctx_create fails
  * with GRLBWT_EDEVICE.
+ *
+ * Process model: ONE context (= one GPU) per process, as in the one-process-per-GPU launch of
+ * torch.distributed; the device, the engine's HIP stream and its slab allocator are process-wide.
+ * The engine runs on its own non-blocking stream: data handed over with grlbwt_text_attach_device must
+ * be complete (synchronise the producing stream first), results are complete when a call returns.
  */
 #ifndef GRLBWT_HIP_H
 #define GRLBWT_HIP_H
