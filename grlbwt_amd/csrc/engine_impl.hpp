@@ -164,9 +164,14 @@ struct HashInsertFn {
     u32 *out_slot;    // [n_occ] slot of every phrase occurrence, text order
     u32 *scal;        // [1] error flag, [2..3] debug
     u64 n, n_occ;
+    static constexpr u64 kCh = 8 / sizeof(cell_t);    // cells per 8-byte chunk
+    GRL_DEV static u64 load8(const cell_t *a) { u64 v; __builtin_memcpy(&v, a, 8); return v; }   // unaligned 8-byte load
     GRL_DEV bool same_phrase(u64 q, u64 p, u64 len, bool check_bits) const {
         if (q + len > n) { scal[1] = 3; scal[2] = (u32)q; scal[3] = (u32)len; return false; }
-        for (u64 j = 0; j < len; j++) {
+        u64 j = 0;
+        if (!check_bits)                                // 8 bytes per load: long phrases are latency-bound per load
+            for (; j + kCh <= len; j += kCh) if (load8(t + q + j) != load8(t + p + j)) return false;
+        for (; j < len; j++) {
             if (t[q + j] != t[p + j]) return false;
             if (check_bits && j > 0 && bit_at(startbits, q + j) != bit_at(startbits, p + j)) return false;
         }
@@ -179,16 +184,33 @@ struct HashInsertFn {
         u64 w = startbits[p >> 6];
         u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
         PhraseHash ph = PhraseHash::init();
-        u64 e = p, wi = p >> 6, wcur = w;       // start-bit word of the current position stays in a register
+        u64 e = p;                               // last cell taken so far
         cell_t c = t[p];
-        for (;;) {
-            ph.add(ops.sym(c));
-            if (ops.isT(c)) break;
+        ph.add(ops.sym(c));
+        bool done = ops.isT(c);
+        // cells are taken 8 bytes at a time while that stays inside the text (one load covers a whole DNA phrase;
+        // phrases of millions of cells -- e.g. N-runs -- would otherwise pay one memory latency per cell)
+        while (!done && e + 1 + kCh <= n) {
+            u64 chunk = load8(t + e + 1);
+            u64 b0 = e + 1;
+            u64 bits = startbits[b0 >> 6] >> (b0 & 63);
+            if ((b0 & 63) + kCh > 64) bits |= startbits[(b0 >> 6) + 1] << (64 - (b0 & 63));
+#pragma unroll
+            for (u64 j = 0; j < kCh; j++) {
+                if (!done) {
+                    cell_t cj = (cell_t)(sizeof(cell_t) == 8 ? chunk : (chunk >> (8 * sizeof(cell_t) * j)));
+                    ph.add(ops.sym(cj));
+                    e = b0 + j;
+                    done = ((bits >> j) & 1ull) || ops.isT(cj);
+                }
+            }
+        }
+        while (!done) {                           // tail of the text: cell by cell
             e++;
             if (e >= n) { scal[1] = 4; scal[2] = (u32)p; return prim::kNoBucket; }
             c = t[e];
-            if ((e >> 6) != wi) { wi = e >> 6; wcur = startbits[wi]; }
-            if ((wcur >> (e & 63)) & 1ull) { ph.add(ops.sym(c)); break; }
+            ph.add(ops.sym(c));
+            done = bit_at(startbits, e) || ops.isT(c);
         }
         if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; return prim::kNoBucket; }
         u64 len = e - p + 1;
