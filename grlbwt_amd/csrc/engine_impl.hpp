@@ -869,6 +869,119 @@ struct LocalValFn {       // metasymbol of my k-th local phrase through the merg
     GRL_DEV void operator()(u64 k) const { val[k] = gval[slot_ph[list_slot[my_first + k]]]; }
 };
 
+// ---- distributed dictionary stage functors ---------------------------------------------
+// Suffixes are partitioned over the ranks by ranges of their packed first-pass key (equal suffixes have
+// equal keys, so a group never spans two ranks and rank order = sorted order).  Positional ranks are
+// global slots (base of the rank + local slot); after every pass the ranks of the (re)sorted suffixes
+// are exchanged as (position, rank) pairs.
+struct OwnFlagIn {
+    const u64 *key0; u64 lo, hi; bool has_hi;
+    GRL_DEV u32 operator()(u64 q) const { u64 k = key0[q]; return (k >= lo && (!has_hi || k < hi)) ? 1u : 0u; }
+};
+struct OwnCompactFn {
+    const u64 *key0; const u32 *ex; u64 lo, hi; bool has_hi; u64 *ka; u32 *va;
+    GRL_DEV void operator()(u64 q) const {
+        u64 k = key0[q];
+        if (k >= lo && (!has_hi || k < hi)) { u32 i = ex[q]; ka[i] = k; va[i] = (u32)q; }
+    }
+};
+struct LessIn {
+    const u64 *key0; u64 lo;
+    GRL_DEV u64 operator()(u64 q) const { return key0[q] < lo ? 1ull : 0ull; }
+};
+struct SampleKeysFn {
+    const u64 *key0; u64 stride; u64 *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = key0[i * stride]; }
+};
+struct RankAllBaseFn {
+    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 base; u32 *rank; u64 *pairs;
+    GRL_DEV void operator()(u64 t) const {
+        u32 q = perm[t], r = base + gstart[ex[t] + hflag[t] - 1];
+        rank[q] = r;
+        pairs[t] = ((u64)q << 32) | r;
+    }
+};
+struct RankRefinedBaseFn {
+    const u32 *uslot; const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 base; u32 *rank; u64 *pairs;
+    GRL_DEV void operator()(u64 i) const {
+        u32 t = uslot[i], q = perm[t], r = base + gstart[ex[t] + hflag[t] - 1];
+        rank[q] = r;
+        pairs[i] = ((u64)q << 32) | r;
+    }
+};
+struct ApplyPairsFn {     // value[pair >> 32] = low 32 bits
+    const u64 *pairs; u32 *value;
+    GRL_DEV void operator()(u64 i) const { u64 p = pairs[i]; value[p >> 32] = (u32)p; }
+};
+struct GroupEmitDistFn {  // like GroupEmitFn, local outputs; pre-BWT indices become global through p_off
+    const u8 *gflag; const u32 *grank; const u32 *pidx; const u32 *gmin; const idx_t *gacc; const u32 *gstart; const u32 *perm;
+    u32 bwt_code, hocc_code, p_off;
+    u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq; u32 *u_to_p0;
+    GRL_DEV void operator()(u64 g) const {
+        u8 f = gflag[g];
+        if (!(f & GF_VALID)) return;
+        u32 j = pidx[g];
+        u32 s = gmin[g];
+        if (f & GF_RANKED) {
+            s = (f & GF_MULTI) ? hocc_code : bwt_code;
+            u32 u = grank[g];
+            has_hocc[u] = (f & GF_MULTI) ? 1 : 0;
+            repq[u] = perm[gstart[g]];
+            u_to_p0[u] = j + p_off;
+        }
+        psym[j] = s;
+        plen[j] = gacc[g];
+    }
+};
+struct MarkFlagIn {       // slot belongs to a ranked group with > 1 member
+    const u32 *gid; const u8 *gflag;
+    GRL_DEV u32 operator()(u64 t) const { return ((gflag[gid[t]] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1u : 0u; }
+};
+struct MarkPairFn {
+    const u32 *gid; const u8 *gflag; const u32 *ex; const u32 *perm; const u32 *grank; u32 m_off; u64 *pairs;
+    GRL_DEV void operator()(u64 t) const {
+        u32 g = gid[t];
+        if ((gflag[g] & (GF_RANKED | GF_MULTI)) != (GF_RANKED | GF_MULTI)) return;
+        pairs[ex[t]] = ((u64)perm[t] << 32) | (u64)(m_off + grank[g]);
+    }
+};
+struct FullFlagIn {       // slot is the whole-phrase suffix of its phrase
+    const u32 *perm; const u32 *dict_phr; const u32 *ph_off;
+    GRL_DEV u32 operator()(u64 t) const { u32 q = perm[t]; return (q == ph_off[dict_phr[q]]) ? 1u : 0u; }
+};
+struct FullPairFn {
+    const u32 *perm; const u32 *dict_phr; const u32 *ph_off; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
+    GRL_DEV void operator()(u64 t) const {
+        u32 q = perm[t], k = dict_phr[q];
+        if (q != ph_off[k]) return;
+        pairs[ex[t]] = ((u64)k << 32) | (u64)(m_off + grank[gid[t]]);
+    }
+};
+struct GrammarDistFn {    // GrammarFn over the replicated position -> metasymbol map of the marked positions
+    const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT; const u32 *mark_rank;
+    u32 sigma3, MD;
+    u32 *g0; u32 *g1;
+    GRL_DEV void operator()(u64 u) const {
+        u64 q = repq[u];
+        u32 k = dict_phr[q];
+        u64 e = (u64)ph_off[k + 1] - 1;
+        if (q == e) { g0[u] = MD; g1[u] = dict_sym[q]; return; }
+        u64 x = q + 1;
+        for (;;) {
+            u32 mr = mark_rank[x];
+            if (mr != 0xFFFFFFFFu) { g0[u] = dict_sym[x - 1]; g1[u] = mr + sigma3; return; }
+            if (x == e) { g0[u] = MD; g1[u] = ph_lastT[k] ? dict_sym[e] : dict_sym[e - 1]; return; }
+            x++;
+        }
+    }
+};
+struct PhraseValDistFn {
+    const u32 *phrase_rank; const idx_t *ph_freq; const u8 *ph_lastT; u32 *phrase_val;
+    GRL_DEV void operator()(u64 k) const {
+        phrase_val[k] = (phrase_rank[k] << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
+    }
+};
+
 // ---- distributed induction functors -------------------------------------------------
 struct BucketSumFn {      // per bucket u: my cells' symbol count, my TAKE symbol count, my first cell
     const u32 *skey; u64 E; const idx_t *lH; const idx_t *lT;
@@ -1661,6 +1774,166 @@ class Engine {
         cur_sigma = (u32)(mx + 1);
     }
 
+    // a5-a8 over the merged dictionary with the suffix sort and the group stage SHARDED over the ranks
+    // (see the functor block above); grammar and the O(S) streaming passes stay replicated.
+    void dict_stage_dist(const Comm &C, const u32 *t, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
+                         const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val) {
+        CellOps<u32, false> ops{0u};
+        L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
+        const u32 bwt_code = sigma + 1, hocc_code = sigma + 2, sigma3 = sigma + 3;
+        DBuf<u32> dict_sym(S), dict_phr(S), suflen(S), rank(S);
+        DBuf<u64> key0(S);
+        int b = (int)bitlen64(sigma);
+        if (b < 1) b = 1;
+        int K = 48 / b;
+        if (K < 1) K = 1;
+        if (K > 16) K = 16;
+        if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
+        u64 lo = 0, hi = 0;
+        bool has_hi = false;
+        {
+            StageTimer st(&tm.dict_sort);
+            prim::for_each((S + 15) / 16, DictBuildFn<u32, false>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
+            prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
+            prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, key0.p, rank.p}, "suffix_keys0");   // rank used as scratch
+            // splitters: quantiles of a strided sample of the keys (identical on every rank: replicated data)
+            u64 ns = S < 8192 ? S : 8192, stride = S / ns;
+            DBuf<u64> samp(ns);
+            prim::for_each(ns, SampleKeysFn{key0.p, stride, samp.p}, "dist.sample_keys");
+            std::vector<u64> hs = samp.to_host(ns);
+            std::sort(hs.begin(), hs.end());
+            if (C.rank > 0) lo = hs[(u64)C.rank * ns / C.size];
+            if (C.rank + 1 < C.size) { hi = hs[(u64)(C.rank + 1) * ns / C.size]; has_hi = true; }
+            if (has_hi && hi < lo) hi = lo;
+        }
+        // ---- my suffixes: compact, sort, first ranks ------------------------------------------
+        u64 Sg, base_g;
+        DBuf<u32> perm, gid, gstart;
+        u64 Gg = 0;
+        {
+            StageTimer st(&tm.dict_sort);
+            DBuf<u32> oex(S + 1);
+            Sg = prim::exclusive_scan<u32>(S, OwnFlagIn{key0.p, lo, hi, has_hi}, oex.p, false, "dist.own_scan");
+            base_g = prim::reduce_sum<u64>(S, LessIn{key0.p, lo}, "dist.base");
+            perm.alloc(Sg); gid.alloc(Sg); gstart.alloc(Sg + 1);
+            DBuf<u8> hflag(Sg), uflag(Sg);
+            DBuf<u32> ex(Sg + 1);
+            {
+                DBuf<u64> ka(Sg), kb(Sg);
+                DBuf<u32> vb(Sg);
+                prim::for_each(S, OwnCompactFn{key0.p, oex.p, lo, hi, has_hi, ka.p, perm.p}, "dist.own_compact");
+                const u64 *ks = ka.p;
+                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, Sg, 0, K * b, "suffix_sort0")) {
+                    prim::d2d(perm.p, vb.p, Sg * sizeof(u32));
+                    ks = kb.p;
+                }
+                prim::for_each(Sg, HeadFlagFn{ks, hflag.p}, "suffix_heads");
+                prim::sync();
+            }
+            oex.release(); key0.release();
+            Gg = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+            prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
+            {
+                DBuf<u64> pairs(Sg);
+                prim::for_each(Sg, RankAllBaseFn{hflag.p, ex.p, gstart.p, perm.p, (u32)base_g, rank.p, pairs.p}, "suffix_ranks");
+                std::vector<u64> pb;
+                DBuf<u64> all = C.allgather_v<u64>(pairs.p, Sg, pb);
+                prim::for_each(pb[C.size], ApplyPairsFn{all.p, rank.p}, "dist.apply_ranks");
+            }
+            const int lowbits = (int)bitlen64(S);
+            u64 Lres = (u64)K, iters = 1;
+            while (Lres < maxlen) {
+                prim::for_each(Sg, UnresolvedFlagFn{hflag.p, ex.p, gstart.p, perm.p, suflen.p, Lres, uflag.p}, "suffix_unresolved");
+                DBuf<u32> uex(Sg + 1);
+                u64 U = prim::exclusive_scan<u32>(Sg, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
+                DBuf<u64> pairs(U);
+                if (U > 0) {
+                    DBuf<u64> ka(U), kb(U);
+                    DBuf<u32> va(U), vb(U), uslot(U);
+                    prim::for_each(Sg, UnresolvedKeyFn{uflag.p, uex.p, perm.p, rank.p, suflen.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
+                    int res = prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort");
+                    prim::for_each(U, RefineWriteFn{res ? kb.p : ka.p, res ? vb.p : va.p, uslot.p, perm.p, hflag.p}, "suffix_refine");
+                    Gg = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+                    prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
+                    prim::for_each(U, RankRefinedBaseFn{uslot.p, hflag.p, ex.p, gstart.p, perm.p, (u32)base_g, rank.p, pairs.p}, "suffix_ranks");
+                }
+                // every rank takes part in the exchange of this pass, also with nothing to refine
+                std::vector<u64> pb;
+                DBuf<u64> all = C.allgather_v<u64>(pairs.p, U, pb);
+                if (pb[C.size] == 0) break;                 // nothing left anywhere (same decision on every rank)
+                prim::for_each(pb[C.size], ApplyPairsFn{all.p, rank.p}, "dist.apply_ranks");
+                Lres *= 2;
+                iters++;
+            }
+            prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
+            prim::sync();
+            L.info.sort_iters = iters;
+        }
+        // ---- my groups ----------------------------------------------------------------------------
+        StageTimer st(&tm.dict_groups);
+        DBuf<u32> grank(Gg + 1), pidx(Gg + 1), gmin(Gg), gmax(Gg);
+        DBuf<idx_t> gacc(Gg);
+        DBuf<u8> gfull(Gg), gflag(Gg);
+        gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
+        {
+            DBuf<u32> rec_left(S);
+            DBuf<idx_t> rec_freq(S);
+            prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec_left.p, rec_freq.p}, "suffix_records");
+            prim::for_each(Gg, GroupAccumSmallFn{perm.p, gstart.p, rec_left.p, rec_freq.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+            prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec_left.p, rec_freq.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p},
+                           "group_accum_large");
+        }
+        prim::for_each(Gg, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
+        u64 Mg = prim::exclusive_scan<u32>(Gg, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
+        u64 P0g = prim::exclusive_scan<u32>(Gg, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
+        std::vector<u64> cnts = C.allgather_u64({Mg, P0g});
+        u64 Moff = 0, P0off = 0, M = 0, P0 = 0;
+        for (int g = 0; g < C.size; g++) {
+            if (g < C.rank) { Moff += cnts[2 * g]; P0off += cnts[2 * g + 1]; }
+            M += cnts[2 * g]; P0 += cnts[2 * g + 1];
+        }
+        if ((u64)sigma3 + M + 8 >= (1ull << 30)) throw prim::Error(-75, "alphabet of the next level >= 2^30");
+        L.M = (u32)M;
+        DBuf<u32> psym0_l(P0g), repq_l(Mg), u2p0_l(Mg);
+        DBuf<idx_t> plen0_l(P0g);
+        DBuf<u8> hh_l(Mg);
+        prim::for_each(Gg, GroupEmitDistFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code, (u32)P0off,
+                                           psym0_l.p, plen0_l.p, hh_l.p, repq_l.p, u2p0_l.p}, "prebwt_emit");
+        std::vector<u64> bb;
+        DBuf<u32> psym0 = C.allgather_v<u32>(psym0_l.p, P0g, bb);
+        DBuf<idx_t> plen0 = C.allgather_v<idx_t>(plen0_l.p, P0g, bb);
+        L.has_hocc = C.allgather_v<u8>(hh_l.p, Mg, bb);
+        DBuf<u32> repq = C.allgather_v<u32>(repq_l.p, Mg, bb);
+        DBuf<u32> u_to_p0 = C.allgather_v<u32>(u2p0_l.p, Mg, bb);
+        DBuf<u32> merged(P0);
+        L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
+        L.u_to_p.alloc(M);
+        prim::for_each(M, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
+        // marked positions -> metasymbol, whole phrases -> metasymbol (exchanged as pairs, applied on every rank)
+        DBuf<u32> mark_rank(S), phrase_rank(D);
+        mark_rank.fill_ff(); phrase_rank.fill_ff();
+        {
+            DBuf<u32> mex(Sg + 1);
+            u64 nm = prim::exclusive_scan<u32>(Sg, MarkFlagIn{gid.p, gflag.p}, mex.p, false, "dist.mark_scan");
+            DBuf<u64> mp(nm);
+            prim::for_each(Sg, MarkPairFn{gid.p, gflag.p, mex.p, perm.p, grank.p, (u32)Moff, mp.p}, "dist.mark_pairs");
+            DBuf<u64> all = C.allgather_v<u64>(mp.p, nm, bb);
+            prim::for_each(bb[C.size], ApplyPairsFn{all.p, mark_rank.p}, "dist.apply_marks");
+            u64 nf = prim::exclusive_scan<u32>(Sg, FullFlagIn{perm.p, dict_phr.p, ph_off}, mex.p, false, "dist.full_scan");
+            DBuf<u64> fp(nf);
+            prim::for_each(Sg, FullPairFn{perm.p, dict_phr.p, ph_off, mex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
+            DBuf<u64> allf = C.allgather_v<u64>(fp.p, nf, bb);
+            if (bb[C.size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+            prim::for_each(D, ApplyPairsFn{allf.p, phrase_rank.p}, "dist.apply_phrase_ranks");
+        }
+        L.g0.alloc(M); L.g1.alloc(M);
+        u32 MD = sigma3 + (u32)M + 1;
+        prim::for_each(M, GrammarDistFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, mark_rank.p, sigma3, MD, L.g0.p, L.g1.p}, "grammar");
+        phrase_val.alloc(D);
+        prim::for_each(D, PhraseValDistFn{phrase_rank.p, ph_freq, ph_lastT, phrase_val.p}, "phrase_values");
+        L.info.M = M;
+    }
+
     template <class cell_t, bool FIRST>
     void dist_round_t(const Comm &C, const cell_t *t, u64 n, u32 sigma, cell_t sep) {
         CellOps<cell_t, FIRST> ops{sep};
@@ -1710,9 +1983,12 @@ class Engine {
         u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dist.dict_syms");
         if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
         u64 S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dist.dict_offsets");
-        // ---- the dictionary stage runs replicated on every rank (its result is canonical) -------
+        // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar replicated ----
         DBuf<u32> gval;
-        dict_stage<u32, false>(gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p, ph_off.p, ph_lastT.p, sigma, L, gval);
+        if (getenv("GRLBWT_DIST_REPLICATED_DICT"))
+            dict_stage<u32, false>(gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p, ph_off.p, ph_lastT.p, sigma, L, gval);
+        else
+            dict_stage_dist(C, gcells.p, D, S, maxlen, ph_pos.p, ph_freq.p, ph_off.p, ph_lastT.p, sigma, L, gval);
         // ---- back to the local parse ---------------------------------------------------------
         DBuf<u32> lval(P.D);
         prim::for_each(P.D, LocalValFn{list_slot.p, slot_ph.p, gval.p, dbase[C.rank], lval.p}, "dist.local_values");

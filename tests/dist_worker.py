@@ -40,6 +40,10 @@ def main():
         w = 2
     elif case == "reads_big":
         data = workloads.sampled_reads(60001, 100, 400000, seed=13)
+    elif case == "longruns":       # long equal runs and long phrases: many refinement passes, empty key ranges
+        parts = [b"A" * 3000 + b"C" * 2000 + b"\n", b"ACGT" * 900 + b"\n", b"\n" * 40, b"T" * 5000 + b"\n",
+                 b"A" * 3000 + b"C" * 2000 + b"\n", b"G" * 100 + b"ACGT" * 50 + b"\n"] * 3
+        data = np.frombuffer(b"".join(parts), dtype=np.uint8)
     elif case == "tiny":
         data = np.frombuffer(b"A\n\nA\nGATTACA\nGATTACA\nT\n", dtype=np.uint8)
     else:

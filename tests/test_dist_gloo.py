@@ -29,9 +29,10 @@ def _run(world, lib, case, out_dir, port):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("world,case", [(2, "reads"), (2, "tokens"), (3, "uniform"), (2, "repetitive"), (3, "tiny")])
+@pytest.mark.parametrize("world,case", [(2, "reads"), (2, "tokens"), (3, "uniform"), (2, "repetitive"), (3, "tiny"),
+                                        (4, "reads"), (3, "longruns")])
 def test_sharded_collection_matches_oracle(sim, oracle_mod, tmp_path, world, case):
-    port = 29500 + 7 * world + ['reads', 'tokens', 'uniform', 'repetitive', 'tiny'].index(case)
+    port = 29500 + 7 * world + ['reads', 'tokens', 'uniform', 'repetitive', 'tiny', 'longruns'].index(case)
     _run(world, sim, case, tmp_path, port)
     data = open(tmp_path / (case + ".input"), "rb").read()
     out = open(tmp_path / (case + ".rl_bwt"), "rb").read()
@@ -52,3 +53,10 @@ def test_replicated_induction_fallback_agrees(sim, oracle_mod, tmp_path, monkeyp
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
     n_ag, n_a2a, _ = map(int, open(tmp_path / "reads.rank0.comm").read().split())
     assert n_ag > 0 and n_a2a == 0
+
+
+def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
+    monkeypatch.setenv("GRLBWT_DIST_REPLICATED_DICT", "1")
+    _run(2, sim, "uniform", tmp_path, 29591)
+    data = open(tmp_path / "uniform.input", "rb").read()
+    assert open(tmp_path / "uniform.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
