@@ -851,22 +851,32 @@ struct ListInsertFn {
         list_slot[i] = found;
     }
 };
-struct ListCompactFn {
-    const u32 *cells; const u64 *off; const u32 *len;
-    const u64 *keys; const idx_t *counts; const u32 *slot_ph;
+// The merged dictionary must have the SAME layout on every rank (the sharded dictionary stage exchanges
+// dictionary positions): which duplicate wins a table slot is a race, so the representative of a phrase is
+// defined as its smallest list index and the phrases are numbered in the order of their representatives.
+struct SlotMinFn {        // slot_min[slot] = smallest list index mapped to the slot
+    const u32 *list_slot; u32 *slot_min;
+    GRL_DEV void operator()(u64 i) const { prim::atomic_min(&slot_min[list_slot[i]], (u32)i); }
+};
+struct IsRepIn {
+    const u32 *list_slot; const u32 *slot_min;
+    GRL_DEV u32 operator()(u64 i) const { return slot_min[list_slot[i]] == (u32)i ? 1u : 0u; }
+};
+struct ListPhraseFn {     // phrase k = rank of its representative among the representatives (list order)
+    const u32 *cells; const u64 *off; const u32 *len; const u32 *list_slot; const u32 *slot_min; const u32 *rep_ex;
+    const idx_t *counts;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u8 *ph_lastT;
-    GRL_DEV void operator()(u64 s) const {
-        u64 k64 = keys[s];
-        if (!k64) return;
-        u32 k = slot_ph[s];
-        u64 i = (k64 & kPosMask) - 1;
+    GRL_DEV void operator()(u64 i) const {
+        u32 s = list_slot[i];
+        if (slot_min[s] != (u32)i) return;
+        u32 k = rep_ex[i];
         ph_pos[k] = off[i]; ph_freq[k] = counts[s]; ph_len[k] = len[i];
         ph_lastT[k] = (u8)(cells[off[i] + len[i] - 1] & 1u);
     }
 };
 struct LocalValFn {       // metasymbol of my k-th local phrase through the merged dictionary
-    const u32 *list_slot; const u32 *slot_ph; const u32 *gval; u64 my_first; u32 *val;
-    GRL_DEV void operator()(u64 k) const { val[k] = gval[slot_ph[list_slot[my_first + k]]]; }
+    const u32 *list_slot; const u32 *slot_min; const u32 *rep_ex; const u32 *gval; u64 my_first; u32 *val;
+    GRL_DEV void operator()(u64 k) const { val[k] = gval[rep_ex[slot_min[list_slot[my_first + k]]]]; }
 };
 
 // ---- distributed dictionary stage functors ---------------------------------------------
@@ -1973,10 +1983,15 @@ class Engine {
         keys.zero(); counts.zero(); scal.zero();
         prim::for_each(Dl, ListInsertFn{gcells.p, goff.p, glen.p, gfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p}, "dist.merge_phrases");
         if (scal.to_host(2)[1]) throw prim::Error(-28, "merged phrase table overflow");
-        u64 D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "dist.merge_compact");
+        // deterministic layout: representatives = smallest list index per slot, phrases in representative order
+        DBuf<u32> &slot_min = slot_ph;           // [cap]
+        slot_min.fill_ff();
+        prim::for_each(Dl, SlotMinFn{list_slot.p, slot_min.p}, "dist.slot_min");
+        DBuf<u32> rep_ex(Dl + 1);
+        u64 D = prim::exclusive_scan<u32>(Dl, IsRepIn{list_slot.p, slot_min.p}, rep_ex.p, false, "dist.merge_compact");
         DBuf<u64> ph_pos(D); DBuf<idx_t> ph_freq(D); DBuf<u32> ph_len(D), ph_off(D + 1); DBuf<u8> ph_lastT(D);
-        prim::for_each(cap, ListCompactFn{gcells.p, goff.p, glen.p, keys.p, counts.p, slot_ph.p, ph_pos.p, ph_freq.p, ph_len.p, ph_lastT.p},
-                       "dist.merge_compact");
+        prim::for_each(Dl, ListPhraseFn{gcells.p, goff.p, glen.p, list_slot.p, slot_min.p, rep_ex.p, counts.p, ph_pos.p, ph_freq.p,
+                                        ph_len.p, ph_lastT.p}, "dist.merge_compact");
         u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dist.freq_check");
         if (fsum != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
         u32 maxlen = prim::reduce_max<u32>(D, LenIn{ph_len.p}, "dist.maxlen");
@@ -1991,7 +2006,7 @@ class Engine {
             dict_stage_dist(C, gcells.p, D, S, maxlen, ph_pos.p, ph_freq.p, ph_off.p, ph_lastT.p, sigma, L, gval);
         // ---- back to the local parse ---------------------------------------------------------
         DBuf<u32> lval(P.D);
-        prim::for_each(P.D, LocalValFn{list_slot.p, slot_ph.p, gval.p, dbase[C.rank], lval.p}, "dist.local_values");
+        prim::for_each(P.D, LocalValFn{list_slot.p, slot_min.p, rep_ex.p, gval.p, dbase[C.rank], lval.p}, "dist.local_values");
         emit_local(P, lval.p);
         finish_round(P, L, g_n_strings, occ_total);
     }
