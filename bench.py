@@ -234,8 +234,9 @@ def main():
                                     % (args.reads, args.read_len, n_bytes)) if args.workload == "uniform" else
                                    ("%d x 150 bp Illumina-style reads per GPU (%d bytes) from a %d bp genome, 0.5%% substitutions; "
                                     "BASELINE configs[3] shape" % (args.reads, n_bytes, args.genome)),
-                       "input_resident": "HBM", "output": ".rl_bwt image in HBM", "parallelism": ("1 GPU" if world == 1 else "collection of %d record shards, one per GPU: local hashing/emission, RCCL all-gather "
-                                       "dictionary merge per round, induction replicated (round-1 form)" % world)},
+                       "input_resident": "HBM", "output": ".rl_bwt image in HBM", "parallelism": ("1 GPU" if world == 1 else "ONE collection of %d record shards, one per GPU: local hashing/emission, RCCL all-gather "
+                                       "dictionary merge + key-range-sharded dictionary stage per round, induction sharded by BWT position "
+                                       "(per-bucket rank-count exchange, all-to-all atom routing)" % world)},
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
             "top_kernels": top, "roofline_by_kernel": others, "rounds": nr,
