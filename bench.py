@@ -162,13 +162,24 @@ def main():
     if rank == 0:
         prof_detail = ctx.profile()
         ctx.profile_enable(False)
-        prof = {}
-        for k, (c, ms) in prof_detail.items():      # fold the per-level tags ("name#level")
+        # fold the per-level tags ("name#level") and group launch sites by the kernel FUNCTION they launch, so that
+        # "dominant kernel" means the same thing as in the rocprofv3 --stats summary under profiles/
+        def kernel_of(site):
+            if site.endswith(".scatter"):
+                return "k_rs_scatter"
+            if site.endswith(".hist"):
+                return "k_rs_hist"
+            return site
+        prof, fam = {}, {}
+        for k, (c, ms, nb) in prof_detail.items():
             b = k.split("#")[0]
-            pc, pm = prof.get(b, (0, 0.0))
-            prof[b] = (pc + c, pm + ms)
+            pc, pm, pb = prof.get(b, (0, 0.0, 0))
+            prof[b] = (pc + c, pm + ms, pb + nb)
+            f = kernel_of(b)
+            fc, fm, fb = fam.get(f, (0, 0.0, 0))
+            fam[f] = (fc + c, fm + ms, fb + nb)
         if os.environ.get("GRLBWT_BENCH_DETAIL"):
-            for k, (c, ms) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:90]:
+            for k, (c, ms, nb) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:90]:
                 print("  %-32s %4d launches %9.3f ms" % (k, c, ms), file=sys.stderr)
         nr = 0
         rounds = []
@@ -181,31 +192,40 @@ def main():
         levels = [ctx.level_info(l) for l in range(nr)]
         cnt = ctx.counters()
         ib = cnt["idx_bytes"]
-        total_kernel_ms = sum(ms for _, ms in prof.values())
-        ranked = sorted(prof.items(), key=lambda kv: -kv[1][1])
+
+        def algo_bytes(kern):
+            c, ms, nb = fam[kern]
+            if nb:                       # stated at the launch site (radix sort passes: pairs read once + written once)
+                return nb
+            return algorithmic_bytes(kern, rounds, levels, 1, ib)
+
+        total_kernel_ms = sum(ms for _, ms, _ in fam.values())
+        ranked = sorted(fam.items(), key=lambda kv: -kv[1][1])
         dom = None
-        for name, (launches, ms) in ranked:
-            ab = algorithmic_bytes(name, rounds, levels, 1, ib)
-            if ab is not None:
+        for name, (launches, ms, nb) in ranked:
+            ab = algo_bytes(name)
+            if ab:
                 dom = (name, launches, ms, ab)
                 break
         roofline = None
         if dom:
             name, launches, ms, ab = dom
             achieved = ab / (ms * 1e-3) / 1e9
+            rocprof_name = {"hash_phrases": "HashInsertFn", "k_rs_scatter": "k_rs_scatter", "k_rs_hist": "k_rs_hist"}.get(name, name)
             roofline = {"bound": "hbm", "kernel": name, "launches": launches,
                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
-                        "traffic": pmc_traffic_per_launch({"hash_phrases": "HashInsertFn"}.get(name, name), launches),
-                        "algorithmic_bytes": ab, "kernel_ms_total": round(ms, 4),
-                        "avg_launch_ms": round(ms / max(launches, 1), 5),
+                        "traffic": pmc_traffic_per_launch(rocprof_name, launches),
+                        "algorithmic_bytes": ab, "algorithmic_bytes_per_launch": round(ab / max(launches, 1)),
+                        "kernel_ms_total": round(ms, 4), "avg_launch_ms": round(ms / max(launches, 1), 5),
                         "share_of_kernel_time": round(ms / max(total_kernel_ms, 1e-9), 4)}
-        top = [{"kernel": k, "launches": c, "ms": round(ms, 3)} for k, (c, ms) in ranked[:12]]
+        top = [{"kernel": k, "launches": c, "ms": round(ms, 3)} for k, (c, ms, _) in ranked[:12]]
         # the same accounting for every kernel with a stated algorithmic byte count
         others = []
-        for kname, (launches, ms) in ranked:
-            ab = algorithmic_bytes(kname, rounds, levels, 1, ib)
-            if ab is not None and ms > 0:
+        for kname, (launches, ms, nb) in sorted(list(fam.items()) + [(k, v) for k, v in prof.items() if k not in fam],
+                                                key=lambda kv: -kv[1][1]):
+            ab = nb if nb else algorithmic_bytes(kname, rounds, levels, 1, ib)
+            if ab and ms > 0:
                 others.append({"kernel": kname, "launches": launches, "ms": round(ms, 4),
                                "achieved_GBps": round(ab / (ms * 1e-3) / 1e9, 2), "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
 

@@ -431,7 +431,8 @@ int grlbwt_profile_dump(grlbwt_ctx *ctx, char *buf, uint64_t capacity) {
         std::string s;
         for (const auto &kv : prim::rt().prof) {
             char line[256];
-            snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.first, kv.second.second);
+            snprintf(line, sizeof line, "%s %llu %.6f %llu\n", kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.ms,
+                     (unsigned long long)kv.second.bytes);
             s += line;
         }
         size_t n = s.size() < capacity - 1 ? s.size() : (size_t)capacity - 1;

@@ -54,9 +54,10 @@ struct Runtime {
     bool trace = false;              // GRLBWT_TRACE=1: print every launch and synchronise after it
     bool profile = false;
     int tag = -1;                    // appended to profile names as "#<tag>" (the engine sets it to the level)
-    struct Prof { std::string name; hipEvent_t a, b; };
+    struct Prof { std::string name; hipEvent_t a, b; u64 bytes; };
     std::vector<Prof> pending;
-    std::map<std::string, std::pair<u64, double>> prof;   // name -> (launches, total ms)
+    struct ProfAcc { u64 launches = 0; double ms = 0; u64 bytes = 0; };
+    std::map<std::string, ProfAcc> prof;              // name -> launches, total ms, stated algorithmic bytes
 };
 inline Runtime &rt() {
     static Runtime r;
@@ -78,11 +79,12 @@ inline void sync() {
     GRL_HIP_CHECK(hipStreamSynchronize(rt().stream));
     if (rt().profile) prof_collect();
 }
-inline void prof_begin(const std::string &name) {
+inline void prof_begin(const std::string &name, u64 algo_bytes = 0) {
     if (rt().trace) { fprintf(stderr, "[grlbwt] launch %s\n", name.c_str()); fflush(stderr); }
     if (!rt().profile) return;
     Runtime::Prof p;
     p.name = rt().tag >= 0 ? name + "#" + std::to_string(rt().tag) : name;
+    p.bytes = algo_bytes;
     GRL_HIP_CHECK(hipEventCreate(&p.a));
     GRL_HIP_CHECK(hipEventCreate(&p.b));
     GRL_HIP_CHECK(hipEventRecord(p.a, rt().stream));
@@ -98,8 +100,9 @@ inline void prof_collect() {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             auto &e = rt().prof[p.name];
-            e.first += 1;
-            e.second += ms;
+            e.launches += 1;
+            e.ms += ms;
+            e.bytes += p.bytes;
         }
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -756,12 +759,12 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         V *vin = cur ? vals_b : vals_a;
         K *kout = cur ? keys_a : keys_b;
         V *vout = cur ? vals_a : vals_b;
-        prof_begin(std::string(name) + ".hist");
+        prof_begin(std::string(name) + ".hist", n * sizeof(K));
         hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, counts, tiles);
         prof_end();
         after_launch(name);
         exclusive_scan_async<u64, RsCountIn>((u64)256 * tiles, RsCountIn{counts}, offsets, nullptr, nullptr, name);
-        prof_begin(std::string(name) + ".scatter");
+        prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + sizeof(V)) * 2);   // pairs read once + written once
         hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
                            shift, offsets, tiles);
         prof_end();

@@ -269,13 +269,13 @@ class Context:
         self._ck(self.L.grlbwt_profile_enable(self._h, 1 if on else 0))
 
     def profile(self):
-        """{kernel name: (launches, total_ms)} measured with HIP events on the engine's stream."""
-        buf = C.create_string_buffer(1 << 16)
+        """{kernel name: (launches, total_ms, stated algorithmic bytes)} measured with HIP events on the engine's stream."""
+        buf = C.create_string_buffer(1 << 17)
         self._ck(self.L.grlbwt_profile_dump(self._h, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.rsplit(" ", 2)
-            out[name] = (int(cnt), float(ms))
+            name, cnt, ms, nbytes = line.rsplit(" ", 3)
+            out[name] = (int(cnt), float(ms), int(nbytes))
         return out
 
     def selftest(self, n=100000, seed=1):

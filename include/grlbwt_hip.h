@@ -178,7 +178,8 @@ int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm);
 
 /* per-kernel timing with HIP events on the engine's stream (bench.py's roofline leg).
  * enable(1) clears the table and starts recording; dump writes one line per kernel name:
- * "<name> <launches> <total_ms>\n" (NUL terminated, truncated to capacity). */
+ * "<name> <launches> <total_ms> <algorithmic_bytes>\n" (NUL terminated, truncated to capacity; bytes = 0 where
+ * the launch site states none; names carry "#<level>"). */
 int grlbwt_profile_enable(grlbwt_ctx *ctx, int on);
 int grlbwt_profile_dump(grlbwt_ctx *ctx, char *buf, uint64_t capacity);
 

@@ -42,7 +42,8 @@ struct Runtime {
     bool sync_each_launch = false;
     bool profile = false;
     int tag = -1;
-    std::map<std::string, std::pair<u64, double>> prof;
+    struct ProfAcc { u64 launches = 0; double ms = 0; u64 bytes = 0; };
+    std::map<std::string, ProfAcc> prof;
 };
 inline Runtime &rt() {
     static Runtime r;
