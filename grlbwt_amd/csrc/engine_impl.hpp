@@ -727,14 +727,25 @@ struct SegFromPreFn {   // non-HOCC pre-BWT runs -> segments
         seg_len[g] = plen[j];
     }
 };
+// induced cells in bucket-major order: either the packed payload that rode through the split
+// (sym<<32 | len) or two separate arrays (64-bit build with a run of >= 2^32 symbols)
+struct CellView {
+    const u64 *packed; const u32 *ssym; const idx_t *slen;
+    GRL_DEV u32 sym(u64 t) const { return packed ? (u32)(packed[t] >> 32) : ssym[t]; }
+    GRL_DEV idx_t len(u64 t) const { return packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t]; }
+};
+struct CellLenIn {
+    CellView c;
+    GRL_DEV idx_t operator()(u64 t) const { return c.len(t); }
+};
 struct SegFromCellFn {  // induced cells (H, bucket-major) -> segments
-    const u32 *skey; const u32 *ssym; const idx_t *slen; const u32 *u_to_p; const idx_t *nhb;
+    const u32 *skey; CellView c; const u32 *u_to_p; const idx_t *nhb;
     u32 *seg_sym; idx_t *seg_len;
     GRL_DEV void operator()(u64 t) const {
         u64 j = u_to_p[skey[t]];                 // pre-BWT (HOCC) run this bucket belongs to
         u64 g = (u64)nhb[j] + t;
-        seg_sym[g] = ssym[t];
-        seg_len[g] = slen[t];
+        seg_sym[g] = c.sym(t);
+        seg_len[g] = c.len(t);
     }
 };
 struct AtomCountIn {    // output atoms per segment: 1 + #(BWT_{r+1} run boundaries strictly inside its T interval)
@@ -1202,8 +1213,13 @@ static inline double now_s() {
 }
 struct StageTimer {
     double *acc, t0;
-    explicit StageTimer(double *a) : acc(a) { prim::sync(); t0 = now_s(); }
-    ~StageTimer() { try { prim::sync(); } catch (...) {} *acc += now_s() - t0; }
+    u64 peak0;
+    explicit StageTimer(double *a) : acc(a) { prim::sync(); t0 = now_s(); peak0 = prim::pool_stage_begin(); }
+    ~StageTimer() {
+        try { prim::sync(); } catch (...) {}
+        *acc += now_s() - t0;
+        prim::pool_stage_end(peak0, acc);
+    }
 };
 
 class Engine {
@@ -1614,7 +1630,7 @@ class Engine {
         }
         I.E = E;
         DBuf<u32> skey;                         // bucket of every induced cell, bucket-major order
-        ssym.alloc(E); slen.alloc(E);
+        DBuf<u64> spack;                        // (sym<<32 | len) of every induced cell, same order (packed path)
         {
             DBuf<u32> ekey(E), ekey2(E);
             int bits = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
@@ -1632,8 +1648,8 @@ class Engine {
                 }
                 StageTimer st(&tm.ind_sort);
                 int res = prim::sort_pairs<u32, u64>(ekey.p, ep.p, ekey2.p, ep2.p, E, 0, bits, "induce_split");
-                prim::for_each(E, UnpackCellFn{res ? ep2.p : ep.p, ssym.p, slen.p}, "induce_unpack");
                 skey = std::move(res ? ekey2 : ekey);
+                spack = std::move(res ? ep2 : ep);
                 prim::sync();
             } else {
                 DBuf<u32> esym(E);
@@ -1644,19 +1660,21 @@ class Engine {
                                                            ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
+                ssym.alloc(E); slen.alloc(E);
                 int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
                 prim::for_each(E, GatherCellFn{res ? eidx2.p : eidx.p, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
                 skey = std::move(res ? ekey2 : ekey);
                 prim::sync();
             }
         }
+        const CellView cells{spack.p, ssym.p, slen.p};
         eoff.release();
         {
             StageTimer st(&tm.ind_assemble);
             DBuf<idx_t> PH(P + 1), nhb(P + 1), Hpos(E + 1), Tpos(R + 1);
             prim::exclusive_scan<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code}, PH.p, true, "asm.PH");
             u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.prebwt.sym.p, hocc_code}, nhb.p, true, "asm.nhb");
-            u64 Hsum = (u64)prim::exclusive_scan<idx_t>(E, IdxIn<idx_t>{slen.p}, Hpos.p, true, "asm.Hpos");
+            u64 Hsum = (u64)prim::exclusive_scan<idx_t>(E, CellLenIn{cells}, Hpos.p, true, "asm.Hpos");
             u64 Tsum = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
             u64 PHsum = (u64)PH.get(P);
             if (Hsum != PHsum) throw prim::Error(-71, "induction: induced symbols do not match the pre-BWT (level " +
@@ -1668,8 +1686,8 @@ class Engine {
             DBuf<idx_t> seg_len(G), Toff(G + 1), abase(G + 1);
             prim::for_each(P, SegFromPreFn{L.prebwt.sym.p, L.prebwt.len.p, PH.p, nhb.p, Hpos.p, E, bwt_code, hocc_code,
                                            take_code, seg_sym.p, seg_len.p}, "asm.seg_pre");
-            prim::for_each(E, SegFromCellFn{skey.p, ssym.p, slen.p, L.u_to_p.p, nhb.p, seg_sym.p, seg_len.p}, "asm.seg_cell");
-            Hpos.release(); skey.release(); ssym.release(); slen.release();
+            prim::for_each(E, SegFromCellFn{skey.p, cells, L.u_to_p.p, nhb.p, seg_sym.p, seg_len.p}, "asm.seg_cell");
+            Hpos.release(); skey.release(); ssym.release(); slen.release(); spack.release();
             u64 Tused = (u64)prim::exclusive_scan<idx_t>(G, CondLenIn{seg_sym.p, seg_len.p, take_code}, Toff.p, true, "asm.Toff");
             if (Tused != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) +
                                                            ": " + std::to_string(Tused) + " vs " + std::to_string(Tsum) + ")");
@@ -1684,6 +1702,11 @@ class Engine {
             DBuf<idx_t> olen(A);
             prim::for_each(A, AtomFn{seg_sym.p, seg_len.p, Toff.p, Tpos.p, abase.p, term.p, tbits.words.p, tbits.base.p,
                                      abits.words.p, abits.base.p, take_code, osym.p, olen.p}, "asm.atoms");
+            // everything but the atoms can go before the merge allocates its scan arrays (peak memory)
+            seg_sym.release(); seg_len.release(); Toff.release(); abase.release(); Tpos.release(); PH.release(); nhb.release();
+            tbits.words.release(); tbits.base.release(); abits.words.release(); abits.base.release();
+            term.release();
+            bwt.sym.release(); bwt.len.release();
             bwt = merge_runs(osym.p, olen.p, A);
         }
         bwt_level = r;

@@ -139,6 +139,20 @@ inline Pool &pool() {
     static Pool p;
     return p;
 }
+// per-stage high-water marks (GRLBWT_MEM_TRACE=1): the stage is identified by the address of its timer slot
+inline u64 pool_stage_begin() {
+    Pool &P = pool();
+    u64 old = P.peak_bytes;
+    P.peak_bytes = P.live_bytes;
+    return old;
+}
+inline void pool_stage_end(u64 old_peak, const void *stage_id) {
+    Pool &P = pool();
+    static const bool trace = getenv("GRLBWT_MEM_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[grlbwt] stage %p level %d: peak live %.2f GB (live at end %.2f GB)\n", stage_id, rt().tag,
+                       P.peak_bytes / 1e9, P.live_bytes / 1e9);
+    if (old_peak > P.peak_bytes) P.peak_bytes = old_peak;
+}
 inline u64 pool_peak_bytes() { return pool().peak_bytes; }
 inline u64 pool_reserved_bytes() { return pool().slab_bytes; }
 inline bool pool_disabled() {

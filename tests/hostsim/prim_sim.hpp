@@ -94,6 +94,8 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
 }
 inline void pool_trim() {}
 inline void pool_reserve(size_t) {}
+inline u64 pool_stage_begin() { return 0; }
+inline void pool_stage_end(u64, const void *) {}
 inline u64 pool_peak_bytes() { return 0; }
 inline u64 pool_reserved_bytes() { return 0; }
 template <class T, class F>
