@@ -78,7 +78,7 @@ def main():
                     help="uniform: BASELINE configs[1] shape (i.i.d. ACGT reads); illumina: configs[3] shape "
                          "(--reads x 150 bp sampled from a --genome bp random genome, 0.5 %% substitutions)")
     ap.add_argument("--genome", type=int, default=330000000)
-    ap.add_argument("--cpu-sample-reads", type=int, default=300000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
