@@ -224,6 +224,7 @@ int selftest(uint64_t n, uint64_t seed) {
 extern "C" {
 
 int grlbwt_abi_version(void) { return GRLBWT_ABI_VERSION; }
+const char *grlbwt_backend_name(void) { return prim::kIsDevice ? "hip-gfx950" : "serial-test-standin"; }
 
 const char *grlbwt_strerror(int code) {
     switch (code) {

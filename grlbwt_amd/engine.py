@@ -20,7 +20,7 @@ EILLFORMED = -84
 
 # every symbol include/grlbwt_hip.h declares
 ABI_SYMBOLS = [
-    "grlbwt_abi_version", "grlbwt_strerror", "grlbwt_last_error", "grlbwt_ctx_create", "grlbwt_ctx_destroy",
+    "grlbwt_abi_version", "grlbwt_backend_name", "grlbwt_strerror", "grlbwt_last_error", "grlbwt_ctx_create", "grlbwt_ctx_destroy",
     "grlbwt_ctx_set_stream", "grlbwt_text_upload", "grlbwt_text_attach_device", "grlbwt_get_stats",
     "grlbwt_parse_round", "grlbwt_parse_phase", "grlbwt_round_info_get", "grlbwt_induce_first",
     "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
@@ -68,17 +68,24 @@ class IllFormedInput(GrlbwtError):
 _libs = {}
 
 
-def load_library(path=None):
-    """dlopen the C-ABI library; fails loudly when it has not been built."""
+def load_library(path=None, allow_test_standin=False):
+    """dlopen the C-ABI library; fails loudly when it has not been built.  Only the HIP build is accepted:
+    the serial stand-in of tests/hostsim identifies itself and is refused unless a test explicitly allows it."""
     path = path or os.environ.get("GRLBWT_HIP_LIB", DEFAULT_LIB)
     if path in _libs:
-        return _libs[path]
+        L = _libs[path]
+        if L.grlbwt_backend_name() != b"hip-gfx950" and not allow_test_standin:
+            raise RuntimeError("%s is not the HIP library (backend %r); the product has no CPU path" % (path, L.grlbwt_backend_name()))
+        return L
     if not os.path.exists(path):
         raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % path)
     L = C.CDLL(path)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.grlbwt_abi_version.restype = i32
+    L.grlbwt_backend_name.restype = C.c_char_p
+    if L.grlbwt_backend_name() != b"hip-gfx950" and not allow_test_standin:
+        raise RuntimeError("%s is not the HIP library (backend %r); the product has no CPU path" % (path, L.grlbwt_backend_name()))
     L.grlbwt_strerror.restype = C.c_char_p
     L.grlbwt_strerror.argtypes = [i32]
     L.grlbwt_last_error.restype = C.c_char_p
@@ -119,8 +126,8 @@ def load_library(path=None):
 class Context:
     """One engine context per GPU (grlbwt_ctx)."""
 
-    def __init__(self, device=0, flags=0, lib=None):
-        self.L = load_library(lib)
+    def __init__(self, device=0, flags=0, lib=None, _test_standin=False):
+        self.L = load_library(lib, allow_test_standin=_test_standin or os.environ.get("GRLBWT_ALLOW_TEST_STANDIN") == "1")
         h = C.c_void_p()
         rc = self.L.grlbwt_ctx_create(device, flags, C.byref(h))
         if rc != OK:

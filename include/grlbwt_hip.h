@@ -89,6 +89,9 @@ typedef struct grlbwt_counters {
 
 /* ---- lifetime ------------------------------------------------------------ */
 int grlbwt_abi_version(void);
+/* "hip-gfx950" for the product library.  (The serial stand-in that the CPU test-suite builds under
+ * tests/hostsim answers "serial-test-standin"; the host mirrors refuse it unless a test asks for it.) */
+const char *grlbwt_backend_name(void);
 const char *grlbwt_strerror(int code);
 /* last error message of this context (valid until the next call on it) */
 const char *grlbwt_last_error(const grlbwt_ctx *ctx);

@@ -63,3 +63,25 @@ def test_product_does_not_touch_oracle():
                         continue
                     bad.append(f)
     assert not bad, bad
+
+
+def test_test_standin_is_refused_by_the_product(monkeypatch):
+    """The serial stand-in of the device primitives (tests/hostsim) identifies itself; the host mirror only
+    accepts it when a test explicitly opts in, so the product cannot end up on a CPU path."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-s", "-C", d], stdout=subprocess.DEVNULL)
+    sim = os.path.join(d, "_build", "libgrlbwt_sim.so")
+    monkeypatch.delenv("GRLBWT_ALLOW_TEST_STANDIN", raising=False)
+    from grlbwt_amd import engine
+    with pytest.raises(RuntimeError, match="not the HIP library"):
+        engine.Context(0, 0, sim)
+    lib = ctypes.CDLL(sim)
+    lib.grlbwt_backend_name.restype = ctypes.c_char_p
+    assert lib.grlbwt_backend_name() == b"serial-test-standin"
+
+
+def test_hip_library_identifies_itself(hip_lib):
+    lib = ctypes.CDLL(hip_lib)
+    lib.grlbwt_backend_name.restype = ctypes.c_char_p
+    assert lib.grlbwt_backend_name() == b"hip-gfx950"
