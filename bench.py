@@ -91,9 +91,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("GRLBWT_BENCH_FORCE_DIST") == "1"   # measure the sharded flow's overhead at world 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("GRLBWT_BENCH_BACKEND") == "gloo":     # functional check of the N > 1 flow on a 1-GPU box
             local_rank = 0
             dist.init_process_group("gloo")
@@ -104,7 +108,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    lib = g.build_hip()
+    lib = os.environ.get("GRLBWT_HIP_LIB") or g.build_hip()
     # shard of this rank: the named workload (rank 0) / same shape with another seed (other ranks)
     # generated on the device (bit-identical to workloads.uniform_reads on the host; tests/test_gpu_parity.py)
     if args.workload == "illumina":
@@ -117,7 +121,7 @@ def main():
 
     comm = None
     flags = 0
-    if world > 1:
+    if world > 1 or force_dist:
         from grlbwt_amd import dist as gdist
         comm = gdist.Communicator(dev)
         if world * n_bytes >= 0xFFFFFF00:
@@ -261,6 +265,10 @@ def main():
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
             "top_kernels": top, "roofline_by_kernel": others, "rounds": nr,
         }
+        if comm is not None:     # totals over warmup + timed + profile steps on rank 0
+            nsteps = args.warmup + args.steps + 1
+            out["collectives_per_step"] = {"allgather": comm.n_allgather // nsteps, "alltoallv": comm.n_alltoall // nsteps,
+                                           "bytes": comm.bytes_moved // nsteps, "ms_in_callbacks": round(comm.seconds / nsteps * 1e3, 3)}
     ctx.close()
     if dist is not None:
         dist.barrier()

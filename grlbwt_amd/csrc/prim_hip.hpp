@@ -683,14 +683,15 @@ inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
 
 // ------------------------------------------------------------------ radix sort
 // Stable LSD radix sort of (key, value) pairs, 8 bits per pass.
-// (Measured alternatives, both slower on MI355X at 7-30 M pairs: one wave per 1024-key tile without any
-// workgroup barrier -- 1.3x slower, shorter write runs and 4x more counters; LDS-staged tile-sorted
-// stores -- 1.9x slower at 2 workgroups/CU.  The direct form below stays.)
 //   pass = k_rs_hist (per-tile digit histogram in LDS)  -> counts[digit][tile]
 //        + exclusive_scan over counts (digit-major = global digit offsets)
-//        + k_rs_scatter (in-tile stable ranking with wave64 ballots)
-static constexpr int kRsItems = 32;                 // rounds of 256 keys per tile
-static constexpr int kRsTile = kBlock * kRsItems;   // 8192 keys per workgroup
+//        + k_rs_scatter (in-tile stable ranking with wave64 ballots, tile permuted in LDS, linear write-out)
+// (Measured on MI355X, 101 MB reads workload, all scatter launches of one build: direct per-key stores with one
+// barrier set per 256 keys 7.6 ms, per 1024 keys 5.9 ms, per 2048 keys 5.6 ms -- bound by the rate of 4-8 byte
+// store requests; the LDS-staged form below 3.8 ms.  One wave per 1024-key tile without workgroup barriers was
+// 1.3x slower than the first of those.)
+static constexpr int kRsItems = 16;                 // keys per lane (24 and 32 measured slower: registers, LDS)
+static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup
 
 template <class K>
 __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 *counts, u32 tiles) {
@@ -707,49 +708,127 @@ __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int sh
     counts[(u64)threadIdx.x * tiles + blockIdx.x] = s_h[threadIdx.x];
 }
 
+// The tile (kBlock x kRsKeys keys, wave w owns a contiguous quarter) is ranked with per-wave running digit
+// counters (no workgroup barrier inside the ranking loop), permuted into digit order in LDS, and written out
+// linearly, so that neighbouring lanes store to neighbouring addresses of the same digit run.  Values are loaded
+// once the keys' registers are free; those loads overlap the key write-out.
+static constexpr int kRsKeys = kRsTile / kBlock;
 template <class K, class V>
 __global__ void __launch_bounds__(kBlock)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift,
-                 const u64 *offsets /*[256][tiles] exclusive*/, u32 tiles) {
-    __shared__ u32 s_wc[4][256];   // per-wave count of each digit in the current round
-    __shared__ u64 s_run[256];     // running global write position of each digit for this tile
+                        const u64 *offsets /*[256][tiles] exclusive*/, u32 tiles) {
+    constexpr int EB = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[kRsTile * EB];
+    __shared__ u32 s_cnt[4][256];     // per wave: running count, then exclusive base, of each digit
+    __shared__ u32 s_start[256];      // tile-local first index of each digit
+    __shared__ u64 s_gbase[256];      // global position of tile-local index 0 of the digit's run (may wrap; mod 2^64)
+    __shared__ u32 s_wsum[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    s_run[threadIdx.x] = offsets[(u64)threadIdx.x * tiles + blockIdx.x];
-    u64 base = (u64)blockIdx.x * kRsTile;
-    for (int r = 0; r < kRsItems; r++) {
-        u64 i = base + (u64)r * kBlock + threadIdx.x;
-        bool valid = i < n;
-        if (__syncthreads_or(valid) == 0) break;     // whole round beyond n (also orders s_run init)
 #pragma unroll
-        for (int k = 0; k < 4; k++) s_wc[k][threadIdx.x] = 0;
-        K key = valid ? keys_in[i] : K(0);
-        V val = valid ? vals_in[i] : V(0);
-        u32 d = (u32)(key >> shift) & 255u;
-        // wave64 match: lanes of this wave holding the same digit
+    for (int k = 0; k < 4; k++) s_cnt[k][threadIdx.x] = 0;
+    const u64 base = (u64)blockIdx.x * kRsTile;
+    const u64 left = n - base;
+    const u32 tile_n = left < (u64)kRsTile ? (u32)left : (u32)kRsTile;
+    const u32 wbase = (u32)w * (64 * kRsKeys);
+    K key[kRsKeys];
+    V val[kRsKeys];
+    u32 idx[kRsKeys];
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        bool valid = t < tile_n;
+        key[q] = valid ? keys_in[base + t] : K(0);
+    }
+    __syncthreads();
+    volatile u32 *cnt = &s_cnt[w][0];
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        bool valid = t < tile_n;
+        u32 d = (u32)(key[q] >> shift) & 255u;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             unsigned long long m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
-        u32 rank_in_wave = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-        __syncthreads();                               // s_wc zeroed by everyone
-        if (valid && rank_in_wave == 0) s_wc[w][d] = (u32)__popcll(peers);
+        u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+        u32 old = 0;
+        if (valid && below == 0) {
+            old = cnt[d];
+            cnt[d] = old + (u32)__popcll(peers);
+        }
+        int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+        old = (u32)__shfl((int)old, leader);
+        idx[q] = old + below;            // rank among this wave's keys of digit d
+    }
+    __syncthreads();
+    {   // thread d: wave bases, tile-local digit starts, global base
+        u32 c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x], c3 = s_cnt[3][threadIdx.x];
+        u32 total = c0 + c1 + c2 + c3;
+        u32 incl = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 o = (u32)__shfl_up((int)incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wsum[w] = incl;
         __syncthreads();
-        u64 pos = 0;
-        if (valid) {
-            u32 before = 0;
-            for (int k = 0; k < w; k++) before += s_wc[k][d];
-            pos = s_run[d] + before + rank_in_wave;
+        u32 wprev = 0;
+        for (int k = 0; k < w; k++) wprev += s_wsum[k];
+        u32 start = wprev + incl - total;
+        s_start[threadIdx.x] = start;
+        s_cnt[0][threadIdx.x] = start;
+        s_cnt[1][threadIdx.x] = start + c0;
+        s_cnt[2][threadIdx.x] = start + c0 + c1;
+        s_cnt[3][threadIdx.x] = start + c0 + c1 + c2;
+        s_gbase[threadIdx.x] = offsets[(u64)threadIdx.x * tiles + blockIdx.x] - (u64)start;
+    }
+    __syncthreads();
+    K *kb = (K *)s_buf;
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        if (t < tile_n) {
+            u32 d = (u32)(key[q] >> shift) & 255u;
+            idx[q] += s_cnt[w][d];
+            kb[idx[q]] = key[q];
         }
-        __syncthreads();                               // all reads of s_run done
-        s_run[threadIdx.x] += (u64)s_wc[0][threadIdx.x] + s_wc[1][threadIdx.x] + s_wc[2][threadIdx.x] +
-                              s_wc[3][threadIdx.x];
-        if (valid) {
-            keys_out[pos] = key;
-            vals_out[pos] = val;
+    }
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        val[q] = t < tile_n ? vals_in[base + t] : V(0);
+    }
+    __syncthreads();
+    u32 dpack[(kRsKeys + 3) / 4];
+#pragma unroll
+    for (int j = 0; j < (kRsKeys + 3) / 4; j++) dpack[j] = 0;
+#pragma unroll
+    for (int j = 0; j < kRsKeys; j++) {
+        u32 t = (u32)j * kBlock + threadIdx.x;
+        if (t < tile_n) {
+            K k = kb[t];
+            u32 d = (u32)(k >> shift) & 255u;
+            dpack[j >> 2] |= d << (8 * (j & 3));
+            keys_out[s_gbase[d] + t] = k;
         }
-        __syncthreads();                               // s_run / s_wc stable before next round
+    }
+    __syncthreads();
+    V *vb = (V *)s_buf;
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        if (t < tile_n) vb[idx[q]] = val[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRsKeys; j++) {
+        u32 t = (u32)j * kBlock + threadIdx.x;
+        if (t < tile_n) {
+            u32 d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
+            vals_out[s_gbase[d] + t] = vb[t];
+        }
     }
 }
 

@@ -6,6 +6,7 @@ module only provides the two collectives the engine calls back for, implemented 
 torch.distributed -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -48,6 +49,7 @@ class Communicator:
         self.bytes_moved = 0
         self.n_allgather = 0
         self.n_alltoall = 0
+        self.seconds = 0.0           # wall time spent inside the callbacks (transport + synchronisation)
         # gloo transport with device-resident engine buffers (tests on a single-GPU box): stage through the host
         self.stage = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
         self._ag = _AG(self._allgather)
@@ -59,6 +61,7 @@ class Communicator:
             torch.cuda.synchronize(self.device)
 
     def _allgather(self, user, send, recv, nbytes):
+        t0 = time.perf_counter()
         try:
             s = _view(send, nbytes, self.device)
             r = _view(recv, nbytes * self.size, self.device)
@@ -71,12 +74,14 @@ class Communicator:
             self._sync()
             self.bytes_moved += nbytes * self.size
             self.n_allgather += 1
+            self.seconds += time.perf_counter() - t0
             return 0
         except Exception as e:          # never let an exception cross the C boundary
             print("grlbwt allgather callback failed:", repr(e), flush=True)
             return 1
 
     def _alltoallv(self, user, send, send_bytes, recv, recv_bytes):
+        t0 = time.perf_counter()
         try:
             sb = [int(send_bytes[i]) for i in range(self.size)]
             rb = [int(recv_bytes[i]) for i in range(self.size)]
@@ -91,6 +96,7 @@ class Communicator:
             self._sync()
             self.bytes_moved += sum(sb)
             self.n_alltoall += 1
+            self.seconds += time.perf_counter() - t0
             return 0
         except Exception as e:
             print("grlbwt alltoallv callback failed:", repr(e), flush=True)
