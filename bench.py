@@ -160,11 +160,14 @@ def main():
     # Every rank takes the step (for N > 1 it contains collectives); only rank 0 records and reports.
     if rank == 0:
         ctx.profile_enable(True)
+        if comm is not None and os.environ.get("GRLBWT_BENCH_DETAIL"):
+            comm.log = []
     step()
     barrier()
     out = None
     if rank == 0:
         prof_detail = ctx.profile()
+        host_syncs = prof_detail.pop("@host_sync", (0, 0.0, 0))[0]
         ctx.profile_enable(False)
         # fold the per-level tags ("name#level") and group launch sites by the kernel FUNCTION they launch, so that
         # "dominant kernel" means the same thing as in the rocprofv3 --stats summary under profiles/
@@ -182,6 +185,9 @@ def main():
             f = kernel_of(b)
             fc, fm, fb = fam.get(f, (0, 0.0, 0))
             fam[f] = (fc + c, fm + ms, fb + nb)
+        if os.environ.get("GRLBWT_BENCH_DETAIL") and comm is not None and comm.log is not None:
+            for kind, nb, sec in comm.log:
+                print("  collective %-10s %12d bytes %8.3f ms" % (kind, nb, sec * 1e3), file=sys.stderr)
         if os.environ.get("GRLBWT_BENCH_DETAIL"):
             for k, (c, ms, nb) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:90]:
                 print("  %-32s %4d launches %9.3f ms" % (k, c, ms), file=sys.stderr)
@@ -264,6 +270,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
             "top_kernels": top, "roofline_by_kernel": others, "rounds": nr,
+            "kernel_launches": sum(c for c, _, _ in prof_detail.values()), "host_syncs": host_syncs,
         }
         if comm is not None:     # totals over warmup + timed + profile steps on rank 0
             nsteps = args.warmup + args.steps + 1

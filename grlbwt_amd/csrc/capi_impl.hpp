@@ -263,7 +263,7 @@ void grlbwt_ctx_destroy(grlbwt_ctx *ctx) {
 }
 int grlbwt_ctx_set_stream(grlbwt_ctx *ctx, void *hip_stream) {
     if (!ctx) return GRLBWT_EINVAL;
-    return guarded(ctx, [&] { prim::set_stream(hip_stream); });
+    return guarded(ctx, [&] { prim::sync(); prim::set_stream(hip_stream); });   // work queued on the old stream finishes first
 }
 
 int grlbwt_text_upload(grlbwt_ctx *ctx, const void *host_cells, uint64_t n_cells, int cell_bytes) {
@@ -380,6 +380,7 @@ int grlbwt_level_bwt_download(const grlbwt_ctx *ctx, int level, uint64_t *sym_ou
 
 int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out) {
     if (!HAS_ENG(ctx) || !out) return GRLBWT_EINVAL;
+    try { prim::sync(); } catch (...) { return GRLBWT_EDEVICE; }   // folds the stage clocks still in flight
     if (ctx->e32) fill_counters(*ctx->e32, out); else fill_counters(*ctx->e64, out);
     return GRLBWT_OK;
 }
@@ -408,10 +409,12 @@ int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm) {
         if (ctx->e32) {
             grl32::Engine::Comm C;
             C.rank = comm->rank; C.size = comm->size; C.user = comm->user; C.ag = comm->allgather; C.a2a = comm->alltoallv;
+            C.stream_ordered = (comm->flags & GRLBWT_COMM_STREAM_ORDERED) != 0;
             ctx->e32->dist_build(C);
         } else {
             grl64::Engine::Comm C;
             C.rank = comm->rank; C.size = comm->size; C.user = comm->user; C.ag = comm->allgather; C.a2a = comm->alltoallv;
+            C.stream_ordered = (comm->flags & GRLBWT_COMM_STREAM_ORDERED) != 0;
             ctx->e64->dist_build(C);
         }
     });

@@ -589,7 +589,7 @@ static inline void build_rankbits(RankBits &rb, const idx_t *pos, u64 count, u64
     rb.base.alloc(nw + 1);
     rb.words.zero();
     prim::for_each((count + 15) / 16, BuildBitsFn{pos, count, rb.words.p}, name);
-    prim::exclusive_scan<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, name);
+    prim::exclusive_scan_nosync<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, name);
 }
 
 // ------------------------------------------------------------ run utilities
@@ -1113,19 +1113,38 @@ struct PermuteAtomsFn {
     const idx_t *perm; const u64 *o; const u32 *s; const u64 *l; u64 *o2; u32 *s2; u64 *l2;
     GRL_DEV void operator()(u64 i) const { u64 y = perm[i]; o2[i] = o[y]; s2[i] = s[y]; l2[i] = l[y]; }
 };
-struct RecvKeyFn {
-    const u64 *o; u64 lo; u64 *key; idx_t *idx;
-    GRL_DEV void operator()(u64 i) const { key[i] = o[i] - lo; idx[i] = (idx_t)i; }
+// Received atoms tile the rank's output range, so "sort by output position" is a placement: mark every atom's start
+// in a bit-vector over the range, rank the bits, and drop each atom at the rank of its own start.
+struct RecvMarkFn {        // one lane per 16 consecutive atoms (each source's atoms arrive in position order: few words per lane)
+    const u64 *o; u64 n, lo, span; u64 *words; u32 *bad;
+    GRL_DEV void operator()(u64 j) const {
+        u64 i0 = j * 16, i1 = i0 + 16 < n ? i0 + 16 : n;
+        u64 cur = ~0ull, m = 0;
+        for (u64 i = i0; i < i1; i++) {
+            u64 x = o[i] - lo;
+            if (o[i] < lo || x >= span) { *bad = 1; continue; }
+            u64 w = x >> 6;
+            if (w != cur) { if (m) prim::atomic_or(&words[cur], m); m = 0; cur = w; }
+            m |= 1ull << (x & 63);
+        }
+        if (m) prim::atomic_or(&words[cur], m);
+    }
 };
-struct GatherRecvFn {
-    const idx_t *perm; const u32 *s; const u64 *l; u32 *os; idx_t *ol;
-    GRL_DEV void operator()(u64 i) const { u64 y = perm[i]; os[i] = s[y]; ol[i] = (idx_t)l[y]; }
-};
-struct CheckSortedAtomsFn {   // every received atom must start where the previous one ended
-    const u64 *key; const idx_t *perm; const u64 *l; u64 n; u32 *bad;
+struct RecvPlaceFn {
+    const u64 *o; const u32 *s; const u64 *l; u64 lo, span; const u64 *words; const idx_t *base;
+    u64 *opos; u32 *os; idx_t *ol;
     GRL_DEV void operator()(u64 i) const {
-        u64 expect = (i == 0) ? 0 : key[i - 1] + l[perm[i - 1]];
-        if (key[i] != expect) *bad = 1;
+        u64 x = o[i] - lo;
+        if (o[i] < lo || x >= span) return;
+        u64 j = rank1(words, base, x);
+        opos[j] = x; os[j] = s[i]; ol[j] = (idx_t)l[i];
+    }
+};
+struct CheckPlacedAtomsFn {   // every atom must start where the previous one ended (also catches two atoms on one start)
+    const u64 *opos; const idx_t *ol; u64 n; u32 *bad;
+    GRL_DEV void operator()(u64 i) const {
+        u64 expect = (i == 0) ? 0 : opos[i - 1] + (u64)ol[i - 1];
+        if (opos[i] != expect) *bad = 1;
     }
 };
 struct OwnerBoundFn {     // first routed atom of every destination rank
@@ -1212,18 +1231,18 @@ static inline double now_s() {
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 struct StageTimer {
-    double *acc, t0;
+    double *acc;
     u64 peak0;
-    explicit StageTimer(double *a) : acc(a) { prim::sync(); t0 = now_s(); peak0 = prim::pool_stage_begin(); }
+    explicit StageTimer(double *a) : acc(a) { prim::stage_begin(); peak0 = prim::pool_stage_begin(); }
     ~StageTimer() {
-        try { prim::sync(); } catch (...) {}
-        *acc += now_s() - t0;
+        prim::stage_end(acc);
         prim::pool_stage_end(peak0, acc);
     }
 };
 
 class Engine {
   public:
+    ~Engine() { prim::stages_drop(); }   // open stage clocks point into tm
     int cell_bytes = 1;
     const void *text0 = nullptr;      // device pointer (owned by own0 or borrowed)
     DBuf<u8> own0;
@@ -1672,7 +1691,7 @@ class Engine {
         {
             StageTimer st(&tm.ind_assemble);
             DBuf<idx_t> PH(P + 1), nhb(P + 1), Hpos(E + 1), Tpos(R + 1);
-            prim::exclusive_scan<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code}, PH.p, true, "asm.PH");
+            prim::exclusive_scan_nosync<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code}, PH.p, true, "asm.PH");
             u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.prebwt.sym.p, hocc_code}, nhb.p, true, "asm.nhb");
             u64 Hsum = (u64)prim::exclusive_scan<idx_t>(E, CellLenIn{cells}, Hpos.p, true, "asm.Hpos");
             u64 Tsum = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
@@ -1741,8 +1760,9 @@ class Engine {
         void *user = nullptr;
         int (*ag)(void *, const void *, void *, u64) = nullptr;
         int (*a2a)(void *, const void *, const u64 *, void *, const u64 *) = nullptr;
+        bool stream_ordered = false;      // callbacks enqueue on the engine's stream: no host synchronisation around them
         void allgather(const void *send, void *recv, u64 bytes) const {
-            prim::sync();
+            if (!stream_ordered) prim::sync();
             if (ag(user, send, recv, bytes) != 0) throw prim::Error(-5, "allgather callback failed");
         }
         std::vector<u64> allgather_u64(const std::vector<u64> &mine) const {
@@ -2130,8 +2150,8 @@ class Engine {
         term.release(); Tlen.release();
         // (3) per-bucket rank counts
         DBuf<idx_t> lH(E + 1), lT(E + 1), lfirst(M + 1);
-        prim::exclusive_scan<idx_t>(E, IdxIn<idx_t>{slen.p}, lH.p, true, "dist.lH");
-        prim::exclusive_scan<idx_t>(E, CondLenIn{ssym.p, slen.p, take_code}, lT.p, true, "dist.lT");
+        prim::exclusive_scan_nosync<idx_t>(E, IdxIn<idx_t>{slen.p}, lH.p, true, "dist.lH");
+        prim::exclusive_scan_nosync<idx_t>(E, CondLenIn{ssym.p, slen.p, take_code}, lT.p, true, "dist.lT");
         DBuf<u64> cntpair(2 * M + 2), allcnt((2 * M + 2) * (u64)C.size);
         prim::for_each(M, BucketSumFn{skey.p, E, lH.p, lT.p, cntpair.p, lfirst.p}, "dist.bucket_counts");
         C.allgather(cntpair.p, allcnt.p, (2 * M + 2) * 8);
@@ -2206,25 +2226,30 @@ class Engine {
         auto a2a = [&](const void *sp, void *rp, u64 elem) {
             std::vector<u64> sb(C.size), rb(C.size);
             for (int g = 0; g < C.size; g++) { sb[g] = send_cnt[g] * elem; rb[g] = recv_cnt[g] * elem; }
-            prim::sync();
+            if (!C.stream_ordered) prim::sync();
             if (C.a2a(C.user, sp, sb.data(), rp, rb.data()) != 0) throw prim::Error(-5, "alltoallv callback failed");
         };
         a2a(s_out.p, r_out.p, 8); a2a(s_len.p, r_len.p, 8); a2a(s_sym.p, r_sym.p, 4);
-        // sort what I received by output position and merge into runs: my slice of BWT_r
-        DBuf<u64> rk(Nr), rk2(Nr);
-        DBuf<idx_t> ri(Nr), ri2(Nr);
-        prim::for_each(Nr, RecvKeyFn{r_out.p, lo, rk.p, ri.p}, "dist.recv_keys");
-        int kb = (int)bitlen64(chunk);
-        if (kb < 1) kb = 1;
-        int res2 = prim::sort_pairs<u64, idx_t>(rk.p, ri.p, rk2.p, ri2.p, Nr, 0, kb, "dist.recv_sort");
-        const u64 *sk = res2 ? rk2.p : rk.p;
-        const idx_t *sp = res2 ? ri2.p : ri.p;
+        // place what I received in output order and merge into runs: my slice of BWT_r
         DBuf<u32> bad(1);
         bad.zero();
-        prim::for_each(Nr, CheckSortedAtomsFn{sk, sp, r_len.p, Nr, bad.p}, "dist.recv_check");
         DBuf<u32> osym(Nr);
         DBuf<idx_t> olen(Nr);
-        prim::for_each(Nr, GatherRecvFn{sp, r_sym.p, r_len.p, osym.p, olen.p}, "dist.recv_gather");
+        {
+            const u64 span = hi - lo;
+            RankBits rb;
+            const u64 nw = span / 64 + 2;
+            rb.words.alloc(nw);
+            rb.base.alloc(nw + 1);
+            rb.words.zero();
+            prim::for_each((Nr + 15) / 16, RecvMarkFn{r_out.p, Nr, lo, span, rb.words.p, bad.p}, "dist.recv_mark");
+            u64 marked = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, "dist.recv_rank");
+            if (marked != Nr || bad.get(0))
+                throw prim::Error(-71, "dist induction: received atoms do not tile my output range (level " + std::to_string(r) + ")");
+            DBuf<u64> opos(Nr);
+            prim::for_each(Nr, RecvPlaceFn{r_out.p, r_sym.p, r_len.p, lo, span, rb.words.p, rb.base.p, opos.p, osym.p, olen.p}, "dist.recv_place");
+            prim::for_each(Nr, CheckPlacedAtomsFn{opos.p, olen.p, Nr, bad.p}, "dist.recv_check");
+        }
         if (bad.get(0)) throw prim::Error(-71, "dist induction: received atoms do not tile my output range (level " + std::to_string(r) + ")");
         bwt = merge_runs(osym.p, olen.p, Nr);
         u64 got = prim::reduce_sum<u64>(bwt.R, IdxIn<idx_t>{bwt.len.p}, "dist.slice_check");

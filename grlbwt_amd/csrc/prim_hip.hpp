@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -56,6 +57,10 @@ struct Runtime {
     int tag = -1;                    // appended to profile names as "#<tag>" (the engine sets it to the level)
     struct Prof { std::string name; hipEvent_t a, b; u64 bytes; };
     std::vector<Prof> pending;
+    // stage clocks: event pairs on the engine's stream, folded into *acc at the next host synchronisation
+    struct Stage { hipEvent_t a, b; double *acc; bool closed; };
+    std::vector<Stage> stages;
+    std::vector<hipEvent_t> spare_events;
     struct ProfAcc { u64 launches = 0; double ms = 0; u64 bytes = 0; };
     std::map<std::string, ProfAcc> prof;              // name -> launches, total ms, stated algorithmic bytes
 };
@@ -75,9 +80,14 @@ inline void init(int device) {
 }
 inline void set_stream(void *s) { rt().stream = (hipStream_t)s; }
 inline void prof_collect();
+inline void stages_collect();
 inline void sync() {
     GRL_HIP_CHECK(hipStreamSynchronize(rt().stream));
-    if (rt().profile) prof_collect();
+    if (!rt().stages.empty()) stages_collect();
+    if (rt().profile) {
+        prof_collect();
+        rt().prof["@host_sync"].launches += 1;    // how often the host waited for the stream (no kernel of that name)
+    }
 }
 inline void prof_begin(const std::string &name, u64 algo_bytes = 0) {
     if (rt().trace) { fprintf(stderr, "[grlbwt] launch %s\n", name.c_str()); fflush(stderr); }
@@ -108,6 +118,48 @@ inline void prof_collect() {
         (void)hipEventDestroy(p.b);
     }
     rt().pending.clear();
+}
+// Stage clocks without draining the stream: stage_begin/stage_end record events; the elapsed device time is added
+// to *acc the next time the host synchronises anyway (every readback does).  stages_drop() forgets open clocks
+// (their accumulators are about to be destroyed).
+inline hipEvent_t stage_event() {
+    Runtime &R = rt();
+    if (!R.spare_events.empty()) { hipEvent_t e = R.spare_events.back(); R.spare_events.pop_back(); return e; }
+    hipEvent_t e;
+    GRL_HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+inline void stage_begin() {
+    Runtime::Stage st{stage_event(), stage_event(), nullptr, false};
+    GRL_HIP_CHECK(hipEventRecord(st.a, rt().stream));
+    rt().stages.push_back(st);
+}
+inline void stage_end(double *acc) {     // closes the innermost open stage (stages nest like scopes)
+    Runtime &R = rt();
+    for (size_t k = R.stages.size(); k-- > 0;)
+        if (!R.stages[k].closed) {
+            (void)hipEventRecord(R.stages[k].b, R.stream);
+            R.stages[k].acc = acc;
+            R.stages[k].closed = true;
+            return;
+        }
+}
+inline void stages_collect() {
+    Runtime &R = rt();
+    std::vector<Runtime::Stage> keep;
+    for (auto &st : R.stages) {
+        if (!st.closed) { keep.push_back(st); continue; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, st.a, st.b) == hipSuccess && st.acc) *st.acc += (double)ms * 1e-3;
+        R.spare_events.push_back(st.a);
+        R.spare_events.push_back(st.b);
+    }
+    R.stages.swap(keep);
+}
+inline void stages_drop() {
+    Runtime &R = rt();
+    for (auto &st : R.stages) { R.spare_events.push_back(st.a); R.spare_events.push_back(st.b); }
+    R.stages.clear();
 }
 inline void after_launch(const char *name) {
     hipError_t e = hipGetLastError();
@@ -271,6 +323,17 @@ inline void h2d(void *d, const void *h, size_t n) {
     sync();
 }
 inline void d2h(void *h, const void *d, size_t n) {
+    // scalars and small tables (scan totals, flags, per-rank counts) come back through a pinned bounce buffer:
+    // a copy to pageable memory is staged and synchronised by the runtime and costs tens of microseconds more
+    static void *pinned = nullptr;
+    constexpr size_t kPinned = 1 << 16;
+    if (n && n <= kPinned) {
+        if (!pinned) GRL_HIP_CHECK(hipHostMalloc(&pinned, kPinned, hipHostMallocDefault));
+        GRL_HIP_CHECK(hipMemcpyAsync(pinned, d, n, hipMemcpyDeviceToHost, rt().stream));
+        sync();
+        std::memcpy(h, pinned, n);
+        return;
+    }
     if (n) GRL_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().stream));
     sync();
 }
@@ -641,6 +704,12 @@ inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, cons
     return total;
 }
 
+// same without the host total (no synchronisation)
+template <class T, class F>
+inline void exclusive_scan_nosync(u64 n, F in, T *out, bool store_total_at_n = false, const char *name = "scan") {
+    exclusive_scan_async<T, F>(n, in, out, nullptr, store_total_at_n ? out + n : nullptr, name);
+}
+
 // ------------------------------------------------------------- byte histogram
 __global__ void __launch_bounds__(kBlock) k_byte_hist(const u8 *p, u64 n, u64 *hist) {
     __shared__ u32 s_h[4][256];
@@ -864,8 +933,7 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         after_launch(name);
         cur ^= 1;
     }
-    sync();
-    dev_free(counts);
+    dev_free(counts);      // stream-ordered reuse: no host synchronisation needed
     dev_free(offsets);
     return cur;
 }

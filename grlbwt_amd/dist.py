@@ -6,6 +6,7 @@ module only provides the two collectives the engine calls back for, implemented 
 torch.distributed -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -19,7 +20,11 @@ _A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_v
 
 
 class CommStruct(C.Structure):
-    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", C.c_void_p), ("allgather", _AG), ("alltoallv", _A2A)]
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", C.c_void_p), ("allgather", _AG), ("alltoallv", _A2A),
+                ("flags", C.c_uint32)]
+
+
+COMM_STREAM_ORDERED = 1
 
 
 class _DevView:
@@ -49,15 +54,29 @@ class Communicator:
         self.bytes_moved = 0
         self.n_allgather = 0
         self.n_alltoall = 0
+        self.log = None              # set to a list to record (kind, bytes, seconds) per call
         self.seconds = 0.0           # wall time spent inside the callbacks (transport + synchronisation)
         # gloo transport with device-resident engine buffers (tests on a single-GPU box): stage through the host
         self.stage = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
+        # RCCL: run the engine on a torch stream and issue the collectives with that stream current, so that they
+        # are ordered on it like the engine's own kernels and nobody waits on the host (GRLBWT_DIST_SYNC_COLLECTIVES=1
+        # restores a full synchronisation around every exchange)
+        self.stream = None
+        if self.device.type == "cuda" and not self.stage and os.environ.get("GRLBWT_DIST_SYNC_COLLECTIVES") != "1":
+            self.stream = torch.cuda.Stream(self.device)
         self._ag = _AG(self._allgather)
         self._a2a = _A2A(self._alltoallv)
-        self.struct = CommStruct(self.rank, self.size, None, self._ag, self._a2a)
+        self.struct = CommStruct(self.rank, self.size, None, self._ag, self._a2a,
+                                 COMM_STREAM_ORDERED if self.stream is not None else 0)
+
+    def attach(self, ctx):
+        """Make `ctx` run on the stream the collectives are issued on (stream-ordered mode)."""
+        if self.stream is not None and getattr(ctx, "_comm_stream", None) is not self.stream:
+            ctx.set_stream(self.stream.cuda_stream)
+            ctx._comm_stream = self.stream
 
     def _sync(self):
-        if self.device.type == "cuda":
+        if self.device.type == "cuda" and self.stream is None:
             torch.cuda.synchronize(self.device)
 
     def _allgather(self, user, send, recv, nbytes):
@@ -69,12 +88,17 @@ class Communicator:
                 hs, hr = s.cpu(), torch.empty(nbytes * self.size, dtype=torch.uint8)
                 dist.all_gather_into_tensor(hr, hs, group=self.group)
                 r.copy_(hr)
+            elif self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    dist.all_gather_into_tensor(r, s, group=self.group)  # the stream waits for it, the host does not
             else:
                 dist.all_gather_into_tensor(r, s, group=self.group)      # also at size 1: same code path as N > 1
             self._sync()
             self.bytes_moved += nbytes * self.size
             self.n_allgather += 1
             self.seconds += time.perf_counter() - t0
+            if self.log is not None:
+                self.log.append(("allgather", nbytes * self.size, time.perf_counter() - t0))
             return 0
         except Exception as e:          # never let an exception cross the C boundary
             print("grlbwt allgather callback failed:", repr(e), flush=True)
@@ -91,12 +115,17 @@ class Communicator:
                 hs, hr = s.cpu(), torch.empty(sum(rb), dtype=torch.uint8)
                 dist.all_to_all_single(hr, hs, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
                 r.copy_(hr)
+            elif self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
             else:
                 dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
             self._sync()
             self.bytes_moved += sum(sb)
             self.n_alltoall += 1
             self.seconds += time.perf_counter() - t0
+            if self.log is not None:
+                self.log.append(("alltoallv", sum(sb), time.perf_counter() - t0))
             return 0
         except Exception as e:
             print("grlbwt alltoallv callback failed:", repr(e), flush=True)
@@ -120,6 +149,7 @@ def shard_records(cells, rank, size, sep=None):
 def dist_build(ctx, comm):
     """Run the collection-level build on a context that already holds this rank's shard."""
     L = ctx.L
+    comm.attach(ctx)
     L.grlbwt_dist_build.argtypes = [C.c_void_p, C.POINTER(CommStruct)]
     ctx._ck(L.grlbwt_dist_build(ctx._h, C.byref(comm.struct)))
 

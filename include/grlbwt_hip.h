@@ -175,7 +175,15 @@ typedef struct grlbwt_comm {
     int (*allgather)(void *user, const void *send, void *recv, uint64_t bytes);
     /* variable all-to-all: send_bytes[size]/recv_bytes[size] (host arrays), blocks contiguous in rank order */
     int (*alltoallv)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+    /* GRLBWT_COMM_STREAM_ORDERED: the callbacks enqueue the exchange on the context's stream
+     * (grlbwt_ctx_set_stream) and return without waiting; the engine then neither drains its stream
+     * before a callback nor expects the data to be complete when it returns -- later work on the same
+     * stream is ordered behind it (RCCL through torch.distributed with that stream current).
+     * 0: the callback may use any stream or the host; the engine synchronises before calling it and
+     * the callback returns only when `recv` is complete (gloo, host staging).                        */
+    uint32_t flags;
 } grlbwt_comm;
+#define GRLBWT_COMM_STREAM_ORDERED 1u
 /* grl_bwt_algo over the sharded collection: par_phase with a dictionary merge per round, ind_phase, image */
 int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm);
 

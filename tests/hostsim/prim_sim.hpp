@@ -92,6 +92,24 @@ template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
 }
+// stage clocks: host wall time here (the HIP runtime uses event pairs on its stream)
+#include <time.h>
+inline double sim_now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+inline std::vector<double> &sim_stage_stack() { static std::vector<double> s; return s; }
+inline void stage_begin() { sim_stage_stack().push_back(sim_now_s()); }
+inline void stage_end(double *acc) {
+    auto &s = sim_stage_stack();
+    if (s.empty()) return;
+    if (acc) *acc += sim_now_s() - s.back();
+    s.pop_back();
+}
+inline void stages_drop() { sim_stage_stack().clear(); }
+template <class T, class F>
+inline void exclusive_scan_nosync(u64 n, F in, T *out, bool store_total_at_n = false, const char * = "") {
+    T acc = 0;
+    for (u64 i = 0; i < n; i++) { T v = (T)in(i); out[i] = acc; acc += v; }
+    if (store_total_at_n) out[n] = acc;
+}
 inline void pool_trim() {}
 inline void pool_reserve(size_t) {}
 inline u64 pool_stage_begin() { return 0; }
