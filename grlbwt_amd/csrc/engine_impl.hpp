@@ -1772,13 +1772,18 @@ class Engine {
             allgather(s.p, r.p, c * 8);
             return r.to_host(c * size);
         }
-        // variable-length all-gather of a typed device array -> dense concatenation in rank order
+        // variable-length all-gather of a typed device array -> dense concatenation in rank order.
+        // same_counts: `base` already holds the prefix of every rank's count (an earlier call with the same counts)
         template <class T>
-        DBuf<T> allgather_v(const T *send, u64 count, std::vector<u64> &base) const {
-            std::vector<u64> cnt = allgather_u64({count});
-            base.assign(size + 1, 0);
+        DBuf<T> allgather_v(const T *send, u64 count, std::vector<u64> &base, bool same_counts = false) const {
+            if (!same_counts || base.size() != (size_t)size + 1) {
+                std::vector<u64> cnt = allgather_u64({count});
+                base.assign(size + 1, 0);
+                for (int g = 0; g < size; g++) base[g + 1] = base[g] + cnt[g];
+            }
+            if (base[rank + 1] - base[rank] != count) throw prim::Error(-71, "allgather_v: counts changed between calls");
             u64 mx = 1;
-            for (int g = 0; g < size; g++) { base[g + 1] = base[g] + cnt[g]; if (cnt[g] > mx) mx = cnt[g]; }
+            for (int g = 0; g < size; g++) if (base[g + 1] - base[g] > mx) mx = base[g + 1] - base[g];
             DBuf<T> sp(mx), rp(mx * size);
             prim::dev_memset(sp.p, 0, mx * sizeof(T));
             prim::d2d(sp.p, send, count * sizeof(T));
@@ -1787,8 +1792,7 @@ class Engine {
             DBuf<u64> dbase(size + 1);
             prim::h2d(dbase.p, base.data(), (size + 1) * 8);
             prim::for_each(base[size], UnpadFn<T>{rp.p, dbase.p, size, mx, dense.p}, "dist.unpad");
-            prim::sync();
-            return dense;
+            return dense;       // scratch goes back to the pool in stream order
         }
     };
 
@@ -1952,12 +1956,13 @@ class Engine {
         DBuf<u8> hh_l(Mg);
         prim::for_each(Gg, GroupEmitDistFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code, (u32)P0off,
                                            psym0_l.p, plen0_l.p, hh_l.p, repq_l.p, u2p0_l.p}, "prebwt_emit");
-        std::vector<u64> bb;
-        DBuf<u32> psym0 = C.allgather_v<u32>(psym0_l.p, P0g, bb);
-        DBuf<idx_t> plen0 = C.allgather_v<idx_t>(plen0_l.p, P0g, bb);
-        L.has_hocc = C.allgather_v<u8>(hh_l.p, Mg, bb);
-        DBuf<u32> repq = C.allgather_v<u32>(repq_l.p, Mg, bb);
-        DBuf<u32> u_to_p0 = C.allgather_v<u32>(u2p0_l.p, Mg, bb);
+        std::vector<u64> bb, bbM(C.size + 1, 0), bbP(C.size + 1, 0);      // every rank's (Mg, P0g) is known from cnts
+        for (int g = 0; g < C.size; g++) { bbM[g + 1] = bbM[g] + cnts[2 * g]; bbP[g + 1] = bbP[g] + cnts[2 * g + 1]; }
+        DBuf<u32> psym0 = C.allgather_v<u32>(psym0_l.p, P0g, bbP, true);
+        DBuf<idx_t> plen0 = C.allgather_v<idx_t>(plen0_l.p, P0g, bbP, true);
+        L.has_hocc = C.allgather_v<u8>(hh_l.p, Mg, bbM, true);
+        DBuf<u32> repq = C.allgather_v<u32>(repq_l.p, Mg, bbM, true);
+        DBuf<u32> u_to_p0 = C.allgather_v<u32>(u2p0_l.p, Mg, bbM, true);
         DBuf<u32> merged(P0);
         L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
         L.u_to_p.alloc(M);
@@ -2004,7 +2009,7 @@ class Engine {
         std::vector<u64> sbase, dbase, dbase2;
         DBuf<u32> gcells = C.allgather_v<u32>(lcells.p, P.S, sbase);
         DBuf<u32> glen = C.allgather_v<u32>(P.ph_len.p, P.D, dbase);
-        DBuf<u64> gfreq = C.allgather_v<u64>(lfreq.p, P.D, dbase2);
+        DBuf<u64> gfreq = C.allgather_v<u64>(lfreq.p, P.D, dbase, true);
         lcells.release(); lfreq.release();
         const u64 Dl = dbase[C.size], Sl = sbase[C.size];
         std::vector<u64> tot = C.allgather_u64({P.n_occ, n});
@@ -2143,7 +2148,7 @@ class Engine {
         // (2) replicate the rewritten BWT_{r+1} (run symbols + lengths)
         std::vector<u64> rbase, rbase2;
         DBuf<u32> Tsym = C.allgather_v<u32>(term.p, R, rbase);
-        DBuf<idx_t> Tlen = C.allgather_v<idx_t>(bwt.len.p, R, rbase2);
+        DBuf<idx_t> Tlen = C.allgather_v<idx_t>(bwt.len.p, R, rbase, true);
         const u64 Rt = rbase[C.size];
         DBuf<idx_t> Tpos(Rt + 1);
         u64 Tsum = (u64)prim::exclusive_scan<idx_t>(Rt, IdxIn<idx_t>{Tlen.p}, Tpos.p, true, "dist.Tpos");
@@ -2263,7 +2268,7 @@ class Engine {
     void dist_finish(const Comm &C) {
         std::vector<u64> b1, b2;
         DBuf<u32> gs = C.allgather_v<u32>(bwt.sym.p, bwt.R, b1);
-        DBuf<idx_t> gl = C.allgather_v<idx_t>(bwt.len.p, bwt.R, b2);
+        DBuf<idx_t> gl = C.allgather_v<idx_t>(bwt.len.p, bwt.R, b1, true);
         bwt = merge_runs(gs.p, gl.p, b1[C.size]);
         stats.n_strings = g_n_strings;
         stats.n_syms = g_n_syms;
