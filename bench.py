@@ -68,6 +68,11 @@ def pmc_traffic_per_launch(kernel_substr, n_launches):
 
 
 def main():
+    # stdout carries exactly one line (the JSON result): anything a library prints to fd 1 on the way
+    # (RCCL's version banner at communicator creation) is sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -281,7 +286,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
