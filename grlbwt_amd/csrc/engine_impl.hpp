@@ -289,14 +289,31 @@ struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: o
     CellOps<cell_t, FIRST> ops;
     const u32 *ph_off; u64 D; u64 S; const u64 *ph_pos;
     u32 *dict_sym; u32 *dict_phr;
+    struct alignas(16) Quad { u32 v[4]; };
     GRL_DEV void operator()(u64 c) const {
         u64 q0 = c * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
         u64 k = upper_bound<u32>(ph_off, D, (u32)q0) - 1;
         u64 nxt = ph_off[k + 1];
-        for (u64 q = q0; q < q1; q++) {
-            while (q >= nxt) { k++; nxt = ph_off[k + 1]; }
-            dict_phr[q] = (u32)k;
-            dict_sym[q] = ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
+        u32 phr[16], sym[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            u64 q = q0 + j;
+            if (q < q1) {
+                while (q >= nxt) { k++; nxt = ph_off[k + 1]; }
+                phr[j] = (u32)k;
+                sym[j] = ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
+            }
+        }
+        if (q1 - q0 == 16) {      // 16-byte stores: a quarter of the store requests of 16 scalar stores per array
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                *reinterpret_cast<Quad *>(dict_phr + q0 + j) = Quad{{phr[j], phr[j + 1], phr[j + 2], phr[j + 3]}};
+                *reinterpret_cast<Quad *>(dict_sym + q0 + j) = Quad{{sym[j], sym[j + 1], sym[j + 2], sym[j + 3]}};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (q0 + j < q1) { dict_phr[q0 + j] = phr[j]; dict_sym[q0 + j] = sym[j]; }
         }
     }
 };
@@ -394,6 +411,44 @@ struct RankRefinedFn {    // new positional rank of the re-sorted suffixes only
     GRL_DEV void operator()(u64 i) const {
         u32 t = uslot[i];
         rank[perm[t]] = gstart[ex[t] + hflag[t] - 1];
+    }
+};
+// The same refinement driven by the list of still-unresolved slots (ascending; nullptr = all slots): a suffix that is
+// resolved stays resolved, so every pass after the first touches only the previous pass's unresolved slots.
+// "My group has >= 2 members" needs no group table: slot t is not a head, or slot t+1 is not one either.
+struct ActiveFlagFn {
+    const u32 *act; const u8 *hflag; const u32 *perm; const u32 *suflen; u64 S; u64 Lres; u8 *uflag;
+    GRL_DEV void operator()(u64 i) const {
+        u64 t = act ? (u64)act[i] : i;
+        bool multi = !hflag[t] || (t + 1 < S && !hflag[t + 1]);
+        uflag[i] = (multi && suflen[perm[t]] >= Lres) ? 1 : 0;
+    }
+};
+struct ActiveKeyFn {      // compact the unresolved slots and build their refinement keys
+    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u32 *rank; const u32 *suflen;
+    u64 h; int lowbits;
+    u64 *keys; u32 *vals; u32 *uslot;
+    GRL_DEV void operator()(u64 i) const {
+        if (!uflag[i]) return;
+        u64 t = act ? (u64)act[i] : i;
+        u64 q = perm[t];
+        u64 sent = (1ull << lowbits) - 1;
+        u64 low = (h < suflen[q]) ? (u64)rank[q + h] : sent;
+        u32 j = uex[i];
+        keys[j] = ((u64)rank[q] << lowbits) | low;
+        vals[j] = (u32)q;
+        uslot[j] = (u32)t;
+    }
+};
+struct HeadSlotFn {       // hpos[k] = slot of the k-th group head among the re-sorted suffixes
+    const u64 *k; const u32 *hex; const u32 *uslot; u32 *hpos;
+    GRL_DEV void operator()(u64 i) const { if (i == 0 || k[i] != k[i - 1]) hpos[hex[i]] = uslot[i]; }
+};
+struct RankFromHeadsFn {  // positional rank = slot of my group's head
+    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; u32 *rank;
+    GRL_DEV void operator()(u64 i) const {
+        u32 head = (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
+        rank[v[i]] = hpos[hex[i] + head - 1];
     }
 };
 struct DenseGidFn {       // final dense group id of every slot
@@ -1473,21 +1528,35 @@ class Engine {
             prim::for_each(S, RankAllFn{hflag.p, ex.p, gstart.p, perm.p, rank.p}, "suffix_ranks");
             const int lowbits = (int)bitlen64(S);
             u64 Lres = (u64)K, iters = 1;
+            DBuf<u32> act;                       // slots still unresolved after the previous pass (empty = all slots)
+            u64 A = S;
+            bool refined = false;
             while (Lres < maxlen) {              // Lres symbols (incl. a possible sentinel) resolved so far
-                prim::for_each(S, UnresolvedFlagFn{hflag.p, ex.p, gstart.p, perm.p, suflen.p, Lres, uflag.p}, "suffix_unresolved");
-                DBuf<u32> uex(S + 1);
-                u64 U = prim::exclusive_scan<u32>(S, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
+                const u32 *ap = refined ? act.p : nullptr;
+                prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, suflen.p, S, Lres, uflag.p}, "suffix_unresolved");
+                DBuf<u32> uex(A + 1);
+                u64 U = prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
                 if (U == 0) break;
                 DBuf<u64> ka(U), kb(U);
                 DBuf<u32> va(U), vb(U), uslot(U);
-                prim::for_each(S, UnresolvedKeyFn{uflag.p, uex.p, perm.p, rank.p, suflen.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
+                prim::for_each(A, ActiveKeyFn{ap, uflag.p, uex.p, perm.p, rank.p, suflen.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
                 int res = prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort");
-                prim::for_each(U, RefineWriteFn{res ? kb.p : ka.p, res ? vb.p : va.p, uslot.p, perm.p, hflag.p}, "suffix_refine");
-                G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-                prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
-                prim::for_each(U, RankRefinedFn{uslot.p, hflag.p, ex.p, gstart.p, perm.p, rank.p}, "suffix_ranks");
+                const u64 *sk = res ? kb.p : ka.p;
+                const u32 *sv = res ? vb.p : va.p;
+                prim::for_each(U, RefineWriteFn{sk, sv, uslot.p, perm.p, hflag.p}, "suffix_refine");
+                DBuf<u32> hex(U + 1), hpos(U);
+                prim::exclusive_scan_nosync<u32>(U, HeadKeyIn{sk}, hex.p, false, "suffix_heads");
+                prim::for_each(U, HeadSlotFn{sk, hex.p, uslot.p, hpos.p}, "suffix_gstart");
+                prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rank.p}, "suffix_ranks");
+                act = std::move(uslot);
+                A = U;
+                refined = true;
                 Lres *= 2;
                 iters++;
+            }
+            if (refined) {                       // group table of the final order
+                G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+                prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
             }
             prim::for_each(S, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
             prim::sync();
