@@ -611,11 +611,11 @@ GRL_DEV T block_excl_scan(T v, T *s_w /*[4]*/, T *block_total) {
 template <class T, class F>
 __global__ void __launch_bounds__(kBlock) k_scan_tile_sums(u64 n, F in, T *tile_sums) {
     __shared__ T s_w[4];
-    u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanItems;
+    u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x;     // striped: a sum does not care about the order
     T acc = 0;
 #pragma unroll
     for (int j = 0; j < kScanItems; j++) {
-        u64 i = base + j;
+        u64 i = base + (u64)j * kBlock;
         if (i < n) acc += (T)in(i);
     }
     acc = wave_reduce<T, Op::Sum>(acc);
@@ -628,17 +628,41 @@ __global__ void __launch_bounds__(kBlock) k_scan_tile_sums(u64 n, F in, T *tile_
 template <class T, class F>
 __global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *tile_offsets, T *out, T *total_a, T *total_b) {
     __shared__ T s_w[4];
-    u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanItems;
+    __shared__ T s_x[kScanTile + kScanTile / 32];      // skewed by one slot per 32: the blocked reads spread over the banks
+    const u64 tile_base = (u64)blockIdx.x * kScanTile;
+    u64 base = tile_base + (u64)threadIdx.x * kScanItems;
+    // the input is read striped (neighbouring lanes, neighbouring elements) and turned into the blocked arrangement
+    // the scan wants through LDS; blocked global loads are kScanItems instructions of 64 addresses 32+ bytes apart
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        u32 k = (u32)j * kBlock + threadIdx.x;
+        u64 i = tile_base + k;
+        s_x[k + (k >> 5)] = (i < n) ? (T)in(i) : T(0);
+    }
+    __syncthreads();
     T v[kScanItems];
     T acc = 0;
 #pragma unroll
     for (int j = 0; j < kScanItems; j++) {
-        u64 i = base + j;
-        v[j] = (i < n) ? (T)in(i) : T(0);
+        u32 k = threadIdx.x * kScanItems + j;
+        v[j] = s_x[k + (k >> 5)];
         acc += v[j];
     }
     T tot;
     T ex = block_excl_scan<T>(acc, s_w, &tot) + (tile_offsets ? tile_offsets[blockIdx.x] : T(0));
+    // A lane's kScanItems results are contiguous: full tiles store them as 16-byte pieces (scalar stores would be
+    // kScanItems store instructions per lane, each hitting 64 different 32-byte-apart addresses).
+    constexpr int kBytes = (int)sizeof(T) * kScanItems;
+    const bool full = (u64)(blockIdx.x + 1) * kScanTile < n;      // uniform; the tile holding n-1 takes the scalar path
+    if (kBytes % 16 == 0 && full && ((uintptr_t)out & 15) == 0) {
+        union { T t[kScanItems]; uint4 q[kBytes / 16 > 0 ? kBytes / 16 : 1]; } u;
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) { u.t[j] = ex; ex = ex + v[j]; }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + base);
+#pragma unroll
+        for (int k = 0; k < kBytes / 16; k++) dst[k] = u.q[k];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < kScanItems; j++) {
         u64 i = base + j;
