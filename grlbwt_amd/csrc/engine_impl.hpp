@@ -569,9 +569,11 @@ struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
 
 // ------------------------------------------------------------- a8: grammar
 struct MarkPosFn {        // mark[q] = 1 iff q's suffix group is ranked and has > 1 member (phr_marks, exact_par_phase.cpp:203-205)
-    const u32 *perm; const u32 *gid; const u8 *gflag; u8 *mark;
-    GRL_DEV void operator()(u64 t) const {
-        mark[perm[t]] = ((gflag[gid[t]] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1 : 0;
+    // by dictionary position: rank[q] = head slot of q's group, gid[slot] = dense group id.  (Two dependent gathers and a
+    // coalesced byte store; the other direction, mark[perm[t]] by slot, is a random one-byte store per suffix.)
+    const u32 *rank; const u32 *gid; const u8 *gflag; u8 *mark;
+    GRL_DEV void operator()(u64 q) const {
+        mark[q] = ((gflag[gid[rank[q]]] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1 : 0;
     }
 };
 struct GrammarFn {
@@ -837,8 +839,12 @@ struct UnpackCellFn {   // (sym<<32 | len) payload carried through the radix spl
 struct PackRunsFn {
     const u32 *sym; const idx_t *len; u32 sb, fb; u8 *out;
     GRL_DEV void operator()(u64 i) const {
-        u8 *p = out + 16 + i * (u64)(sb + fb);
+        const u32 rec = sb + fb;
+        u8 *p = out + 16 + i * (u64)rec;
         u64 s = sym[i], l = len[i];
+        // records of 4 or 8 bytes (DNA: 1+3; tokens: 2+2 ... ) are one aligned store, not `rec` byte stores
+        if (rec == 4 && ((uintptr_t)out & 3) == 0) { *reinterpret_cast<u32 *>(p) = (u32)(s | (l << (8 * sb))); return; }
+        if (rec == 8 && ((uintptr_t)out & 7) == 0) { *reinterpret_cast<u64 *>(p) = s | (l << (8 * sb)); return; }
         for (u32 b = 0; b < sb; b++) p[b] = (u8)(s >> (8 * b));
         for (u32 b = 0; b < fb; b++) p[sb + b] = (u8)(l >> (8 * b));
     }
@@ -1601,7 +1607,7 @@ class Engine {
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
             DBuf<u8> mark(S);
-            prim::for_each(S, MarkPosFn{perm.p, gid.p, gflag.p, mark.p}, "grammar_marks");
+            prim::for_each(S, MarkPosFn{rank.p, gid.p, gflag.p, mark.p}, "grammar_marks");
             prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, rank.p, gid.p, mark.p, grank.p,
                                         sigma3, MD, L.g0.p, L.g1.p}, "grammar");
             // ---- a9: metasymbol of every phrase --------------------------------
