@@ -132,6 +132,26 @@ struct U32Raw {
     GRL_DEV uint32_t operator()(uint64_t i) const { return v[i]; }
 };
 
+template <class A, class B>
+struct PairOfIn {
+    const uint32_t *v;
+    GRL_DEV prim::Pair<A, B> operator()(uint64_t i) const { return prim::Pair<A, B>((A)(v[i] & 1u), (B)(v[i] & 4095u)); }
+};
+template <class A, class B>
+int test_pair_scan(uint64_t n, const std::vector<uint32_t> &h, const uint32_t *d) {
+    typedef prim::Pair<A, B> P;
+    grl32::DBuf<P> o(n + 1);
+    P tot = prim::exclusive_scan<P>(n, PairOfIn<A, B>{d}, o.p, true, "selftest.pairscan");
+    std::vector<P> ho = o.to_host(n + 1);
+    A a = 0; B b = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (ho[i].a != a || ho[i].b != b) return 1;
+        a += (A)(h[i] & 1u); b += (B)(h[i] & 4095u);
+    }
+    if (ho[n].a != a || ho[n].b != b || tot.a != a || tot.b != b) return 2;
+    return 0;
+}
+
 template <class K, class V>
 int test_sort(uint64_t n, uint64_t seed, int bits) {
     std::vector<K> hk(n);
@@ -216,6 +236,10 @@ int selftest(uint64_t n, uint64_t seed) {
     { int r = test_sort<uint64_t, uint32_t>(n, seed + 2, 45); if (r) return -30 - r; }
     { int r = test_sort<uint32_t, uint64_t>(n, seed + 3, 8); if (r) return -40 - r; }
     { int r = test_sort<uint64_t, uint32_t>(n, seed + 4, 3); if (r) return -50 - r; }   // heavy duplicates
+    { int r = test_sort<uint64_t, uint64_t>(n, seed + 5, 33); if (r) return -60 - r; }
+    // 7: fused pair scans (8- and 16-byte elements: the 16-byte result stores and the LDS staging of the scan)
+    { int r = test_pair_scan<uint32_t, uint32_t>(n, h, d.p); if (r) return -70 - r; }
+    { int r = test_pair_scan<uint64_t, uint64_t>(n, h, d.p); if (r) return -80 - r; }
     return 0;
 }
 

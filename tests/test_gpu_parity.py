@@ -30,7 +30,7 @@ def test_native_library_is_loaded(hip):
     assert "libgrlbwt_hip.so" in maps
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097, 100000, 3000001])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 2048, 2049, 4096, 4097, 100000, 131072, 131073, 3000001, 20000001])
 def test_primitives_selftest(hip, n):
     with engine.Context(0, 0, hip) as ctx:
         assert ctx.selftest(n, 11 + n) == 0
