@@ -625,13 +625,30 @@ struct RankBits {
 };
 struct BuildBitsFn {      // one lane per 16 consecutive (sorted, distinct) positions: OR them into their words
     const idx_t *pos; u64 count; u64 *words;
+    struct alignas(16) Chunk { idx_t v[16 / sizeof(idx_t)]; };     // 16 bytes of positions per load
     GRL_DEV void operator()(u64 j) const {
         u64 i0 = j * 16, i1 = i0 + 16 < count ? i0 + 16 : count;
-        u64 cur = (u64)pos[i0] >> 6, m = 0;
-        for (u64 i = i0; i < i1; i++) {
-            u64 x = pos[i], w = x >> 6;
-            if (w != cur) { prim::atomic_or(&words[cur], m); m = 0; cur = w; }
-            m |= 1ull << (x & 63);
+        idx_t x16[16];
+        if (i1 - i0 == 16 && ((uintptr_t)pos & 15) == 0) {
+            constexpr int per = 16 / (int)sizeof(idx_t);
+#pragma unroll
+            for (int c = 0; c < 16 / per; c++) {
+                Chunk ch = *reinterpret_cast<const Chunk *>(pos + i0 + c * per);
+#pragma unroll
+                for (int k = 0; k < per; k++) x16[c * per + k] = ch.v[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x16[k] = (i0 + k < i1) ? pos[i0 + k] : (idx_t)0;
+        }
+        u64 cur = (u64)x16[0] >> 6, m = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (i0 + k < i1) {
+                u64 x = x16[k], w = x >> 6;
+                if (w != cur) { prim::atomic_or(&words[cur], m); m = 0; cur = w; }
+                m |= 1ull << (x & 63);
+            }
         }
         prim::atomic_or(&words[cur], m);
     }
@@ -664,15 +681,6 @@ struct HeadLenIn {
     const u32 *s; const idx_t *len;
     GRL_DEV HeadLen operator()(u64 t) const { return HeadLen((t == 0 || s[t] != s[t - 1]) ? (idx_t)1 : (idx_t)0, len[t]); }
 };
-struct MergeHeadsFn {
-    const u32 *sym; const HeadLen *ps; u64 n;
-    u32 *osym; idx_t *ostart;
-    GRL_DEV void operator()(u64 t) const {
-        bool head = (t == 0 || sym[t] != sym[t - 1]);
-        if (head) { idx_t r = ps[t].a; osym[r] = sym[t]; ostart[r] = ps[t].b; }
-        if (t == n - 1) ostart[ps[n].a] = ps[n].b;
-    }
-};
 struct DiffFn {
     const idx_t *start; idx_t *len;
     GRL_DEV void operator()(u64 r) const { len[r] = start[r + 1] - start[r]; }
@@ -688,24 +696,30 @@ struct Runs {
     u64 R = 0;
 };
 
-struct MergedIndexFn {   // merged run index of every input run
-    const u32 *sym; const HeadLen *ps; u32 *map;
-    GRL_DEV void operator()(u64 t) const { map[t] = (u32)(ps[t].a + ((t == 0 || sym[t] != sym[t - 1]) ? 1 : 0) - 1); }
-};
 // merge adjacent equal symbols (bwt_io.h push_back/inc_freq_last idiom): -> maximal runs.
-// One fused scan gives every input run its output run index and its symbol offset.
+// One fused scan gives every input run its output run index and its symbol offset; the scan hands both straight to
+// the run heads (no prefix array of n pairs in between).
+struct MergeEmitFn {
+    const u32 *sym; u64 n;
+    u32 *osym; idx_t *ostart; u32 *map;
+    GRL_DEV void operator()(u64 t, HeadLen ex, HeadLen v) const {
+        if (v.a) { osym[ex.a] = sym[t]; ostart[ex.a] = ex.b; }
+        if (t == n - 1) ostart[ex.a + v.a] = ex.b + v.b;
+        if (map) map[t] = (u32)(ex.a + v.a - 1);
+    }
+};
 static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merged_index = nullptr) {
     Runs out;
     if (n == 0) { out.sym.alloc(0); out.len.alloc(0); return out; }
-    DBuf<HeadLen> ps(n + 1);
-    HeadLen tot = prim::exclusive_scan<HeadLen>(n, HeadLenIn{sym, len}, ps.p, true, "merge_runs.scan");
+    // the number of output runs is not known before the scan: heads land in scratch sized for the worst case
+    DBuf<u32> hsym(n);
+    DBuf<idx_t> ostart(n + 1);
+    HeadLen tot = prim::exclusive_scan_emit<HeadLen>(n, HeadLenIn{sym, len}, MergeEmitFn{sym, n, hsym.p, ostart.p, merged_index}, "merge_runs.scan");
     u64 R = (u64)tot.a;
-    out.sym.alloc(R);
     out.len.alloc(R);
-    DBuf<idx_t> ostart(R + 1);
-    prim::for_each(n, MergeHeadsFn{sym, ps.p, n, out.sym.p, ostart.p}, "merge_runs.heads");
     prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
-    if (merged_index) prim::for_each(n, MergedIndexFn{sym, ps.p, merged_index}, "merge_runs.index");
+    if (R == n) out.sym = std::move(hsym);
+    else { out.sym.alloc(R); prim::d2d(out.sym.p, hsym.p, R * sizeof(u32)); }
     out.R = R;
     return out;
 }

@@ -18,6 +18,7 @@
 #include <vector>
 #include <map>
 #include <utility>
+#include <type_traits>
 
 #define GRL_HD __host__ __device__ __forceinline__
 #define GRL_DEV __device__ __forceinline__
@@ -625,19 +626,23 @@ __global__ void __launch_bounds__(kBlock) k_scan_tile_sums(u64 n, F in, T *tile_
 }
 // tile_offsets == nullptr: single tile, offset 0.  The thread holding element n-1 stores the grand
 // total to total_a / total_b when they are non-null (no separate copy kernels for scalars).
-template <class T, class F>
-__global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *tile_offsets, T *out, T *total_a, T *total_b) {
+struct NoEmit {};
+template <class T, class F, class E = NoEmit>
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *tile_offsets, T *out, T *total_a, T *total_b, E emit = E()) {
     __shared__ T s_w[4];
     __shared__ T s_x[kScanTile + kScanTile / 32];      // skewed by one slot per 32: the blocked reads spread over the banks
     const u64 tile_base = (u64)blockIdx.x * kScanTile;
     u64 base = tile_base + (u64)threadIdx.x * kScanItems;
     // the input is read striped (neighbouring lanes, neighbouring elements) and turned into the blocked arrangement
     // the scan wants through LDS; blocked global loads are kScanItems instructions of 64 addresses 32+ bytes apart
+    T vs[std::is_same<E, NoEmit>::value ? 1 : kScanItems];     // striped copies, kept for the fused consumer
 #pragma unroll
     for (int j = 0; j < kScanItems; j++) {
         u32 k = (u32)j * kBlock + threadIdx.x;
         u64 i = tile_base + k;
-        s_x[k + (k >> 5)] = (i < n) ? (T)in(i) : T(0);
+        T x = (i < n) ? (T)in(i) : T(0);
+        s_x[k + (k >> 5)] = x;
+        if constexpr (!std::is_same<E, NoEmit>::value) vs[j] = x;
     }
     __syncthreads();
     T v[kScanItems];
@@ -654,6 +659,34 @@ __global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *til
     // kScanItems store instructions per lane, each hitting 64 different 32-byte-apart addresses).
     constexpr int kBytes = (int)sizeof(T) * kScanItems;
     const bool full = (u64)(blockIdx.x + 1) * kScanTile < n;      // uniform; the tile holding n-1 takes the scalar path
+    if constexpr (!std::is_same<E, NoEmit>::value) {
+        // fused consumer: emit(i, exclusive prefix, own value) instead of materialising the prefix array.  The
+        // prefixes go back through LDS into the striped arrangement, so that neighbouring lanes emit neighbouring
+        // elements (a compaction then writes neighbouring addresses).
+        __syncthreads();                       // everybody has read its blocked inputs
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            u32 k = threadIdx.x * kScanItems + j;
+            s_x[k + (k >> 5)] = ex;
+            ex = ex + v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            u32 k = (u32)j * kBlock + threadIdx.x;
+            u64 i = tile_base + k;
+            if (i < n) {
+                T e = s_x[k + (k >> 5)];
+                if (i == n - 1) {
+                    T nx = e + vs[j];
+                    if (total_a) *total_a = nx;
+                    if (total_b) *total_b = nx;
+                }
+                emit(i, e, vs[j]);
+            }
+        }
+        return;
+    }
     if (kBytes % 16 == 0 && full && ((uintptr_t)out & 15) == 0) {
         union { T t[kScanItems]; uint4 q[kBytes / 16 > 0 ? kBytes / 16 : 1]; } u;
 #pragma unroll
@@ -714,6 +747,37 @@ inline void exclusive_scan_async(u64 n, F in, T *out, T *total_a, T *total_b = n
     prof_end();
     after_launch(name);
     dev_free(sums);      // stream-ordered reuse (pool)
+}
+
+// Scan fused with its consumer: emit(i, sum_{j<i} in(j), in(i)) is called for every i instead of storing the prefix
+// array (stream compaction and "scan then scatter at heads" patterns).  Returns the grand total (host value, one sync).
+template <class T, class F, class E>
+inline T exclusive_scan_emit(u64 n, F in, E emit, const char *name = "scan") {
+    if (n == 0) return T(0);
+    T *tot = (T *)dev_alloc(sizeof(T));
+    u64 tiles = (n + kScanTile - 1) / kScanTile;
+    if (tiles == 1) {
+        prof_begin(name);
+        hipLaunchKernelGGL((k_scan_tiles<T, F, E>), dim3(1), dim3(kBlock), 0, rt().stream, n, in, (const T *)nullptr, (T *)nullptr, tot, (T *)nullptr, emit);
+        prof_end();
+        after_launch(name);
+    } else {
+        T *sums = (T *)dev_alloc(sizeof(T) * (tiles + 1));
+        prof_begin(name);
+        hipLaunchKernelGGL((k_scan_tile_sums<T, F>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, sums);
+        prof_end();
+        after_launch(name);
+        exclusive_scan_async<T, PtrIn<T>>(tiles, PtrIn<T>{sums}, sums, nullptr, nullptr, name);
+        prof_begin(name);
+        hipLaunchKernelGGL((k_scan_tiles<T, F, E>), dim3((unsigned)tiles), dim3(kBlock), 0, rt().stream, n, in, (const T *)sums, (T *)nullptr, tot, (T *)nullptr, emit);
+        prof_end();
+        after_launch(name);
+        dev_free(sums);
+    }
+    T total;
+    d2h(&total, tot, sizeof(T));
+    dev_free(tot);
+    return total;
 }
 
 // out[i] = sum_{j<i} in(j) for i in [0,n); returns the grand total (host value, one sync).

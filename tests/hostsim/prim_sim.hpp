@@ -145,6 +145,12 @@ inline T exclusive_scan(u64 n, F in, T *out, bool store_total_at_n = false, cons
     if (store_total_at_n) out[n] = acc;
     return acc;
 }
+template <class T, class F, class E>
+inline T exclusive_scan_emit(u64 n, F in, E emit, const char * = "") {
+    T acc = 0;
+    for (u64 i = 0; i < n; i++) { T v = (T)in(i); emit(i, acc, v); acc += v; }
+    return acc;
+}
 inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
     std::memset(hist_host, 0, 256 * 8);
     for (u64 i = 0; i < n; i++) hist_host[p[i]]++;
