@@ -466,13 +466,16 @@ struct GroupStartFn {
 };
 // Per dictionary position q (coalesced pass): left symbol (or the BWT marker for a whole phrase)
 // and the frequency of its phrase, so that the pass over the sorted suffixes needs ONE gather.
+struct alignas(sizeof(idx_t) == 4 ? 8 : 16) SufRec { idx_t freq; u32 left; };   // one 8/16-byte gather per sorted suffix
 struct SuffixRecFn {
     const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq; u32 bwt_code;
-    u32 *rec_left; idx_t *rec_freq;
+    SufRec *rec;
     GRL_DEV void operator()(u64 q) const {
         u32 k = dict_phr[q];
-        rec_left[q] = (q == ph_off[k]) ? bwt_code : dict_sym[q - 1];
-        rec_freq[q] = ph_freq[k];
+        SufRec r;
+        r.freq = ph_freq[k];
+        r.left = (q == ph_off[k]) ? bwt_code : dict_sym[q - 1];
+        rec[q] = r;
     }
 };
 // Per equal-suffix group: min/max of the left symbol, sum of frequencies, "contains a whole
@@ -482,7 +485,7 @@ struct SuffixRecFn {
 // atomics per chunk (GroupAccumLargeFn; 32x fewer same-address atomics than one per member).
 static constexpr u32 kGroupChunk = 32;
 struct GroupAccumSmallFn {
-    const u32 *perm; const u32 *gstart; const u32 *rec_left; const idx_t *rec_freq;
+    const u32 *perm; const u32 *gstart; const SufRec *rec;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
     GRL_DEV void operator()(u64 g) const {
@@ -490,17 +493,17 @@ struct GroupAccumSmallFn {
         if (t1 - t0 > kGroupChunk) return;
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = t0; j < t1; j++) {
-            u64 q = perm[j];
-            u32 left = rec_left[q];
+            SufRec r = rec[perm[j]];
+            u32 left = r.left;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
-            acc += rec_freq[q];
+            acc += r.freq;
             fl |= (left == bwt_code) ? 1 : 0;
         }
         gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
     }
 };
 struct GroupAccumLargeFn {
-    const u32 *perm; const u32 *gid; const u32 *gstart; const u32 *rec_left; const idx_t *rec_freq;
+    const u32 *perm; const u32 *gid; const u32 *gstart; const SufRec *rec;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
     GRL_DEV void operator()(u64 t) const {
@@ -510,10 +513,10 @@ struct GroupAccumLargeFn {
         u32 te = (u32)t + kGroupChunk < t1 ? (u32)t + kGroupChunk : t1;
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = (u32)t; j < te; j++) {
-            u64 q = perm[j];
-            u32 left = rec_left[q];
+            SufRec r = rec[perm[j]];
+            u32 left = r.left;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
-            acc += rec_freq[q];
+            acc += r.freq;
             fl |= (left == bwt_code) ? 1 : 0;
         }
         prim::atomic_min(&gmin[g], mn);
@@ -737,19 +740,25 @@ struct StoreFn {          // out[i] = f(i): materialise an expensive scan input 
 };
 
 // ----------------------------------------------------- a13/a14: induction
+// Grammar cell of a metasymbol for the chain walks: g0 | has_hocc<<31 in the low word, g1 in the high word, so that a
+// chain step is ONE random 8-byte load (symbols are < 2^30).
+struct PackGrammarFn {
+    const u32 *g0; const u32 *g1; const u8 *has_hocc; u64 *gp;
+    GRL_DEV void operator()(u64 u) const { gp[u] = ((u64)g1[u] << 32) | (u64)(g0[u] | (has_hocc[u] ? 0x80000000u : 0u)); }
+};
 struct ChainCountFn {
-    const u32 *nsym; const u32 *g1; const u8 *has_hocc; u32 sigma3;
+    const u32 *nsym; const u64 *gp; u32 sigma3;
     GRL_DEV idx_t operator()(u64 i) const {
-        u32 cur = nsym[i];
-        idx_t c = has_hocc[cur] ? 1 : 0;
-        u32 nx = g1[cur];
-        while (nx >= sigma3) { cur = nx - sigma3; c++; nx = g1[cur]; }
+        u64 c0 = gp[nsym[i]];
+        idx_t c = (c0 & 0x80000000ull) ? 1 : 0;
+        u32 nx = (u32)(c0 >> 32);
+        while (nx >= sigma3) { c++; nx = (u32)(gp[nx - sigma3] >> 32); }
         return c;
     }
 };
 template <bool PACKED>
 struct ChainExpandFn {
-    const u32 *nsym; const idx_t *nlen; const u32 *g0; const u32 *g1; const u8 *has_hocc; const idx_t *eoff;
+    const u32 *nsym; const idx_t *nlen; const u64 *gp; const idx_t *eoff;
     u32 sigma3, take_code;
     u32 *ekey; idx_t *eidx; u32 *esym; idx_t *elen; u64 *epack; u32 *term;
     GRL_DEV void put(u64 e, u32 key, u32 sym, idx_t f) const {
@@ -761,13 +770,14 @@ struct ChainExpandFn {
         u32 cur = nsym[i];
         idx_t f = nlen[i];
         u64 e = eoff[i];
-        if (has_hocc[cur]) put(e++, cur, take_code, f);
-        u32 nx = g1[cur];
+        u64 c = gp[cur];
+        if (c & 0x80000000ull) put(e++, cur, take_code, f);
+        u32 nx = (u32)(c >> 32);
         while (nx >= sigma3) {
             u32 b = nx - sigma3;
-            put(e++, b, g0[cur], f);
-            cur = b;
-            nx = g1[cur];
+            put(e++, b, (u32)c & 0x7FFFFFFFu, f);
+            c = gp[b];
+            nx = (u32)(c >> 32);
         }
         term[i] = nx;                                       // exact_ind_phase.cpp:257 write_sym
     }
@@ -1594,12 +1604,11 @@ class Engine {
             StageTimer st(&tm.dict_groups);
             gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
             {
-                DBuf<u32> rec_left(S);
-                DBuf<idx_t> rec_freq(S);
-                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec_left.p, rec_freq.p}, "suffix_records");
-                prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec_left.p, rec_freq.p, bwt_code,
+                DBuf<SufRec> rec(S);
+                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec.p}, "suffix_records");
+                prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code,
                                                     gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
-                prim::for_each(S, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec_left.p, rec_freq.p, bwt_code,
+                prim::for_each(S, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code,
                                                     gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum_large");
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
@@ -1723,17 +1732,20 @@ class Engine {
         prim::rt().tag = r;
         LevelData &L = levels[r];
         const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
-        const u64 R = bwt.R, P = L.prebwt.R;
+        const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
         LevelInfo &I = linfo[r];
         I.R_next = R; I.P = P;
 
         DBuf<idx_t> eoff(R + 1);
         DBuf<u32> term(R);
         DBuf<u32> ssym; DBuf<idx_t> slen;
+        DBuf<u64> gp;                           // packed grammar cells (chain walks)
         u64 E;
         {
             StageTimer st(&tm.ind_expand);
-            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p}, "induce_count");
+            gp.alloc(M);
+            prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
+            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, gp.p, sigma3}, eoff.p}, "induce_count");
             E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
         }
         I.E = E;
@@ -1751,7 +1763,7 @@ class Engine {
                 DBuf<u64> ep(E), ep2(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
                                                           ekey.p, nullptr, nullptr, nullptr, ep.p, term.p}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
@@ -1764,7 +1776,7 @@ class Engine {
                 DBuf<idx_t> eidx(E), eidx2(E), elen(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
                                                            ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
@@ -2022,11 +2034,10 @@ class Engine {
         DBuf<u8> gfull(Gg), gflag(Gg);
         gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
         {
-            DBuf<u32> rec_left(S);
-            DBuf<idx_t> rec_freq(S);
-            prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec_left.p, rec_freq.p}, "suffix_records");
-            prim::for_each(Gg, GroupAccumSmallFn{perm.p, gstart.p, rec_left.p, rec_freq.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
-            prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec_left.p, rec_freq.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p},
+            DBuf<SufRec> rec(S);
+            prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec.p}, "suffix_records");
+            prim::for_each(Gg, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+            prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p},
                            "group_accum_large");
         }
         prim::for_each(Gg, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
@@ -2190,10 +2201,13 @@ class Engine {
         // (1) local expansion and stable split by bucket
         DBuf<idx_t> eoff(R + 1);
         DBuf<u32> term(R);
+        DBuf<u64> gp;                           // packed grammar cells (chain walks)
         u64 E;
         {
             StageTimer st(&tm.ind_expand);
-            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, L.g1.p, L.has_hocc.p, sigma3}, eoff.p}, "induce_count");
+            gp.alloc(M);
+            prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
+            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, gp.p, sigma3}, eoff.p}, "induce_count");
             E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
         }
         I.E = E;
@@ -2209,7 +2223,7 @@ class Engine {
                 DBuf<u64> ep(E), ep2(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
                                                           ekey.p, nullptr, nullptr, nullptr, ep.p, term.p}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
@@ -2222,7 +2236,7 @@ class Engine {
                 DBuf<idx_t> eidx(E), eidx2(E), elen(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, L.g0.p, L.g1.p, L.has_hocc.p, eoff.p, sigma3, take_code,
+                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
                                                            ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
