@@ -467,14 +467,17 @@ struct GroupStartFn {
 // Per dictionary position q (coalesced pass): left symbol (or the BWT marker for a whole phrase)
 // and the frequency of its phrase, so that the pass over the sorted suffixes needs ONE gather.
 struct alignas(sizeof(idx_t) == 4 ? 8 : 16) SufRec { idx_t freq; u32 left; };   // one 8/16-byte gather per sorted suffix
+// left carries two flags above the symbol (symbols are < 2^30): the suffix is the last cell of its phrase, and that
+// phrase ends a string -- what the group decision needs from the group's first member.
+static constexpr u32 kRecSym = 0x3FFFFFFFu, kRecFinal = 0x40000000u, kRecLastT = 0x80000000u;
 struct SuffixRecFn {
-    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq; u32 bwt_code;
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; u32 bwt_code;
     SufRec *rec;
     GRL_DEV void operator()(u64 q) const {
         u32 k = dict_phr[q];
         SufRec r;
         r.freq = ph_freq[k];
-        r.left = (q == ph_off[k]) ? bwt_code : dict_sym[q - 1];
+        r.left = ((q == ph_off[k]) ? bwt_code : dict_sym[q - 1]) | ((q + 1 == ph_off[k + 1]) ? kRecFinal : 0u) | (ph_lastT[k] ? kRecLastT : 0u);
         rec[q] = r;
     }
 };
@@ -487,19 +490,24 @@ static constexpr u32 kGroupChunk = 32;
 struct GroupAccumSmallFn {
     const u32 *perm; const u32 *gstart; const SufRec *rec;
     u32 bwt_code;
-    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
+    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag;
     GRL_DEV void operator()(u64 g) const {
         u32 t0 = gstart[g], t1 = gstart[g + 1];
         if (t1 - t0 > kGroupChunk) return;
-        u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
+        u32 mn = 0xFFFFFFFFu, mx = 0, first = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = t0; j < t1; j++) {
             SufRec r = rec[perm[j]];
-            u32 left = r.left;
+            if (j == t0) first = r.left;
+            u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
             fl |= (left == bwt_code) ? 1 : 0;
         }
         gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
+        // the group decision (GroupDecideFn) from what is already in registers
+        bool valid = !(first & kRecFinal) || (first & kRecLastT);     // exact_par_phase.cpp:162
+        bool ranked = valid && (mn != mx || fl);                       // :187
+        gflag[g] = (valid ? 1 : 0) | (ranked ? 2 : 0) | (t1 - t0 > 1 ? 4 : 0);
     }
 };
 struct GroupAccumLargeFn {
@@ -514,7 +522,7 @@ struct GroupAccumLargeFn {
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = (u32)t; j < te; j++) {
             SufRec r = rec[perm[j]];
-            u32 left = r.left;
+            u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
             fl |= (left == bwt_code) ? 1 : 0;
@@ -532,6 +540,7 @@ struct GroupDecideFn {
     u8 *gflag;
     GRL_DEV void operator()(u64 g) const {
         u32 t0 = gstart[g], size = gstart[g + 1] - t0;
+        if (size <= kGroupChunk) return;                            // decided by GroupAccumSmallFn
         u64 q = perm[t0];
         u32 k = dict_phr[q];
         bool pfinal = (q + 1 == ph_off[k + 1]);
@@ -1605,9 +1614,9 @@ class Engine {
             gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
             {
                 DBuf<SufRec> rec(S);
-                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec.p}, "suffix_records");
+                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
                 prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code,
-                                                    gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+                                                    gmin.p, gmax.p, gacc.p, gfull.p, gflag.p}, "group_accum");
                 prim::for_each(S, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code,
                                                     gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum_large");
             }
@@ -2035,8 +2044,8 @@ class Engine {
         gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
         {
             DBuf<SufRec> rec(S);
-            prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, bwt_code, rec.p}, "suffix_records");
-            prim::for_each(Gg, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum");
+            prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
+            prim::for_each(Gg, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p, gflag.p}, "group_accum");
             prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p},
                            "group_accum_large");
         }
