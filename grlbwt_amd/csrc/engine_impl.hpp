@@ -580,18 +580,27 @@ struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
 };
 
 // ------------------------------------------------------------- a8: grammar
-struct MarkPosFn {        // mark[q] = 1 iff q's suffix group is ranked and has > 1 member (phr_marks, exact_par_phase.cpp:203-205)
-    // by dictionary position: rank[q] = head slot of q's group, gid[slot] = dense group id.  (Two dependent gathers and a
-    // coalesced byte store; the other direction, mark[perm[t]] by slot, is a random one-byte store per suffix.)
-    const u32 *rank; const u32 *gid; const u8 *gflag; u8 *mark;
+// meta[q] = metasymbol of the suffix at dictionary position q if its group is ranked and has > 1 member (the marked
+// positions, phr_marks, exact_par_phase.cpp:203-205), else 0 (metasymbols are >= sigma3 > 0).  By dictionary position:
+// rank[q] = head slot of q's group, gid[slot] = dense group id, ginfo[g] = grank<<1 | marked -- two dependent gathers and
+// a coalesced store, after which the grammar walk below reads meta[] sequentially and needs no further lookups.
+struct PackGroupInfoFn {
+    const u32 *grank; const u8 *gflag; u32 *ginfo;
+    GRL_DEV void operator()(u64 g) const {       // grank < 2^30 (alphabet bound of the next level)
+        ginfo[g] = (grank[g] << 1) | (((gflag[g] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1u : 0u);
+    }
+};
+struct MetaPosFn {
+    const u32 *rank; const u32 *gid; const u32 *ginfo; u32 sigma3; u32 *meta;
     GRL_DEV void operator()(u64 q) const {
-        mark[q] = ((gflag[gid[rank[q]]] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1 : 0;
+        u32 gi = ginfo[gid[rank[q]]];
+        meta[q] = (gi & 1u) ? (gi >> 1) + sigma3 : 0u;
     }
 };
 struct GrammarFn {
     const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
-    const u32 *rank; const u32 *gid; const u8 *mark; const u32 *grank;
-    u32 sigma3, MD;
+    const u32 *meta;
+    u32 MD;
     u32 *g0; u32 *g1;
     GRL_DEV void operator()(u64 u) const {
         u64 q = repq[u];
@@ -600,9 +609,8 @@ struct GrammarFn {
         if (q == e) { g0[u] = MD; g1[u] = dict_sym[q]; return; }                    // :38-41
         u64 x = q + 1;
         for (;;) {
-            if (mark[x]) {             // positional rank -> slot of the group head -> dense group id -> metasymbol
-                g0[u] = dict_sym[x - 1]; g1[u] = grank[gid[rank[x]]] + sigma3; return;       // :49-80
-            }
+            u32 m = meta[x];
+            if (m) { g0[u] = dict_sym[x - 1]; g1[u] = m; return; }                   // :49-80
             if (x == e) { g0[u] = MD; g1[u] = ph_lastT[k] ? dict_sym[e] : dict_sym[e - 1]; return; }   // :81-85
             x++;
         }
@@ -1638,10 +1646,12 @@ class Engine {
             // ---- a8: grammar ------------------------------------------------
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
-            DBuf<u8> mark(S);
-            prim::for_each(S, MarkPosFn{rank.p, gid.p, gflag.p, mark.p}, "grammar_marks");
-            prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, rank.p, gid.p, mark.p, grank.p,
-                                        sigma3, MD, L.g0.p, L.g1.p}, "grammar");
+            {
+                DBuf<u32> ginfo(G), meta(S);
+                prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, ginfo.p}, "grammar_ginfo");
+                prim::for_each(S, MetaPosFn{rank.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
+                prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, meta.p, MD, L.g0.p, L.g1.p}, "grammar");
+            }
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
             prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rank.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
