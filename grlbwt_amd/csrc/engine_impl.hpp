@@ -1444,7 +1444,7 @@ class Engine {
         u64 n_occ;
         {
             StageTimer st(&tm.classify);
-            prim::bitvector_from_pred(n, StartPred<cell_t, FIRST>{t, ops}, startbits.p, "lms_breaks");
+            prim::start_bitvector(n, t, ops, StartPred<cell_t, FIRST>{t, ops}, startbits.p, "lms_breaks");
             n_occ = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{startbits.p}, wordbase.p, true, "phrase_ordinals");
         }
         P.n_occ = n_occ;

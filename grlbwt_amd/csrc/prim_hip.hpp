@@ -413,6 +413,94 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char *name = "b
     after_launch(name);
 }
 
+// Phrase-start bit-vector of a text level (LMS breaks + string starts), one wave per 64 positions.
+//   start(p) = p == 0 | T(p-1) | ( sym(p-1) > sym(p) & rep(p-1) & rep(p) & S(p) )
+//   S(p)     = !T(p) & ( sym(p+1) > sym(p)  |  sym(p+1) == sym(p) & S(p+1) )            (type of p is S)
+// S runs right-to-left through runs of equal symbols.  On the 64-bit masks G = !T & (next > own) and P = !T & (next ==
+// own) that recurrence is the carry chain of an addition once the bits are reversed: carry_out(k) = G'(k) | P'(k) &
+// carry_in(k) is exactly what (G'|P') + G' produces, so one 64-bit add resolves every run inside the word; only a run
+// that reaches the last position of the word needs a look at the following cells (a wave-uniform walk).
+// `ops` supplies sym()/rep()/isT() of a cell; `pred` is the per-position definition (used by the serial test stand-in
+// of this header, and here for nothing: kept so that both take the same arguments).
+template <class cell_t, class OPS>
+__global__ void __launch_bounds__(kBlock) k_start_bits(u64 n, const cell_t *t, OPS ops, u64 *words) {
+    // A tile of kBlock x 16 bytes is read with 16-byte loads (one byte per lane per load keeps far too few bytes in
+    // flight) and staged in LDS with one cell of halo on either side; the waves then take the tile's words in turn.
+    constexpr int CPL = 16 / (int)sizeof(cell_t);      // cells per lane per load
+    constexpr int TILE = kBlock * CPL;                 // cells per tile (a multiple of 64)
+    struct alignas(16) Vec { cell_t v[CPL]; };
+    __shared__ __attribute__((aligned(16))) cell_t s_raw[TILE + 2 * CPL];   // tile at [CPL, CPL+TILE): 16-byte aligned
+    cell_t *s_c = s_raw + CPL;                          // s_c[-1] = t[base-1], s_c[TILE] = t[base+TILE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 ntiles = (n + TILE - 1) / TILE;
+    const bool aligned = ((uintptr_t)t & 15) == 0;
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const u64 base = tile * TILE;
+        const u64 q0 = base + (u64)threadIdx.x * CPL;
+        if (aligned && q0 + CPL <= n) {
+            *reinterpret_cast<Vec *>(s_c + threadIdx.x * CPL) = *reinterpret_cast<const Vec *>(t + q0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPL; k++) s_c[threadIdx.x * CPL + k] = (q0 + k < n) ? t[q0 + k] : cell_t(0);
+        }
+        if (threadIdx.x == 0) s_c[-1] = base > 0 ? t[base - 1] : cell_t(0);
+        if (threadIdx.x == 64) s_c[TILE] = (base + TILE < n) ? t[base + TILE] : cell_t(0);
+        __syncthreads();
+        for (int wv = wave; wv < TILE / 64; wv += kBlock / 64) {
+            const int o = wv * 64 + lane;
+            const u64 p = base + (u64)o;
+            const bool in = p < n;
+            const bool has_nx = p + 1 < n;
+            const cell_t c = s_c[o], nx = s_c[o + 1], pv = s_c[o - 1];
+            const u32 s = ops.sym(c), sn = ops.sym(nx), sp = ops.sym(pv);
+            const bool T = ops.isT(c);
+            const unsigned long long G = __ballot(in && has_nx && !T && sn > s);
+            const unsigned long long P = __ballot(in && has_nx && !T && sn == s);
+            const unsigned long long first = __ballot(in && (p == 0 || ops.isT(pv)));
+            const unsigned long long cand = __ballot(in && p > 0 && sp > s && ops.rep(pv) && ops.rep(c));
+            // carry into the word: type of the position after the word, within the run of the word's last symbol.
+            // Only the word that holds the START of that run can need it (a candidate is the first cell of its run);
+            // the words inside a long run must not walk it again (that would be quadratic in the run length).
+            unsigned long long cin = 0;
+            const int trailing = (~P == 0ull) ? 64 : __builtin_clzll(~P);    // length of the run of set bits ending at bit 63
+            const int rstart = 64 - trailing;                    // first position of that run inside the word
+            if ((P >> 63) && ((cand >> rstart) & 1ull)) {         // uniform branch
+                const u32 sl = ops.sym(s_c[wv * 64 + 63]);
+                u64 q = base + (u64)wv * 64 + 64;                // t[q] continues the run (P bit 63), q < n
+                for (;;) {
+                    cell_t cq = t[q];
+                    if (ops.isT(cq) || q + 1 >= n) break;        // the run reaches the string end: type L
+                    u32 sq = ops.sym(t[q + 1]);
+                    if (sq != sl) { cin = sq > sl ? 1 : 0; break; }
+                    q++;
+                }
+            }
+            const unsigned long long Gr = __brevll(G), Pr = __brevll(P);
+            const unsigned long long a = Gr | Pr, b = Gr;
+            const unsigned long long s1 = a + b;
+            const unsigned long long sum = s1 + cin;
+            const unsigned long long ovf = ((s1 < a) || (sum < s1)) ? 1ull : 0ull;
+            const unsigned long long cinto = sum ^ a ^ b;        // carry into every bit
+            const unsigned long long Sr = (cinto >> 1) | (ovf << 63);   // carry out of every bit
+            const unsigned long long S = __brevll(Sr);
+            if (lane == 0 && (base + (u64)wv * 64) < n) words[(base >> 6) + wv] = first | (cand & S);
+        }
+        __syncthreads();
+    }
+}
+template <class cell_t, class OPS, class F>
+inline void start_bitvector(u64 n, const cell_t *t, OPS ops, F /*pred*/, u64 *words, const char *name = "start_bits") {
+    if (n == 0) return;
+    u64 nwords = (n + 63) >> 6;
+    prof_begin(name);
+    (void)nwords;
+    u64 ntiles = (n + (u64)kBlock * (16 / sizeof(cell_t)) - 1) / ((u64)kBlock * (16 / sizeof(cell_t)));
+    u64 cap = (u64)rt().num_cus * 32;
+    hipLaunchKernelGGL((k_start_bits<cell_t, OPS>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(kBlock), 0, rt().stream, n, t, ops, words);
+    prof_end();
+    after_launch(name);
+}
+
 // ------------------------------------------ for_each with LDS count aggregation
 // f(i) returns a bucket id (u32) or kNoBucket; every returned id must be counted once
 // in a global table through add(id, count).  Same-address global atomics serialise at

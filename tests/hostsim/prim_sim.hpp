@@ -87,6 +87,8 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char * = "") {
         words[w] = m;
     }
 }
+template <class cell_t, class OPS, class F>
+inline void start_bitvector(u64 n, const cell_t *, OPS, F pred, u64 *words, const char * = "") { bitvector_from_pred(n, pred, words); }
 static constexpr u32 kNoBucket = 0xFFFFFFFFu;
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
