@@ -93,6 +93,25 @@ def test_long_equal_runs_and_long_phrases(hip, oracle_mod):
     parity.check_final(hip, data, 1)
 
 
+@pytest.mark.parametrize("w", [1, 2, 4])
+def test_equal_runs_across_word_and_tile_boundaries(hip, oracle_mod, w):
+    # run-length structured strings: runs of 1..200 equal symbols end on every offset modulo 64 (the word of the
+    # start-bit kernel) and modulo its LDS tile, with descents into and ascents out of the runs, plus runs that
+    # reach the end of a string
+    rng = np.random.default_rng(77 + w)
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[w]
+    sep, hi = 1, {1: 6, 2: 300, 4: 70000}[w]
+    pieces = []
+    for _ in range(40):
+        syms = rng.integers(2, hi, size=400)
+        lens = rng.integers(1, 200, size=400)
+        lens[rng.integers(0, 400, size=5)] += 4096              # a few runs longer than a tile
+        pieces.append(np.repeat(syms, lens).astype(dt))
+        pieces.append(np.array([sep], dtype=dt))
+    data = np.concatenate(pieces)
+    parity.check_stagewise(hip, data.tobytes(), w)
+
+
 def test_device_resident_input_torch(hip, oracle_mod):
     """The bench path: input already in HBM (torch tensor), output image stays in HBM."""
     import torch
