@@ -519,32 +519,31 @@ template <int SLOTS, bool AGG, class F, class A>
 __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F f, A add) {
     __shared__ u32 c_key[AGG ? SLOTS : 1];
     __shared__ u32 c_cnt[AGG ? SLOTS : 1];
-    __shared__ u32 s_queue[kAggChunk];
-    __shared__ u32 s_qn;
+    // every wave compacts and processes its own quarter of the chunk: no workgroup barrier inside the loop, the
+    // waves drift apart freely and hide each other's gather latency
+    constexpr int kWaveChunk = kAggChunk / (kBlock / 64);
+    __shared__ u32 s_queue[kBlock / 64][kWaveChunk];
     if (AGG) {
         for (int i = threadIdx.x; i < SLOTS; i += kBlock) { c_key[i] = kNoBucket; c_cnt[i] = 0; }
+        __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    volatile u32 *queue = s_queue[w];
     u64 start = (u64)blockIdx.x * per_block;
     u64 end = start + per_block < n ? start + per_block : n;
-    for (u64 base = start; base < end; base += kAggChunk) {
-        __syncthreads();                      // queue consumed (and cache initialised on the first trip)
-        if (threadIdx.x == 0) s_qn = 0;
-        __syncthreads();
+    for (u64 cbase = start; cbase < end; cbase += kAggChunk) {
+        const u64 base = cbase + (u64)w * kWaveChunk;
+        u32 qn = 0;
 #pragma unroll
-        for (int k = 0; k < kAggChunk / kBlock; k++) {
-            u64 i = base + (u64)k * kBlock + threadIdx.x;
+        for (int k = 0; k < kWaveChunk / 64; k++) {
+            u64 i = base + (u64)k * 64 + lane;
             bool st = (i < end) && f.is_start(i);
             unsigned long long m = __ballot(st);
-            u32 wbase = 0;
-            if (lane == 0 && m) wbase = atomicAdd(&s_qn, (u32)__popcll(m));
-            wbase = __shfl(wbase, 0, 64);
-            if (st) s_queue[wbase + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)(i - base);
+            if (st) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)(i - base);
+            qn += (u32)__popcll(m);
         }
-        __syncthreads();
-        const u32 qn = s_qn;
-        for (u32 q = threadIdx.x; q < qn; q += kBlock) {
-            u32 s = f.process(base + s_queue[q]);
+        for (u32 q = lane; q < qn; q += 64) {
+            u32 s = f.process(base + queue[q]);
             if (s != kNoBucket) {
                 if (AGG) {
                     u32 h = (s * 2654435761u) >> (32 - __builtin_ctz(SLOTS));
