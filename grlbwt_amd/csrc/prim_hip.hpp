@@ -938,26 +938,56 @@ inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
 static constexpr int kRsItems = 16;                 // keys per lane (24 and 32 measured slower: registers, LDS)
 static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup
 
+// Counting without LDS atomics (they retire about one lane per clock per CU: the atomic form of this kernel ran at
+// 0.8 keys/clock/CU whatever the key width).  Per row of 64 keys the wave takes one ballot per digit bit; lane l owns
+// the four bins l, l+64, l+128, l+192: the keys whose low six digit bits equal l are the AND of the six ballots (or
+// their complements) selected by l's own bits, and the two high bits split that set four ways with wave-uniform masks.
 template <class K>
 __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 *counts, u32 tiles) {
-    __shared__ u32 s_h[256];
-    s_h[threadIdx.x] = 0;
-    __syncthreads();
-    u64 base = (u64)blockIdx.x * kRsTile;
-    if (base + kRsTile <= n) {       // full tile: all loads in flight before the first LDS atomic
-        K k[kRsItems];
+    __shared__ u32 s_h[kBlock / 64][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const u64 base = (u64)blockIdx.x * kRsTile;
+    K k[kRsItems];
+    const bool full = base + kRsTile <= n;
+    constexpr int per = 16 / (int)sizeof(K);            // keys per 16-byte load (a count does not care which lane sees a key)
+    struct alignas(16) Vec { K v[per]; };
+    if (full && ((uintptr_t)keys & 15) == 0) {
 #pragma unroll
-        for (int r = 0; r < kRsItems; r++) k[r] = keys[base + (u64)r * kBlock + threadIdx.x];
+        for (int j = 0; j < kRsItems / per; j++) {
+            Vec x = *reinterpret_cast<const Vec *>(keys + base + ((u64)j * kBlock + threadIdx.x) * per);
 #pragma unroll
-        for (int r = 0; r < kRsItems; r++) atomicAdd(&s_h[(u32)(k[r] >> shift) & 255u], 1u);
+            for (int e = 0; e < per; e++) k[j * per + e] = x.v[e];
+        }
     } else {
+#pragma unroll
         for (int r = 0; r < kRsItems; r++) {
             u64 i = base + (u64)r * kBlock + threadIdx.x;
-            if (i < n) atomicAdd(&s_h[(u32)(keys[i] >> shift) & 255u], 1u);
+            k[r] = (i < n) ? keys[i] : K(0);
         }
     }
+    u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < kRsItems; r++) {
+        const u64 i = base + (u64)r * kBlock + threadIdx.x;      // only meaningful on the guarded path
+        const u32 d = (u32)(k[r] >> shift) & 255u;
+        unsigned long long lm = __ballot(full || i < n);
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            unsigned long long m = __ballot((d >> b) & 1u);
+            lm &= ((lane >> b) & 1) ? m : ~m;
+        }
+        const unsigned long long b6 = __ballot((d >> 6) & 1u), b7 = __ballot((d >> 7) & 1u);
+        c0 += (u32)__popcll(lm & ~b6 & ~b7);
+        c1 += (u32)__popcll(lm & b6 & ~b7);
+        c2 += (u32)__popcll(lm & ~b6 & b7);
+        c3 += (u32)__popcll(lm & b6 & b7);
+    }
+    s_h[w][lane] = c0; s_h[w][lane + 64] = c1; s_h[w][lane + 128] = c2; s_h[w][lane + 192] = c3;
     __syncthreads();
-    counts[(u64)blockIdx.x * 256 + threadIdx.x] = s_h[threadIdx.x];      // tile-major: one coalesced row per tile
+    u32 tot = 0;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; q++) tot += s_h[q][threadIdx.x];
+    counts[(u64)blockIdx.x * 256 + threadIdx.x] = tot;      // tile-major: one coalesced row per tile
 }
 
 // Global write positions from the tile-major counts.  The order of a stable pass is digit-major (all tiles of digit
