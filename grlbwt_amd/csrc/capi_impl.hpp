@@ -420,6 +420,40 @@ int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_b
     });
 }
 
+static bool image_is_big(const grlbwt_ctx *ctx, uint64_t image_bytes) {
+    // >= 2^32 - 256 symbols cannot be told from the size alone; be conservative: images of >= 2 GiB use 64-bit positions
+    return image_bytes >= (1ull << 31) || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+}
+int grlbwt_image_plain(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, void *dev_out_u8,
+                       uint64_t capacity, int null_char, uint64_t *n_out) {
+    if (!ctx || !dev_image || !dev_out_u8 || null_char > 255) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        bool big = image_is_big(ctx, image_bytes) || capacity >= 0xFFFFFF00ull;
+        uint64_t n = big ? grl64::Engine::image_plain(dev_image, image_bytes, (uint8_t *)dev_out_u8, capacity, null_char)
+                         : grl32::Engine::image_plain(dev_image, image_bytes, (uint8_t *)dev_out_u8, capacity, null_char);
+        if (n_out) *n_out = n;
+    });
+}
+int grlbwt_image_rle(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, void *dev_syms_u8, void *dev_lens_u32,
+                     uint64_t capacity_runs, uint64_t *n_runs_out) {
+    if (!ctx || !dev_image || !dev_syms_u8 || !dev_lens_u32) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        uint64_t r = grl64::Engine::image_rle(dev_image, image_bytes, (uint8_t *)dev_syms_u8, (uint32_t *)dev_lens_u32, capacity_runs);
+        if (n_runs_out) *n_runs_out = r;
+    });
+}
+int grlbwt_image_stats_get(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, grlbwt_image_stats *out) {
+    if (!ctx || !dev_image || !out) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        grl64::Engine::ImageStats st;
+        grl64::Engine::image_stats(dev_image, image_bytes, st);
+        out->n_runs = st.n_runs; out->sigma = st.sigma; out->text_size = st.text_size; out->min_run = st.min_run; out->max_run = st.max_run;
+        out->fit1 = st.fit1; out->fit2 = st.fit2; out->fit3 = st.fit3;
+        for (int c = 0; c < 256; c++) { out->runs_of[c] = st.runs_of[c]; out->freq_of[c] = st.freq_of[c]; }
+        for (int i = 0; i < 9; i++) out->deciles[i] = st.deciles[i];
+    });
+}
+
 int grlbwt_memory_usage(const grlbwt_ctx *ctx, uint64_t *peak_live_bytes, uint64_t *reserved_bytes) {
     if (!ctx) return GRLBWT_EINVAL;
     if (peak_live_bytes) *peak_live_bytes = prim::pool_peak_bytes();

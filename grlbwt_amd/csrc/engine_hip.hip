@@ -2,6 +2,7 @@
 // prim_hip.hpp: hand-written device primitives; engine_impl.hpp: the engine,
 // instantiated for 32-bit and 64-bit positions/lengths; capi_impl.hpp: C-ABI.
 #include <time.h>
+#include <cmath>
 #include <type_traits>
 #include <utility>
 #include <vector>

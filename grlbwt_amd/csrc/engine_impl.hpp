@@ -696,6 +696,10 @@ struct IdxIn {
     const L *p;
     GRL_DEV idx_t operator()(u64 i) const { return (idx_t)p[i]; }
 };
+struct IdxIn64 {
+    const idx_t *p;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)p[i]; }
+};
 typedef prim::Pair<idx_t, idx_t> HeadLen;      // (#run heads, #symbols) scanned together
 struct HeadLenIn {
     const u32 *s; const idx_t *len;
@@ -1276,6 +1280,40 @@ struct UnpackRunsFn {     // (sym: sb bytes LE, len: fb bytes LE) records -> arr
         for (u32 b = 0; b < fb; b++) l |= (u64)p[sb + b] << (8 * b);
         sym[i] = (u32)s; len[i] = (idx_t)l;
     }
+};
+struct PlainRunsFn {      // scripts/grl2plain.cpp:30-45: one output byte per BWT position, (char)sym, optional null replacement
+    const u32 *rsym; const u64 *rw; const idx_t *rb; int null_char; u8 *out;
+    GRL_DEV void operator()(u64 i) const {
+        u32 sy = rsym[rank1(rw, rb, i + 1) - 1];
+        if (sy == 0 && null_char >= 0) sy = (u32)null_char;
+        out[i] = (u8)sy;
+    }
+};
+struct RleExportFn {      // scripts/grlbwt2rle.cpp:22-30: .syms as uint8, .len as uint32 (the reference's casts)
+    const u32 *rsym; const idx_t *rlen; u8 *syms; u32 *lens;
+    GRL_DEV void operator()(u64 i) const { syms[i] = (u8)rsym[i]; lens[i] = (u32)rlen[i]; }
+};
+struct RunSymFn {         // for_each_agg protocol: every run is a work item, its bucket is its symbol
+    const u32 *rsym;
+    GRL_DEV bool is_start(u64) const { return true; }
+    GRL_DEV u32 process(u64 i) const { return rsym[i]; }
+    GRL_DEV u32 operator()(u64 i) const { return rsym[i]; }
+};
+struct BinAddFn {
+    u64 *bins;
+    GRL_DEV void operator()(u32 b, u32 c) const { prim::atomic_add(&bins[b & 255u], (u64)c); }
+};
+struct LenFitIn {         // 1 if the run length needs exactly `cls` bytes class (1: <=255, 2: <=65535, 3: more)
+    const idx_t *len; int cls;
+    GRL_DEV u64 operator()(u64 i) const {
+        u64 l = len[i];
+        int c = l <= 255 ? 1 : (l <= 65535 ? 2 : 3);
+        return c == cls ? 1ull : 0ull;
+    }
+};
+struct LenKeyFn {
+    const idx_t *len; u32 *key; u32 *val;
+    GRL_DEV void operator()(u64 i) const { key[i] = (u32)len[i]; val[i] = (u32)i; }
 };
 struct ExpandRunsFn {     // grl2plain: symbol of every BWT position through the run-start bitmap
     const u32 *rsym; const u64 *rw; const idx_t *rb; u32 *out; idx_t *idx;
@@ -2476,6 +2514,87 @@ class Engine {
             case 4: return invert_t<u32>(img, R, (u32)sb, (u32)fb, (u32 *)dev_text_out, capacity_cells);
             case 8: return invert_t<u64>(img, R, (u32)sb, (u32)fb, (u64 *)dev_text_out, capacity_cells);
             default: throw prim::Error(-22, "bad cell width");
+        }
+    }
+
+    // ---- the other .rl_bwt consumers of scripts/ (SURVEY 8f-2), on an image in device memory --------------
+    struct ImageHeader { u64 sb, fb, R; };
+    static ImageHeader image_header(const void *dev_image, u64 image_bytes) {
+        if (image_bytes < 16) throw prim::Error(-22, "not an .rl_bwt image");
+        u64 hdr[2];
+        prim::d2h(hdr, dev_image, 16);
+        if (hdr[0] == 0 || hdr[0] > 8 || hdr[1] == 0 || hdr[1] > 8 || (image_bytes - 16) % (hdr[0] + hdr[1]))
+            throw prim::Error(-22, "bad .rl_bwt header");
+        return ImageHeader{hdr[0], hdr[1], (image_bytes - 16) / (hdr[0] + hdr[1])};
+    }
+    // grl2plain (scripts/grl2plain.cpp): the plain BWT, one byte per symbol; null_char >= 0 replaces symbol 0
+    static u64 image_plain(const void *dev_image, u64 image_bytes, u8 *dev_out, u64 capacity, int null_char) {
+        ImageHeader h = image_header(dev_image, image_bytes);
+        DBuf<u32> rsym(h.R);
+        DBuf<idx_t> rlen(h.R), rpos(h.R + 1);
+        prim::for_each(h.R, UnpackRunsFn{(const u8 *)dev_image, (u32)h.sb, (u32)h.fb, rsym.p, rlen.p}, "plain.unpack");
+        u64 n = (u64)prim::exclusive_scan<idx_t>(h.R, IdxIn<idx_t>{rlen.p}, rpos.p, true, "plain.positions");
+        if (n > capacity) throw prim::Error(-22, "grl2plain: output buffer too small");
+        RankBits rb;
+        build_rankbits(rb, rpos.p, h.R, n + 1, "plain.runbits");
+        prim::for_each(n, PlainRunsFn{rsym.p, rb.words.p, rb.base.p, null_char, dev_out}, "plain.expand");
+        prim::sync();
+        return n;
+    }
+    // grlbwt2rle (scripts/grlbwt2rle.cpp): the two RLE arrays
+    static u64 image_rle(const void *dev_image, u64 image_bytes, u8 *dev_syms, u32 *dev_lens, u64 capacity_runs) {
+        ImageHeader h = image_header(dev_image, image_bytes);
+        if (h.R > capacity_runs) throw prim::Error(-22, "grlbwt2rle: output buffers too small");
+        DBuf<u32> rsym(h.R);
+        DBuf<idx_t> rlen(h.R);
+        prim::for_each(h.R, UnpackRunsFn{(const u8 *)dev_image, (u32)h.sb, (u32)h.fb, rsym.p, rlen.p}, "rle.unpack");
+        prim::for_each(h.R, RleExportFn{rsym.p, rlen.p, dev_syms, dev_lens}, "rle.export");
+        prim::sync();
+        return h.R;
+    }
+    // bwt_stats (scripts/bwt_stats.cpp:18-98), byte alphabets (the reference indexes 256-entry tables by the symbol)
+    struct ImageStats {
+        u64 n_runs, sigma, text_size, min_run, max_run, fit1, fit2, fit3;
+        u64 runs_of[256], freq_of[256];
+        u64 deciles[9];
+    };
+    static void image_stats(const void *dev_image, u64 image_bytes, ImageStats &st) {
+        ImageHeader h = image_header(dev_image, image_bytes);
+        if (h.sb != 1) throw prim::Error(-22, "bwt_stats: byte alphabets only (sb == 1)");
+        if (h.R == 0) throw prim::Error(-22, "bwt_stats: empty BWT");
+        const u64 R = h.R;
+        DBuf<u32> rsym(R);
+        DBuf<idx_t> rlen(R);
+        prim::for_each(R, UnpackRunsFn{(const u8 *)dev_image, (u32)h.sb, (u32)h.fb, rsym.p, rlen.p}, "stats.unpack");
+        st.n_runs = R;
+        st.min_run = prim::reduce_min<u64>(R, IdxIn64{rlen.p}, "stats.min_run");
+        st.max_run = prim::reduce_max<u64>(R, IdxIn64{rlen.p}, "stats.max_run");
+        st.text_size = prim::reduce_sum<u64>(R, IdxIn64{rlen.p}, "stats.text_size");
+        st.fit1 = prim::reduce_sum<u64>(R, LenFitIn{rlen.p, 1}, "stats.fit1");
+        st.fit2 = prim::reduce_sum<u64>(R, LenFitIn{rlen.p, 2}, "stats.fit2");
+        st.fit3 = R - st.fit1 - st.fit2;
+        DBuf<u64> bins(256);
+        bins.zero();
+        prim::for_each_agg(R, RunSymFn{rsym.p}, BinAddFn{bins.p}, true, "stats.runs_per_symbol");
+        std::vector<u64> hb = bins.to_host(256);
+        st.sigma = 0;
+        for (int c = 0; c < 256; c++) {
+            st.runs_of[c] = hb[c];
+            st.freq_of[c] = hb[c] ? prim::reduce_sum<u64>(R, SepLenIn{rsym.p, rlen.p, (u32)c}, "stats.freq") : 0;
+            if ((hb[c] & 0xFFu) != 0) st.sigma++;       // the reference iterates the table as unsigned char (:57-62)
+        }
+        // deciles of the sorted run lengths (uint32 like the reference's vector), index ceil(R * k/10) with the
+        // reference's accumulated double (:83-89); an index past the end (R < 10) is clamped to the last run
+        DBuf<u32> ka(R), kb(R), va(R), vb(R);
+        prim::for_each(R, LenKeyFn{rlen.p, ka.p, va.p}, "stats.len_keys");
+        int res = prim::sort_pairs<u32, u32>(ka.p, va.p, kb.p, vb.p, R, 0, 32, "stats.sort");
+        const DBuf<u32> &sorted = res ? kb : ka;
+        double l = (double)R, prop = 0.1;
+        for (int i = 0; i < 9; i++) {
+            u64 q = (u64)std::ceil(l * prop);
+            if (q >= R) q = R - 1;
+            st.deciles[i] = sorted.get(q);
+            prop += 0.1;
         }
     }
 

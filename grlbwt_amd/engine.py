@@ -27,7 +27,13 @@ ABI_SYMBOLS = [
     "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
     "grlbwt_level_text_download", "grlbwt_level_bwt_size", "grlbwt_level_bwt_download", "grlbwt_get_counters",
     "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump", "grlbwt_dist_build", "grlbwt_memory_usage", "grlbwt_invert_image",
+    "grlbwt_image_plain", "grlbwt_image_rle", "grlbwt_image_stats_get",
 ]
+
+
+class ImageStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_runs", "sigma", "text_size", "min_run", "max_run", "fit1", "fit2", "fit3")] + \
+               [("runs_of", C.c_uint64 * 256), ("freq_of", C.c_uint64 * 256), ("deciles", C.c_uint64 * 9)]
 
 
 class Stats(C.Structure):
@@ -80,6 +86,14 @@ def load_library(path=None, allow_test_standin=False):
     if not os.path.exists(path):
         raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % path)
+    if not allow_test_standin:
+        # PyTorch ships its own copy of the HIP runtime.  If torch is imported AFTER this library has pulled in
+        # /opt/rocm's copy, the process ends up with two runtimes and torch reports "No HIP GPUs are available";
+        # importing torch first makes both sides bind to one.  (Processes that never use torch are unaffected.)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(path)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.grlbwt_abi_version.restype = i32
@@ -117,6 +131,9 @@ def load_library(path=None, allow_test_standin=False):
     L.grlbwt_selftest.argtypes = [vp, u64, u64]
     L.grlbwt_memory_usage.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.grlbwt_invert_image.argtypes = [vp, vp, u64, i32, vp, u64, C.POINTER(u64)]
+    L.grlbwt_image_plain.argtypes = [vp, vp, u64, vp, u64, i32, C.POINTER(u64)]
+    L.grlbwt_image_rle.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
+    L.grlbwt_image_stats_get.argtypes = [vp, vp, u64, C.POINTER(ImageStats)]
     L.grlbwt_profile_enable.argtypes = [vp, i32]
     L.grlbwt_profile_dump.argtypes = [vp, C.c_char_p, u64]
     _libs[path] = L
@@ -266,6 +283,28 @@ class Context:
         self._ck(self.L.grlbwt_invert_image(self._h, C.c_void_p(dev_image_ptr), image_bytes, cell_bytes,
                                             C.c_void_p(dev_out_ptr), capacity_cells, C.byref(n)))
         return n.value
+
+    def image_plain(self, dev_image_ptr, image_bytes, dev_out_ptr, capacity, null_char=-1):
+        """grl2plain on the device (scripts/grl2plain.cpp): plain BWT bytes; returns their number."""
+        n = C.c_uint64()
+        self._ck(self.L.grlbwt_image_plain(self._h, C.c_void_p(dev_image_ptr), image_bytes, C.c_void_p(dev_out_ptr), capacity,
+                                           null_char, C.byref(n)))
+        return n.value
+
+    def image_rle(self, dev_image_ptr, image_bytes, dev_syms_ptr, dev_lens_ptr, capacity_runs):
+        """grlbwt2rle on the device (scripts/grlbwt2rle.cpp): uint8 symbols + uint32 lengths; returns #runs."""
+        n = C.c_uint64()
+        self._ck(self.L.grlbwt_image_rle(self._h, C.c_void_p(dev_image_ptr), image_bytes, C.c_void_p(dev_syms_ptr),
+                                         C.c_void_p(dev_lens_ptr), capacity_runs, C.byref(n)))
+        return n.value
+
+    def image_stats(self, dev_image_ptr, image_bytes):
+        """bwt_stats on the device (scripts/bwt_stats.cpp)."""
+        st = ImageStats()
+        self._ck(self.L.grlbwt_image_stats_get(self._h, C.c_void_p(dev_image_ptr), image_bytes, C.byref(st)))
+        d = {k: int(getattr(st, k)) for k in ("n_runs", "sigma", "text_size", "min_run", "max_run", "fit1", "fit2", "fit3")}
+        d["runs_of"] = list(st.runs_of); d["freq_of"] = list(st.freq_of); d["deciles"] = list(st.deciles)
+        return d
 
     def memory_usage(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -148,6 +148,24 @@ int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path);
 int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int cell_bytes,
                         void *dev_text_out, uint64_t capacity_cells, uint64_t *n_cells_out);
 
+/* The other .rl_bwt consumers of the reference's scripts/ (SURVEY 8f-2), on an image in device memory:
+ * grl2plain  (scripts/grl2plain.cpp:18-50): plain BWT, one byte per symbol ((char)sym); null_char >= 0 replaces
+ *            symbol 0, -1 leaves it.
+ * grlbwt2rle (scripts/grlbwt2rle.cpp:17-33): run symbols as uint8 and run lengths as uint32.
+ * bwt_stats  (scripts/bwt_stats.cpp:18-98): run statistics of a byte-alphabet image; sigma reproduces the script's
+ *            count (table entries whose low byte is non-zero, :57-62); decile indices past the end are clamped. */
+typedef struct grlbwt_image_stats {
+    uint64_t n_runs, sigma, text_size, min_run, max_run;
+    uint64_t fit1, fit2, fit3;            /* runs whose length fits 1 byte / 2 bytes / needs 3 or more */
+    uint64_t runs_of[256], freq_of[256];  /* per symbol: number of runs, total length */
+    uint64_t deciles[9];                  /* sorted run lengths at ceil(n_runs * k/10), k = 1..9 */
+} grlbwt_image_stats;
+int grlbwt_image_plain(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, void *dev_out_u8,
+                       uint64_t capacity, int null_char, uint64_t *n_out);
+int grlbwt_image_rle(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, void *dev_syms_u8, void *dev_lens_u32,
+                     uint64_t capacity_runs, uint64_t *n_runs_out);
+int grlbwt_image_stats_get(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, grlbwt_image_stats *out);
+
 /* ---- inspection (parity tests; need GRLBWT_FLAG_KEEP_LEVELS) --------------- */
 /* text of level >= 1 as (rank<<1 | rep) cells, the reference's on-disk parse format */
 int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells);

@@ -4,6 +4,7 @@
 // Exports the same C-ABI symbols as libgrlbwt_hip.so from a DIFFERENT library
 // (tests/hostsim/_build/libgrlbwt_sim.so) that only tests/ load.
 #include <time.h>
+#include <cmath>
 #include <type_traits>
 #include <utility>
 #include <vector>
