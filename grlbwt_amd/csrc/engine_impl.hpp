@@ -1592,7 +1592,9 @@ class Engine {
             prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
-            int K = 48 / b;                      // first pass: <= 48 key bits (6 radix passes over all suffixes)
+            int K = 48 / b;                      // first pass: <= 48 key bits (6 radix passes over all suffixes) ...
+            if (K < 2 && 2 * b <= 64) K = 2;     // ... but never a single symbol: with alphabets above 2^24 that left nearly
+                                                 // every suffix to a first refinement pass over 2*bitlen(S) key bits
             if (K < 1) K = 1;
             if (K > 16) K = 16;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
@@ -2001,6 +2003,7 @@ class Engine {
         int b = (int)bitlen64(sigma);
         if (b < 1) b = 1;
         int K = 48 / b;
+        if (K < 2 && 2 * b <= 64) K = 2;         // as in the single-GPU stage
         if (K < 1) K = 1;
         if (K > 16) K = 16;
         if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
