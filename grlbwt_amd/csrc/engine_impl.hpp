@@ -1592,9 +1592,11 @@ class Engine {
             prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
-            int K = 48 / b;                      // first pass: <= 48 key bits (6 radix passes over all suffixes) ...
-            if (K < 2 && 2 * b <= 64) K = 2;     // ... but never a single symbol: with alphabets above 2^24 that left nearly
-                                                 // every suffix to a first refinement pass over 2*bitlen(S) key bits
+            // first pass: as many symbols as fit 64 key bits (up to 8 radix passes over all suffixes).  A refinement
+            // pass gathers two ranks per unresolved suffix at random and sorts 2*bitlen(S) key bits, so symbols taken
+            // here are the cheaper ones: 48-bit keys were 7 % slower on the 10 GB build (levels with alphabets above
+            // 2^24 got a single symbol and left nearly every suffix to the first refinement).
+            int K = 64 / b;
             if (K < 1) K = 1;
             if (K > 16) K = 16;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
@@ -2002,8 +2004,7 @@ class Engine {
         DBuf<u64> key0(S);
         int b = (int)bitlen64(sigma);
         if (b < 1) b = 1;
-        int K = 48 / b;
-        if (K < 2 && 2 * b <= 64) K = 2;         // as in the single-GPU stage
+        int K = 64 / b;                          // as in the single-GPU stage
         if (K < 1) K = 1;
         if (K > 16) K = 16;
         if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
