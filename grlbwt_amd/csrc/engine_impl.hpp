@@ -370,10 +370,6 @@ struct GroupStartsFn {    // gstart[dense group id] = head slot ; gstart[G] = S
         if (t == S - 1) gstart[ex[t] + hflag[t]] = (u32)S;
     }
 };
-struct RankAllFn {        // rank of every suffix after the first pass
-    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 *rank;
-    GRL_DEV void operator()(u64 t) const { rank[perm[t]] = gstart[ex[t] + hflag[t] - 1]; }
-};
 struct UnresolvedFlagFn { // member of a group of >1 suffixes that are all at least as long as the resolved prefix
     const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; const u32 *suflen; u64 Lres; u8 *uflag;
     GRL_DEV void operator()(u64 t) const {
@@ -413,19 +409,30 @@ struct RankRefinedFn {    // new positional rank of the re-sorted suffixes only
         rank[perm[t]] = gstart[ex[t] + hflag[t] - 1];
     }
 };
+// Positional rank and suffix length of a dictionary position in ONE 8-byte record: the refinement looks both up at the
+// same random position q (and the rank again at q+h, usually in the same cache line).
+struct RankLen { u32 rank; u32 suflen; };
+struct SufLenPFn {        // suffix length of every dictionary position (coalesced)
+    const u32 *dict_phr; const u32 *ph_off; RankLen *rl;
+    GRL_DEV void operator()(u64 q) const { rl[q].suflen = ph_off[dict_phr[q] + 1] - (u32)q; }
+};
+struct RankAllPFn {       // rank of every suffix after the first pass
+    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; RankLen *rl;
+    GRL_DEV void operator()(u64 t) const { rl[perm[t]].rank = gstart[ex[t] + hflag[t] - 1]; }
+};
 // The same refinement driven by the list of still-unresolved slots (ascending; nullptr = all slots): a suffix that is
 // resolved stays resolved, so every pass after the first touches only the previous pass's unresolved slots.
 // "My group has >= 2 members" needs no group table: slot t is not a head, or slot t+1 is not one either.
 struct ActiveFlagFn {
-    const u32 *act; const u8 *hflag; const u32 *perm; const u32 *suflen; u64 S; u64 Lres; u8 *uflag;
+    const u32 *act; const u8 *hflag; const u32 *perm; const RankLen *rl; u64 S; u64 Lres; u8 *uflag;
     GRL_DEV void operator()(u64 i) const {
         u64 t = act ? (u64)act[i] : i;
         bool multi = !hflag[t] || (t + 1 < S && !hflag[t + 1]);
-        uflag[i] = (multi && suflen[perm[t]] >= Lres) ? 1 : 0;
+        uflag[i] = (multi && rl[perm[t]].suflen >= Lres) ? 1 : 0;
     }
 };
 struct ActiveKeyFn {      // compact the unresolved slots and build their refinement keys
-    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u32 *rank; const u32 *suflen;
+    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const RankLen *rl;
     u64 h; int lowbits;
     u64 *keys; u32 *vals; u32 *uslot;
     GRL_DEV void operator()(u64 i) const {
@@ -433,9 +440,10 @@ struct ActiveKeyFn {      // compact the unresolved slots and build their refine
         u64 t = act ? (u64)act[i] : i;
         u64 q = perm[t];
         u64 sent = (1ull << lowbits) - 1;
-        u64 low = (h < suflen[q]) ? (u64)rank[q + h] : sent;
+        RankLen me = rl[q];
+        u64 low = (h < me.suflen) ? (u64)rl[q + h].rank : sent;
         u32 j = uex[i];
-        keys[j] = ((u64)rank[q] << lowbits) | low;
+        keys[j] = ((u64)me.rank << lowbits) | low;
         vals[j] = (u32)q;
         uslot[j] = (u32)t;
     }
@@ -445,10 +453,10 @@ struct HeadSlotFn {       // hpos[k] = slot of the k-th group head among the re-
     GRL_DEV void operator()(u64 i) const { if (i == 0 || k[i] != k[i - 1]) hpos[hex[i]] = uslot[i]; }
 };
 struct RankFromHeadsFn {  // positional rank = slot of my group's head
-    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; u32 *rank;
+    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; RankLen *rl;
     GRL_DEV void operator()(u64 i) const {
         u32 head = (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
-        rank[v[i]] = hpos[hex[i] + head - 1];
+        rl[v[i]].rank = hpos[hex[i] + head - 1];
     }
 };
 struct DenseGidFn {       // final dense group id of every slot
@@ -591,9 +599,9 @@ struct PackGroupInfoFn {
     }
 };
 struct MetaPosFn {
-    const u32 *rank; const u32 *gid; const u32 *ginfo; u32 sigma3; u32 *meta;
+    const RankLen *rl; const u32 *gid; const u32 *ginfo; u32 sigma3; u32 *meta;
     GRL_DEV void operator()(u64 q) const {
-        u32 gi = ginfo[gid[rank[q]]];
+        u32 gi = ginfo[gid[rl[q].rank]];
         meta[q] = (gi & 1u) ? (gi >> 1) + sigma3 : 0u;
     }
 };
@@ -619,10 +627,10 @@ struct GrammarFn {
 
 // ------------------------------------------- a9 + a10: ranks -> next text
 struct PhraseValFn {
-    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *rank; const u32 *gid; const u32 *grank;
+    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const RankLen *rl; const u32 *gid; const u32 *grank;
     u32 *phrase_val;
     GRL_DEV void operator()(u64 k) const {
-        u32 r = grank[gid[rank[ph_off[k]]]];
+        u32 r = grank[gid[rl[ph_off[k]].rank]];
         phrase_val[k] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
     }
 };
@@ -1583,13 +1591,14 @@ class Engine {
             prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
         }
         // ---- a6: sort all phrase suffixes (radix + filtered prefix doubling) ----------
-        DBuf<u32> perm(S), gid(S), rank(S), gstart(S + 1);
+        DBuf<u32> perm(S), gid(S), gstart(S + 1);
+        DBuf<RankLen> rl(S);                     // (positional rank, suffix length) of every dictionary position
         u64 G;
         {
             StageTimer st(&tm.dict_sort);
             DBuf<u8> hflag(S), uflag(S);
-            DBuf<u32> ex(S + 1), suflen(S);
-            prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
+            DBuf<u32> ex(S + 1);
+            prim::for_each(S, SufLenPFn{dict_phr.p, ph_off, rl.p}, "suffix_len");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
             // first pass: as many symbols as fit 64 key bits (up to 8 radix passes over all suffixes).  A refinement
@@ -1614,7 +1623,7 @@ class Engine {
             }
             G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
             prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
-            prim::for_each(S, RankAllFn{hflag.p, ex.p, gstart.p, perm.p, rank.p}, "suffix_ranks");
+            prim::for_each(S, RankAllPFn{hflag.p, ex.p, gstart.p, perm.p, rl.p}, "suffix_ranks");
             const int lowbits = (int)bitlen64(S);
             u64 Lres = (u64)K, iters = 1;
             DBuf<u32> act;                       // slots still unresolved after the previous pass (empty = all slots)
@@ -1622,13 +1631,13 @@ class Engine {
             bool refined = false;
             while (Lres < maxlen) {              // Lres symbols (incl. a possible sentinel) resolved so far
                 const u32 *ap = refined ? act.p : nullptr;
-                prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, suflen.p, S, Lres, uflag.p}, "suffix_unresolved");
+                prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, rl.p, S, Lres, uflag.p}, "suffix_unresolved");
                 DBuf<u32> uex(A + 1);
                 u64 U = prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
                 if (U == 0) break;
                 DBuf<u64> ka(U), kb(U);
                 DBuf<u32> va(U), vb(U), uslot(U);
-                prim::for_each(A, ActiveKeyFn{ap, uflag.p, uex.p, perm.p, rank.p, suflen.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
+                prim::for_each(A, ActiveKeyFn{ap, uflag.p, uex.p, perm.p, rl.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
                 int res = prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort");
                 const u64 *sk = res ? kb.p : ka.p;
                 const u32 *sv = res ? vb.p : va.p;
@@ -1636,7 +1645,7 @@ class Engine {
                 DBuf<u32> hex(U + 1), hpos(U);
                 prim::exclusive_scan_nosync<u32>(U, HeadKeyIn{sk}, hex.p, false, "suffix_heads");
                 prim::for_each(U, HeadSlotFn{sk, hex.p, uslot.p, hpos.p}, "suffix_gstart");
-                prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rank.p}, "suffix_ranks");
+                prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rl.p}, "suffix_ranks");
                 act = std::move(uslot);
                 A = U;
                 refined = true;
@@ -1691,12 +1700,12 @@ class Engine {
             {
                 DBuf<u32> ginfo(G), meta(S);
                 prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, ginfo.p}, "grammar_ginfo");
-                prim::for_each(S, MetaPosFn{rank.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
+                prim::for_each(S, MetaPosFn{rl.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
                 prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, meta.p, MD, L.g0.p, L.g1.p}, "grammar");
             }
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
-            prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rank.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
+            prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rl.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
         }
         L.info.M = M;
     }
