@@ -1873,11 +1873,12 @@ class Engine {
             const u64 G = NH + E;
             I.G = G;
             DBuf<u32> seg_sym(G);
-            DBuf<idx_t> seg_len(G), Toff(G + 1), abase(G + 1);
+            DBuf<idx_t> seg_len(G);
             prim::for_each(P, SegFromPreFn{L.prebwt.sym.p, L.prebwt.len.p, PH.p, nhb.p, Hpos.p, E, bwt_code, hocc_code,
                                            take_code, seg_sym.p, seg_len.p}, "asm.seg_pre");
             prim::for_each(E, SegFromCellFn{skey.p, cells, L.u_to_p.p, nhb.p, seg_sym.p, seg_len.p}, "asm.seg_cell");
-            Hpos.release(); skey.release(); ssym.release(); slen.release(); spack.release();
+            Hpos.release(); skey.release(); ssym.release(); slen.release(); spack.release(); gp.release();
+            DBuf<idx_t> Toff(G + 1), abase(G + 1);      // only now: the cells are gone (this level's peak memory)
             u64 Tused = (u64)prim::exclusive_scan<idx_t>(G, CondLenIn{seg_sym.p, seg_len.p, take_code}, Toff.p, true, "asm.Toff");
             if (Tused != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) +
                                                            ": " + std::to_string(Tused) + " vs " + std::to_string(Tsum) + ")");
