@@ -152,6 +152,24 @@ int test_pair_scan(uint64_t n, const std::vector<uint32_t> &h, const uint32_t *d
     return 0;
 }
 
+int test_sort_keys(uint64_t n, uint64_t seed, int bits) {       // keys-only sort on the low `bits` bits: stability through the high bits
+    std::vector<uint64_t> hk(n);
+    uint64_t s = seed;
+    uint64_t mask = (1ull << bits) - 1;
+    for (uint64_t i = 0; i < n; i++) hk[i] = (sm64(s) & mask) | (i << bits);       // original index rides above the sorted bits
+    grl32::DBuf<uint64_t> ka(n), kb(n);
+    prim::h2d(ka.p, hk.data(), n * 8);
+    int res = prim::sort_keys<uint64_t>(ka.p, kb.p, n, 0, bits, "selftest.sort_keys");
+    std::vector<uint64_t> ok = (res ? kb : ka).to_host(n);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t idx = ok[i] >> bits;
+        if (idx >= n || hk[idx] != ok[i]) return 1;
+        if (i > 0 && (ok[i - 1] & mask) > (ok[i] & mask)) return 2;
+        if (i > 0 && (ok[i - 1] & mask) == (ok[i] & mask) && (ok[i - 1] >> bits) >= idx) return 3;
+    }
+    return 0;
+}
+
 template <class K, class V>
 int test_sort(uint64_t n, uint64_t seed, int bits) {
     std::vector<K> hk(n);
@@ -237,6 +255,7 @@ int selftest(uint64_t n, uint64_t seed) {
     { int r = test_sort<uint32_t, uint64_t>(n, seed + 3, 8); if (r) return -40 - r; }
     { int r = test_sort<uint64_t, uint32_t>(n, seed + 4, 3); if (r) return -50 - r; }   // heavy duplicates
     { int r = test_sort<uint64_t, uint64_t>(n, seed + 5, 33); if (r) return -60 - r; }
+    { int r = test_sort_keys(n, seed + 6, 21); if (r) return -90 - r; }
     // 7: fused pair scans (8- and 16-byte elements: the 16-byte result stores and the LDS staging of the scan)
     { int r = test_pair_scan<uint32_t, uint32_t>(n, h, d.p); if (r) return -70 - r; }
     { int r = test_pair_scan<uint64_t, uint64_t>(n, h, d.p); if (r) return -80 - r; }

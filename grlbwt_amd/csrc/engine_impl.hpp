@@ -785,14 +785,17 @@ struct ChainCountFn {
         return c;
     }
 };
-template <bool PACKED>
+enum { CELLS_SEPARATE = 0, CELLS_PACKED = 1, CELLS_FUSED = 2 };
+template <int MODE>
 struct ChainExpandFn {
     const u32 *nsym; const idx_t *nlen; const u64 *gp; const idx_t *eoff;
     u32 sigma3, take_code;
     u32 *ekey; idx_t *eidx; u32 *esym; idx_t *elen; u64 *epack; u32 *term;
+    int kb, lb;                                   // CELLS_FUSED: epack[e] = sym << (kb+lb) | len << kb | bucket
     GRL_DEV void put(u64 e, u32 key, u32 sym, idx_t f) const {
+        if (MODE == CELLS_FUSED) { epack[e] = ((u64)sym << (kb + lb)) | ((u64)f << kb) | (u64)key; return; }
         ekey[e] = key;
-        if (PACKED) epack[e] = ((u64)sym << 32) | (u64)f;
+        if (MODE == CELLS_PACKED) epack[e] = ((u64)sym << 32) | (u64)f;
         else { eidx[e] = (idx_t)e; esym[e] = sym; elen[e] = f; }
     }
     GRL_DEV void operator()(u64 i) const {
@@ -837,22 +840,27 @@ struct SegFromPreFn {   // non-HOCC pre-BWT runs -> segments
         seg_len[g] = plen[j];
     }
 };
-// induced cells in bucket-major order: either the packed payload that rode through the split
-// (sym<<32 | len) or two separate arrays (64-bit build with a run of >= 2^32 symbols)
+// induced cells in bucket-major order, in one of three forms: ONE 64-bit word per cell, sym | len | bucket (the word
+// the split sorted, when the three fields fit); bucket array + packed payload (sym<<32 | len); bucket array + two
+// separate arrays (64-bit build with a run of >= 2^32 symbols).
 struct CellView {
-    const u64 *packed; const u32 *ssym; const idx_t *slen;
-    GRL_DEV u32 sym(u64 t) const { return packed ? (u32)(packed[t] >> 32) : ssym[t]; }
-    GRL_DEV idx_t len(u64 t) const { return packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t]; }
+    const u64 *fused; int kb, lb;
+    const u32 *skey; const u64 *packed; const u32 *ssym; const idx_t *slen;
+    GRL_DEV u32 key(u64 t) const { return fused ? (u32)(fused[t] & ((1ull << kb) - 1ull)) : skey[t]; }
+    GRL_DEV u32 sym(u64 t) const { return fused ? (u32)(fused[t] >> (kb + lb)) : packed ? (u32)(packed[t] >> 32) : ssym[t]; }
+    GRL_DEV idx_t len(u64 t) const {
+        return fused ? (idx_t)((fused[t] >> kb) & ((1ull << lb) - 1ull)) : packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t];
+    }
 };
 struct CellLenIn {
     CellView c;
     GRL_DEV idx_t operator()(u64 t) const { return c.len(t); }
 };
 struct SegFromCellFn {  // induced cells (H, bucket-major) -> segments
-    const u32 *skey; CellView c; const u32 *u_to_p; const idx_t *nhb;
+    CellView c; const u32 *u_to_p; const idx_t *nhb;
     u32 *seg_sym; idx_t *seg_len;
     GRL_DEV void operator()(u64 t) const {
-        u64 j = u_to_p[skey[t]];                 // pre-BWT (HOCC) run this bucket belongs to
+        u64 j = u_to_p[c.key(t)];                // pre-BWT (HOCC) run this bucket belongs to
         u64 g = (u64)nhb[j] + t;
         seg_sym[g] = c.sym(t);
         seg_len[g] = c.len(t);
@@ -1821,20 +1829,38 @@ class Engine {
         I.E = E;
         DBuf<u32> skey;                         // bucket of every induced cell, bucket-major order
         DBuf<u64> spack;                        // (sym<<32 | len) of every induced cell, same order (packed path)
+        DBuf<u64> sfused;                       // sym | len | bucket in one word per cell (fused path)
+        int kb = (int)bitlen64(L.M > 0 ? L.M - 1 : 0), lb = 0;
+        if (kb < 1) kb = 1;
         {
-            DBuf<u32> ekey(E), ekey2(E);
-            int bits = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
-            if (bits < 1) bits = 1;
-            // payload (sym, len) rides through the split as one u64 whenever every run length fits 32 bits
-            // (always in the 32-bit index build; in the 64-bit build unless a single run is >= 2^32 symbols long)
-            bool packed = sizeof(idx_t) == 4;
-            if (!packed) packed = prim::reduce_max<u64>(R, IdxIn<idx_t>{bwt.len.p}, "induce_maxrun") < 0xFFFFFFFFull;
-            if (packed) {
+            const int bits = kb;
+            const u64 maxrun = prim::reduce_max<u64>(R, IdxIn64{bwt.len.p}, "induce_maxrun");
+            lb = (int)bitlen64(maxrun);
+            if (lb < 1) lb = 1;
+            const int sbits = (int)bitlen64((u64)sigma3);
+            // Whenever bucket, run length and symbol fit 64 bits together (always at DNA scales), the cell IS the sort
+            // key: the split moves 8 bytes per cell and pass instead of 12, and holds 16 instead of 24 bytes per cell.
+            const bool fused = kb + lb + sbits <= 64;
+            // otherwise the payload (sym, len) rides through the split as one u64 whenever every run length fits 32 bits
+            const bool packed = !fused && maxrun < 0xFFFFFFFFull;
+            if (fused) {
+                DBuf<u64> ef(E), ef2(E);
+                {
+                    StageTimer st(&tm.ind_expand);
+                    prim::for_each(R, ChainExpandFn<CELLS_FUSED>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                                                                 nullptr, nullptr, nullptr, nullptr, ef.p, term.p, kb, lb}, "induce_expand");
+                }
+                StageTimer st(&tm.ind_sort);
+                int res = prim::sort_keys<u64>(ef.p, ef2.p, E, 0, bits, "induce_split");
+                sfused = std::move(res ? ef2 : ef);
+                prim::sync();
+            } else if (packed) {
+                DBuf<u32> ekey(E), ekey2(E);
                 DBuf<u64> ep(E), ep2(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
-                                                          ekey.p, nullptr, nullptr, nullptr, ep.p, term.p}, "induce_expand");
+                    prim::for_each(R, ChainExpandFn<CELLS_PACKED>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                                                                  ekey.p, nullptr, nullptr, nullptr, ep.p, term.p, 0, 0}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
                 int res = prim::sort_pairs<u32, u64>(ekey.p, ep.p, ekey2.p, ep2.p, E, 0, bits, "induce_split");
@@ -1842,12 +1868,13 @@ class Engine {
                 spack = std::move(res ? ep2 : ep);
                 prim::sync();
             } else {
+                DBuf<u32> ekey(E), ekey2(E);
                 DBuf<u32> esym(E);
                 DBuf<idx_t> eidx(E), eidx2(E), elen(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
-                                                           ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
+                    prim::for_each(R, ChainExpandFn<CELLS_SEPARATE>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                                                                    ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p, 0, 0}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
                 ssym.alloc(E); slen.alloc(E);
@@ -1857,7 +1884,7 @@ class Engine {
                 prim::sync();
             }
         }
-        const CellView cells{spack.p, ssym.p, slen.p};
+        const CellView cells{sfused.p, kb, lb, skey.p, spack.p, ssym.p, slen.p};
         eoff.release();
         {
             StageTimer st(&tm.ind_assemble);
@@ -1876,8 +1903,8 @@ class Engine {
             DBuf<idx_t> seg_len(G);
             prim::for_each(P, SegFromPreFn{L.prebwt.sym.p, L.prebwt.len.p, PH.p, nhb.p, Hpos.p, E, bwt_code, hocc_code,
                                            take_code, seg_sym.p, seg_len.p}, "asm.seg_pre");
-            prim::for_each(E, SegFromCellFn{skey.p, cells, L.u_to_p.p, nhb.p, seg_sym.p, seg_len.p}, "asm.seg_cell");
-            Hpos.release(); skey.release(); ssym.release(); slen.release(); spack.release(); gp.release();
+            prim::for_each(E, SegFromCellFn{cells, L.u_to_p.p, nhb.p, seg_sym.p, seg_len.p}, "asm.seg_cell");
+            Hpos.release(); skey.release(); ssym.release(); slen.release(); spack.release(); sfused.release(); gp.release();
             DBuf<idx_t> Toff(G + 1), abase(G + 1);      // only now: the cells are gone (this level's peak memory)
             u64 Tused = (u64)prim::exclusive_scan<idx_t>(G, CondLenIn{seg_sym.p, seg_len.p, take_code}, Toff.p, true, "asm.Toff");
             if (Tused != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) +
@@ -2294,8 +2321,8 @@ class Engine {
                 DBuf<u64> ep(E), ep2(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<true>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
-                                                          ekey.p, nullptr, nullptr, nullptr, ep.p, term.p}, "induce_expand");
+                    prim::for_each(R, ChainExpandFn<CELLS_PACKED>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                                                          ekey.p, nullptr, nullptr, nullptr, ep.p, term.p, 0, 0}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
                 int res = prim::sort_pairs<u32, u64>(ekey.p, ep.p, ekey2.p, ep2.p, E, 0, bits, "induce_split");
@@ -2307,8 +2334,8 @@ class Engine {
                 DBuf<idx_t> eidx(E), eidx2(E), elen(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<false>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
-                                                           ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p}, "induce_expand");
+                    prim::for_each(R, ChainExpandFn<CELLS_SEPARATE>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                                                           ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p, 0, 0}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
                 int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");

@@ -944,7 +944,7 @@ static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup
 // (Measured equal to the form with one LDS atomic per key, and to 4/8-byte instead of 16-byte key loads, within 6 %:
 // 29 M 8-byte keys in 64 us either way.  Kept because its cost does not depend on how skewed the digits are.)
 template <class K>
-__global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 *counts, u32 tiles) {
+__global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 dmask, u32 *counts, u32 tiles) {
     __shared__ u32 s_h[kBlock / 64][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u64 base = (u64)blockIdx.x * kRsTile;
@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int sh
 #pragma unroll
     for (int r = 0; r < kRsItems; r++) {
         const u64 i = base + (u64)r * kBlock + threadIdx.x;      // only meaningful on the guarded path
-        const u32 d = (u32)(k[r] >> shift) & 255u;
+        const u32 d = (u32)(k[r] >> shift) & dmask;
         unsigned long long lm = __ballot(full || i < n);
 #pragma unroll
         for (int b = 0; b < 6; b++) {
@@ -1025,9 +1025,10 @@ __global__ void __launch_bounds__(kBlock) k_rs_tile_offsets(const u32 *counts, c
 // linearly, so that neighbouring lanes store to neighbouring addresses of the same digit run.  Values are loaded
 // once the keys' registers are free; those loads overlap the key write-out.
 static constexpr int kRsKeys = kRsTile / kBlock;
+struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays are read or written
 template <class K, class V>
 __global__ void __launch_bounds__(kBlock)
-    k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift,
+    k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
                         const u64 *offsets /*[tiles][256] exclusive*/, u32 tiles) {
     constexpr int EB = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[kRsTile * EB];
@@ -1043,7 +1044,7 @@ __global__ void __launch_bounds__(kBlock)
     const u32 tile_n = left < (u64)kRsTile ? (u32)left : (u32)kRsTile;
     const u32 wbase = (u32)w * (64 * kRsKeys);
     K key[kRsKeys];
-    V val[kRsKeys];
+    V val[std::is_same<V, NoVal>::value ? 1 : kRsKeys];
     u32 idx[kRsKeys];
 #pragma unroll
     for (int q = 0; q < kRsKeys; q++) {
@@ -1057,7 +1058,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int q = 0; q < kRsKeys; q++) {
         u32 t = wbase + q * 64 + lane;
         bool valid = t < tile_n;
-        u32 d = (u32)(key[q] >> shift) & 255u;
+        u32 d = (u32)(key[q] >> shift) & dmask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -1102,15 +1103,17 @@ __global__ void __launch_bounds__(kBlock)
     for (int q = 0; q < kRsKeys; q++) {
         u32 t = wbase + q * 64 + lane;
         if (t < tile_n) {
-            u32 d = (u32)(key[q] >> shift) & 255u;
+            u32 d = (u32)(key[q] >> shift) & dmask;
             idx[q] += s_cnt[w][d];
             kb[idx[q]] = key[q];
         }
     }
+    if constexpr (!std::is_same<V, NoVal>::value) {
 #pragma unroll
-    for (int q = 0; q < kRsKeys; q++) {
-        u32 t = wbase + q * 64 + lane;
-        val[q] = t < tile_n ? vals_in[base + t] : V(0);
+        for (int q = 0; q < kRsKeys; q++) {
+            u32 t = wbase + q * 64 + lane;
+            val[q] = t < tile_n ? vals_in[base + t] : V(0);
+        }
     }
     __syncthreads();
     u32 dpack[(kRsKeys + 3) / 4];
@@ -1121,25 +1124,27 @@ __global__ void __launch_bounds__(kBlock)
         u32 t = (u32)j * kBlock + threadIdx.x;
         if (t < tile_n) {
             K k = kb[t];
-            u32 d = (u32)(k >> shift) & 255u;
+            u32 d = (u32)(k >> shift) & dmask;
             dpack[j >> 2] |= d << (8 * (j & 3));
             keys_out[s_gbase[d] + t] = k;
         }
     }
-    __syncthreads();
-    V *vb = (V *)s_buf;
+    if constexpr (!std::is_same<V, NoVal>::value) {
+        __syncthreads();
+        V *vb = (V *)s_buf;
 #pragma unroll
-    for (int q = 0; q < kRsKeys; q++) {
-        u32 t = wbase + q * 64 + lane;
-        if (t < tile_n) vb[idx[q]] = val[q];
-    }
-    __syncthreads();
+        for (int q = 0; q < kRsKeys; q++) {
+            u32 t = wbase + q * 64 + lane;
+            if (t < tile_n) vb[idx[q]] = val[q];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kRsKeys; j++) {
-        u32 t = (u32)j * kBlock + threadIdx.x;
-        if (t < tile_n) {
-            u32 d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
-            vals_out[s_gbase[d] + t] = vb[t];
+        for (int j = 0; j < kRsKeys; j++) {
+            u32 t = (u32)j * kBlock + threadIdx.x;
+            if (t < tile_n) {
+                u32 d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
+                vals_out[s_gbase[d] + t] = vb[t];
+            }
         }
     }
 }
@@ -1158,12 +1163,15 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
     u64 *chunk_off = (u64 *)dev_alloc((u64)256 * chunks * sizeof(u64));
     int cur = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        // the last digit may be narrower than 8 bits: key bits at and above end_bit (a payload riding in the key)
+        // must not take part in the order
+        const u32 dmask = end_bit - shift >= 8 ? 255u : (1u << (end_bit - shift)) - 1u;
         K *kin = cur ? keys_b : keys_a;
         V *vin = cur ? vals_b : vals_a;
         K *kout = cur ? keys_a : keys_b;
         V *vout = cur ? vals_a : vals_b;
         prof_begin(std::string(name) + ".hist", n * sizeof(K));
-        hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, counts, tiles);
+        hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
         prof_end();
         after_launch(name);
         hipLaunchKernelGGL(k_rs_chunk_sums, dim3(chunks), dim3(kBlock), 0, rt().stream, counts, tiles, chunk_sums);
@@ -1171,9 +1179,9 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         exclusive_scan_async<u64, RsChunkIn>((u64)256 * chunks, RsChunkIn{chunk_sums, chunks}, chunk_off, nullptr, nullptr, name);
         hipLaunchKernelGGL(k_rs_tile_offsets, dim3(chunks), dim3(kBlock), 0, rt().stream, counts, chunk_off, tiles, chunks, offsets);
         after_launch(name);
-        prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + sizeof(V)) * 2);   // pairs read once + written once
+        prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
         hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
-                           shift, offsets, tiles);
+                           shift, dmask, offsets, tiles);
         prof_end();
         after_launch(name);
         cur ^= 1;
@@ -1183,6 +1191,12 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
     dev_free(chunk_sums);
     dev_free(chunk_off);
     return cur;
+}
+
+// keys only: returns 0 if the result is in keys_a, 1 if in keys_b
+template <class K>
+inline int sort_keys(K *keys_a, K *keys_b, u64 n, int begin_bit, int end_bit, const char *name = "radix_sort") {
+    return sort_pairs<K, NoVal>(keys_a, (NoVal *)nullptr, keys_b, (NoVal *)nullptr, n, begin_bit, end_bit, name);
 }
 
 }   // namespace prim

@@ -179,4 +179,17 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
     return 1;
 }
 
+template <class K>
+inline int sort_keys(K *keys_a, K *keys_b, u64 n, int begin_bit, int end_bit, const char * = "") {
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    int bits = end_bit - begin_bit;
+    K mask = bits >= (int)(8 * sizeof(K)) ? ~K(0) : (K)(((K(1) << bits) - 1));
+    std::vector<K> v(keys_a, keys_a + n);
+    std::stable_sort(v.begin(), v.end(), [&](K a, K b) { return ((a >> begin_bit) & mask) < ((b >> begin_bit) & mask); });
+    int passes = (bits + 7) / 8;
+    K *dst = (passes % 2 == 0) ? keys_a : keys_b;
+    std::memcpy(dst, v.data(), n * sizeof(K));
+    return passes % 2 == 0 ? 0 : 1;
+}
+
 }   // namespace prim
