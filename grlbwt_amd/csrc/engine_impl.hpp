@@ -1623,7 +1623,7 @@ class Engine {
                 prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, ka.p, perm.p}, "suffix_keys0");
                 const u64 *ks = ka.p;
                 if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, S, 0, K * b, "suffix_sort0")) {
-                    prim::d2d(perm.p, vb.p, S * sizeof(u32));
+                    std::swap(perm, vb);         // the result sits in the second buffer: take it, no copy
                     ks = kb.p;
                 }
                 prim::for_each(S, HeadFlagFn{ks, hflag.p}, "suffix_heads");
