@@ -763,6 +763,11 @@ struct CellSymFn {
 };
 
 template <class F>
+struct StoreByteFn {      // out[i] = f(i) as a byte flag
+    F f; u8 *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = (u8)f(i); }
+};
+template <class F>
 struct StoreFn {          // out[i] = f(i): materialise an expensive scan input once
     F f; idx_t *out;
     GRL_DEV void operator()(u64 i) const { out[i] = f(i); }
@@ -2175,7 +2180,9 @@ class Engine {
             prim::for_each(Sg, MarkPairFn{gid.p, gflag.p, mex.p, perm.p, grank.p, (u32)Moff, mp.p}, "dist.mark_pairs");
             DBuf<u64> all = C.allgather_v<u64>(mp.p, nm, bb);
             prim::for_each(bb[C.size], ApplyPairsFn{all.p, mark_rank.p}, "dist.apply_marks");
-            u64 nf = prim::exclusive_scan<u32>(Sg, FullFlagIn{perm.p, dict_phr.p, ph_off}, mex.p, false, "dist.full_scan");
+            DBuf<u8> fflag(Sg);                  // the flag costs two dependent gathers: evaluate it once, scan the bytes
+            prim::for_each(Sg, StoreByteFn<FullFlagIn>{FullFlagIn{perm.p, dict_phr.p, ph_off}, fflag.p}, "dist.full_flags");
+            u64 nf = prim::exclusive_scan<u32>(Sg, ByteIn{fflag.p}, mex.p, false, "dist.full_scan");
             DBuf<u64> fp(nf);
             prim::for_each(Sg, FullPairFn{perm.p, dict_phr.p, ph_off, mex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
             DBuf<u64> allf = C.allgather_v<u64>(fp.p, nf, bb);
@@ -2392,8 +2399,9 @@ class Engine {
         skey.release(); ssym.release(); slen.release(); lH.release(); lT.release();
         RankBits tbits, abits, pbits;
         build_rankbits(tbits, Tpos.p, Rt, Tsum + 1, "dist.tbits");
-        u64 A = (u64)prim::exclusive_scan<idx_t>(G, DistAtomCountIn{seg_sym.p, seg_len.p, seg_toff.p, tbits.words.p, tbits.base.p, take_code},
-                                                 abase.p, true, "dist.atom_count");
+        prim::for_each(G, StoreFn<DistAtomCountIn>{DistAtomCountIn{seg_sym.p, seg_len.p, seg_toff.p, tbits.words.p, tbits.base.p, take_code}, abase.p},
+                       "dist.atom_count");
+        u64 A = (u64)prim::exclusive_scan<idx_t>(G, IdxIn<idx_t>{abase.p}, abase.p, true, "dist.atom_scan");
         I.A = A;
         build_rankbits(abits, abase.p, G, A + 1, "dist.abits");
         DBuf<u64> a_out(A), a_len(A);
