@@ -1098,10 +1098,10 @@ struct FullFlagIn {       // slot is the whole-phrase suffix of its phrase
     GRL_DEV u32 operator()(u64 t) const { u32 q = perm[t]; return (q == ph_off[dict_phr[q]]) ? 1u : 0u; }
 };
 struct FullPairFn {
-    const u32 *perm; const u32 *dict_phr; const u32 *ph_off; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
+    const u8 *fflag; const u32 *perm; const u32 *dict_phr; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
     GRL_DEV void operator()(u64 t) const {
-        u32 q = perm[t], k = dict_phr[q];
-        if (q != ph_off[k]) return;
+        if (!fflag[t]) return;                   // FullFlagIn, evaluated once: only whole-phrase slots pay the gathers again
+        u32 k = dict_phr[perm[t]];
         pairs[ex[t]] = ((u64)k << 32) | (u64)(m_off + grank[gid[t]]);
     }
 };
@@ -1244,15 +1244,30 @@ struct PermuteAtomsFn {
 // in a bit-vector over the range, rank the bits, and drop each atom at the rank of its own start.
 struct RecvMarkFn {        // one lane per 16 consecutive atoms (each source's atoms arrive in position order: few words per lane)
     const u64 *o; u64 n, lo, span; u64 *words; u32 *bad;
+    struct alignas(16) Two { u64 v[2]; };
     GRL_DEV void operator()(u64 j) const {
         u64 i0 = j * 16, i1 = i0 + 16 < n ? i0 + 16 : n;
+        u64 x16[16];
+        if (i1 - i0 == 16 && ((uintptr_t)o & 15) == 0) {      // 16-byte loads (see BuildBitsFn)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                Two t2 = *reinterpret_cast<const Two *>(o + i0 + 2 * c);
+                x16[2 * c] = t2.v[0]; x16[2 * c + 1] = t2.v[1];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x16[k] = (i0 + k < i1) ? o[i0 + k] : lo;
+        }
         u64 cur = ~0ull, m = 0;
-        for (u64 i = i0; i < i1; i++) {
-            u64 x = o[i] - lo;
-            if (o[i] < lo || x >= span) { *bad = 1; continue; }
-            u64 w = x >> 6;
-            if (w != cur) { if (m) prim::atomic_or(&words[cur], m); m = 0; cur = w; }
-            m |= 1ull << (x & 63);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (i0 + k < i1) {
+                u64 x = x16[k] - lo;
+                if (x16[k] < lo || x >= span) { *bad = 1; continue; }
+                u64 w = x >> 6;
+                if (w != cur) { if (m) prim::atomic_or(&words[cur], m); m = 0; cur = w; }
+                m |= 1ull << (x & 63);
+            }
         }
         if (m) prim::atomic_or(&words[cur], m);
     }
@@ -2184,7 +2199,7 @@ class Engine {
             prim::for_each(Sg, StoreByteFn<FullFlagIn>{FullFlagIn{perm.p, dict_phr.p, ph_off}, fflag.p}, "dist.full_flags");
             u64 nf = prim::exclusive_scan<u32>(Sg, ByteIn{fflag.p}, mex.p, false, "dist.full_scan");
             DBuf<u64> fp(nf);
-            prim::for_each(Sg, FullPairFn{perm.p, dict_phr.p, ph_off, mex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
+            prim::for_each(Sg, FullPairFn{fflag.p, perm.p, dict_phr.p, mex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
             DBuf<u64> allf = C.allgather_v<u64>(fp.p, nf, bb);
             if (bb[C.size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
             prim::for_each(D, ApplyPairsFn{allf.p, phrase_rank.p}, "dist.apply_phrase_ranks");

@@ -320,6 +320,20 @@ inline void dev_free(void *p) {
     sl.free_list.emplace(off, len);
 }
 inline void h2d(void *d, const void *h, size_t n) {
+    // small uploads (counts, offsets tables, headers) go through a ring of pinned staging slots and do NOT wait: the
+    // caller's buffer is free as soon as this returns and the copy is ordered on the stream; the ring is drained
+    // before a slot is reused
+    constexpr size_t kSlot = 4096, kSlots = 64;
+    static char *ring = nullptr;
+    static size_t next = 0;
+    if (n && n <= kSlot) {
+        if (!ring) GRL_HIP_CHECK(hipHostMalloc((void **)&ring, kSlot * kSlots, hipHostMallocDefault));
+        if (next == kSlots) { GRL_HIP_CHECK(hipStreamSynchronize(rt().stream)); next = 0; }
+        char *slot = ring + kSlot * next++;
+        std::memcpy(slot, h, n);
+        GRL_HIP_CHECK(hipMemcpyAsync(d, slot, n, hipMemcpyHostToDevice, rt().stream));
+        return;
+    }
     if (n) GRL_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().stream));
     sync();
 }
