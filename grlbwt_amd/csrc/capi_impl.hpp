@@ -470,6 +470,7 @@ int grlbwt_image_stats_get(grlbwt_ctx *ctx, const void *dev_image, uint64_t imag
         out->fit1 = st.fit1; out->fit2 = st.fit2; out->fit3 = st.fit3;
         for (int c = 0; c < 256; c++) { out->runs_of[c] = st.runs_of[c]; out->freq_of[c] = st.freq_of[c]; }
         for (int i = 0; i < 9; i++) out->deciles[i] = st.deciles[i];
+        out->non_maximal = st.non_maximal;
     });
 }
 

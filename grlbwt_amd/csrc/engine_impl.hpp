@@ -704,6 +704,10 @@ struct IdxIn {
     const L *p;
     GRL_DEV idx_t operator()(u64 i) const { return (idx_t)p[i]; }
 };
+struct SymHeadIn64 {
+    const u32 *s;
+    GRL_DEV u64 operator()(u64 t) const { return (t == 0 || s[t] != s[t - 1]) ? 1ull : 0ull; }
+};
 struct IdxIn64 {
     const idx_t *p;
     GRL_DEV u64 operator()(u64 i) const { return (u64)p[i]; }
@@ -2623,6 +2627,7 @@ class Engine {
         u64 n_runs, sigma, text_size, min_run, max_run, fit1, fit2, fit3;
         u64 runs_of[256], freq_of[256];
         u64 deciles[9];
+        u64 non_maximal;
     };
     static void image_stats(const void *dev_image, u64 image_bytes, ImageStats &st) {
         ImageHeader h = image_header(dev_image, image_bytes);
@@ -2639,6 +2644,7 @@ class Engine {
         st.fit1 = prim::reduce_sum<u64>(R, LenFitIn{rlen.p, 1}, "stats.fit1");
         st.fit2 = prim::reduce_sum<u64>(R, LenFitIn{rlen.p, 2}, "stats.fit2");
         st.fit3 = R - st.fit1 - st.fit2;
+        st.non_maximal = R - prim::reduce_sum<u64>(R, SymHeadIn64{rsym.p}, "stats.maximal");
         DBuf<u64> bins(256);
         bins.zero();
         prim::for_each_agg(R, RunSymFn{rsym.p}, BinAddFn{bins.p}, true, "stats.runs_per_symbol");

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
 
 class ImageStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_runs", "sigma", "text_size", "min_run", "max_run", "fit1", "fit2", "fit3")] + \
-               [("runs_of", C.c_uint64 * 256), ("freq_of", C.c_uint64 * 256), ("deciles", C.c_uint64 * 9)]
+               [("runs_of", C.c_uint64 * 256), ("freq_of", C.c_uint64 * 256), ("deciles", C.c_uint64 * 9), ("non_maximal", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -304,6 +304,7 @@ class Context:
         self._ck(self.L.grlbwt_image_stats_get(self._h, C.c_void_p(dev_image_ptr), image_bytes, C.byref(st)))
         d = {k: int(getattr(st, k)) for k in ("n_runs", "sigma", "text_size", "min_run", "max_run", "fit1", "fit2", "fit3")}
         d["runs_of"] = list(st.runs_of); d["freq_of"] = list(st.freq_of); d["deciles"] = list(st.deciles)
+        d["non_maximal"] = int(st.non_maximal)
         return d
 
     def memory_usage(self):

@@ -159,6 +159,7 @@ typedef struct grlbwt_image_stats {
     uint64_t fit1, fit2, fit3;            /* runs whose length fits 1 byte / 2 bytes / needs 3 or more */
     uint64_t runs_of[256], freq_of[256];  /* per symbol: number of runs, total length */
     uint64_t deciles[9];                  /* sorted run lengths at ceil(n_runs * k/10), k = 1..9 */
+    uint64_t non_maximal;                 /* runs with the same symbol as the run before them (0 for a grlBWT output) */
 } grlbwt_image_stats;
 int grlbwt_image_plain(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, void *dev_out_u8,
                        uint64_t capacity, int null_char, uint64_t *n_out);

@@ -34,6 +34,7 @@ def expected(blob):
         dec.append(int(srt[q]))
         prop += 0.1
     st["deciles"] = dec
+    st["non_maximal"] = int((sym[1:] == sym[:-1]).sum())
     return sym, ln, st
 
 
