@@ -122,10 +122,11 @@ struct PopcIn {
 };
 
 // ------------------------------------------------- a3: phrase hashing/count
-// phrase table, struct-of-arrays: u64 keys[] (tag:12 | len:12 | pos+1:40, 0 = empty) are written once
-// and then read-mostly, so they stay cacheable; idx_t counts[] take the atomic traffic.  (An
-// array-of-structs layout was measured 4x slower: the atomics on a hot phrase's count kept
-// invalidating the line every probe of that phrase has to read.)
+// phrase table: u64 keys (tag:12 | len:12 | pos+1:40, 0 = empty) and idx_t counts.  Struct-of-arrays when few phrases
+// are hot (level 0): the keys are written once and then read-mostly, so they stay cacheable, while the counts take
+// the atomic traffic (16-byte slots were measured 4x slower there: the atomics on a hot phrase's count kept
+// invalidating the line every probe of that phrase has to read).  16-byte (key, count) slots when most phrases are
+// distinct: then every occurrence would fetch two random lines instead of one (hash_local).
 static constexpr u64 kPosBits = 40;
 static constexpr u64 kPosMask = (1ull << kPosBits) - 1;
 static constexpr u64 kLenSat = 4095;               // lengths >= 4095 saturate; verified through the start bits
@@ -161,6 +162,7 @@ struct HashInsertFn {
     u64 *keys;
     u64 mask;
     u64 probe_limit;  // give up (overflow flag) after this many probes: the host retries with a larger table
+    int ks = 0;       // key of slot s at keys[s << ks]: 0 = keys[] on its own, 1 = interleaved with the counts (16-byte slots)
     u32 *out_slot;    // [n_occ] slot of every phrase occurrence, text order
     u32 *scal;        // [1] error flag, [2..3] debug
     u64 n, n_occ;
@@ -232,9 +234,9 @@ struct HashInsertFn {
             // once probing gets long, look at the overflow flag (L1-bypassing load; done rarely: a coherent load of one
             // address by every lane was measured to serialise and cost 20 ms per 10 M phrases)
             if (probes == 16 && prim::load_relaxed(&scal[1])) return prim::kNoBucket;
-            u64 cur = prim::load_relaxed(&keys[slot]);   // L1-bypassing: a stale 0 from L1 would turn every later occurrence of a hot phrase into a CAS on one address
+            u64 cur = prim::load_relaxed(&keys[slot << ks]);   // L1-bypassing: a stale 0 from L1 would turn every later occurrence of a hot phrase into a CAS on one address
             if (cur == 0) {
-                u64 old = prim::atomic_cas(&keys[slot], 0ull, mine);
+                u64 old = prim::atomic_cas(&keys[slot << ks], 0ull, mine);
                 if (old == 0) cur = mine;
                 else cur = old;
             }
@@ -248,13 +250,13 @@ struct HashInsertFn {
     }
 };
 struct SlotCountAdd {
-    idx_t *counts;
-    GRL_DEV void operator()(u32 slot, u32 c) const { prim::atomic_add(&counts[slot], (idx_t)c); }
+    idx_t *counts; u64 cs;     // count of slot s at counts[s * cs]
+    GRL_DEV void operator()(u32 slot, u32 c) const { prim::atomic_add(&counts[(u64)slot * cs], (idx_t)c); }
 };
 
 struct OccIn {
-    const u64 *keys;
-    GRL_DEV u32 operator()(u64 i) const { return keys[i] != 0 ? 1u : 0u; }
+    const u64 *keys; int ks;
+    GRL_DEV u32 operator()(u64 i) const { return keys[i << ks] != 0 ? 1u : 0u; }
 };
 
 // ------------------------------------------------------ a5: dictionary view
@@ -265,8 +267,9 @@ struct CompactTableFn {
     const u64 *startbits;
     const u64 *keys; const idx_t *counts; const u32 *slot_ph;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
+    int ks; u64 cs;
     GRL_DEV void operator()(u64 s) const {
-        u64 k64 = keys[s];
+        u64 k64 = keys[s << ks];
         if (!k64) return;
         u32 k = slot_ph[s];
         u64 pos = key_pos(k64), len = key_len(k64);
@@ -275,7 +278,7 @@ struct CompactTableFn {
             for (;;) { if (ops.isT(t[e])) break; e++; if (bit_at(startbits, e)) break; }
             len = e - pos + 1;
         }
-        ph_pos[k] = pos; ph_freq[k] = counts[s]; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
+        ph_pos[k] = pos; ph_freq[k] = counts[s * cs]; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
         ph_lastT[k] = ops.isT(t[pos + len - 1]) ? 1 : 0;
     }
 };
@@ -1512,8 +1515,8 @@ class Engine {
     // (a tiled variant -- 64 positions per lane, text staged in LDS, per-tile de-duplication of <= 7-byte phrases --
     // was built and measured at 1.9-3.2 ms vs 2.2 ms for this form on 101 MB of reads, and dropped)
     template <class cell_t, bool FIRST>
-    void launch_hash(HashInsertFn<cell_t, FIRST> f, idx_t *counts, u64 n, bool aggregate) {
-        prim::for_each_agg(n, f, SlotCountAdd{counts}, aggregate, "hash_phrases");
+    void launch_hash(HashInsertFn<cell_t, FIRST> f, idx_t *counts, u64 cs, u64 n, bool aggregate) {
+        prim::for_each_agg(n, f, SlotCountAdd{counts, cs}, aggregate, "hash_phrases");
     }
 
     template <class cell_t, bool FIRST>
@@ -1554,10 +1557,10 @@ class Engine {
                 DBuf<u64> tk(cap_s);
                 DBuf<idx_t> tc(cap_s);
                 tk.zero(); tc.zero(); scal.zero();
-                prim::for_each_agg(n_s, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s,
+                prim::for_each_agg(n_s, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0,
                                                                     P.next_text.p, scal.p, n, n_occ},
-                                   SlotCountAdd{tc.p}, true, "hash_sample");
-                u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p}, "hash_sample_count");
+                                   SlotCountAdd{tc.p, 1}, true, "hash_sample");
+                u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
                 frac = (double)d_s / (double)occ_s;
                 if (frac > 1.0) frac = 1.0;
                 u64 want = (u64)(1.7 * frac * (double)n_occ) + 4096;      // target load <= ~0.6 if the prefix is representative
@@ -1571,14 +1574,30 @@ class Engine {
         // LDS pre-aggregation of the counts pays when few distinct phrases take most occurrences (level 0 of
         // DNA: 20 k phrases, 30 M occurrences); with mostly-distinct phrases the cache only thrashes.
         const bool aggregate = frac < 0.25;
+        // Table layout.  With few hot phrases the keys stay on lines of their own (the atomics on a hot count would keep
+        // invalidating the key every probe reads: measured 4x slower interleaved).  With mostly-distinct phrases every
+        // occurrence fetches a random key AND a random count: 16-byte (key, count) slots make that one line.
+        const bool interleaved = !aggregate;      // (10 GB build: 0.6 % faster than separate arrays on the same box)
+        const int ks = interleaved ? 1 : 0;
+        const u64 cs = interleaved ? 16 / sizeof(idx_t) : 1;
+        const idx_t *counts_p = nullptr;
         {
             StageTimer st(&tm.hash);
             for (;;) {
-                keys.alloc(cap); counts.alloc(cap);
-                keys.zero(); counts.zero(); scal.zero();
+                idx_t *cnt;
+                if (interleaved) {
+                    keys.alloc(2 * cap); keys.zero();
+                    cnt = (idx_t *)(keys.p + 1);          // the count lives in the second half of the slot
+                } else {
+                    keys.alloc(cap); counts.alloc(cap);
+                    keys.zero(); counts.zero();
+                    cnt = counts.p;
+                }
+                counts_p = cnt;
+                scal.zero();
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
-                launch_hash<cell_t, FIRST>(HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit,
-                                                                     P.next_text.p, scal.p, n, n_occ}, counts.p, n, aggregate);
+                launch_hash<cell_t, FIRST>(HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit, ks,
+                                                                     P.next_text.p, scal.p, n, n_occ}, cnt, cs, n, aggregate);
                 std::vector<u32> sc = scal.to_host(4);
                 if (sc[1] == 1) {
                     if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");
@@ -1598,11 +1617,11 @@ class Engine {
         {
             StageTimer st(&tm.dict_sort);
             DBuf<u32> slot_ph(cap);
-            u64 D = prim::exclusive_scan<u32>(cap, OccIn{keys.p}, slot_ph.p, false, "table_compact");
+            u64 D = prim::exclusive_scan<u32>(cap, OccIn{keys.p, ks}, slot_ph.p, false, "table_compact");
             P.D = D;
             P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
-            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts.p, slot_ph.p, P.ph_pos.p,
-                                                              P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p}, "table_compact");
+            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, slot_ph.p, P.ph_pos.p,
+                                                              P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p, ks, cs}, "table_compact");
             u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{P.ph_freq.p}, "dict_freq_check");
             if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
                                                            std::to_string(n_occ) + ")");
