@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- input MB/s building the BCR BWT (.rl_bwt image) on MI355X.
 
-A "step" is one pass of the whole parse-then-induce path over the workload,
-input cells already resident in HBM, output .rl_bwt image left in HBM.
-N=1 workload: BASELINE.json configs[1] (1,000,000 x 100 bp uniform ACGT reads,
-101,000,000 bytes).  N>1: records are sharded (weak scaling: one such shard per
-GPU, different seeds), one process per GPU; the ranks build ONE BWT of the whole sharded collection
-(grlbwt_amd/dist.py), so value = total input bytes of the collection / time.
+A "step" is one pass of the whole parse-then-induce path (grl_bwt_algo: par_phase + ind_phase) over the
+workload, input cells already resident in HBM, output .rl_bwt image left in HBM.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, algorithmic bytes
-/ HIP-event time on the engine's stream) and `cpu_baseline` (the CPU oracle,
-"port", single core, on a bounded prefix sample of the same workload).
+Workload (default): BASELINE.json's metric configuration -- configs[3], 66,225,166 x 150 bp Illumina-style
+reads from a 330 Mbp genome, 0.5 % substitutions, 10,000,000,066 bytes.  At N = 1 the whole collection is on
+one GPU.  At N > 1 the SAME collection is sharded by record (rank g holds reads [g*R/N, (g+1)*R/N)), one
+process per GPU, and the ranks build ONE BWT of the whole collection (grlbwt_amd/dist.py: RCCL all-gather
+dictionary merge per round, per-bucket rank-count exchange + all-to-all per induction level): strong scaling,
+value = collection bytes / time.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(`python -m torch.distributed.run` as a child process, before this process touches torch or the GPU) and
+relays rank 0's JSON line; under torchrun (WORLD_SIZE set) it is one of the ranks.
+
+Prints ONE JSON line (rank 0) with
+  roofline      the induction pass A+B group (the kernels of exact_ind_phase.cpp:42-109,143-258): SURVEY.md 8(d)'s
+                algorithmic bytes / the summed HIP-event time of the group's launches on the engine's stream
+  cpu_baseline  the CPU oracle ("port", 1 core) on a bounded prefix sample of the same workload
+and the same accounting for the other groups (roofline_groups), per-pass scatter efficiency (pass_efficiency),
+and the 101 MB configs[1] figure as an extra key.
 """
 import argparse
 import json
@@ -26,75 +36,152 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes(name, rounds, levels, cell_bytes, idx_bytes):
-    """Must-touch bytes of ONE launch-set of kernel `name` summed over its launches."""
-    ib = idx_bytes
-    if name == "hash_phrases":        # n_r*w_r read + n_{r+1}*4 slot ids written
-        return sum(r["n_in"] * (cell_bytes if i == 0 else 4) + r["parse_size"] * 4 for i, r in enumerate(rounds))
-    if name == "lms_breaks":          # n_r*w_r read + n_r/8 bits written
-        return sum(r["n_in"] * (cell_bytes if i == 0 else 4) + r["n_in"] // 8 for i, r in enumerate(rounds))
-    if name == "emit_parse":
-        return sum(r["parse_size"] * 8 for r in rounds)
-    if name == "induce_split.scatter":  # stable multi-split of the induced cells: key+index in, key+index out (one pass minimum)
-        return sum(l["induced_cells"] * (4 + ib) * 2 for l in levels)
-    if name == "induce_expand":       # R*(4+ib) runs read + R*4 rewritten + E*(4+4+ib+ib) cells written
-        return sum(l["runs_next"] * (8 + ib) + l["induced_cells"] * (8 + 2 * ib) for l in levels)
-    if name == "induce_count":
-        return sum(l["runs_next"] * (4 + ib) for l in levels)
-    if name == "asm.atoms":
-        return sum(l["atoms"] * (4 + ib) + l["segments"] * (4 + 2 * ib) for l in levels)
-    return None
+def bitlen(v):
+    return int(v).bit_length()
 
 
-def pmc_traffic_per_launch(kernel_substr, n_launches):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/<round>/pmc_traffic.json, collected with separate --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    same command; FETCH_SIZE doubled per the gfx950 correction).  None when no summary is committed."""
+def cdiv8(bits):
+    return max(1, (bits + 7) // 8)
+
+
+# ---------------------------------------------------------------------------------------------
+# algorithmic (must-touch) bytes per level in the REFERENCE's own cell widths, so that the
+# figure does not move with this engine's layout choices.  r = level, sigma_r its alphabet, M_r its metasymbols.
+#   sbN, fbN   bytes per run symbol / run length of bwt_lev_{r+1}: symbols are metasymbols < M_r, rewritten in place to
+#              symbols < sigma_r+3 (exact_ind_phase.cpp:257), lengths are bounded by n_{r+1}
+#   al_b, b    hocc cell: ceil(sym_width(sigma_r+3)/8) symbol bytes + the -b run-length bytes (default 1)
+#   c_r        grammar cell: ceil(sym_width(metasym_dummy)/8), metasym_dummy = sigma_r+3+M_r+1 (exact_par_phase.cpp:19-20)
+#   pass A+B   R_{r+1}*(sbN+fbN) read + R_{r+1}*sbN rewritten + E_r*(al_b+b) written + 2*c_r*E'_r gathered
+#   pass C     P_r*(sbP+fbP) + E_r*(al_b+b) + R_{r+1}*(sbN+fbN) read + R_r*(sbR+fbR) written
+#   E_r = hocc cells after the in-bucket merge, E'_r = grammar-chain steps (both counted by the engine while profiling)
+def induction_bytes(rounds, levels, r, run_len_bytes=1):
+    rd, lv = rounds[r], levels[r]
+    sigma3 = rd["sigma"] + 3
+    M = rd["n_metasyms"]
+    n_next = levels[r + 1]["n"]
+    sbN, fbN = cdiv8(bitlen(max(M, sigma3))), cdiv8(bitlen(n_next))
+    cell = cdiv8(bitlen(sigma3)) + run_len_bytes
+    c_r = cdiv8(bitlen(sigma3 + M + 1))
+    E = lv["merged_cells"] or lv["induced_cells"]
+    Es = lv["chain_steps"] or lv["induced_cells"]
+    sigma_prev = rounds[r - 1]["sigma"] + 3 if r > 0 else 0
+    sbR, fbR = cdiv8(bitlen(max(sigma3, sigma_prev))), cdiv8(bitlen(lv["n"]))
+    sbP, fbP = cdiv8(bitlen(sigma3)), cdiv8(bitlen(lv["n"]))
+    ab = lv["runs_next"] * (sbN + fbN) + lv["runs_next"] * sbN + E * cell + 2 * c_r * Es
+    c = lv["prebwt_runs"] * (sbP + fbP) + E * cell + lv["runs_next"] * (sbN + fbN) + lv["n_runs"] * (sbR + fbR)
+    return ab, c
+
+
+def parse_bytes(rounds, cell_bytes):
+    """classify+hash pass: n_r*w_r read; lookup-emit pass: n_r*w_r read + n_{r+1}*w_{r+1} written (w = 4 above level 0)."""
+    hash_b = emit_b = 0
+    for i, r in enumerate(rounds):
+        w = cell_bytes if i == 0 else 4
+        hash_b += r["n_in"] * w
+        emit_b += r["n_in"] * w + r["parse_size"] * 4
+    return hash_b, emit_b
+
+
+# launch sites (prim::prof names, "#<phase><level>" stripped) of each accounting group
+GROUP_SITES = {
+    "induce_AB": lambda s, ph: ph == "i" and (s.startswith("induce_") or s.startswith("induce.")),
+    "induce_C": lambda s, ph: ph == "i" and (s.startswith("asm.") or s.startswith("merge_runs")),
+    "hash_emit": lambda s, ph: ph == "p" and s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases",
+                                                    "slot_values", "emit_parse", "hash_prepare", "hash_lookup"),
+}
+# rocprofv3 kernel-name fragments of the kernels a group launches (PMC traffic lookup)
+GROUP_KERNELS = {
+    "induce_AB": ["ChainCount", "ChainExpand", "ChainSplit", "PackGrammar", "k_induce"],
+    "induce_C": ["Seg", "Atom", "MergeEmit", "BuildBits"],
+    "hash_emit": ["HashInsert", "k_start_bits", "MapFn", "k_hash"],
+}
+
+
+def pmc_traffic(kernel_fragments):
+    """HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected as the microarchitecture guide prescribes) summed over the
+    kernels whose names contain one of `kernel_fragments`, per build, from the committed rocprofv3 PMC passes of
+    this same command (profiles/<round>/pmc_traffic.json).  None when no summary is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
+        steps = max(1, int(d.get("builds_profiled", 1)))
         tot = 0.0
-        launches = 0
+        hit = False
         for name, e in d["kernels"].items():
-            if kernel_substr in name:
-                tot += 2.0 * e.get("fetch_kib_total", 0.0) * 1024 + e.get("write_kib_total", 0.0) * 1024
-                launches += max(e.get("fetch_launches", 0), e.get("write_launches", 0))
-        return round(tot / launches) if launches else None
+            if any(f in name for f in kernel_fragments):
+                hit = True
+                tot += e.get("hbm_bytes_total", 0.0)
+        return round(tot / steps) if hit else None
     except Exception:
         return None
 
 
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks as a CHILD (this process has not imported torch or touched the
+    GPU), relay rank 0's line, exit with the child's code."""
+    port = int(os.environ.get("MASTER_PORT", "29517"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    out, _ = p.communicate()
+    line = None
+    for ln in out.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    if p.returncode == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        sys.exit(3)
+    sys.exit(p.returncode)
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="illumina", choices=["illumina", "uniform"],
+                    help="illumina: BASELINE configs[3], the metric's configuration (--reads x 150 bp sampled from a --genome bp "
+                         "random genome, 0.5 %% substitutions); uniform: configs[1] shape (i.i.d. ACGT reads of --read-len)")
+    ap.add_argument("--reads", type=int, default=None, help="reads of the WHOLE collection (default 66225166 / 1000000)")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--genome", type=int, default=330000000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=400000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 101 MB configs[1] side measurement")
+    args = ap.parse_args()
+    if args.reads is None:
+        args.reads = 66225166 if args.workload == "illumina" else 1000000
+    if args.workload == "illumina":
+        args.read_len = 150
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args, sys.argv[1:])        # never returns
+
     # stdout carries exactly one line (the JSON result): anything a library prints to fd 1 on the way
     # (RCCL's version banner at communicator creation) is sent to stderr instead
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1000000)
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--workload", default="uniform", choices=["uniform", "illumina"],
-                    help="uniform: BASELINE configs[1] shape (i.i.d. ACGT reads); illumina: configs[3] shape "
-                         "(--reads x 150 bp sampled from a --genome bp random genome, 0.5 %% substitutions)")
-    ap.add_argument("--genome", type=int, default=330000000)
-    ap.add_argument("--cpu-sample-reads", type=int, default=600000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import __graft_entry__ as g
-    from grlbwt_amd import engine, workloads
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to mislabel the run\n" % (args.gpus, world))
+        sys.exit(2)
+
+    import torch
+    import __graft_entry__ as g
+    from grlbwt_amd import engine, workloads
+
     dist = None
     force_dist = os.environ.get("GRLBWT_BENCH_FORCE_DIST") == "1"   # measure the sharded flow's overhead at world 1
     if world > 1 or force_dist:
@@ -114,14 +201,20 @@ def main():
     torch.cuda.set_device(dev)
 
     lib = os.environ.get("GRLBWT_HIP_LIB") or g.build_hip()
-    # shard of this rank: the named workload (rank 0) / same shape with another seed (other ranks)
-    # generated on the device (bit-identical to workloads.uniform_reads on the host; tests/test_gpu_parity.py)
-    if args.workload == "illumina":
-        args.read_len = 150
-        text = workloads.sampled_reads_torch(args.reads, 150, args.genome, seed=20260003 + 10 * rank, device=dev)
-    else:
-        text = workloads.uniform_reads_torch(args.reads, args.read_len, seed=20260001 + rank, device=dev)
+
+    # this rank's record shard of the ONE collection, generated on the device (bit-identical to the host generators
+    # of grlbwt_amd/workloads.py; tests/test_gpu_parity.py)
+    lo, hi = args.reads * rank // world, args.reads * (rank + 1) // world
+
+    def make_text(workload, reads, read_len, lo, hi):
+        if workload == "illumina":
+            return workloads.sampled_reads_torch(reads, 150, args.genome, seed=20260003, device=dev, read_lo=lo, read_hi=hi)
+        full = workloads.uniform_reads_torch(reads, read_len, seed=20260001, device=dev)     # small: slice the whole
+        return full[lo * (read_len + 1): hi * (read_len + 1)].clone()
+
+    text = make_text(args.workload, args.reads, args.read_len, lo, hi)
     n_bytes = int(text.numel())
+    total_bytes = args.reads * (args.read_len + 1)
     torch.cuda.synchronize()
 
     comm = None
@@ -129,16 +222,16 @@ def main():
     if world > 1 or force_dist:
         from grlbwt_amd import dist as gdist
         comm = gdist.Communicator(dev)
-        if world * n_bytes >= 0xFFFFFF00:
+        if total_bytes >= 0xFFFFFF00:
             flags |= engine.FLAG_FORCE_IDX64
     ctx = engine.Context(local_rank, flags, lib)
 
-    def step():
-        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+    def step(c=ctx, t=text):
+        c.attach_device(t.data_ptr(), t.numel(), 1, keepalive=t)
         if comm is None:
-            ctx.build()
+            c.build()
         else:
-            gdist.dist_build(ctx, comm)      # BWT of the whole collection (all shards), identical on every rank
+            gdist.dist_build(c, comm)      # BWT of the whole collection (all shards), identical on every rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -146,20 +239,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed(step, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
-    value = world * n_bytes * args.steps / dt / 1e6
+    value = total_bytes * args.steps / dt / 1e6
 
     # ---- roofline leg: one more step with HIP-event timing of every kernel on the engine's stream.
     # Every rank takes the step (for N > 1 it contains collectives); only rank 0 records and reports.
@@ -174,114 +271,163 @@ def main():
         prof_detail = ctx.profile()
         host_syncs = prof_detail.pop("@host_sync", (0, 0.0, 0))[0]
         ctx.profile_enable(False)
-        # fold the per-level tags ("name#level") and group launch sites by the kernel FUNCTION they launch, so that
-        # "dominant kernel" means the same thing as in the rocprofv3 --stats summary under profiles/
-        def kernel_of(site):
-            if site.endswith(".scatter"):
-                return "k_rs_scatter"
-            if site.endswith(".hist"):
-                return "k_rs_hist"
-            return site
-        prof, fam = {}, {}
-        for k, (c, ms, nb) in prof_detail.items():
-            b = k.split("#")[0]
-            pc, pm, pb = prof.get(b, (0, 0.0, 0))
-            prof[b] = (pc + c, pm + ms, pb + nb)
-            f = kernel_of(b)
-            fc, fm, fb = fam.get(f, (0, 0.0, 0))
-            fam[f] = (fc + c, fm + ms, fb + nb)
-        if os.environ.get("GRLBWT_BENCH_DETAIL") and comm is not None and comm.log is not None:
-            for kind, nb, sec in comm.log:
-                print("  collective %-10s %12d bytes %8.3f ms" % (kind, nb, sec * 1e3), file=sys.stderr)
-        if os.environ.get("GRLBWT_BENCH_DETAIL"):
-            for k, (c, ms, nb) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:90]:
-                print("  %-32s %4d launches %9.3f ms" % (k, c, ms), file=sys.stderr)
-        nr = 0
         rounds = []
         while True:
             try:
-                rounds.append(ctx.round_info(nr))
-                nr += 1
+                rounds.append(ctx.round_info(len(rounds)))
             except engine.GrlbwtError:
                 break
-        levels = [ctx.level_info(l) for l in range(nr)]
+        nr = len(rounds)
+        levels = [ctx.level_info(l) for l in range(nr + 1)]
         cnt = ctx.counters()
-        ib = cnt["idx_bytes"]
+        mem = ctx.memory_usage()
 
-        def algo_bytes(kern):
-            c, ms, nb = fam[kern]
-            if nb:                       # stated at the launch site (radix sort passes: pairs read once + written once)
-                return nb
-            return algorithmic_bytes(kern, rounds, levels, 1, ib)
+        # launch sites -> (site, phase, level); groups of SURVEY 8(d)
+        def split(k):
+            site, _, tag = k.partition("#")
+            ph = tag[:1] if tag[:1].isalpha() else ""
+            return site, ph
+        grp = {gname: [0, 0.0] for gname in GROUP_SITES}
+        sites = {}
+        for k, (c, ms, nb) in prof_detail.items():
+            site, ph = split(k)
+            e = sites.setdefault(site, [0, 0.0, 0])
+            e[0] += c; e[1] += ms; e[2] += nb
+            for gname, pred in GROUP_SITES.items():
+                if pred(site, ph):
+                    grp[gname][0] += c
+                    grp[gname][1] += ms
+        ab_bytes = c_bytes = 0
+        per_level = []
+        if comm is None:
+            for r in range(nr):
+                ab, cb = induction_bytes(rounds, levels, r)
+                ab_bytes += ab
+                c_bytes += cb
+                per_level.append({"level": r, "AB_bytes": ab, "C_bytes": cb})
+        hash_b, emit_b = parse_bytes(rounds, 1)
+        gbytes = {"induce_AB": ab_bytes, "induce_C": c_bytes, "hash_emit": hash_b + emit_b}
+        total_kernel_ms = sum(ms for _, ms, _ in prof_detail.values())
 
-        total_kernel_ms = sum(ms for _, ms, _ in fam.values())
-        ranked = sorted(fam.items(), key=lambda kv: -kv[1][1])
-        dom = None
-        for name, (launches, ms, nb) in ranked:
-            ab = algo_bytes(name)
-            if ab:
-                dom = (name, launches, ms, ab)
-                break
-        roofline = None
-        if dom:
-            name, launches, ms, ab = dom
-            achieved = ab / (ms * 1e-3) / 1e9
-            rocprof_name = {"hash_phrases": "HashInsertFn", "k_rs_scatter": "k_rs_scatter", "k_rs_hist": "k_rs_hist"}.get(name, name)
-            roofline = {"bound": "hbm", "kernel": name, "launches": launches,
-                        "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5),
-                        "traffic": pmc_traffic_per_launch(rocprof_name, launches),
-                        "algorithmic_bytes": ab, "algorithmic_bytes_per_launch": round(ab / max(launches, 1)),
-                        "kernel_ms_total": round(ms, 4), "avg_launch_ms": round(ms / max(launches, 1), 5),
-                        "share_of_kernel_time": round(ms / max(total_kernel_ms, 1e-9), 4)}
-        top = [{"kernel": k, "launches": c, "ms": round(ms, 3)} for k, (c, ms, _) in ranked[:12]]
-        # the same accounting for every kernel with a stated algorithmic byte count
-        others = []
-        for kname, (launches, ms, nb) in sorted(list(fam.items()) + [(k, v) for k, v in prof.items() if k not in fam],
-                                                key=lambda kv: -kv[1][1]):
-            ab = nb if nb else algorithmic_bytes(kname, rounds, levels, 1, ib)
-            if ab and ms > 0:
-                others.append({"kernel": kname, "launches": launches, "ms": round(ms, 4),
-                               "achieved_GBps": round(ab / (ms * 1e-3) / 1e9, 2), "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
+        def group_obj(gname):
+            launches, ms = grp[gname]
+            nb = gbytes[gname]
+            if not nb or ms <= 0:
+                return None
+            ach = nb / (ms * 1e-3) / 1e9
+            tr = pmc_traffic(GROUP_KERNELS[gname])
+            return {"bound": "hbm", "kernel": gname, "launches": launches, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr,
+                    "algorithmic_bytes": nb, "kernel_ms_total": round(ms, 4),
+                    "share_of_kernel_time": round(ms / max(total_kernel_ms, 1e-9), 4)}
 
-        # ---- CPU baseline leg (reported, not the target): the oracle ("port"), 1 core, bounded sample
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
-            from oracle import oracle
-            oracle.build()
-            m = min(args.cpu_sample_reads, args.reads)
-            sample = text[: m * (args.read_len + 1)].cpu().numpy()
-            with tempfile.TemporaryDirectory() as td:
-                fi, fo = os.path.join(td, "in.txt"), os.path.join(td, "out.rl_bwt")
-                sample.tofile(fi)
-                tc = time.perf_counter()
-                subprocess.check_call([oracle.CLI, fi, fo, "-q"])
-                tcpu = time.perf_counter() - tc
-            cpu = {"value": round(sample.size / 1e6 / tcpu, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-                   "sample": "first %d reads (%d bytes) of the same workload, oracle/oracle_cli, %.1f s"
-                             % (m, sample.size, tcpu),
-                   "host_cpus": os.cpu_count()}
+        roofline = group_obj("induce_AB")
+        if roofline:
+            roofline["kernel"] = ("induction pass A+B (compute_hocc_size + infer_lvl_bwt scatter, exact_ind_phase.cpp:42-109,143-258): "
+                                  "launch sites induce_*; bytes = SURVEY 8(d) formula in the reference's cell widths (DESIGN.md section 4)")
+            roofline["per_launch"] = {"algorithmic_bytes": round(roofline["algorithmic_bytes"] / max(1, roofline["launches"])),
+                                      "avg_launch_ms": round(roofline["kernel_ms_total"] / max(1, roofline["launches"]), 5)}
+        groups = {gname: group_obj(gname) for gname in GROUP_SITES}
+        if gbytes["induce_AB"] or gbytes["hash_emit"]:
+            whole = (ab_bytes + c_bytes + hash_b + emit_b)
+            groups["whole_job"] = {"algorithmic_bytes": whole, "ms": round(ms_per_step, 3),
+                                   "achieved": round(whole / (ms_per_step * 1e-3) / 1e9, 3),
+                                   "frac": round(whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        # per-pass efficiency of the streaming kernels whose launch sites state their own read+write bytes
+        pass_eff = []
+        for site, (c, ms, nb) in sorted(sites.items(), key=lambda kv: -kv[1][1]):
+            if nb and ms > 0:
+                pass_eff.append({"site": site, "launches": c, "ms": round(ms, 4), "GBps": round(nb / (ms * 1e-3) / 1e9, 1),
+                                 "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        top = [{"site": k, "launches": c, "ms": round(ms, 3)} for k, (c, ms, _) in
+               sorted(sites.items(), key=lambda kv: -kv[1][1])[:16]]
+        if os.environ.get("GRLBWT_BENCH_DETAIL"):
+            if comm is not None and comm.log is not None:
+                for kind, nb, sec in comm.log:
+                    print("  collective %-10s %12d bytes %8.3f ms" % (kind, nb, sec * 1e3), file=sys.stderr)
+            for k, (c, ms, nb) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:120]:
+                print("  %-32s %4d launches %9.3f ms" % (k, c, ms), file=sys.stderr)
+
+    # ---- extra: the 101 MB configs[1] workload on one GPU (round-1's headline), a few steps
+    extra = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_extra and not (args.workload == "uniform" and args.reads == 1000000):
+        ctx.close()
+        t1 = workloads.uniform_reads_torch(1000000, 100, seed=20260001, device=dev)
+        torch.cuda.synchronize()
+        c1 = engine.Context(local_rank, 0, lib)
+
+        def step1():
+            c1.attach_device(t1.data_ptr(), t1.numel(), 1, keepalive=t1)
+            c1.build()
+        for _ in range(2):
+            step1()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step1()
+        torch.cuda.synchronize()
+        d1 = (time.perf_counter() - t0) / 10
+        extra = {"workload": "1000000 x 100 bp uniform ACGT reads (101000000 bytes), BASELINE configs[1]",
+                 "ms_per_step": round(d1 * 1e3, 3), "value_MBps": round(101.0 / d1, 1), "steps": 10}
+        c1.close()
+        del t1
+
+    # ---- CPU baseline leg (reported, not the target): the oracle ("port"), 1 core, bounded sample
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not force_dist:
+        from oracle import oracle
+        oracle.build()
+        m = min(args.cpu_sample_reads, hi - lo)
+        sample = text[: m * (args.read_len + 1)].cpu().numpy()
+        with tempfile.TemporaryDirectory() as td:
+            fi, fo = os.path.join(td, "in.txt"), os.path.join(td, "out.rl_bwt")
+            sample.tofile(fi)
+            tc = time.perf_counter()
+            subprocess.check_call([oracle.CLI, fi, fo, "-q"])
+            tcpu = time.perf_counter() - tc
+        cpu = {"value": round(sample.size / 1e6 / tcpu, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+               "sample": "first %d reads (%d bytes) of the same workload, oracle/oracle_cli (CPU restatement of the path; the "
+                         "reference binary needs SDSL-lite and cannot be built in this image), %.1f s" % (m, sample.size, tcpu),
+               "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        if args.workload == "illumina":
+            wl = ("%d x 150 bp Illumina-style reads (%d bytes) from a %d bp genome, 0.5%% substitutions; BASELINE configs[3]%s"
+                  % (args.reads, total_bytes, args.genome, "" if args.reads == 66225166 else " shape (reduced read count)"))
+        else:
+            wl = ("%d x %d bp uniform ACGT reads (%d bytes), sigma=5, byte alphabet; BASELINE configs[1]%s"
+                  % (args.reads, args.read_len, total_bytes, "" if (args.reads, args.read_len) == (1000000, 100) else " shape"))
         out = {
-            "metric": "input MB/s building BCR BWT (.rl_bwt) of DNA reads", "value": round(value, 3), "unit": "MB/s",
+            "metric": "input MB/s building BCR BWT on 10 GB DNA reads, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("%d x %d bp uniform ACGT reads per GPU (%d bytes), sigma=5, byte alphabet; BASELINE configs[1]"
-                                    % (args.reads, args.read_len, n_bytes)) if args.workload == "uniform" else
-                                   ("%d x 150 bp Illumina-style reads per GPU (%d bytes) from a %d bp genome, 0.5%% substitutions; "
-                                    "BASELINE configs[3] shape" % (args.reads, n_bytes, args.genome)),
-                       "input_resident": "HBM", "output": ".rl_bwt image in HBM", "parallelism": ("1 GPU" if world == 1 else "ONE collection of %d record shards, one per GPU: local hashing/emission, RCCL all-gather "
-                                       "dictionary merge + key-range-sharded dictionary stage per round, induction sharded by BWT position "
-                                       "(per-bucket rank-count exchange, all-to-all atom routing)" % world)},
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": wl, "input_resident": "HBM", "output": ".rl_bwt image in HBM",
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       "the ONE collection sharded by record over %d GPUs (%d reads each): local LMS parsing/hashing/emission, "
+                                       "RCCL all-gather dictionary merge + key-range-sharded dictionary stage per round, induction sharded by "
+                                       "BWT position (per-bucket rank-count exchange, all-to-all atom routing)" % (world, hi - lo))},
             "roofline": roofline, "cpu_baseline": cpu,
+            "roofline_groups": groups, "pass_efficiency": pass_eff[:12],
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
-            "top_kernels": top, "roofline_by_kernel": others, "rounds": nr,
+            "top_sites": top, "rounds": nr,
+            "levels": [{k: lv[k] for k in ("n", "n_runs", "runs_next", "induced_cells", "chain_steps", "merged_cells", "prebwt_runs")}
+                       for lv in levels],
+            "round_shapes": [{k: rd[k] for k in ("n_in", "n_phrases", "dict_syms", "n_metasyms", "parse_size")} for rd in rounds],
+            "induction_bytes_per_level": per_level,
             "kernel_launches": sum(c for c, _, _ in prof_detail.values()), "host_syncs": host_syncs,
+            "kernel_ms_total": round(total_kernel_ms, 3),
+            "device_memory": {"peak_live_bytes": mem["peak_live_bytes"], "reserved_bytes": mem["reserved_bytes"]},
+            "idx_bytes": cnt["idx_bytes"], "extra_configs1_101MB": extra,
         }
         if comm is not None:     # totals over warmup + timed + profile steps on rank 0
             nsteps = args.warmup + args.steps + 1
             out["collectives_per_step"] = {"allgather": comm.n_allgather // nsteps, "alltoallv": comm.n_alltoall // nsteps,
                                            "bytes": comm.bytes_moved // nsteps, "ms_in_callbacks": round(comm.seconds / nsteps * 1e3, 3)}
-    ctx.close()
+    try:
+        ctx.close()
+    except Exception:
+        pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -53,7 +53,7 @@ template <class E>
 void fill_level(const E &e, int l, grlbwt_level_info *o) {
     const auto &I = e.linfo[l];
     o->n = I.n; o->n_runs = I.R; o->runs_next = I.R_next; o->induced_cells = I.E; o->prebwt_runs = I.P;
-    o->segments = I.G; o->atoms = I.A;
+    o->segments = I.G; o->atoms = I.A; o->chain_steps = I.Esteps; o->merged_cells = I.Emerged;
 }
 template <class E>
 void fill_counters(const E &e, grlbwt_counters *o) {
@@ -292,8 +292,9 @@ int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out) {
     c->flags = flags;
     c->device = device_id;
     int rc = guarded(c, [&] {
-        prim::init(device_id);
+        prim::init(device_id);            // refuses a second device while contexts are alive (one GPU per process)
         if (flags & GRLBWT_FLAG_SYNC_DEBUG) prim::rt().sync_each_launch = true;
+        prim::rt().live_ctx++;
     });
     if (rc != GRLBWT_OK) { delete c; return rc; }
     *out = c;
@@ -301,7 +302,14 @@ int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out) {
 }
 void grlbwt_ctx_destroy(grlbwt_ctx *ctx) {
     if (!ctx) return;
-    try { ctx->e32.reset(); ctx->e64.reset(); prim::sync(); prim::pool_trim(); } catch (...) {}
+    try {
+        ctx->e32.reset(); ctx->e64.reset(); prim::sync(); prim::pool_trim();
+        if (--prim::rt().live_ctx <= 0) {      // process-wide debug settings and a borrowed stream end with the last context
+            prim::rt().live_ctx = 0;
+            prim::rt().sync_each_launch = false;
+            prim::set_stream(nullptr);
+        }
+    } catch (...) {}
     delete ctx;
 }
 int grlbwt_ctx_set_stream(grlbwt_ctx *ctx, void *hip_stream) {
@@ -432,22 +440,25 @@ int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_b
                         void *dev_text_out, uint64_t capacity_cells, uint64_t *n_cells_out) {
     if (!ctx || !dev_image || !dev_text_out) return GRLBWT_EINVAL;
     return guarded(ctx, [&] {
-        bool big = capacity_cells >= 0xFFFFFF00ull || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+        // the index width follows the number of symbols the image DESCRIBES (summed in 64 bits), not the buffer sizes:
+        // a small image can describe >= 2^32 symbols, and a 32-bit scan of its run lengths would wrap
+        const uint64_t total = grl64::Engine::image_total_symbols(dev_image, image_bytes);
+        if (total > capacity_cells) throw prim::Error(GRLBWT_EINVAL, "inversion: output buffer too small");
+        bool big = total >= 0xFFFFFF00ull || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
         uint64_t n = big ? grl64::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells)
                          : grl32::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells);
         if (n_cells_out) *n_cells_out = n;
     });
 }
 
-static bool image_is_big(const grlbwt_ctx *ctx, uint64_t image_bytes) {
-    // >= 2^32 - 256 symbols cannot be told from the size alone; be conservative: images of >= 2 GiB use 64-bit positions
-    return image_bytes >= (1ull << 31) || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
-}
+
 int grlbwt_image_plain(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, void *dev_out_u8,
                        uint64_t capacity, int null_char, uint64_t *n_out) {
     if (!ctx || !dev_image || !dev_out_u8 || null_char > 255) return GRLBWT_EINVAL;
     return guarded(ctx, [&] {
-        bool big = image_is_big(ctx, image_bytes) || capacity >= 0xFFFFFF00ull;
+        const uint64_t total = grl64::Engine::image_total_symbols(dev_image, image_bytes);
+        if (total > capacity) throw prim::Error(GRLBWT_EINVAL, "grl2plain: output buffer too small");
+        bool big = total >= 0xFFFFFF00ull || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
         uint64_t n = big ? grl64::Engine::image_plain(dev_image, image_bytes, (uint8_t *)dev_out_u8, capacity, null_char)
                          : grl32::Engine::image_plain(dev_image, image_bytes, (uint8_t *)dev_out_u8, capacity, null_char);
         if (n_out) *n_out = n;

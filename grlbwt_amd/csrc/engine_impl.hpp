@@ -797,6 +797,10 @@ struct ChainCountFn {
         return c;
     }
 };
+struct TakeCountIn {      // 1 if the run's symbol has hidden occurrences (it drops a TAKE cell)
+    const u32 *nsym; const u64 *gp;
+    GRL_DEV u64 operator()(u64 i) const { return (gp[nsym[i]] & 0x80000000ull) ? 1ull : 0ull; }
+};
 enum { CELLS_SEPARATE = 0, CELLS_PACKED = 1, CELLS_FUSED = 2 };
 template <int MODE>
 struct ChainExpandFn {
@@ -867,6 +871,10 @@ struct CellView {
 struct CellLenIn {
     CellView c;
     GRL_DEV idx_t operator()(u64 t) const { return c.len(t); }
+};
+struct CellHeadIn {     // 1 where a cell does not merge with its predecessor (other bucket or other symbol): the reference's n_runs
+    CellView c;
+    GRL_DEV u64 operator()(u64 t) const { return (t == 0 || c.key(t) != c.key(t - 1) || c.sym(t) != c.sym(t - 1)) ? 1ull : 0ull; }
 };
 struct SegFromCellFn {  // induced cells (H, bucket-major) -> segments
     CellView c; const u32 *u_to_p; const idx_t *nhb;
@@ -1326,6 +1334,15 @@ struct UnpackRunsFn {     // (sym: sb bytes LE, len: fb bytes LE) records -> arr
         sym[i] = (u32)s; len[i] = (idx_t)l;
     }
 };
+struct ImageLenIn {        // run length straight from the packed records (64-bit sum: decides the index width of a consumer)
+    const u8 *img; u32 sb, fb;
+    GRL_DEV u64 operator()(u64 i) const {
+        const u8 *p = img + 16 + i * (u64)(sb + fb) + sb;
+        u64 l = 0;
+        for (u32 b = 0; b < fb; b++) l |= (u64)p[b] << (8 * b);
+        return l;
+    }
+};
 struct PlainRunsFn {      // scripts/grl2plain.cpp:30-45: one output byte per BWT position, (char)sym, optional null replacement
     const u32 *rsym; const u64 *rw; const idx_t *rb; int null_char; u8 *out;
     GRL_DEV void operator()(u64 i) const {
@@ -1392,6 +1409,7 @@ struct RoundInfo {
 };
 struct LevelInfo {
     u64 R_next = 0, E = 0, P = 0, G = 0, A = 0, R = 0, n = 0;
+    u64 Esteps = 0, Emerged = 0;      // measured only while profiling (SURVEY 8d's E'_r and E_r): chain steps, cells after the in-bucket merge
 };
 struct Stats {
     u64 n_strings = 0, n_syms = 0, min_sym = 0, max_sym = 0, max_sym_freq = 0, sb = 0, fb = 0;
@@ -1479,6 +1497,7 @@ class Engine {
         if (sizeof(idx_t) == 4 && n >= 0xFFFFFF00ull) throw prim::Error(-75, "input too large for the 32-bit index build");
         if (n >= kPosMask) throw prim::Error(-75, "input too large");
         cell_bytes = w; text0 = dev_cells; n0 = n;
+        prim::rt().tag = -1; prim::rt().phase = 0;
         // scratch for the whole build in one slab: ~22x the input for the 32-bit index build, ~30x for the 64-bit one
         prim::pool_reserve((size_t)(n * (u64)w) * (sizeof(idx_t) == 4 ? 22 : 30));
         levels.clear(); linfo.clear(); kept_texts.clear(); kept_bwts.clear();
@@ -1790,6 +1809,7 @@ class Engine {
     void par_round_t(const cell_t *t, u64 n, u32 sigma, cell_t sep) {
         CellOps<cell_t, FIRST> ops{sep};
         prim::rt().tag = (int)levels.size();
+        prim::rt().phase = 'p';
         LevelData L;
         L.sigma = sigma;
         L.info.n_in = n;
@@ -1827,6 +1847,8 @@ class Engine {
     // ---- a12 ---------------------------------------------------------------
     void first_bwt() {
         if (!parse_done) throw prim::Error(-22, "parse phase not finished");
+        prim::rt().tag = (int)levels.size();
+        prim::rt().phase = 'i';
         StageTimer st(&tm.ind_assemble);
         DBuf<u32> s(cur_n);
         DBuf<idx_t> l(cur_n);
@@ -1853,6 +1875,7 @@ class Engine {
         if (bwt_level <= 0) throw prim::Error(-22, "no level left to induce");
         const int r = bwt_level - 1;
         prim::rt().tag = r;
+        prim::rt().phase = 'i';
         LevelData &L = levels[r];
         const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
         const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
@@ -1931,6 +1954,10 @@ class Engine {
         }
         const CellView cells{sfused.p, kb, lb, skey.p, spack.p, ssym.p, slen.p};
         eoff.release();
+        if (prim::rt().profile) {              // SURVEY 8d's E'_r and E_r for the roofline accounting (bench.py)
+            I.Esteps = E - prim::reduce_sum<u64>(R, TakeCountIn{bwt.sym.p, gp.p}, "stat.take_cells");
+            I.Emerged = prim::reduce_sum<u64>(E, CellHeadIn{cells}, "stat.merged_cells");
+        }
         {
             StageTimer st(&tm.ind_assemble);
             DBuf<idx_t> PH(P + 1), nhb(P + 1), Hpos(E + 1), Tpos(R + 1);
@@ -1987,6 +2014,7 @@ class Engine {
     // ---- a16/a17: .rl_bwt image in HBM --------------------------------------
     void finish() {
         if (bwt_level != 0) throw prim::Error(-22, "induction not finished");
+        prim::rt().tag = -1; prim::rt().phase = 0;
         StageTimer st(&tm.finish);
         u32 sb = (u32)stats.sb, fb = (u32)stats.fb;
         image_bytes = 16 + bwt.R * (u64)(sb + fb);
@@ -1995,6 +2023,9 @@ class Engine {
         for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
         prim::h2d(image.p, hdr, 16);
         prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, bwt.len.p, sb, fb, image.p}, "pack_rl_bwt");
+        // "results are complete when a call returns" (include/grlbwt_hip.h): the image pointer may be handed to another
+        // stream (torch, a copy engine) right after the build, so the engine's stream is drained here
+        prim::sync();
     }
     // =====================================================================
     // collection-level multi-GPU: this engine holds one record shard
@@ -2241,6 +2272,7 @@ class Engine {
     void dist_round_t(const Comm &C, const cell_t *t, u64 n, u32 sigma, cell_t sep) {
         CellOps<cell_t, FIRST> ops{sep};
         prim::rt().tag = (int)levels.size();
+        prim::rt().phase = 'p';
         LevelData L;
         L.sigma = sigma;
         L.info.sigma = sigma;
@@ -2338,6 +2370,7 @@ class Engine {
         if (bwt_level <= 0) throw prim::Error(-22, "no level left to induce");
         const int r = bwt_level - 1;
         prim::rt().tag = r;
+        prim::rt().phase = 'i';
         LevelData &L = levels[r];
         const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
         const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
@@ -2615,6 +2648,11 @@ class Engine {
         if (hdr[0] == 0 || hdr[0] > 8 || hdr[1] == 0 || hdr[1] > 8 || (image_bytes - 16) % (hdr[0] + hdr[1]))
             throw prim::Error(-22, "bad .rl_bwt header");
         return ImageHeader{hdr[0], hdr[1], (image_bytes - 16) / (hdr[0] + hdr[1])};
+    }
+    // number of symbols an image describes, summed in 64 bits whatever the index width of the caller
+    static u64 image_total_symbols(const void *dev_image, u64 image_bytes) {
+        ImageHeader h = image_header(dev_image, image_bytes);
+        return prim::reduce_sum<u64>(h.R, ImageLenIn{(const u8 *)dev_image, (u32)h.sb, (u32)h.fb}, "image.total");
     }
     // grl2plain (scripts/grl2plain.cpp): the plain BWT, one byte per symbol; null_char >= 0 replaces symbol 0
     static u64 image_plain(const void *dev_image, u64 image_bytes, u8 *dev_out, u64 capacity, int null_char) {

@@ -48,14 +48,17 @@ struct Error : std::runtime_error {
 // ---------------------------------------------------------------- runtime state
 struct Runtime {
     hipStream_t stream = nullptr;
-    int device = 0;
+    hipStream_t own_stream = nullptr; // the stream init() created (set_stream may point `stream` at a caller's)
+    int device = -1;                  // device the stream and the slabs belong to (-1: not initialised)
+    int live_ctx = 0;                 // contexts alive in this process (they share stream and allocator)
     int num_cus = 256;
     u64 bytes_allocated = 0, peak_bytes = 0;
     bool sync_each_launch = false;   // debug: catch faults at the launch site
     // per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
     bool trace = false;              // GRLBWT_TRACE=1: print every launch and synchronise after it
     bool profile = false;
-    int tag = -1;                    // appended to profile names as "#<tag>" (the engine sets it to the level)
+    int tag = -1;                    // appended to profile names as "#<phase><tag>" (the engine sets it to the level)
+    char phase = 0;                  // 'p' parsing round, 'i' induction level (both use the level number as tag)
     struct Prof { std::string name; hipEvent_t a, b; u64 bytes; };
     std::vector<Prof> pending;
     // stage clocks: event pairs on the engine's stream, folded into *acc at the next host synchronisation
@@ -70,16 +73,32 @@ inline Runtime &rt() {
     return r;
 }
 
+inline void pool_trim();
+// Stream and slab allocator are process-wide and belong to ONE device.  A context for another device is refused while
+// contexts are alive; with none alive the runtime moves over (old stream drained, idle slabs returned).
 inline void init(int device) {
+    Runtime &R = rt();
+    if (R.device >= 0 && R.device != device) {
+        if (R.live_ctx > 0)
+            throw Error(-22, "this process already runs device " + std::to_string(R.device) + ": one GPU per process (asked for device " +
+                                 std::to_string(device) + ")");
+        if (R.stream) (void)hipStreamSynchronize(R.stream);
+        pool_trim();
+        if (R.own_stream) { (void)hipStreamDestroy(R.own_stream); R.own_stream = nullptr; }
+        R.stream = nullptr;
+    }
     GRL_HIP_CHECK(hipSetDevice(device));
     hipDeviceProp_t p;
     GRL_HIP_CHECK(hipGetDeviceProperties(&p, device));
-    rt().device = device;
-    if (const char *t = getenv("GRLBWT_TRACE")) { rt().trace = t[0] == '1'; rt().sync_each_launch = rt().trace; }
-    rt().num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    if (!rt().stream) GRL_HIP_CHECK(hipStreamCreateWithFlags(&rt().stream, hipStreamNonBlocking));
+    R.device = device;
+    if (const char *t = getenv("GRLBWT_TRACE")) { R.trace = t[0] == '1'; R.sync_each_launch = R.trace; }
+    R.num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    if (!R.stream) {
+        if (!R.own_stream) GRL_HIP_CHECK(hipStreamCreateWithFlags(&R.own_stream, hipStreamNonBlocking));
+        R.stream = R.own_stream;
+    }
 }
-inline void set_stream(void *s) { rt().stream = (hipStream_t)s; }
+inline void set_stream(void *s) { rt().stream = s ? (hipStream_t)s : rt().own_stream; }
 inline void prof_collect();
 inline void stages_collect();
 inline void sync() {
@@ -94,7 +113,7 @@ inline void prof_begin(const std::string &name, u64 algo_bytes = 0) {
     if (rt().trace) { fprintf(stderr, "[grlbwt] launch %s\n", name.c_str()); fflush(stderr); }
     if (!rt().profile) return;
     Runtime::Prof p;
-    p.name = rt().tag >= 0 ? name + "#" + std::to_string(rt().tag) : name;
+    p.name = rt().tag >= 0 ? name + "#" + (rt().phase ? std::string(1, rt().phase) : std::string()) + std::to_string(rt().tag) : name;
     p.bytes = algo_bytes;
     GRL_HIP_CHECK(hipEventCreate(&p.a));
     GRL_HIP_CHECK(hipEventCreate(&p.b));

@@ -47,7 +47,7 @@ class RoundInfo(C.Structure):
 
 class LevelInfo(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n", "n_runs", "runs_next", "induced_cells", "prebwt_runs", "segments",
-                                          "atoms")]
+                                          "atoms", "chain_steps", "merged_cells")]
 
 
 class Counters(C.Structure):

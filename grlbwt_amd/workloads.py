@@ -128,10 +128,13 @@ def _splitmix64_torch(seed, i0, i1, device):
     return z ^ ((z >> 31) & ((1 << 33) - 1))
 
 
-def sampled_reads_torch(n_reads, read_len, genome_len, seed=20260003, err=0.005, device="cuda", chunk_reads=2_000_000):
+def sampled_reads_torch(n_reads, read_len, genome_len, seed=20260003, err=0.005, device="cuda", chunk_reads=2_000_000,
+                        read_lo=0, read_hi=None):
     """Same bytes as sampled_reads() (config 4: Illumina-style reads from a random genome, substitution errors),
-    generated on `device`."""
+    generated on `device`.  read_lo/read_hi select the contiguous record range [read_lo, read_hi) of the n_reads-read
+    collection (a record shard of the SAME collection: the bytes equal that slice of the full output)."""
     import torch
+    read_hi = n_reads if read_hi is None else read_hi
     acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
     g = torch.empty(genome_len, dtype=torch.uint8, device=device)
     for a in range(0, genome_len, 1 << 26):
@@ -139,12 +142,12 @@ def sampled_reads_torch(n_reads, read_len, genome_len, seed=20260003, err=0.005,
         g[a:b] = acgt[(_splitmix64_torch(seed, a, b, device) >> 62) & 3]
     code = torch.zeros(256, dtype=torch.int64, device=device)
     code[acgt.long()] = torch.arange(4, device=device)
-    out = torch.empty(n_reads * (read_len + 1), dtype=torch.uint8, device=device)
-    view = out.view(n_reads, read_len + 1)
+    out = torch.empty((read_hi - read_lo) * (read_len + 1), dtype=torch.uint8, device=device)
+    view = out.view(read_hi - read_lo, read_len + 1)
     ar = torch.arange(read_len, dtype=torch.int64, device=device)
     span = genome_len - read_len
-    for r0 in range(0, n_reads, chunk_reads):
-        r1 = min(n_reads, r0 + chunk_reads)
+    for r0 in range(read_lo, read_hi, chunk_reads):
+        r1 = min(read_hi, r0 + chunk_reads)
         z = _splitmix64_torch(seed + 1, r0, r1, device)
         # uint64 modulo on int64 bit patterns: split off the sign bit
         hi = (z >> 63) & 1
@@ -159,7 +162,7 @@ def sampled_reads_torch(n_reads, read_len, genome_len, seed=20260003, err=0.005,
             sub = acgt[(code[bases.long()] + shift) % 4]
             bases = torch.where(hit, sub, bases)
             del e, u, hit, shift, sub
-        view[r0:r1, :read_len] = bases
-        view[r0:r1, read_len] = 10
+        view[r0 - read_lo:r1 - read_lo, :read_len] = bases
+        view[r0 - read_lo:r1 - read_lo, read_len] = 10
         del z, hi, lo, starts, bases
     return out

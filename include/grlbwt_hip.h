@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GRLBWT_ABI_VERSION 1
+#define GRLBWT_ABI_VERSION 2
 
 #define GRLBWT_OK 0
 #define GRLBWT_EINVAL (-22)     /* bad argument / call out of order                                  */
@@ -74,6 +74,9 @@ typedef struct grlbwt_level_info {
     uint64_t runs_next;         /* runs of BWT_{r+1} scanned                        */
     uint64_t induced_cells;     /* chain steps + TAKE cells scattered (pass B)      */
     uint64_t prebwt_runs, segments, atoms;
+    /* SURVEY 8d's E'_r (grammar-chain steps) and E_r (cells after the in-bucket merge = n_runs of compute_hocc_size,
+     * exact_ind_phase.cpp:42-109); counted only while grlbwt_profile_enable(1) is on, else 0 */
+    uint64_t chain_steps, merged_cells;
 } grlbwt_level_info;
 
 /* wall-clock seconds per stage (stream-synchronised) and algorithmic byte counts */

@@ -24,6 +24,28 @@ def build(force=False):
     return _LIB
 
 
+REF_DIR = os.path.join(_HERE, "_ref")
+REF_PROGS = ("bwt_stats", "grl2plain", "grlbwt2rle", "split_runs")
+REFERENCE_ROOT = "/root/reference"
+
+
+def build_ref(force=False):
+    """Compile the reference's own .rl_bwt consumer programs from /root/reference/scripts (oracle/Makefile target
+    `ref`) into oracle/_ref/.  Only possible where the reference tree exists (the build container); elsewhere the
+    prebuilt binaries that travelled with the repository are used.  Returns the directory or None."""
+    have = all(os.path.exists(os.path.join(REF_DIR, p)) for p in REF_PROGS)
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "scripts")) and (force or not have):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+        have = True
+    return REF_DIR if have else None
+
+
+def ref_prog(name):
+    """Path of a built reference program (oracle/_ref/<name>) or None."""
+    p = os.path.join(REF_DIR, name)
+    return p if os.path.exists(p) else None
+
+
 _lib = None
 
 

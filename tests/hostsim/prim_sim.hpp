@@ -38,10 +38,12 @@ struct Error : std::runtime_error {
 struct Runtime {
     void *stream = nullptr;
     int device = 0;
+    int live_ctx = 0;
     int num_cus = 1;
     bool sync_each_launch = false;
     bool profile = false;
     int tag = -1;
+    char phase = 0;
     struct ProfAcc { u64 launches = 0; double ms = 0; u64 bytes = 0; };
     std::map<std::string, ProfAcc> prof;
 };
