@@ -90,6 +90,17 @@ void bwt_download(const E &e, int level, uint64_t *sym, uint64_t *len) {
     for (uint64_t i = 0; i < b.R; i++) { sym[i] = hs[i]; len[i] = hl[i]; }
 }
 
+template <class E>
+void grammar_download(const E &e, int level, uint64_t *g0, uint64_t *g1, uint8_t *hh, uint64_t *ps, uint64_t *pl) {
+    const auto &L = e.levels[level];
+    const uint64_t M = L.M, P = L.prebwt.R;
+    auto a = L.g0.to_host(M), b = L.g1.to_host(M);
+    auto h = L.has_hocc.to_host(M);
+    for (uint64_t i = 0; i < M; i++) { if (g0) g0[i] = a[i]; if (g1) g1[i] = b[i]; if (hh) hh[i] = h[i]; }
+    auto s = L.prebwt.sym.to_host(P);
+    auto l = L.prebwt.len.to_host(P);
+    for (uint64_t i = 0; i < P; i++) { if (ps) ps[i] = s[i]; if (pl) pl[i] = l[i]; }
+}
 #define ENG(ctx, expr) ((ctx)->e32 ? (ctx)->e32->expr : (ctx)->e64->expr)
 #define HAS_ENG(ctx) ((ctx) && ((ctx)->e32 || (ctx)->e64))
 
@@ -429,6 +440,22 @@ int grlbwt_level_bwt_download(const grlbwt_ctx *ctx, int level, uint64_t *sym_ou
     });
 }
 
+int grlbwt_level_grammar_size(const grlbwt_ctx *ctx, int level, uint64_t *n_metasyms, uint64_t *prebwt_runs) {
+    if (!HAS_ENG(ctx) || level < 0 || level >= (int)ENG(ctx, levels.size())) return GRLBWT_EINVAL;
+    if (ENG(ctx, levels[level].g0.p) == nullptr) return GRLBWT_EINVAL;           // already consumed by the induction of this level
+    if (n_metasyms) *n_metasyms = ENG(ctx, levels[level].M);
+    if (prebwt_runs) *prebwt_runs = ENG(ctx, levels[level].prebwt.R);
+    return GRLBWT_OK;
+}
+int grlbwt_level_grammar_download(const grlbwt_ctx *ctx, int level, uint64_t *g0, uint64_t *g1, uint8_t *has_hocc,
+                                  uint64_t *prebwt_sym, uint64_t *prebwt_len) {
+    if (grlbwt_level_grammar_size(ctx, level, nullptr, nullptr) != GRLBWT_OK) return GRLBWT_EINVAL;
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] {
+        if (ctx->e32) grammar_download(*ctx->e32, level, g0, g1, has_hocc, prebwt_sym, prebwt_len);
+        else grammar_download(*ctx->e64, level, g0, g1, has_hocc, prebwt_sym, prebwt_len);
+    });
+}
+
 int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out) {
     if (!HAS_ENG(ctx) || !out) return GRLBWT_EINVAL;
     try { prim::sync(); } catch (...) { return GRLBWT_EDEVICE; }   // folds the stage clocks still in flight
@@ -482,6 +509,28 @@ int grlbwt_image_stats_get(grlbwt_ctx *ctx, const void *dev_image, uint64_t imag
         for (int c = 0; c < 256; c++) { out->runs_of[c] = st.runs_of[c]; out->freq_of[c] = st.freq_of[c]; }
         for (int i = 0; i < 9; i++) out->deciles[i] = st.deciles[i];
         out->non_maximal = st.non_maximal;
+    });
+}
+
+int grlbwt_image_split_runs(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int bits, uint64_t block_size,
+                            void *dev_out, uint64_t capacity_bytes, grlbwt_split_info *info) {
+    if (!ctx || !dev_image || !dev_out) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        const uint64_t total = grl64::Engine::image_total_symbols(dev_image, image_bytes);
+        bool big = total >= 0xFFFFFF00ull || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+        uint64_t v[6];
+        if (big) {
+            auto si = grl64::Engine::image_split_runs(dev_image, image_bytes, bits, block_size, (uint8_t *)dev_out, capacity_bytes);
+            v[0] = si.runs_before; v[1] = si.runs_after; v[2] = si.overflow_splits; v[3] = si.block_splits; v[4] = si.n_syms; v[5] = si.out_bytes;
+        } else {
+            auto si = grl32::Engine::image_split_runs(dev_image, image_bytes, bits, block_size, (uint8_t *)dev_out, capacity_bytes);
+            v[0] = si.runs_before; v[1] = si.runs_after; v[2] = si.overflow_splits; v[3] = si.block_splits; v[4] = si.n_syms; v[5] = si.out_bytes;
+        }
+        if (info) {
+            info->runs_before = v[0]; info->runs_after = v[1]; info->overflow_splits = v[2]; info->block_splits = v[3];
+            info->n_syms = v[4]; info->out_bytes = v[5];
+            info->n_blocks = block_size ? (v[4] > 0 ? 1 + (v[4] - 1) / block_size : 0) : 0;
+        }
     });
 }
 

@@ -1355,6 +1355,36 @@ struct RleExportFn {      // scripts/grlbwt2rle.cpp:22-30: .syms as uint8, .len 
     const u32 *rsym; const idx_t *rlen; u8 *syms; u32 *lens;
     GRL_DEV void operator()(u64 i) const { syms[i] = (u8)rsym[i]; lens[i] = (u32)rlen[i]; }
 };
+// split_runs (scripts/split_runs.cpp:44-109).  A run is first cut into pieces of at most L = 2^bits - 1 symbols
+// (`while(len>max_length)`), every piece then at the multiples of the block size B that fall strictly inside it; a piece
+// that STARTS on a block boundary (other than position 0) is preceded by a zero-length record of its own symbol (the
+// reference arrives there with acc_block == block_size and emits `push_back(sym, 0)`, :87-90).  Each boundary in (0, n)
+// therefore costs exactly one extra record, so the first record of piece j of run i sits at
+//   (#pieces before it) + (#multiples of B in (0, start of the piece)).
+struct PieceCountFn {     // number of L-pieces of every run
+    const idx_t *len; u64 L;
+    GRL_DEV idx_t operator()(u64 i) const { u64 l = len[i]; return (idx_t)(l == 0 ? 1 : (l + L - 1) / L); }
+};
+struct SplitRunsFn {      // one lane per L-piece
+    const u32 *rsym; const idx_t *rlen; const idx_t *rpos; const idx_t *jbase; const u64 *jw; const idx_t *jb;
+    u64 L, B;
+    u32 *osym; idx_t *olen;
+    GRL_DEV void operator()(u64 x) const {
+        const u64 i = rank1(jw, jb, x + 1) - 1;          // run owning piece x
+        const u64 j = x - (u64)jbase[i];
+        const u64 l = rlen[i];
+        const u64 k = l == 0 ? 0 : (l + L - 1) / L - 1;  // full pieces peeled off in front of the remainder
+        u64 cur = (u64)rpos[i] + j * L;
+        const u64 end = cur + (j < k ? L : l - k * L);
+        const u32 sy = rsym[i];
+        u64 o = x + ((B && cur > 0) ? (cur - 1) / B : 0);
+        if (B) {
+            if (cur > 0 && cur % B == 0) { osym[o] = sy; olen[o] = 0; o++; }
+            for (u64 nb = (cur / B + 1) * B; nb < end; nb += B) { osym[o] = sy; olen[o] = (idx_t)(nb - cur); o++; cur = nb; }
+        }
+        osym[o] = sy; olen[o] = (idx_t)(end - cur);
+    }
+};
 struct RunSymFn {         // for_each_agg protocol: every run is a work item, its bucket is its symbol
     const u32 *rsym;
     GRL_DEV bool is_start(u64) const { return true; }
@@ -2725,6 +2755,36 @@ class Engine {
             st.deciles[i] = sorted.get(q);
             prop += 0.1;
         }
+    }
+
+    // split_runs (scripts/split_runs.cpp): re-encode an image with run lengths of at most 2^bits - 1 and, for
+    // block_size > 0, no run crossing a multiple of block_size; run-length field of ceil(bits/8) bytes.  block_size 0
+    // = no partition (what the reference's usage text promises; its own code asserts there).
+    struct SplitInfo { u64 runs_before, runs_after, overflow_splits, block_splits, n_syms, out_bytes; };
+    static SplitInfo image_split_runs(const void *dev_image, u64 image_bytes, int bits, u64 block_size, u8 *dev_out, u64 capacity_bytes) {
+        ImageHeader h = image_header(dev_image, image_bytes);
+        if (bits < 1 || bits > 63) throw prim::Error(-22, "split_runs: bits must be in [1, 63]");
+        const u64 L = (1ull << bits) - 1, B = block_size, R = h.R;
+        const u32 fb2 = (u32)((bits + 7) / 8);
+        DBuf<u32> rsym(R);
+        DBuf<idx_t> rlen(R), rpos(R + 1), jbase(R + 1);
+        prim::for_each(R, UnpackRunsFn{(const u8 *)dev_image, (u32)h.sb, (u32)h.fb, rsym.p, rlen.p}, "split.unpack");
+        const u64 n = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{rlen.p}, rpos.p, true, "split.positions");
+        const u64 J = (u64)prim::exclusive_scan<idx_t>(R, PieceCountFn{rlen.p, L}, jbase.p, true, "split.pieces");
+        const u64 cuts = (B && n > 0) ? (n - 1) / B : 0;
+        SplitInfo si{R, J + cuts, J - R, cuts, n, 16 + (J + cuts) * (u64)(h.sb + fb2)};
+        if (si.out_bytes > capacity_bytes) throw prim::Error(-22, "split_runs: output buffer too small");
+        RankBits jb;
+        build_rankbits(jb, jbase.p, R, J + 1, "split.piecebits");
+        DBuf<u32> osym(si.runs_after);
+        DBuf<idx_t> olen(si.runs_after);
+        prim::for_each(J, SplitRunsFn{rsym.p, rlen.p, rpos.p, jbase.p, jb.words.p, jb.base.p, L, B, osym.p, olen.p}, "split.emit");
+        u8 hdr[16] = {0};
+        for (int i = 0; i < 8; i++) { hdr[i] = (u8)(h.sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb2 >> (8 * i)); }
+        prim::h2d(dev_out, hdr, 16);
+        prim::for_each(si.runs_after, PackRunsFn{osym.p, olen.p, (u32)h.sb, fb2, dev_out}, "split.pack");
+        prim::sync();
+        return si;
     }
 
     void run_all() {

@@ -27,13 +27,18 @@ ABI_SYMBOLS = [
     "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
     "grlbwt_level_text_download", "grlbwt_level_bwt_size", "grlbwt_level_bwt_download", "grlbwt_get_counters",
     "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump", "grlbwt_dist_build", "grlbwt_memory_usage", "grlbwt_invert_image",
-    "grlbwt_image_plain", "grlbwt_image_rle", "grlbwt_image_stats_get",
+    "grlbwt_image_plain", "grlbwt_image_rle", "grlbwt_image_stats_get", "grlbwt_image_split_runs",
+    "grlbwt_level_grammar_size", "grlbwt_level_grammar_download",
 ]
 
 
 class ImageStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_runs", "sigma", "text_size", "min_run", "max_run", "fit1", "fit2", "fit3")] + \
                [("runs_of", C.c_uint64 * 256), ("freq_of", C.c_uint64 * 256), ("deciles", C.c_uint64 * 9), ("non_maximal", C.c_uint64)]
+
+
+class SplitInfo(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("runs_before", "runs_after", "overflow_splits", "block_splits", "n_syms", "n_blocks", "out_bytes")]
 
 
 class Stats(C.Structure):
@@ -127,6 +132,8 @@ def load_library(path=None, allow_test_standin=False):
     L.grlbwt_level_text_download.argtypes = [vp, i32, vp]
     L.grlbwt_level_bwt_size.argtypes = [vp, i32, C.POINTER(u64)]
     L.grlbwt_level_bwt_download.argtypes = [vp, i32, vp, vp]
+    L.grlbwt_level_grammar_size.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64)]
+    L.grlbwt_level_grammar_download.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.grlbwt_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.grlbwt_selftest.argtypes = [vp, u64, u64]
     L.grlbwt_memory_usage.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -134,6 +141,7 @@ def load_library(path=None, allow_test_standin=False):
     L.grlbwt_image_plain.argtypes = [vp, vp, u64, vp, u64, i32, C.POINTER(u64)]
     L.grlbwt_image_rle.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.grlbwt_image_stats_get.argtypes = [vp, vp, u64, C.POINTER(ImageStats)]
+    L.grlbwt_image_split_runs.argtypes = [vp, vp, u64, i32, u64, vp, u64, C.POINTER(SplitInfo)]
     L.grlbwt_profile_enable.argtypes = [vp, i32]
     L.grlbwt_profile_dump.argtypes = [vp, C.c_char_p, u64]
     _libs[path] = L
@@ -272,6 +280,17 @@ class Context:
         self._ck(self.L.grlbwt_level_bwt_download(self._h, lvl, s.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p)))
         return s, l
 
+    def level_grammar(self, lvl):
+        """(g0, g1, has_hocc, prebwt_sym, prebwt_len) of a level that has been parsed and not yet induced."""
+        import numpy as np
+        m, p = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.grlbwt_level_grammar_size(self._h, lvl, C.byref(m), C.byref(p)))
+        g0 = np.zeros(m.value, dtype=np.uint64); g1 = np.zeros(m.value, dtype=np.uint64); hh = np.zeros(m.value, dtype=np.uint8)
+        ps = np.zeros(p.value, dtype=np.uint64); pl = np.zeros(p.value, dtype=np.uint64)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._ck(self.L.grlbwt_level_grammar_download(self._h, lvl, ptr(g0), ptr(g1), ptr(hh), ptr(ps), ptr(pl)))
+        return g0, g1, hh, ps, pl
+
     def counters(self):
         c = Counters()
         self._ck(self.L.grlbwt_get_counters(self._h, C.byref(c)))
@@ -306,6 +325,13 @@ class Context:
         d["runs_of"] = list(st.runs_of); d["freq_of"] = list(st.freq_of); d["deciles"] = list(st.deciles)
         d["non_maximal"] = int(st.non_maximal)
         return d
+
+    def image_split_runs(self, dev_image_ptr, image_bytes, bits, block_size, dev_out_ptr, capacity_bytes):
+        """split_runs on the device (scripts/split_runs.cpp): the re-encoded image lands in dev_out; returns the counters."""
+        si = SplitInfo()
+        self._ck(self.L.grlbwt_image_split_runs(self._h, C.c_void_p(dev_image_ptr), image_bytes, bits, block_size,
+                                                C.c_void_p(dev_out_ptr), capacity_bytes, C.byref(si)))
+        return _as_dict(si)
 
     def memory_usage(self):
         a, b = C.c_uint64(), C.c_uint64()

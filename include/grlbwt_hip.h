@@ -169,6 +169,20 @@ int grlbwt_image_plain(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_by
 int grlbwt_image_rle(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, void *dev_syms_u8, void *dev_lens_u32,
                      uint64_t capacity_runs, uint64_t *n_runs_out);
 int grlbwt_image_stats_get(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, grlbwt_image_stats *out);
+/* split_runs (scripts/split_runs.cpp:44-125; its argv order is `file.rlbwt bits n output_file`): re-encode the image so
+ * that no run is longer than 2^bits - 1 and, for block_size > 0, no run crosses a multiple of block_size; the output is
+ * an .rl_bwt image with the input's symbol width and ceil(bits/8) length bytes, byte-identical to the reference's output
+ * file -- including the zero-length record the reference emits in front of a piece that starts exactly on a block
+ * boundary (:87-90).  block_size 0 = no partition (the reference asserts on it).  1 <= bits <= 63.
+ * dev_out needs 16 + runs_after * (sb + ceil(bits/8)) bytes; runs_after = runs + overflow_splits + block_splits. */
+typedef struct grlbwt_split_info {
+    uint64_t runs_before, runs_after;     /* "Number of runs before" / "Number of runs now" */
+    uint64_t overflow_splits, block_splits;
+    uint64_t n_syms, n_blocks;            /* symbols described; "Number of blocks" = ceil(n_syms / block_size) */
+    uint64_t out_bytes;
+} grlbwt_split_info;
+int grlbwt_image_split_runs(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int bits, uint64_t block_size,
+                            void *dev_out, uint64_t capacity_bytes, grlbwt_split_info *info);
 
 /* ---- inspection (parity tests; need GRLBWT_FLAG_KEEP_LEVELS) --------------- */
 /* text of level >= 1 as (rank<<1 | rep) cells, the reference's on-disk parse format */
@@ -176,6 +190,14 @@ int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells);
 int grlbwt_level_text_download(const grlbwt_ctx *ctx, int level, uint64_t *cells_out);
 int grlbwt_level_bwt_size(const grlbwt_ctx *ctx, int level, uint64_t *n_runs);
 int grlbwt_level_bwt_download(const grlbwt_ctx *ctx, int level, uint64_t *sym_out, uint64_t *len_out);
+
+/* the level's grammar (produce_grammar, exact_par_phase.cpp:14-95: two cells per metasymbol, g1 >= sigma+3 = nested
+ * metasymbol + sigma+3; has_hocc = phrases_has_hocc) and pre-BWT runs (produce_pre_bwt, :136-242: BWT marker = sigma+1,
+ * hocc marker = sigma+2), i.e. the contents of the reference's dict_lev_r / pre_bwt_lev_r files.  Available for every
+ * level once the parsing phase is done and until that level has been induced. */
+int grlbwt_level_grammar_size(const grlbwt_ctx *ctx, int level, uint64_t *n_metasyms, uint64_t *prebwt_runs);
+int grlbwt_level_grammar_download(const grlbwt_ctx *ctx, int level, uint64_t *g0, uint64_t *g1, uint8_t *has_hocc,
+                                  uint64_t *prebwt_sym, uint64_t *prebwt_len);
 
 int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out);
 /* device memory taken by the engine's slab allocator: peak bytes in use, bytes reserved from the runtime */

@@ -29,6 +29,26 @@ def main():
         dist.init_process_group("gloo")
         device = "cpu"
     w = 1
+    if case.startswith("illumina_dev:"):
+        # record shard of ONE Illumina-style collection generated on the device (bench.py's N > 1 workload shape):
+        # illumina_dev:<reads>:<genome>; every rank writes the md5 of the collection's .rl_bwt it computed
+        _, reads, genome = case.split(":")
+        reads, genome = int(reads), int(genome)
+        lo, hi = reads * rank // world, reads * (rank + 1) // world
+        dev = torch.device(device)
+        text = workloads.sampled_reads_torch(reads, 150, genome, seed=20260003, device=dev, read_lo=lo, read_hi=hi)
+        torch.cuda.synchronize()
+        comm = gdist.Communicator(dev)
+        flags = engine.FLAG_FORCE_IDX64 if reads * 151 >= 0xFFFFFF00 else 0
+        with engine.Context(dev.index or 0, flags, lib) as ctx:
+            ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+            gdist.dist_build(ctx, comm)
+            out = ctx.result_bytes()
+        with open(os.path.join(out_dir, "illumina_dev.rank%d.md5" % rank), "w") as f:
+            f.write("%s %d" % (hashlib.md5(out).hexdigest(), len(out)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if case == "reads":
         data = workloads.sampled_reads(3001, 100, 20000, seed=11)
     elif case == "uniform":

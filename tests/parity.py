@@ -45,6 +45,14 @@ def check_stagewise(lib, data, cell_bytes=1, flags=0):
             if done:
                 break
         assert r == o.n_rounds
+        # a7/a8: every level's grammar cells, has_hocc flags and pre-BWT (the reference's dict_lev_r / pre_bwt_lev_r)
+        for lvl in range(r):
+            g0, g1, hh, ps, pl = ctx.level_grammar(lvl)
+            og0, og1, ohh = o.level_grammar(lvl)
+            assert np.array_equal(g0, og0) and np.array_equal(g1, og1), "grammar of level %d differs" % lvl
+            assert np.array_equal(hh, ohh), "has_hocc of level %d differs" % lvl
+            ops, opl = o.level_prebwt(lvl)
+            assert _merged(ps, pl) == _merged(ops, opl), "pre-BWT of level %d differs" % lvl
         ctx.parse2bwt()
         s, l = ctx.level_bwt(r)
         os_, ol = o.level_bwt(r)
@@ -58,6 +66,18 @@ def check_stagewise(lib, data, cell_bytes=1, flags=0):
             assert li["n_runs"] == len(os_) and li["n"] == int(ol.sum())
         assert ctx.result_bytes() == o.rl_bwt
     o.close()
+
+
+def _merged(sym, ln):
+    """Run list with adjacent equal symbols merged (the reference leaves a few pre-BWT runs unmerged -- the size()>1 quirk of
+    exact_par_phase.cpp:212 -- which SURVEY A.9 lists as not part of the contract; the symbol sequence is what counts)."""
+    out = []
+    for s, l in zip(sym.tolist(), ln.tolist()):
+        if out and out[-1][0] == s:
+            out[-1][1] += l
+        else:
+            out.append([s, l])
+    return out
 
 
 def rand_collection(rng, kind):

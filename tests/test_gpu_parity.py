@@ -225,3 +225,75 @@ def test_dist_kernels_multi_rank_on_one_gpu(hip, oracle_mod, tmp_path, world, ca
     data = open(tmp_path / (case + ".input"), "rb").read()
     w = 2 if case == "tokens" else 1
     assert open(tmp_path / (case + ".rl_bwt"), "rb").read() == oracle_mod.rl_bwt(data, w)
+
+
+def test_result_pointer_is_complete_when_build_returns(hip, oracle_mod):
+    """include/grlbwt_hip.h: "results are complete when a call returns" -- the image is read from ANOTHER stream (torch's
+    default stream) right after build(), with no synchronisation of the engine's stream by the caller."""
+    import torch
+    from grlbwt_amd import dist as gdist
+    data = workloads.sampled_reads(300000, 100, 3000000, seed=31)
+    dev = torch.from_numpy(data.copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    exp = oracle_mod.rl_bwt(data.tobytes(), 1)
+    with engine.Context(0, 0, hip) as ctx:
+        for _ in range(3):
+            ctx.attach_device(dev.data_ptr(), dev.numel(), 1, keepalive=dev)
+            ctx.build()
+            nb, _ = ctx.result_size()
+            img = gdist._view(ctx.result_device_ptr(), nb, torch.device("cuda:0")).clone()     # default stream, immediately
+            assert bytes(img.cpu().numpy()) == exp
+
+
+def test_idx64_build_round_trip_4_3GB(hip):
+    """A TRUE 64-bit index build (n >= 2^32 - 256 cells, no FORCE flag): 28,443,491 x 150 bp Illumina-style reads
+    (4,294,967,141 bytes), built and inverted on the device (grl2plain + reverse_bwt kernels), compared byte for byte."""
+    import torch
+    reads = 28443491
+    text = workloads.sampled_reads_torch(reads, 150, 140000000, seed=20260003, device="cuda:0")
+    assert text.numel() >= 0xFFFFFF00
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+        assert ctx.counters()["idx_bytes"] == 8
+        st = ctx.stats()
+        assert (st["n_strings"], st["n_syms"]) == (reads, text.numel())
+        nb, nr = ctx.result_size()
+        img = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+        from grlbwt_amd import dist as gdist
+        img.copy_(gdist._view(ctx.result_device_ptr(), nb, torch.device("cuda:0")))
+        torch.cuda.synchronize()
+    # a fresh context: the build's buffers are gone, the inversion has the device to itself (36 B per symbol)
+    out = torch.zeros_like(text)
+    with engine.Context(0, 0, hip) as ctx:
+        n = ctx.invert_image(img.data_ptr(), nb, 1, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    assert n == text.numel()
+    assert torch.equal(out, text)
+
+
+def test_sharded_equals_single_gpu_image(hip, tmp_path):
+    """bench.py's N > 1 path on this single-GPU box: the SAME Illumina-style collection (2,000,000 x 150 bp, 302 MB) built
+    by one context and by two record shards (two ranks sharing cuda:0, gloo transport) must give identical .rl_bwt bytes."""
+    import subprocess
+    import sys
+    import torch
+    reads, genome = 2000000, 10000000
+    text = workloads.sampled_reads_torch(reads, 150, genome, seed=20260003, device="cuda:0")
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+        single = ctx.result_bytes()
+    del text
+    torch.cuda.empty_cache()
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29671",
+           os.path.join(here, "dist_worker.py"), hip, "gloo-cuda", "illumina_dev:%d:%d" % (reads, genome), str(tmp_path)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    want = "%s %d" % (hashlib.md5(single).hexdigest(), len(single))
+    for r in range(2):
+        assert open(tmp_path / ("illumina_dev.rank%d.md5" % r)).read() == want
