@@ -224,6 +224,7 @@ def main():
         comm = gdist.Communicator(dev)
         if total_bytes >= 0xFFFFFF00:
             flags |= engine.FLAG_FORCE_IDX64
+        flags |= gdist.pool_flags(comm)
     ctx = engine.Context(local_rank, flags, lib)
 
     def step(c=ctx, t=text):

@@ -54,9 +54,19 @@ static void usage(const char *prog) {
 static bool is_dir(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 static bool is_file(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
 
+// the reference's report_time (external/cdt/include/utils.h:109-126): same wording, same padding argument
+static void report_ms(double seconds, int pad) {
+    long long total = (long long)(seconds * 1000.0 + 0.5);
+    long long h = total / 3600000, m = (total / 60000) % 60, s = (total / 1000) % 60, ms = total % 1000;
+    std::printf("%*s", pad, "");
+    if (h > 0) std::printf("Elapsed time (hh:mm:ss.ms): %02lld:%02lld:%02lld.%lld\n", h, m, s, ms);
+    else if (m > 0) std::printf("Elapsed time (mm:ss.ms): %02lld:%02lld.%lld\n", m, s, ms);
+    else if (s > 0) std::printf("Elapsed time (ss.ms): %02lld.%lld\n", s, ms);
+    else std::printf("Elapsed time (ms): %lld\n", ms);
+    std::fflush(stdout);
+}
 static void report_time(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b, int pad) {
-    double s = std::chrono::duration<double>(b - a).count();
-    std::printf("%*sElapsed time: %.3f s\n", pad, "", s);
+    report_ms(std::chrono::duration<double>(b - a).count(), pad);
 }
 
 int main(int argc, char **argv) {
@@ -102,14 +112,7 @@ int main(int argc, char **argv) {
     std::cout << "Temporary folder: (none: all levels stay resident in HBM)" << std::endl;
     std::cout << "BWT type:         BCR exact" << std::endl;
 
-    // read the whole file (the reference streams it through i_file_stream)
-    std::ifstream ifs(args.input_file, std::ios::binary | std::ios::ate);
-    std::streamsize sz = ifs.tellg();
-    ifs.seekg(0);
-    std::vector<char> buf((size_t)sz);
-    if (sz > 0 && !ifs.read(buf.data(), sz)) fail(105, "TEXT: cannot read " + args.input_file);
-    if (sz == 0 || (sz % args.alph_bytes) != 0) { std::cout << "Error: the file is ill formed" << std::endl; return 1; }
-
+    const auto t_start = std::chrono::steady_clock::now();
     grlbwt_ctx *ctx = nullptr;
     int rc = grlbwt_ctx_create(args.device, 0, &ctx);
     if (rc != GRLBWT_OK) {
@@ -123,54 +126,99 @@ int main(int argc, char **argv) {
         return 2;
     };
 
-    std::cout << "Reading the file" << std::endl;                                      // exact_par_phase.cpp:287
-    rc = grlbwt_text_upload(ctx, buf.data(), (uint64_t)sz / args.alph_bytes, args.alph_bytes);
+    // the file goes to HBM through pinned staging buffers, chunk k+1 read while chunk k is copied; the symbol
+    // statistics of collection_stats are taken on the device behind the copies (the reference streams the file
+    // through i_file_stream twice: once for the statistics, once for the first parsing round)
+    std::cout << "Reading the file" << std::endl;                                      // exact_par_phase.cpp:288
+    rc = grlbwt_text_load_file(ctx, args.input_file.c_str(), args.alph_bytes);
     if (rc != GRLBWT_OK) return die(rc);
-    std::vector<char>().swap(buf);
+    const auto t_loaded = std::chrono::steady_clock::now();
     grlbwt_stats st;
     grlbwt_get_stats(ctx, &st);
-    std::cout << "Stats: " << std::endl;                                               // exact_par_phase.cpp:289-293
+    std::cout << "Stats: " << std::endl;                                               // exact_par_phase.cpp:290-294
     std::cout << "  Smallest symbol               : " << st.min_sym << std::endl;
     std::cout << "  Greatest symbol               : " << st.max_sym << std::endl;
     std::cout << "  Number of symbols in the file : " << st.n_syms << std::endl;
     std::cout << "  Number of strings             : " << st.n_strings << std::endl;
 
-    std::cout << "Parsing the text:    " << std::endl;
+    // Stage labels of par_round (exact_par_phase.cpp:380,410,111,124,428,452) with the device time of the kernels
+    // that replace each stage (stage clocks of the engine, grlbwt_get_counters); the stages of one round run back
+    // to back on the GPU, so the labels are printed once the round is done.
+    grlbwt_counters c0, c1;
+    std::memset(&c0, 0, sizeof c0);
+    std::cout << "Parsing the text:    " << std::endl;                                 // exact_par_phase.cpp:301
     int done = 0, iter = 1;
     while (!done) {
-        std::cout << "  Parsing round " << iter++ << std::endl;
+        std::cout << "  Parsing round " << iter++ << std::endl;                        // :327,340
         auto t0 = std::chrono::steady_clock::now();
         grlbwt_round_info ri;
         rc = grlbwt_parse_round(ctx, &ri, &done);
         if (rc != GRLBWT_OK) return die(rc);
-        std::cout << "    Stats:" << std::endl;                                        // exact_par_phase.cpp:484-488
+        grlbwt_get_counters(ctx, &c1);
+        std::cout << "    Computing the dictionary of LMS phrases" << std::flush;     // :380  (LMS breaks + phrase hashing)
+        report_ms((c1.t_classify - c0.t_classify) + (c1.t_hash - c0.t_hash), 22);
+        std::cout << "    Compacting the dictionary" << std::flush;                   // :410  (+ :111 sorting, pre-BWT)
+        report_ms(0.0, 36);
+        std::cout << "    Sorting the dictionary and constructing the preliminary BWT" << std::flush;   // :111
+        report_ms(c1.t_dict_sort - c0.t_dict_sort, 2);
+        std::cout << "    Compressing the dictionary" << std::flush;                  // :124  (groups, grammar)
+        report_ms(c1.t_dict_groups - c0.t_dict_groups, 35);
+        std::cout << "    Assigning metasymbols to the LMS phrases" << std::flush;    // :428
+        report_ms(0.0, 21);
+        std::cout << "    Creating the parse of the text" << std::flush;              // :452
+        report_ms(c1.t_emit - c0.t_emit, 31);
+        c0 = c1;
+        std::cout << "    Stats:" << std::endl;                                        // :484-488
         std::cout << "      Parsing phrases:                  " << ri.n_phrases << std::endl;
         std::cout << "      Number of symbols in the phrases: " << ri.dict_syms << std::endl;
         std::cout << "      Number of unsolved BWT blocks:    " << ri.n_metasyms << std::endl;
         std::cout << "      Parse size:                       " << ri.parse_size << std::endl;
-        report_time(t0, std::chrono::steady_clock::now(), 4);
+        report_time(t0, std::chrono::steady_clock::now(), 4);                          // :332,356
     }
 
     std::cout << "Inferring the BWT" << std::endl;                                     // exact_ind_phase.cpp:679
-    std::cout << "  Computing the deepest recursive BWT" << std::endl;
+    std::cout << "  Computing the deepest recursive BWT" << std::endl;                 // :605
     rc = grlbwt_induce_first(ctx);
     if (rc != GRLBWT_OK) return die(rc);
     int level = iter - 1;
     while (level > 0) {
-        std::cout << "  Inducing the BWT for parse " << level << std::endl;
+        std::cout << "  Inducing the BWT for parse " << level << std::endl;            // :683
         auto t0 = std::chrono::steady_clock::now();
         grlbwt_level_info li;
         rc = grlbwt_induce_level(ctx, &level, &li);
         if (rc != GRLBWT_OK) return die(rc);
-        std::cout << "    Stats:       " << std::endl;                                 // exact_ind_phase.cpp:372-376
+        grlbwt_get_counters(ctx, &c1);
+        std::cout << "    Computing the number of induced symbols" << std::flush;     // :121
+        report_ms(c1.t_ind_expand - c0.t_ind_expand, 9);
+        std::cout << "    Performing the induction from the previous BWT" << std::flush;   // :141
+        report_ms(c1.t_ind_split - c0.t_ind_split, 2);
+        std::cout << "    Assembling the new BWT" << std::flush;                      // :270
+        report_ms(c1.t_ind_assemble - c0.t_ind_assemble, 26);
+        c0 = c1;
+        std::cout << "    Stats:       " << std::endl;                                 // :372-378
         std::cout << "      BWT size (n):                        " << li.n << std::endl;
         std::cout << "      Number of runs (r):                  " << li.n_runs << std::endl;
         std::cout << "      n/r:                                 " << double(li.n) / double(li.n_runs ? li.n_runs : 1) << std::endl;
-        report_time(t0, std::chrono::steady_clock::now(), 4);
+        if (level == 0) {
+            std::cout << "      Bytes per run symbol:                " << st.sb << std::endl;
+            std::cout << "      Bytes per run length:                " << st.fb << std::endl;
+        }
+        std::cout << "      Bytes per induced run length:        " << args.b_f_r << " (fixed by CLI)" << std::endl;
+        std::cout << "        Induced runs with length overflow: 0" << std::endl;
+        report_time(t0, std::chrono::steady_clock::now(), 4);                          // :691
     }
+    const auto t_built = std::chrono::steady_clock::now();
     rc = grlbwt_result_write_file(ctx, args.output_file.c_str());
     if (rc != GRLBWT_OK) return die(rc);
+    const auto t_written = std::chrono::steady_clock::now();
     std::cout << "The resulting BCR BWT was stored in " << args.output_file << std::endl;   // grl_bwt.hpp:78
+    // one machine-readable line for harnesses: wall seconds of the three legs of the run and the input rate
+    {
+        auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        const double tr = sec(t_start, t_loaded), tb = sec(t_loaded, t_built), tw = sec(t_built, t_written), tt = sec(t_start, t_written);
+        std::printf("grlbwt-timing: read+upload %.3f s, build %.3f s, write %.3f s, total %.3f s, %.1f MB/s (input bytes / total)\n", tr, tb, tw, tt,
+                    (double)st.n_syms * args.alph_bytes / 1e6 / (tt > 0 ? tt : 1e-9));
+    }
     grlbwt_ctx_destroy(ctx);
     return 0;
 }

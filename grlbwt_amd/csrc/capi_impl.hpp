@@ -2,13 +2,17 @@
 // instantiations of the engine (grl32 / grl64).  Included by engine_hip.hip.
 #include "../../include/grlbwt_hip.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
-#define GRLBWT_FLAG_FORCE_IDX64 4u   /* tests: run the 64-bit index build on small inputs */
 
 struct grlbwt_ctx {
     uint32_t flags = 0;
@@ -120,6 +124,132 @@ void load(grlbwt_ctx *ctx, const void *cells, uint64_t n, int w, bool host) {
         if (host) e->upload_text(cells, n, w); else e->load_text(cells, n, w);
         ctx->e32 = std::move(e);
     }
+}
+
+// ---- file in / file out: pinned staging buffers, reader/writer threads, copies overlapped with the I/O ---------
+// pread/pwrite of [off, off+len) split over `nthr` threads (page-cache copies are memory-bound per thread)
+bool par_io(int fd, char *buf, uint64_t off, uint64_t len, bool write, int nthr) {
+    auto one = [&](uint64_t a, uint64_t b, bool *ok) {
+        while (a < b) {
+            ssize_t r = write ? pwrite(fd, buf + (a - off), b - a, (off_t)a) : pread(fd, buf + (a - off), b - a, (off_t)a);
+            if (r <= 0) { *ok = false; return; }
+            a += (uint64_t)r;
+        }
+    };
+    if (nthr < 1) nthr = 1;
+    if (len < ((uint64_t)4 << 20)) nthr = 1;
+    std::vector<std::thread> th;
+    std::vector<char> oks(nthr, 1);
+    const uint64_t part = (len + nthr - 1) / nthr;
+    for (int t = 0; t < nthr; t++) {
+        uint64_t a = off + (uint64_t)t * part, b = a + part < off + len ? a + part : off + len;
+        if (a >= b) break;
+        th.emplace_back(one, a, b, (bool *)&oks[t]);
+    }
+    for (auto &x : th) x.join();
+    for (char c : oks) if (!c) return false;
+    return true;
+}
+constexpr uint64_t kIoChunk = (uint64_t)64 << 20;
+constexpr int kIoBufs = 3, kIoThreads = 4;
+
+// file -> HBM: chunk k+1 is read from the file while chunk k travels over PCIe; for byte cells the histogram of
+// collection_stats is taken from every chunk on the device as soon as it has landed (no second pass over the text)
+template <class E>
+void load_file_into(E &e, int fd, uint64_t bytes, int w) {
+    e.own0.alloc(bytes + 16);
+    char *bufs[kIoBufs] = {nullptr, nullptr, nullptr};
+    prim::Fence fences[kIoBufs];
+    uint64_t *d_hist = nullptr;
+    auto cleanup = [&] {
+        for (int k = 0; k < kIoBufs; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); bufs[k] = nullptr; }
+        if (d_hist) prim::dev_free(d_hist);
+        d_hist = nullptr;
+    };
+    try {
+        const uint64_t chunk = bytes < kIoChunk ? (bytes + 15) / 16 * 16 : kIoChunk;
+        for (int k = 0; k < kIoBufs; k++) bufs[k] = (char *)prim::pinned_alloc(chunk ? chunk : 16);
+        if (w == 1) { d_hist = (uint64_t *)prim::dev_alloc(256 * 8); prim::dev_memset(d_hist, 0, 256 * 8); }
+        int k = 0;
+        for (uint64_t off = 0; off < bytes; off += chunk, k = (k + 1) % kIoBufs) {
+            const uint64_t len = bytes - off < chunk ? bytes - off : chunk;
+            prim::fence_wait(fences[k]);                                // the copy that last used this buffer is done
+            if (!par_io(fd, bufs[k], off, len, false, kIoThreads)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+            prim::h2d_async(e.own0.p + off, bufs[k], len);
+            if (d_hist) prim::byte_histogram_accumulate(e.own0.p + off, len, d_hist);
+            prim::fence_record(fences[k]);
+        }
+        uint64_t hist[256];
+        if (d_hist) prim::d2h(hist, d_hist, sizeof hist); else prim::sync();
+        cleanup();
+        e.load_text(e.own0.p, bytes / (uint64_t)w, w, w == 1 ? hist : nullptr);
+    } catch (...) {
+        try { prim::sync(); } catch (...) {}
+        cleanup();
+        throw;
+    }
+}
+void load_file(grlbwt_ctx *ctx, const char *path, int w) {
+    ctx->e32.reset();
+    ctx->e64.reset();
+    if (!(w == 1 || w == 2 || w == 4 || w == 8)) throw prim::Error(GRLBWT_EINVAL, "bad cell width");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw prim::Error(GRLBWT_EINVAL, std::string("cannot stat ") + path); }
+    const uint64_t bytes = (uint64_t)st.st_size;
+    try {
+        if (bytes == 0 || bytes % (uint64_t)w) throw prim::Error(GRLBWT_EILLFORMED, "Error: the file is ill formed");
+        const uint64_t n = bytes / (uint64_t)w;
+        bool big = (n >= 0xFFFFFF00ull) || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+        bool keep = ctx->flags & GRLBWT_FLAG_KEEP_LEVELS;
+        if (big) {
+            std::unique_ptr<grl64::Engine> e(new grl64::Engine());
+            e->keep_texts = keep;
+            load_file_into(*e, fd, bytes, w);
+            ctx->e64 = std::move(e);
+        } else {
+            std::unique_ptr<grl32::Engine> e(new grl32::Engine());
+            e->keep_texts = keep;
+            load_file_into(*e, fd, bytes, w);
+            ctx->e32 = std::move(e);
+        }
+    } catch (...) { close(fd); throw; }
+    close(fd);
+}
+// HBM image -> file: chunk k is written while chunk k+1 comes down
+void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
+    char *bufs[2] = {nullptr, nullptr};
+    prim::Fence fences[2];
+    bool ok = true;
+    try {
+        const uint64_t chunk = nb < kIoChunk ? nb : kIoChunk;
+        for (int k = 0; k < 2; k++) bufs[k] = (char *)prim::pinned_alloc(chunk ? chunk : 16);
+        if (ftruncate(fd, (off_t)nb) != 0) ok = false;
+        std::thread writer;
+        uint64_t poff = 0, plen = 0;
+        int k = 0, pk = 0;
+        for (uint64_t off = 0; off < nb && ok; off += chunk, k ^= 1) {
+            const uint64_t len = nb - off < chunk ? nb - off : chunk;
+            prim::d2h_async(bufs[k], dev_image + off, len);           // buffer k was written out two chunks ago (joined below)
+            prim::fence_record(fences[k]);
+            if (writer.joinable()) writer.join();
+            prim::fence_wait(fences[k]);
+            poff = off; plen = len; pk = k;
+            writer = std::thread([&, poff, plen, pk] { if (!par_io(fd, bufs[pk], poff, plen, true, kIoThreads)) ok = false; });
+        }
+        if (writer.joinable()) writer.join();
+    } catch (...) {
+        try { prim::sync(); } catch (...) {}
+        for (int k = 0; k < 2; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
+        close(fd);
+        throw;
+    }
+    for (int k = 0; k < 2; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
+    if (close(fd) != 0) ok = false;
+    if (!ok) throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path);
 }
 
 // ---- primitive self-test (device vs host loops) -----------------------------
@@ -304,6 +434,7 @@ int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out) {
     c->device = device_id;
     int rc = guarded(c, [&] {
         prim::init(device_id);            // refuses a second device while contexts are alive (one GPU per process)
+        if (flags & GRLBWT_FLAG_CLASSIC_POOL) prim::pool_classic();
         if (flags & GRLBWT_FLAG_SYNC_DEBUG) prim::rt().sync_each_launch = true;
         prim::rt().live_ctx++;
     });
@@ -331,6 +462,10 @@ int grlbwt_ctx_set_stream(grlbwt_ctx *ctx, void *hip_stream) {
 int grlbwt_text_upload(grlbwt_ctx *ctx, const void *host_cells, uint64_t n_cells, int cell_bytes) {
     if (!ctx || !host_cells) return GRLBWT_EINVAL;
     return guarded(ctx, [&] { load(ctx, host_cells, n_cells, cell_bytes, true); });
+}
+int grlbwt_text_load_file(grlbwt_ctx *ctx, const char *path, int cell_bytes) {
+    if (!ctx || !path) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { load_file(ctx, path, cell_bytes); });
 }
 int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes) {
     if (!ctx || !dev_cells || ((uintptr_t)dev_cells & 15)) return GRLBWT_EINVAL;
@@ -405,16 +540,7 @@ int grlbwt_result_download(const grlbwt_ctx *ctx, void *host_out, uint64_t capac
 }
 int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path) {
     if (!HAS_ENG(ctx) || !path || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
-    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] {
-        uint64_t nb = ENG(ctx, image_bytes);
-        std::vector<uint8_t> h(nb);
-        prim::d2h(h.data(), ENG(ctx, image.p), nb);
-        FILE *f = fopen(path, "wb");
-        if (!f) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
-        size_t wr = fwrite(h.data(), 1, nb, f);
-        int rc = fclose(f);
-        if (wr != nb || rc != 0) throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path);
-    });
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { write_image(ENG(ctx, image.p), ENG(ctx, image_bytes), path); });
 }
 
 int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells) {

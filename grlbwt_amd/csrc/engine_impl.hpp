@@ -830,6 +830,24 @@ struct ChainExpandFn {
         term[i] = nx;                                       // exact_ind_phase.cpp:257 write_sym
     }
 };
+// The same walk as a generator for prim::expand_count / expand_sort (chain expansion fused with the first pass of the
+// bucket split; protocol in prim_hip.hpp): nodes are metasymbols, a node's record is its packed grammar cell, keys are
+// the fused cells sym << (kb+lb) | len << kb | bucket, finish() rewrites the run's symbol (exact_ind_phase.cpp:257).
+struct ChainGen {
+    const u32 *nsym; const idx_t *nlen; const u64 *gp;
+    u32 sigma3, take_code;
+    u32 *term;
+    int kb, lb;
+    GRL_DEV u32 start(u64 i) const { return nsym[i]; }
+    GRL_DEV u64 node(u32 u) const { return gp[u]; }
+    GRL_DEV bool owns(u64 rec) const { return (rec & 0x80000000ull) != 0; }
+    GRL_DEV bool more(u64 rec) const { return (u32)(rec >> 32) >= sigma3; }
+    GRL_DEV u32 next(u64 rec) const { return (u32)(rec >> 32) - sigma3; }
+    GRL_DEV u64 item_bits(u64 i) const { return (u64)nlen[i] << kb; }
+    GRL_DEV u64 key_own(u32 u, u64 ib) const { return ((u64)take_code << (kb + lb)) | ib | (u64)u; }
+    GRL_DEV u64 key_step(u64 rec, u32 b, u64 ib) const { return ((u64)((u32)rec & 0x7FFFFFFFu) << (kb + lb)) | ib | (u64)b; }
+    GRL_DEV void finish(u64 i, u64 rec) const { term[i] = (u32)(rec >> 32); }
+};
 struct GatherCellFn {
     const idx_t *perm; const u32 *esym; const idx_t *elen; u32 *ssym; idx_t *slen;
     GRL_DEV void operator()(u64 t) const { u64 e = perm[t]; ssym[t] = esym[e]; slen[t] = elen[e]; }
@@ -1498,14 +1516,15 @@ class Engine {
 
     // ---- a1 ------------------------------------------------------------
     template <class cell_t>
-    void stats_t(const cell_t *t, u64 n) {
+    void stats_t(const cell_t *t, u64 n, const u64 *hist256 = nullptr) {
         StageTimer st(&tm.stats);
         cell_t sep;
         prim::d2h(&sep, t + (n - 1), sizeof(cell_t));
         u64 mn, mx, F = n;
         if (sizeof(cell_t) == 1) {
             u64 h[256];
-            prim::byte_histogram((const u8 *)t, n, h);
+            if (hist256) std::memcpy(h, hist256, sizeof h);      // counted while the text was uploaded (file loader)
+            else prim::byte_histogram((const u8 *)t, n, h);
             mn = 0; while (h[mn] == 0) mn++;
             mx = 255; while (h[mx] == 0) mx--;
             F = 0; for (int i = 0; i < 256; i++) if (h[i] > F) F = h[i];      // utils.cpp:161-175
@@ -1522,7 +1541,7 @@ class Engine {
         stats.fb = (bitlen64(F) + 7) / 8;
     }
 
-    void load_text(const void *dev_cells, u64 n, int w) {
+    void load_text(const void *dev_cells, u64 n, int w, const u64 *hist256 = nullptr) {
         if (n == 0 || !(w == 1 || w == 2 || w == 4 || w == 8)) throw prim::Error(-22, "bad input size or cell width");
         if (sizeof(idx_t) == 4 && n >= 0xFFFFFF00ull) throw prim::Error(-75, "input too large for the 32-bit index build");
         if (n >= kPosMask) throw prim::Error(-75, "input too large");
@@ -1534,7 +1553,7 @@ class Engine {
         parse_done = false; bwt_level = -1; image_bytes = 0;
         tm = Timers();
         switch (w) {
-            case 1: stats_t<u8>((const u8 *)dev_cells, n); break;
+            case 1: stats_t<u8>((const u8 *)dev_cells, n, hist256); break;
             case 2: stats_t<u16>((const u16 *)dev_cells, n); break;
             case 4: stats_t<u32>((const u32 *)dev_cells, n); break;
             default: stats_t<u64>((const u64 *)dev_cells, n); break;
@@ -1912,19 +1931,11 @@ class Engine {
         LevelInfo &I = linfo[r];
         I.R_next = R; I.P = P;
 
-        DBuf<idx_t> eoff(R + 1);
+        DBuf<idx_t> eoff;
         DBuf<u32> term(R);
         DBuf<u32> ssym; DBuf<idx_t> slen;
         DBuf<u64> gp;                           // packed grammar cells (chain walks)
-        u64 E;
-        {
-            StageTimer st(&tm.ind_expand);
-            gp.alloc(M);
-            prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
-            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, gp.p, sigma3}, eoff.p}, "induce_count");
-            E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
-        }
-        I.E = E;
+        u64 E = 0;
         DBuf<u32> skey;                         // bucket of every induced cell, bucket-major order
         DBuf<u64> spack;                        // (sym<<32 | len) of every induced cell, same order (packed path)
         DBuf<u64> sfused;                       // sym | len | bucket in one word per cell (fused path)
@@ -1932,7 +1943,13 @@ class Engine {
         if (kb < 1) kb = 1;
         {
             const int bits = kb;
-            const u64 maxrun = prim::reduce_max<u64>(R, IdxIn64{bwt.len.p}, "induce_maxrun");
+            u64 maxrun;
+            {
+                StageTimer st(&tm.ind_expand);
+                gp.alloc(M);
+                prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
+                maxrun = prim::reduce_max<u64>(R, IdxIn64{bwt.len.p}, "induce_maxrun");
+            }
             lb = (int)bitlen64(maxrun);
             if (lb < 1) lb = 1;
             const int sbits = (int)bitlen64((u64)sigma3);
@@ -1941,7 +1958,34 @@ class Engine {
             const bool fused = kb + lb + sbits <= 64;
             // otherwise the payload (sym, len) rides through the split as one u64 whenever every run length fits 32 bits
             const bool packed = !fused && maxrun < 0xFFFFFFFFull;
+            bool done = false;
             if (fused) {
+                // chain expansion fused with the first pass of the bucket split (prim::expand_*): the cells are never
+                // written in run order, there is no offset array and no scan over the runs
+                const ChainGen gen{bwt.sym.p, bwt.len.p, gp.p, sigma3, take_code, term.p, kb, lb};
+                prim::XsPlan plan;
+                {
+                    StageTimer st(&tm.ind_expand);
+                    E = prim::expand_count(R, gen, bits, plan, "induce");
+                }
+                if (plan.ok) {
+                    DBuf<u64> ef(E), ef2(E);
+                    StageTimer st(&tm.ind_sort);
+                    int res = prim::expand_sort(gen, plan, ef.p, ef2.p, "induce");
+                    sfused = std::move(res ? ef2 : ef);
+                    done = true;
+                }
+                plan.release();
+                if (done) prim::sync();
+            }
+            if (!done) {     // offsets of every run's cells (an item with more than 32 cells, or cells that do not fit one word)
+                StageTimer st(&tm.ind_expand);
+                eoff.alloc(R + 1);
+                prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, gp.p, sigma3}, eoff.p}, "induce_count");
+                E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
+            }
+            if (done) {
+            } else if (fused) {
                 DBuf<u64> ef(E), ef2(E);
                 {
                     StageTimer st(&tm.ind_expand);
@@ -1982,6 +2026,7 @@ class Engine {
                 prim::sync();
             }
         }
+        I.E = E;
         const CellView cells{sfused.p, kb, lb, skey.p, spack.p, ssym.p, slen.p};
         eoff.release();
         if (prim::rt().profile) {              // SURVEY 8d's E'_r and E_r for the roofline accounting (bench.py)

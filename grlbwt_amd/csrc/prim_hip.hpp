@@ -197,15 +197,28 @@ inline void after_launch(const char *name) {
 // offset-ordered free list with coalescing (the engine's allocation pattern is close to a stack,
 // so fragmentation stays low).  Everything is stream-ordered on ONE stream: a block freed by the
 // host right after its last kernel was enqueued may be handed to a later launch on that stream.
+//
+// The preferred slab is an ARENA: one virtual address range as large as the device's memory, reserved once
+// (hipMemAddressReserve costs nothing) and backed with physical memory in 1 GiB steps as the high-water mark rises
+// (hipMemCreate + hipMemMap + hipMemSetAccess: ~0.03 ms per GiB measured).  One contiguous slab never fragments across
+// slabs and costs only what a build touches -- a single hipMalloc of > ~130 GB was measured at 6 s on this device
+// (tools/alloc_probe.hip: 128 GB 0.000 s, 200 GB 6.18 s), which is what a whole-device reservation used to cost a
+// one-shot run.  hipMalloc slabs (1 GiB, doubling) remain as the fallback when the virtual-memory calls are not
+// available and for the multi-process RCCL path (GRLBWT_FLAG_CLASSIC_POOL), whose buffers are handed to the
+// communication library.
 struct Slab {
     char *base = nullptr;
-    size_t size = 0;
+    size_t size = 0;                          // bytes usable (arena: bytes mapped so far)
     std::map<size_t, size_t> free_list;      // offset -> length
+    bool arena = false;
+    size_t va_size = 0;                       // arena: reserved address range
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;   // arena: physical pieces, in address order
 };
 struct Pool {
     std::vector<Slab> slabs;
     std::map<void *, std::pair<int, size_t>> live;   // ptr -> (slab, length)
     size_t live_bytes = 0, peak_bytes = 0, slab_bytes = 0, next_slab = (size_t)1 << 30;
+    int arena_state = 0;                      // 0 not tried, 1 in use, -1 unavailable / switched off
 };
 inline Pool &pool() {
     static Pool p;
@@ -225,6 +238,7 @@ inline void pool_stage_end(u64 old_peak, const void *stage_id) {
                        P.peak_bytes / 1e9, P.live_bytes / 1e9);
     if (old_peak > P.peak_bytes) P.peak_bytes = old_peak;
 }
+inline void pool_classic() { if (pool().arena_state == 0) pool().arena_state = -1; }   // hipMalloc slabs only (before the first allocation)
 inline u64 pool_peak_bytes() { return pool().peak_bytes; }
 inline u64 pool_reserved_bytes() { return pool().slab_bytes; }
 inline bool pool_disabled() {
@@ -234,6 +248,16 @@ inline bool pool_disabled() {
 inline void pool_trim() {                    // give every fully free slab back to the runtime
     Pool &P = pool();
     for (auto &sl : P.slabs) {
+        if (sl.arena) {                      // unmap the backing, keep the (free) address range
+            if (sl.size && sl.free_list.size() == 1 && sl.free_list.begin()->second == sl.size) {
+                size_t off = 0;
+                for (auto &ch : sl.chunks) { (void)hipMemUnmap(sl.base + off, ch.second); (void)hipMemRelease(ch.first); off += ch.second; }
+                sl.chunks.clear();
+                P.slab_bytes -= sl.size;
+                sl.size = 0; sl.free_list.clear();
+            }
+            continue;
+        }
         if (sl.base && sl.free_list.size() == 1 && sl.free_list.begin()->second == sl.size) {
             (void)hipFree(sl.base);
             P.slab_bytes -= sl.size;
@@ -243,6 +267,55 @@ inline void pool_trim() {                    // give every fully free slab back 
     bool any = false;
     for (auto &sl : P.slabs) any = any || sl.base;
     if (!any) { P.slabs.clear(); P.next_slab = (size_t)1 << 30; }
+}
+// ---- arena: reserve once, back on demand
+inline bool arena_create(Pool &P) {
+    if (P.arena_state != 0) return P.arena_state > 0;
+    P.arena_state = -1;
+    if (getenv("GRLBWT_POOL_CLASSIC")) return false;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) { (void)hipGetLastError(); return false; }
+    const size_t gib = (size_t)1 << 30;
+    size_t va = (tot + gib - 1) / gib * gib;
+    void *base = nullptr;
+    if (hipMemAddressReserve(&base, va, gib, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    Slab sl;
+    sl.base = (char *)base; sl.size = 0; sl.arena = true; sl.va_size = va;
+    P.slabs.insert(P.slabs.begin(), sl);
+    for (auto &kv : P.live) kv.second.first += 1;
+    P.arena_state = 1;
+    return true;
+}
+// back at least `more` further bytes of the arena (slab 0); false when the device has no memory left for it
+inline bool arena_grow(Pool &P, size_t more) {
+    Slab &sl = P.slabs[0];
+    const size_t gib = (size_t)1 << 30;
+    size_t want = (more + gib - 1) / gib * gib;
+    if (sl.size + want > sl.va_size) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = rt().device;
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, want, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemMap(sl.base + sl.size, want, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+    hipMemAccessDesc ad = {};
+    ad.location = prop.location;
+    ad.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(sl.base + sl.size, want, &ad, 1) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipMemUnmap(sl.base + sl.size, want); (void)hipMemRelease(h); return false;
+    }
+    sl.chunks.emplace_back(h, want);
+    // the new range joins the free list (coalescing with a free tail)
+    size_t off = sl.size, len = want;
+    if (!sl.free_list.empty()) {
+        auto last = std::prev(sl.free_list.end());
+        if (last->first + last->second == off) { off = last->first; len += last->second; sl.free_list.erase(last); }
+    }
+    sl.free_list.emplace(off, len);
+    sl.size += want;
+    P.slab_bytes += want;
+    return true;
 }
 inline void *slab_take(Pool &P, int si, size_t need) {
     Slab &sl = P.slabs[si];
@@ -265,6 +338,7 @@ inline void *slab_take(Pool &P, int si, size_t need) {
 inline void pool_reserve(size_t bytes) {
     if (pool_disabled()) return;
     Pool &P = pool();
+    if (arena_create(P)) return;                     // the arena grows with the build: nothing to reserve
     for (auto &sl : P.slabs) if (sl.base && sl.size >= bytes) return;
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
@@ -293,6 +367,14 @@ inline void *dev_alloc(size_t bytes) {
     size_t need = (bytes + 255) & ~(size_t)255;
     for (int si = 0; si < (int)P.slabs.size(); si++)
         if (P.slabs[si].base) if (void *p = slab_take(P, si, need)) return p;
+    if (arena_create(P)) {
+        // back as much more of the arena as the request needs beyond its free tail
+        Slab &ar = P.slabs[0];
+        size_t tail = 0;
+        if (!ar.free_list.empty()) { auto last = std::prev(ar.free_list.end()); if (last->first + last->second == ar.size) tail = last->second; }
+        if (arena_grow(P, need - tail)) if (void *p = slab_take(P, 0, need)) return p;
+        // no memory left for the arena: fall through to the runtime's own allocator, which reports the failure
+    }
     // new slab: at least the request, otherwise the doubling schedule, never more than what is free
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
@@ -371,6 +453,19 @@ inline void d2h(void *h, const void *d, size_t n) {
     if (n) GRL_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().stream));
     sync();
 }
+// pinned staging + stream-ordered copies with completion fences (the file reader / image writer of the C-ABI)
+inline void *pinned_alloc(size_t n) { void *p = nullptr; GRL_HIP_CHECK(hipHostMalloc(&p, n, hipHostMallocDefault)); return p; }
+inline void pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+inline void h2d_async(void *d, const void *h, size_t n) { if (n) GRL_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().stream)); }
+inline void d2h_async(void *h, const void *d, size_t n) { if (n) GRL_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().stream)); }
+struct Fence { hipEvent_t e = nullptr; bool armed = false; };
+inline void fence_record(Fence &f) {
+    if (!f.e) GRL_HIP_CHECK(hipEventCreateWithFlags(&f.e, hipEventDisableTiming));
+    GRL_HIP_CHECK(hipEventRecord(f.e, rt().stream));
+    f.armed = true;
+}
+inline void fence_wait(Fence &f) { if (f.armed) { GRL_HIP_CHECK(hipEventSynchronize(f.e)); f.armed = false; } }
+inline void fence_destroy(Fence &f) { if (f.e) (void)hipEventDestroy(f.e); f.e = nullptr; f.armed = false; }
 inline void d2d(void *dst, const void *src, size_t n) {
     if (n) GRL_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, rt().stream));
 }
@@ -945,6 +1040,14 @@ __global__ void __launch_bounds__(kBlock) k_byte_hist(const u8 *p, u64 n, u64 *h
     u32 t = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
     if (t) atomicAdd(reinterpret_cast<unsigned long long *>(&hist[threadIdx.x]), (unsigned long long)t);
 }
+// adds the byte frequencies of p[0..n) to the device table d_hist[256] (stream-ordered, no synchronisation)
+inline void byte_histogram_accumulate(const u8 *p, u64 n, u64 *d_hist) {
+    if (!n) return;
+    prof_begin("byte_hist");
+    hipLaunchKernelGGL(k_byte_hist, dim3(grid_for(n, kBlock * 16 * 4)), dim3(kBlock), 0, rt().stream, p, n, d_hist);
+    prof_end();
+    after_launch("byte_hist");
+}
 // hist_host[256] = byte frequencies of p[0..n) (p must be 16-byte aligned)
 inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
     u64 *d = (u64 *)dev_alloc(256 * 8);
@@ -1030,27 +1133,43 @@ __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int sh
 // Instead: column sums over chunks of kRsChunk tiles -> digit-major scan of the small chunk table -> running column
 // prefix inside each chunk, all with coalesced rows.
 static constexpr int kRsChunk = 32;
+template <int NB>
 __global__ void __launch_bounds__(kBlock) k_rs_chunk_sums(const u32 *counts, u32 tiles, u32 *chunk_sums) {
     u32 t0 = blockIdx.x * kRsChunk, t1 = t0 + kRsChunk < tiles ? t0 + kRsChunk : tiles;
-    u32 acc = 0;
+    for (int d = threadIdx.x; d < NB; d += kBlock) {
+        u32 acc = 0;
 #pragma unroll 8
-    for (u32 t = t0; t < t1; t++) acc += counts[(u64)t * 256 + threadIdx.x];
-    chunk_sums[(u64)blockIdx.x * 256 + threadIdx.x] = acc;
+        for (u32 t = t0; t < t1; t++) acc += counts[(u64)t * NB + d];
+        chunk_sums[(u64)blockIdx.x * NB + d] = acc;
+    }
 }
 struct RsChunkIn {       // chunk table read in digit-major order
-    const u32 *c; u32 chunks;
-    GRL_HD u64 operator()(u64 i) const { u64 d = i / chunks, k = i % chunks; return (u64)c[k * 256 + d]; }
+    const u32 *c; u32 chunks; u32 nb;
+    GRL_HD u64 operator()(u64 i) const { u64 d = i / chunks, k = i % chunks; return (u64)c[k * nb + d]; }
 };
-__global__ void __launch_bounds__(kBlock) k_rs_tile_offsets(const u32 *counts, const u64 *chunk_off /*[256][chunks]*/, u32 tiles,
-                                                            u32 chunks, u64 *offsets /*[tiles][256]*/) {
+template <int NB>
+__global__ void __launch_bounds__(kBlock) k_rs_tile_offsets(const u32 *counts, const u64 *chunk_off /*[NB][chunks]*/, u32 tiles,
+                                                            u32 chunks, u64 *offsets /*[tiles][NB]*/) {
     u32 t0 = blockIdx.x * kRsChunk, t1 = t0 + kRsChunk < tiles ? t0 + kRsChunk : tiles;
-    u64 run = chunk_off[(u64)threadIdx.x * chunks + blockIdx.x];
+    for (int d = threadIdx.x; d < NB; d += kBlock) {
+        u64 run = chunk_off[(u64)d * chunks + blockIdx.x];
 #pragma unroll 8
-    for (u32 t = t0; t < t1; t++) {
-        u32 c = counts[(u64)t * 256 + threadIdx.x];
-        offsets[(u64)t * 256 + threadIdx.x] = run;
-        run += c;
+        for (u32 t = t0; t < t1; t++) {
+            u32 c = counts[(u64)t * NB + d];
+            offsets[(u64)t * NB + d] = run;
+            run += c;
+        }
     }
+}
+// offsets[tile][digit] (exclusive, digit-major order) from counts[tile][digit]; *total = number of counted keys (optional)
+template <int NB>
+inline void rs_offsets(const u32 *counts, u32 tiles, u32 *chunk_sums, u64 *chunk_off, u64 *offsets, u64 *total, const char *name) {
+    u32 chunks = (tiles + kRsChunk - 1) / kRsChunk;
+    hipLaunchKernelGGL(k_rs_chunk_sums<NB>, dim3(chunks), dim3(kBlock), 0, rt().stream, counts, tiles, chunk_sums);
+    after_launch(name);
+    exclusive_scan_async<u64, RsChunkIn>((u64)NB * chunks, RsChunkIn{chunk_sums, chunks, (u32)NB}, chunk_off, total, nullptr, name);
+    hipLaunchKernelGGL(k_rs_tile_offsets<NB>, dim3(chunks), dim3(kBlock), 0, rt().stream, counts, chunk_off, tiles, chunks, offsets);
+    after_launch(name);
 }
 
 // The tile (kBlock x kRsKeys keys, wave w owns a contiguous quarter) is ranked with per-wave running digit
@@ -1182,6 +1301,316 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+inline int sort_keys_fwd(u64 *a, u64 *b, u64 n, int begin_bit, int end_bit, const char *name);
+// ------------------------------------------------------- expand + multi-split
+// Stable multi-split of GENERATED keys.  Item i (0 <= i < n) walks a chain through a table of packed node records and
+// drops one u64 key per step; the result is the sequence of all keys ordered by key bits [0, bits), stable with respect
+// to (item, step).  (Induction pass B: item = run of BWT_{r+1}, node = metasymbol, key = hocc cell, sort bits = bucket.)
+// The generator GEN describes the walk:
+//     u32  start(i)            first node of item i            u64  node(u)        packed record of node u
+//     bool owns(rec)           the start node drops a key      bool more(rec)      the chain goes on behind this node
+//     u32  next(rec)           the node behind it              u64  item_bits(i)   key bits shared by all keys of item i
+//     u64  key_own(u, ib)      key dropped for the start node  u64  key_step(rec, b, ib)  key dropped when stepping from rec to b
+//     void finish(i, rec)      side effect at the end of the walk (rec = record of the last node)
+// and the low bits of a key are its sort bits (key_own(u, 0) / key_step(rec, b, 0) suffice for counting).
+//
+// The generation is FUSED with the first radix pass: the keys are never written in generation order.
+//   k_xs_count    walks every item once: per-tile digit histogram of the first digit (LDS atomics on per-wave copies),
+//                 the number of keys of every item (one byte), the largest such number
+//   rs_offsets    digit-major exclusive offsets per (tile, digit); their grand total is the number of keys E
+//   k_xs_scatter  per sub-batch of 1024 items (4 per thread, their 4 chains walked INTERLEAVED: the walk is a chain of
+//                 dependent gathers, and 4 independent chains per lane is what hides their latency at the occupancy
+//                 the LDS staging leaves): key counts -> block scan -> keys straight into an LDS window in sequence
+//                 order -> the in-tile stable ranking of k_rs_scatter (wave64 ballots, per-wave running counters,
+//                 in-place LDS permutation) -> linear write-out at the tile's running digit offsets
+// Traffic per key: 8 B written by the fused pass (+ the items' own arrays), then 8 B hist + 16 B scatter per further
+// pass -- against 8 B expand + 24 B per pass for expand-then-sort.  The first digit takes 9 bits when that saves a pass.
+static constexpr int kXsIpt = 4;                          // items per thread and sub-batch
+static constexpr int kXsBatch = kBlock * kXsIpt;          // 1024 items per sub-batch
+static constexpr int kXsTileItems = 4096;                 // items per tile (4 sub-batches)
+static constexpr int kXsWin = 4096;                       // keys staged and ranked per round (16 rows of 64 per wave)
+struct XsPlan {
+    bool ok = false;         // false: the fused path does not apply (an item with more than 32 keys); E is still valid
+    u64 n = 0, E = 0;
+    u32 maxc = 0, tiles = 0;
+    int bits = 0, db = 8;    // sort bits, bits of the first digit
+    u8 *cnt8 = nullptr; u32 *counts = nullptr; u64 *offsets = nullptr;
+    void release() {
+        if (cnt8) dev_free(cnt8);
+        if (counts) dev_free(counts);
+        if (offsets) dev_free(offsets);
+        cnt8 = nullptr; counts = nullptr; offsets = nullptr;
+    }
+};
+// workgroup -> tile so that every XCD (workgroups are dealt to the 8 XCDs round-robin) takes a CONTIGUOUS range of
+// tiles: neighbouring tiles write neighbouring pieces of every digit's run, and the partially written lines then meet
+// in one L2 instead of two
+GRL_DEV u32 xcd_tile(u32 b, u32 g) {
+    const u32 per = g >> 3, rem = g & 7u, x = b & 7u, k = b >> 3;
+    return x * per + (x < rem ? x : rem) + k;
+}
+template <class GEN, int DB>
+__global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, u8 *cnt8, u32 *counts, u32 *scal /*[0] max keys per item*/) {
+    constexpr int NB = 1 << DB;
+    __shared__ u32 s_h[kBlock / 64][NB];
+    __shared__ u32 s_max;
+    for (int i = threadIdx.x; i < (kBlock / 64) * NB; i += kBlock) (&s_h[0][0])[i] = 0;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    u32 *h = s_h[threadIdx.x >> 6];
+    const u64 base = (u64)blockIdx.x * kXsTileItems;
+    u32 mx = 0;
+    for (int b = 0; b < kXsTileItems / kBlock; b++) {
+        const u64 i = base + (u64)b * kBlock + threadIdx.x;
+        if (i < n) {
+            u32 c = 0;
+            const u32 cur = gen.start(i);
+            u64 rec = gen.node(cur);
+            if (gen.owns(rec)) { atomicAdd(&h[(u32)gen.key_own(cur, 0) & dmask], 1u); c++; }
+            while (gen.more(rec)) {
+                const u32 nx = gen.next(rec);
+                atomicAdd(&h[(u32)gen.key_step(rec, nx, 0) & dmask], 1u);
+                c++;
+                rec = gen.node(nx);
+            }
+            cnt8[i] = (u8)(c < 255u ? c : 255u);
+            mx = c > mx ? c : mx;
+        }
+    }
+    mx = wave_reduce<u32, Op::Max>(mx);
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_max, mx);
+    __syncthreads();
+    for (int d = threadIdx.x; d < NB; d += kBlock) {
+        u32 t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += s_h[w][d];
+        counts[(u64)blockIdx.x * NB + d] = t;
+    }
+    if (threadIdx.x == 0 && s_max) atomicMax(&scal[0], s_max);
+}
+template <class GEN, int DB>
+__global__ void __launch_bounds__(kBlock, 3) k_xs_scatter(u64 n, GEN gen, u32 dmask, const u8 *cnt8, const u64 *offsets /*[tiles][NB]*/, u64 *out,
+                                                       int xcd_aware) {
+    constexpr int NB = 1 << DB, BPT = NB / kBlock > 0 ? NB / kBlock : 1;     // bins per thread (contiguous)
+    constexpr int ROWS = kXsWin / kBlock;                                   // 16 rows of 64 keys per wave and round
+    __shared__ __attribute__((aligned(16))) u64 s_cells[kXsWin];
+    __shared__ u32 s_cnt[kBlock / 64][NB];
+    __shared__ u64 s_goff[NB];       // running global offset of every digit for this tile
+    __shared__ u64 s_gbase[NB];      // global position of round-local index 0 of the digit's run (mod 2^64)
+    __shared__ u64 s_w[4];
+    __shared__ u32 s_wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const u32 tile = xcd_aware ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+    for (int d = threadIdx.x; d < NB; d += kBlock) s_goff[d] = offsets[(u64)tile * NB + d];
+    const u64 base = (u64)tile * kXsTileItems;
+    for (int b = 0; b < kXsTileItems / kXsBatch; b++) {
+        const u64 i0 = base + (u64)b * kXsBatch;
+        if (i0 >= n) break;                                          // uniform
+        // ---- key counts of my 4 items (slab j holds items i0 + j*256 ..): one packed scan gives every item its
+        // position in the sub-batch's key sequence (16 bits per slab: a slab has at most 256 * 32 keys)
+        u64 item[kXsIpt];
+        u32 c[kXsIpt];
+        u64 packed = 0;
+#pragma unroll
+        for (int j = 0; j < kXsIpt; j++) {
+            item[j] = i0 + (u64)j * kBlock + threadIdx.x;
+            c[j] = item[j] < n ? (u32)cnt8[item[j]] : 0u;
+            packed |= (u64)c[j] << (16 * j);
+        }
+        u64 ptot;
+        const u64 pex = block_excl_scan<u64>(packed, s_w, &ptot);     // (barriers inside: also fences the previous sub-batch)
+        u32 o[kXsIpt], tot = 0;
+#pragma unroll
+        for (int j = 0; j < kXsIpt; j++) {
+            o[j] = tot + (u32)((pex >> (16 * j)) & 0xFFFFu);
+            tot += (u32)((ptot >> (16 * j)) & 0xFFFFu);
+        }
+        for (u32 win = 0; win == 0 || win < tot; win += kXsWin) {     // windows of the key sequence (almost always one)
+            // ---- walk: the 4 chains of a lane advance together; every step is 4 independent gathers
+            bool act[kXsIpt];
+            u32 cur[kXsIpt], pos[kXsIpt];
+            u64 rec[kXsIpt], ib[kXsIpt];
+#pragma unroll
+            for (int j = 0; j < kXsIpt; j++) {
+                act[j] = item[j] < n && (c[j] ? (o[j] < win + kXsWin && o[j] + c[j] > win) : win == 0);
+                cur[j] = gen.start(act[j] ? item[j] : 0);
+            }
+#pragma unroll
+            for (int j = 0; j < kXsIpt; j++) rec[j] = gen.node(cur[j]);
+#pragma unroll
+            for (int j = 0; j < kXsIpt; j++) {
+                pos[j] = o[j] - win;                                   // may wrap below zero: the window test below is unsigned
+                ib[j] = act[j] ? gen.item_bits(item[j]) : 0;
+                if (act[j] && gen.owns(rec[j])) {
+                    if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = gen.key_own(cur[j], ib[j]);
+                    pos[j]++;
+                }
+            }
+            for (;;) {
+                bool m[kXsIpt], any = false;
+                u32 nx[kXsIpt];
+#pragma unroll
+                for (int j = 0; j < kXsIpt; j++) { m[j] = act[j] && gen.more(rec[j]); any = any || m[j]; nx[j] = m[j] ? gen.next(rec[j]) : 0u; }
+                if (!any) break;
+                u64 nrec[kXsIpt];
+#pragma unroll
+                for (int j = 0; j < kXsIpt; j++) nrec[j] = gen.node(nx[j]);       // unconditional: 4 loads in flight per lane
+#pragma unroll
+                for (int j = 0; j < kXsIpt; j++) {
+                    if (m[j]) {
+                        if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = gen.key_step(rec[j], nx[j], ib[j]);
+                        pos[j]++;
+                        rec[j] = nrec[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kXsIpt; j++) if (act[j]) gen.finish(item[j], rec[j]);
+            __syncthreads();
+            // ---- rank the window's keys by the digit and write them out (the body of k_rs_scatter)
+            const u32 hn = tot - win < (u32)kXsWin ? tot - win : (u32)kXsWin;
+            if (hn == 0) continue;                                    // uniform (tot == 0)
+            const u32 rpw = ((hn + 63) / 64 + 3) / 4;                // rows per wave: every wave takes a contiguous share
+            for (int d = threadIdx.x; d < (kBlock / 64) * NB; d += kBlock) (&s_cnt[0][0])[d] = 0;
+            u64 key[ROWS];
+            u32 idx[ROWS];
+#pragma unroll
+            for (int q = 0; q < ROWS; q++) {
+                const u32 t = ((u32)w * rpw + q) * 64 + lane;
+                key[q] = ((u32)q < rpw && t < hn) ? s_cells[t] : 0ull;
+            }
+            __syncthreads();
+            volatile u32 *cnt = &s_cnt[w][0];
+#pragma unroll
+            for (int q = 0; q < ROWS; q++) {
+                const u32 t = ((u32)w * rpw + q) * 64 + lane;
+                const bool valid = (u32)q < rpw && t < hn;
+                const u32 d = (u32)key[q] & dmask;
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int bb = 0; bb < DB; bb++) {
+                    unsigned long long mk = __ballot((d >> bb) & 1u);
+                    peers &= ((d >> bb) & 1u) ? mk : ~mk;
+                }
+                const u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+                u32 old = 0;
+                if (valid && below == 0) {
+                    old = cnt[d];
+                    cnt[d] = old + (u32)__popcll(peers);
+                }
+                const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+                old = (u32)__shfl((int)old, leader);
+                idx[q] = old + below;
+            }
+            __syncthreads();
+            {   // thread t owns bins [t*BPT, (t+1)*BPT): wave bases, round-local digit starts, global bases
+                u32 cw[BPT][4], tt[BPT], sum = 0;
+#pragma unroll
+                for (int e = 0; e < BPT; e++) {
+                    const int d = threadIdx.x * BPT + e;
+                    tt[e] = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { cw[e][k] = d < NB ? s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
+                    sum += tt[e];
+                }
+                u32 incl = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    u32 v = (u32)__shfl_up((int)incl, off);
+                    if (lane >= off) incl += v;
+                }
+                if (lane == 63) s_wsum[w] = incl;
+                __syncthreads();
+                u32 start = incl - sum;
+                for (int k = 0; k < w; k++) start += s_wsum[k];
+#pragma unroll
+                for (int e = 0; e < BPT; e++) {
+                    const int d = threadIdx.x * BPT + e;
+                    if (d < NB) {
+                        s_cnt[0][d] = start;
+                        s_cnt[1][d] = start + cw[e][0];
+                        s_cnt[2][d] = start + cw[e][0] + cw[e][1];
+                        s_cnt[3][d] = start + cw[e][0] + cw[e][1] + cw[e][2];
+                        const u64 g = s_goff[d];
+                        s_gbase[d] = g - (u64)start;
+                        s_goff[d] = g + tt[e];
+                        start += tt[e];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < ROWS; q++) {
+                const u32 t = ((u32)w * rpw + q) * 64 + lane;
+                if ((u32)q < rpw && t < hn) s_cells[idx[q] + s_cnt[w][(u32)key[q] & dmask]] = key[q];   // in place: the round's keys are in registers
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ROWS; j++) {
+                const u32 t = (u32)j * kBlock + threadIdx.x;
+                if (t < hn) {
+                    const u64 k = s_cells[t];
+                    out[s_gbase[(u32)k & dmask] + t] = k;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+// Phase 1: count.  Returns the number of keys; plan.ok tells whether expand_sort may follow (else the caller expands
+// by other means; the plan's buffers are released either way by plan.release()).
+template <class GEN>
+inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char *name = "expand") {
+    plan = XsPlan();
+    plan.n = n; plan.bits = bits;
+    if (n == 0) { plan.ok = true; return 0; }
+    // 9-bit first digit when that saves a pass over all keys (the later passes take 8 bits each)
+    plan.db = (bits > 8 && (bits - 9 + 7) / 8 < (bits - 8 + 7) / 8) ? 9 : 8;
+    const int NB = 1 << plan.db;
+    const u32 dmask = bits >= plan.db ? (u32)NB - 1u : (1u << bits) - 1u;
+    plan.tiles = (u32)((n + kXsTileItems - 1) / kXsTileItems);
+    plan.cnt8 = (u8 *)dev_alloc(n);
+    plan.counts = (u32 *)dev_alloc((u64)NB * plan.tiles * sizeof(u32));
+    plan.offsets = (u64 *)dev_alloc((u64)NB * plan.tiles * sizeof(u64));
+    u32 chunks = (plan.tiles + kRsChunk - 1) / kRsChunk;
+    u32 *chunk_sums = (u32 *)dev_alloc((u64)NB * chunks * sizeof(u32));
+    u64 *chunk_off = (u64 *)dev_alloc((u64)NB * chunks * sizeof(u64));
+    u64 *scal = (u64 *)dev_alloc(16);
+    dev_memset(scal, 0, 16);
+    prof_begin(std::string(name) + ".xcount");
+    if (plan.db == 9) hipLaunchKernelGGL((k_xs_count<GEN, 9>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, n, gen, dmask, plan.cnt8, plan.counts, (u32 *)scal);
+    else hipLaunchKernelGGL((k_xs_count<GEN, 8>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, n, gen, dmask, plan.cnt8, plan.counts, (u32 *)scal);
+    prof_end();
+    after_launch(name);
+    if (plan.db == 9) rs_offsets<512>(plan.counts, plan.tiles, chunk_sums, chunk_off, plan.offsets, scal + 1, name);
+    else rs_offsets<256>(plan.counts, plan.tiles, chunk_sums, chunk_off, plan.offsets, scal + 1, name);
+    u64 h[2];
+    d2h(h, scal, 16);
+    dev_free(chunk_sums); dev_free(chunk_off); dev_free(scal);
+    plan.maxc = (u32)h[0];
+    plan.E = h[1];
+    plan.ok = plan.maxc <= 32;
+    return plan.E;
+}
+// Phase 2: generate + first pass into buf_a, remaining passes ping-pong; returns 0 if the result is in buf_a, 1 if in buf_b
+template <class GEN>
+inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char *name = "expand") {
+    if (!plan.ok) throw Error(-71, "expand_sort: plan not usable");
+    if (plan.n == 0) return 0;                 // (with E == 0 the walk still runs: cells() has side effects)
+    const int NB = 1 << plan.db;
+    const u32 dmask = plan.bits >= plan.db ? (u32)NB - 1u : (1u << plan.bits) - 1u;
+    // XCD-contiguous tile ranges were measured 7 % SLOWER for this kernel on the 10 GB build (32.8 vs 30.6 ms at level 0,
+    // 16.9 vs 14.8 at level 1): the round-robin deal already lets the 8 L2s share every digit's write front; opt-in only
+    static const int xcd_aware = getenv("GRLBWT_XCD_MAP") ? 1 : 0;
+    prof_begin(std::string(name) + ".xscatter", plan.E * 8);
+    if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+    else hipLaunchKernelGGL((k_xs_scatter<GEN, 8>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+    prof_end();
+    after_launch(name);
+    if (plan.bits <= plan.db || plan.E == 0) return 0;
+    return sort_keys_fwd(buf_a, buf_b, plan.E, plan.db, plan.bits, name);
+}
+
 // Sorts n pairs by key bits [begin_bit, end_bit).  Buffers a/b ping-pong; returns
 // 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b).
 template <class K, class V>
@@ -1207,11 +1636,7 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
         prof_end();
         after_launch(name);
-        hipLaunchKernelGGL(k_rs_chunk_sums, dim3(chunks), dim3(kBlock), 0, rt().stream, counts, tiles, chunk_sums);
-        after_launch(name);
-        exclusive_scan_async<u64, RsChunkIn>((u64)256 * chunks, RsChunkIn{chunk_sums, chunks}, chunk_off, nullptr, nullptr, name);
-        hipLaunchKernelGGL(k_rs_tile_offsets, dim3(chunks), dim3(kBlock), 0, rt().stream, counts, chunk_off, tiles, chunks, offsets);
-        after_launch(name);
+        rs_offsets<256>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
         prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
         hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
                            shift, dmask, offsets, tiles);
@@ -1230,6 +1655,9 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
 template <class K>
 inline int sort_keys(K *keys_a, K *keys_b, u64 n, int begin_bit, int end_bit, const char *name = "radix_sort") {
     return sort_pairs<K, NoVal>(keys_a, (NoVal *)nullptr, keys_b, (NoVal *)nullptr, n, begin_bit, end_bit, name);
+}
+inline int sort_keys_fwd(u64 *a, u64 *b, u64 n, int begin_bit, int end_bit, const char *name) {
+    return sort_keys<u64>(a, b, n, begin_bit, end_bit, name);
 }
 
 }   // namespace prim

@@ -132,6 +132,12 @@ class Communicator:
             return 1
 
 
+def pool_flags(comm):
+    """Context flags for a build whose buffers are handed to the communication library: with RCCL the engine takes its
+    device memory from plain hipMalloc slabs (engine.FLAG_CLASSIC_POOL), not from the on-demand virtual-memory arena."""
+    return engine.FLAG_CLASSIC_POOL if (comm.device.type == "cuda" and not comm.stage) else 0
+
+
 def shard_records(cells, rank, size, sep=None):
     """Contiguous record range of `cells` (numpy array of whole strings) for `rank`: the reference's
     thread_ranges split (parsing_strategies.h:208-214), by string count."""
@@ -139,11 +145,25 @@ def shard_records(cells, rank, size, sep=None):
     sep = cells[-1] if sep is None else sep
     ends = np.flatnonzero(cells == sep)
     n_str = len(ends)
+    if n_str < size:       # every rank computes the same verdict: nobody is left waiting in a collective
+        raise ValueError("%d strings cannot be sharded over %d ranks (a rank would hold no record)" % (n_str, size))
     lo_s = (n_str * rank) // size
     hi_s = (n_str * (rank + 1)) // size
     lo = 0 if lo_s == 0 else int(ends[lo_s - 1]) + 1
     hi = int(ends[hi_s - 1]) + 1 if hi_s > 0 else 0
     return cells[lo:hi]
+
+
+def agree_or_raise(err, device, group=None):
+    """All ranks learn whether any rank failed a local step; every rank then raises (its own error, or a notice that a
+    peer failed) before the next collective."""
+    bad = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=device)
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if int(bad.item()):
+        if err is not None:
+            raise err
+        raise engine.GrlbwtError(-22, "another rank rejected its shard")
 
 
 def dist_build(ctx, comm):
@@ -168,7 +188,14 @@ def grl_bwt_algo_sharded(shard, cell_bytes=1, device="cpu", lib=None, flags=0, g
     if int(n_local.item()) >= 0xFFFFFF00:
         flags |= engine.FLAG_FORCE_IDX64           # collection-wide positions/frequencies need 64 bits
     index = dev.index if dev.type == "cuda" and dev.index is not None else 0
-    with engine.Context(index, flags, lib) as ctx:
-        ctx.upload(shard, cell_bytes)
+    with engine.Context(index, flags | pool_flags(comm), lib) as ctx:
+        # the shard-local checks of the upload (ill-formed shard, empty shard) must not leave the other ranks waiting in
+        # the first collective of the build: the verdict is agreed on first
+        err = None
+        try:
+            ctx.upload(shard, cell_bytes)
+        except engine.GrlbwtError as e:
+            err = e
+        agree_or_raise(err, dev, group)
         dist_build(ctx, comm)
         return ctx.result_bytes()

@@ -14,6 +14,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libgrlbwt_hip.so")
 FLAG_KEEP_LEVELS = 1
 FLAG_SYNC_DEBUG = 2
 FLAG_FORCE_IDX64 = 4
+FLAG_CLASSIC_POOL = 8
 
 OK = 0
 EILLFORMED = -84
@@ -21,7 +22,7 @@ EILLFORMED = -84
 # every symbol include/grlbwt_hip.h declares
 ABI_SYMBOLS = [
     "grlbwt_abi_version", "grlbwt_backend_name", "grlbwt_strerror", "grlbwt_last_error", "grlbwt_ctx_create", "grlbwt_ctx_destroy",
-    "grlbwt_ctx_set_stream", "grlbwt_text_upload", "grlbwt_text_attach_device", "grlbwt_get_stats",
+    "grlbwt_ctx_set_stream", "grlbwt_text_upload", "grlbwt_text_load_file", "grlbwt_text_attach_device", "grlbwt_get_stats",
     "grlbwt_parse_round", "grlbwt_parse_phase", "grlbwt_round_info_get", "grlbwt_induce_first",
     "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
     "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
@@ -114,6 +115,7 @@ def load_library(path=None, allow_test_standin=False):
     L.grlbwt_ctx_destroy.restype = None
     L.grlbwt_ctx_set_stream.argtypes = [vp, vp]
     L.grlbwt_text_upload.argtypes = [vp, vp, u64, i32]
+    L.grlbwt_text_load_file.argtypes = [vp, C.c_char_p, i32]
     L.grlbwt_text_attach_device.argtypes = [vp, vp, u64, i32]
     L.grlbwt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.grlbwt_parse_round.argtypes = [vp, C.POINTER(RoundInfo), C.POINTER(i32)]
@@ -195,6 +197,11 @@ class Context:
                                    else np.asarray(data).view(np.uint8).reshape(-1))
         self._keep = buf
         self._ck(self.L.grlbwt_text_upload(self._h, buf.ctypes.data_as(C.c_void_p), len(buf) // cell_bytes, cell_bytes))
+
+    def load_file(self, path, cell_bytes=1):
+        """collection_stats + first-round input straight from a file of raw cells (pinned, overlapped upload)."""
+        self._keep = None
+        self._ck(self.L.grlbwt_text_load_file(self._h, os.fsencode(path), cell_bytes))
 
     def attach_device(self, dev_ptr, n_cells, cell_bytes=1, keepalive=None):
         """Use cells already resident in HBM (e.g. a torch tensor's data_ptr())."""

@@ -47,6 +47,9 @@ extern "C" {
 /* ctx flags */
 #define GRLBWT_FLAG_KEEP_LEVELS 1u   /* keep every level's text and BWT for parity inspection        */
 #define GRLBWT_FLAG_SYNC_DEBUG 2u    /* synchronise after every kernel launch (fault localisation)   */
+#define GRLBWT_FLAG_FORCE_IDX64 4u   /* 64-bit positions/lengths whatever the input size (sharded collections, tests) */
+#define GRLBWT_FLAG_CLASSIC_POOL 8u  /* device memory from hipMalloc slabs, not from the on-demand virtual-memory arena:
+                                      * for buffers that are handed to a communication library (multi-process RCCL) */
 
 typedef struct grlbwt_ctx grlbwt_ctx;
 
@@ -109,6 +112,11 @@ int grlbwt_ctx_set_stream(grlbwt_ctx *ctx, void *hip_stream);
  * the i_file_stream reads of the first round (file_streams.hpp:93-105) ---------- */
 /* copy n_cells cells of cell_bytes in {1,2,4,8} from host memory to HBM and scan them */
 int grlbwt_text_upload(grlbwt_ctx *ctx, const void *host_cells, uint64_t n_cells, int cell_bytes);
+/* the same from a file of raw cells (the reference's i_file_stream + collection_stats, file_streams.hpp:93-105,
+ * utils.cpp:100-189): chunks are read into pinned staging buffers by reader threads and copied to HBM while the next
+ * chunk is read; for byte cells the symbol histogram is taken per chunk on the device behind the copies.  A file whose
+ * size is 0 or not a multiple of cell_bytes is ill formed (GRLBWT_EILLFORMED). */
+int grlbwt_text_load_file(grlbwt_ctx *ctx, const char *path, int cell_bytes);
 /* use cells already resident in HBM (borrowed until the context is reset/destroyed; 16-byte aligned) */
 int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes);
 int grlbwt_get_stats(const grlbwt_ctx *ctx, grlbwt_stats *out);
@@ -141,6 +149,7 @@ int grlbwt_result_size(const grlbwt_ctx *ctx, uint64_t *image_bytes, uint64_t *n
 /* device pointer of the .rl_bwt image (16-byte header + records), valid until reset/destroy */
 int grlbwt_result_device_ptr(const grlbwt_ctx *ctx, const void **dev_ptr);
 int grlbwt_result_download(const grlbwt_ctx *ctx, void *host_out, uint64_t capacity);
+/* (pinned double-buffered download, the file is written while the next chunk comes down) */
 int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path);
 
 /* ---- .rl_bwt consumers: scripts/grl2plain.cpp (expand the runs) + scripts/reverse_bwt.cpp with

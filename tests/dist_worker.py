@@ -40,12 +40,27 @@ def main():
         torch.cuda.synchronize()
         comm = gdist.Communicator(dev)
         flags = engine.FLAG_FORCE_IDX64 if reads * 151 >= 0xFFFFFF00 else 0
-        with engine.Context(dev.index or 0, flags, lib) as ctx:
+        with engine.Context(dev.index or 0, flags | gdist.pool_flags(comm), lib) as ctx:
             ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
             gdist.dist_build(ctx, comm)
             out = ctx.result_bytes()
         with open(os.path.join(out_dir, "illumina_dev.rank%d.md5" % rank), "w") as f:
             f.write("%s %d" % (hashlib.md5(out).hexdigest(), len(out)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if case == "illformed":
+        # rank 1 holds a shard that does not end with the separator: EVERY rank must raise (no rank may be left waiting
+        # in the first collective of the build)
+        good = workloads.sampled_reads(400, 50, 3000, seed=3).tobytes()
+        shard = good if rank != 1 else good[:-1]
+        try:
+            gdist.grl_bwt_algo_sharded(shard, 1, device, lib, 0)
+            verdict = "returned"
+        except engine.GrlbwtError as e:
+            verdict = "raised %d" % e.code
+        with open(os.path.join(out_dir, "illformed.rank%d" % rank), "w") as f:
+            f.write(verdict)
         dist.barrier()
         dist.destroy_process_group()
         return

@@ -64,6 +64,14 @@ inline void dev_free(void *p) { std::free(p); }
 inline void h2d(void *d, const void *h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void d2h(void *h, const void *d, size_t n) { if (n) std::memcpy(h, d, n); }
 inline void d2d(void *dst, const void *src, size_t n) { if (n) std::memmove(dst, src, n); }
+inline void *pinned_alloc(size_t n) { void *p = std::malloc(n ? n : 16); if (!p) throw Error(-12, "malloc"); return p; }
+inline void pinned_free(void *p) { std::free(p); }
+inline void h2d_async(void *d, const void *h, size_t n) { if (n) std::memcpy(d, h, n); }
+inline void d2h_async(void *h, const void *d, size_t n) { if (n) std::memcpy(h, d, n); }
+struct Fence { bool armed = false; };
+inline void fence_record(Fence &f) { f.armed = true; }
+inline void fence_wait(Fence &f) { f.armed = false; }
+inline void fence_destroy(Fence &) {}
 inline void dev_memset(void *d, int v, size_t n) { if (n) std::memset(d, v, n); }
 
 inline u32 atomic_add(u32 *p, u32 v) { u32 o = *p; *p += v; return o; }
@@ -115,6 +123,7 @@ inline void exclusive_scan_nosync(u64 n, F in, T *out, bool store_total_at_n = f
     if (store_total_at_n) out[n] = acc;
 }
 inline void pool_trim() {}
+inline void pool_classic() {}
 inline void pool_reserve(size_t) {}
 inline u64 pool_stage_begin() { return 0; }
 inline void pool_stage_end(u64, const void *) {}
@@ -155,6 +164,7 @@ inline T exclusive_scan_emit(u64 n, F in, E emit, const char * = "") {
     for (u64 i = 0; i < n; i++) { T v = (T)in(i); emit(i, acc, v); acc += v; }
     return acc;
 }
+inline void byte_histogram_accumulate(const u8 *p, u64 n, u64 *d_hist) { for (u64 i = 0; i < n; i++) d_hist[p[i]]++; }
 inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
     std::memset(hist_host, 0, 256 * 8);
     for (u64 i = 0; i < n; i++) hist_host[p[i]]++;
@@ -192,6 +202,51 @@ inline int sort_keys(K *keys_a, K *keys_b, u64 n, int begin_bit, int end_bit, co
     K *dst = (passes % 2 == 0) ? keys_a : keys_b;
     std::memcpy(dst, v.data(), n * sizeof(K));
     return passes % 2 == 0 ? 0 : 1;
+}
+
+// expand + multi-split (serial): same contract as the HIP version
+struct XsPlan {
+    bool ok = false;
+    u64 n = 0, E = 0;
+    u32 maxc = 0;
+    int bits = 0, db = 8;
+    void release() {}
+};
+template <class GEN, class F>
+inline void xs_walk(const GEN &gen, u64 i, bool with_bits, F put) {
+    const u32 cur = gen.start(i);
+    u64 rec = gen.node(cur);
+    const u64 ib = with_bits ? gen.item_bits(i) : 0;
+    if (gen.owns(rec)) put(gen.key_own(cur, ib));
+    while (gen.more(rec)) {
+        const u32 nx = gen.next(rec);
+        put(gen.key_step(rec, nx, ib));
+        rec = gen.node(nx);
+    }
+    if (with_bits) gen.finish(i, rec);
+}
+template <class GEN>
+inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char * = "") {
+    plan = XsPlan();
+    plan.n = n; plan.bits = bits;
+    for (u64 i = 0; i < n; i++) {
+        u32 c = 0;
+        xs_walk(gen, i, false, [&](u64) { c++; });
+        plan.E += c;
+        if (c > plan.maxc) plan.maxc = c;
+    }
+    // the stand-in has no staging limit; GRLBWT_SIM_XS_MAXC lets a test push items over the HIP limit's fallback branch
+    const char *lim = getenv("GRLBWT_SIM_XS_MAXC");
+    plan.ok = plan.maxc <= (lim ? (u32)atoi(lim) : 32u);
+    return plan.E;
+}
+template <class GEN>
+inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char * = "") {
+    if (!plan.ok) throw Error(-71, "expand_sort: plan not usable");
+    u64 e = 0;
+    for (u64 i = 0; i < plan.n; i++) xs_walk(gen, i, true, [&](u64 k) { buf_a[e++] = k; });
+    if (e != plan.E) throw Error(-71, "expand_sort: generator produced a different number of keys");
+    return sort_keys<u64>(buf_a, buf_b, plan.E, 0, plan.bits);
 }
 
 }   // namespace prim

@@ -61,3 +61,17 @@ def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkey
     _run(2, sim, "uniform", tmp_path, 29591)
     data = open(tmp_path / "uniform.input", "rb").read()
     assert open(tmp_path / "uniform.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+
+
+def test_ill_formed_shard_fails_on_every_rank(sim, tmp_path):
+    """A shard-local validation error is agreed on before the first collective: all ranks raise, nobody hangs."""
+    _run(3, sim, "illformed", tmp_path, 29593)
+    got = [open(tmp_path / ("illformed.rank%d" % r)).read() for r in range(3)]
+    assert got[1] == "raised -84" and got[0].startswith("raised") and got[2].startswith("raised"), got
+
+
+def test_fewer_strings_than_ranks_is_rejected():
+    import numpy as np
+    from grlbwt_amd import dist as gdist
+    with pytest.raises(ValueError):
+        gdist.shard_records(np.frombuffer(b"AC\nGT\n", dtype=np.uint8), 0, 3)

@@ -125,3 +125,33 @@ def test_invert_image_round_trip(sim, kind, w):
             out = np.zeros(data.size, dtype=data.dtype)
             n = ctx.invert_image(ctx.result_device_ptr(), nb, w, out.ctypes.data, data.size)   # stand-in: device == host
             assert n == data.size and np.array_equal(out, data)
+
+
+def test_unfused_expansion_branch(sim, oracle_mod, monkeypatch):
+    """The HIP engine falls back to count + scan + expand + split when a run would drop more cells than the fused
+    kernel stages in LDS (> 32); the stand-in's limit is lowered to take that branch on ordinary inputs."""
+    monkeypatch.setenv("GRLBWT_SIM_XS_MAXC", "1")
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+
+
+def test_file_in_file_out(sim, oracle_mod, tmp_path):
+    """grlbwt_text_load_file / grlbwt_result_write_file (the CLI's path): chunked staging, histogram taken per chunk."""
+    for data, w in ((workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1),
+                    (workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2), (b"\n", 1)):
+        fi, fo = tmp_path / "in.bin", tmp_path / "out.rl_bwt"
+        fi.write_bytes(data)
+        with engine.Context(0, 0, sim) as ctx:
+            ctx.load_file(str(fi), w)
+            st = ctx.stats()
+            ctx.build()
+            ctx.write_file(str(fo))
+        assert fo.read_bytes() == oracle_mod.rl_bwt(data, w)
+        assert st["n_syms"] == len(data) // w
+    bad = tmp_path / "odd.bin"
+    bad.write_bytes(b"\x01\x00\x02")
+    with engine.Context(0, 0, sim) as ctx:
+        with pytest.raises(engine.IllFormedInput):
+            ctx.load_file(str(bad), 2)                # size not a multiple of the cell width
+        with pytest.raises(engine.GrlbwtError):
+            ctx.load_file(str(tmp_path / "missing.bin"), 1)

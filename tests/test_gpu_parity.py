@@ -274,12 +274,13 @@ def test_idx64_build_round_trip_4_3GB(hip):
 
 
 def test_sharded_equals_single_gpu_image(hip, tmp_path):
-    """bench.py's N > 1 path on this single-GPU box: the SAME Illumina-style collection (2,000,000 x 150 bp, 302 MB) built
-    by one context and by two record shards (two ranks sharing cuda:0, gloo transport) must give identical .rl_bwt bytes."""
+    """bench.py's N > 1 path on this single-GPU box: the SAME Illumina-style collection (a 1 GB instance of the headline
+    distribution: 6,622,517 x 150 bp from a 33 Mbp genome) built by one context and by two record shards (two ranks
+    sharing cuda:0, gloo transport) must give identical .rl_bwt bytes."""
     import subprocess
     import sys
     import torch
-    reads, genome = 2000000, 10000000
+    reads, genome = 6622517, 33000000
     text = workloads.sampled_reads_torch(reads, 150, genome, seed=20260003, device="cuda:0")
     torch.cuda.synchronize()
     with engine.Context(0, 0, hip) as ctx:
