@@ -733,6 +733,7 @@ struct Runs {
     DBuf<u32> sym;
     DBuf<idx_t> len;
     u64 R = 0;
+    u64 n = 0;            // symbols described (set by merge_runs)
 };
 
 // merge adjacent equal symbols (bwt_io.h push_back/inc_freq_last idiom): -> maximal runs.
@@ -755,6 +756,7 @@ static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merg
     DBuf<idx_t> ostart(n + 1);
     HeadLen tot = prim::exclusive_scan_emit<HeadLen>(n, HeadLenIn{sym, len}, MergeEmitFn{sym, n, hsym.p, ostart.p, merged_index}, "merge_runs.scan");
     u64 R = (u64)tot.a;
+    out.n = (u64)tot.b;
     out.len.alloc(R);
     prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
     if (R == n) out.sym = std::move(hsym);
@@ -927,6 +929,138 @@ struct AtomFn {
         idx_t e = Tpos[k + 1] < b ? Tpos[k + 1] : b;
         osym[x] = term[k];
         olen[x] = e - s;
+    }
+};
+// ---- pass C without materialised segments --------------------------------------------------------------------
+// Output order = pre-BWT order with every HOCC run replaced by the cells of its buckets.  A "segment" is a non-HOCC
+// pre-BWT run or a cell; segment index of cell t: nhb[j] + t (j = pre-BWT run of its bucket), of pre-BWT run j:
+// nhb[j] + #cells of buckets in front of it.  TAKE segments (TAKE cells, BWT-marker runs) tile the T axis (the symbols
+// of BWT_{r+1}); X = T prefix of a segment = (TAKE lengths of the cells before it) + (BWT-marker lengths of the pre-BWT
+// runs before it).  A TAKE segment [a, b) becomes one atom per run of BWT_{r+1} it touches.  First atom of a segment:
+//     abase = g + #(run starts of BWT_{r+1} strictly inside TAKE segments in front of it)
+//           = g + (#run starts in (0, X)) - (#positions in (0, X) that are a run start AND a TAKE segment start)
+// both counts are ranks in bit-vectors over the T axis (n_{r+1} bits): nothing of segment size is scanned twice, no
+// segment or atom-count arrays exist, and only the cells' TAKE prefix (one scan) is stored.
+typedef prim::Pair<idx_t, idx_t> HoccBwt;      // (HOCC-marker symbols, BWT-marker symbols) scanned together over the pre-BWT
+struct PreScanIn {
+    const u32 *sym; const idx_t *len; u32 hocc_code, bwt_code;
+    GRL_DEV HoccBwt operator()(u64 j) const {
+        u32 s = sym[j];
+        return HoccBwt(s == hocc_code ? len[j] : (idx_t)0, s == bwt_code ? len[j] : (idx_t)0);
+    }
+};
+template <class TC>
+struct CellTakeIn {       // TAKE length of a cell (0 for literal cells)
+    CellView c; u32 take_code;
+    GRL_DEV TC operator()(u64 t) const { return c.sym(t) == take_code ? (TC)c.len(t) : (TC)0; }
+};
+// first cell whose bucket is >= u (cells are sorted by bucket)
+GRL_DEV u64 cell_lower_bound(const CellView &c, u64 E, u32 u) {
+    u64 lo = 0, hi = E;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (c.key(mid) < u) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+template <class TC>
+struct PrePlaceFn {       // non-HOCC pre-BWT runs: segment index, T prefix; BWT-marker runs mark their T start
+    const u32 *psym; const HoccBwt *PHB; const idx_t *nhb; const u32 *u_to_p; u64 M; CellView c; u64 E; const TC *Tc;
+    u32 hocc_code, bwt_code;
+    idx_t *pre_g; idx_t *pre_x; u64 *sw;
+    GRL_DEV void operator()(u64 j) const {
+        u32 s = psym[j];
+        if (s == hocc_code) return;
+        u64 ustar = lower_bound<u32>(u_to_p, M, (u32)j);           // metasymbols whose pre-BWT run lies in front of j
+        u64 cs = cell_lower_bound(c, E, (u32)ustar);                 // ... and their cells
+        u64 x = (u64)PHB[j].b + (u64)Tc[cs];
+        pre_g[j] = (idx_t)((u64)nhb[j] + cs);
+        pre_x[j] = (idx_t)x;
+        if (s == bwt_code) prim::atomic_or(&sw[x >> 6], 1ull << (x & 63));
+    }
+};
+template <class TC>
+struct CellTakeBitsFn {   // TAKE cells mark their T start; one lane per 16 consecutive cells (increasing positions: few words)
+    CellView c; const u32 *u_to_p; const HoccBwt *PHB; const TC *Tc; u64 E; u32 take_code; u64 *sw;
+    GRL_DEV void operator()(u64 q) const {
+        u64 t0 = q * 16, t1 = t0 + 16 < E ? t0 + 16 : E;
+        u64 cur = ~0ull, m = 0;
+        for (u64 t = t0; t < t1; t++) {
+            if (c.sym(t) != take_code) continue;
+            u64 x = (u64)Tc[t] + (u64)PHB[u_to_p[c.key(t)]].b;
+            u64 w = x >> 6;
+            if (w != cur) { if (m) prim::atomic_or(&sw[cur], m); m = 0; cur = w; }
+            m |= 1ull << (x & 63);
+        }
+        if (m) prim::atomic_or(&sw[cur], m);
+    }
+};
+struct CoincFn {          // sw &= tw, position 0 excluded: the positions that are a run start AND a TAKE segment start
+    const u64 *tw; u64 *sw;
+    GRL_DEV void operator()(u64 i) const { u64 v = sw[i] & tw[i]; if (i == 0) v &= ~1ull; sw[i] = v; }
+};
+// atoms of one segment; a TAKE segment touching more than kInlineAtoms runs is queued for the wide kernel
+static constexpr u32 kInlineAtoms = 16;
+struct BigSeg { u64 abase, a, b, k0; };
+struct AtomEmitter {
+    const u64 *tw; const idx_t *tb; const u64 *cw; const idx_t *cb; const idx_t *Tpos; const u32 *term;
+    u32 *osym; idx_t *olen; BigSeg *big; u32 *big_n; u32 big_cap;
+    GRL_DEV u64 abase_of(u64 g, u64 x) const {
+        return x ? g + (rank1(tw, tb, x) - 1) - rank1(cw, cb, x) : g;
+    }
+    GRL_DEV void literal(u64 g, u64 x, u32 sym, idx_t len) const {
+        u64 o = abase_of(g, x);
+        osym[o] = sym; olen[o] = len;
+    }
+    GRL_DEV void take(u64 g, u64 a, u64 len) const {
+        const u64 b = a + len, o = abase_of(g, a);
+        const u64 k0 = rank1(tw, tb, a + 1) - 1;                     // run of BWT_{r+1} holding T position a
+        const u64 cnt = rank1(tw, tb, b) - (k0 + 1) + 1;
+        if (cnt > kInlineAtoms) {
+            u32 slot = prim::atomic_add(big_n, 1u);
+            if (slot < big_cap) big[slot] = BigSeg{o, a, b, k0};
+            return;
+        }
+        u64 s = a;
+        for (u64 x = 0; x < cnt; x++) {
+            u64 e = (u64)Tpos[k0 + x + 1];
+            if (e > b) e = b;
+            osym[o + x] = term[k0 + x]; olen[o + x] = (idx_t)(e - s);
+            s = e;
+        }
+    }
+};
+template <class TC>
+struct CellAtomsFn {
+    CellView c; const u32 *u_to_p; const HoccBwt *PHB; const idx_t *nhb; const TC *Tc; u32 take_code; AtomEmitter em;
+    GRL_DEV void operator()(u64 t) const {
+        const u32 j = u_to_p[c.key(t)];
+        const u64 g = (u64)nhb[j] + t, x = (u64)Tc[t] + (u64)PHB[j].b;
+        const u32 sy = c.sym(t);
+        if (sy == take_code) em.take(g, x, (u64)c.len(t));
+        else em.literal(g, x, sy, c.len(t));
+    }
+};
+struct PreAtomsFn {
+    const u32 *psym; const idx_t *plen; const idx_t *pre_g; const idx_t *pre_x; u32 hocc_code, bwt_code; AtomEmitter em;
+    GRL_DEV void operator()(u64 j) const {
+        const u32 s = psym[j];
+        if (s == hocc_code) return;
+        if (s == bwt_code) em.take((u64)pre_g[j], (u64)pre_x[j], (u64)plen[j]);
+        else em.literal((u64)pre_g[j], (u64)pre_x[j], s, plen[j]);
+    }
+};
+struct BigCountIn {
+    const BigSeg *big; const u64 *tw; const idx_t *tb;
+    GRL_DEV u64 operator()(u64 i) const { return rank1(tw, tb, big[i].b) - big[i].k0; }
+};
+struct BigAtomsFn {       // one lane per atom of the queued segments
+    const BigSeg *big; const u64 *bbase; u64 nbig; const idx_t *Tpos; const u32 *term; u32 *osym; idx_t *olen;
+    GRL_DEV void operator()(u64 y) const {
+        const u64 i = upper_bound<u64>(bbase, nbig, y) - 1;
+        const BigSeg sg = big[i];
+        const u64 x = y - bbase[i], k = sg.k0 + x;
+        u64 s = (u64)Tpos[k], e = (u64)Tpos[k + 1];
+        if (s < sg.a) s = sg.a;
+        if (e > sg.b) e = sg.b;
+        osym[sg.abase + x] = term[k]; olen[sg.abase + x] = (idx_t)(e - s);
     }
 };
 struct UnpackCellFn {   // (sym<<32 | len) payload carried through the radix split
@@ -1926,7 +2060,7 @@ class Engine {
         prim::rt().tag = r;
         prim::rt().phase = 'i';
         LevelData &L = levels[r];
-        const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
+        const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, take_code = bwt_code;
         const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
         LevelInfo &I = linfo[r];
         I.R_next = R; I.P = P;
@@ -2027,52 +2161,21 @@ class Engine {
             }
         }
         I.E = E;
-        const CellView cells{sfused.p, kb, lb, skey.p, spack.p, ssym.p, slen.p};
+        // the cells move to the engine: pass C drops them before its run merge (peak memory)
+        c_skey = std::move(skey); c_ssym = std::move(ssym); c_slen = std::move(slen); c_spack = std::move(spack);
+        c_sfused = std::move(sfused); c_gp = std::move(gp);
+        const CellView cells{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p};
         eoff.release();
         if (prim::rt().profile) {              // SURVEY 8d's E'_r and E_r for the roofline accounting (bench.py)
-            I.Esteps = E - prim::reduce_sum<u64>(R, TakeCountIn{bwt.sym.p, gp.p}, "stat.take_cells");
+            I.Esteps = E - prim::reduce_sum<u64>(R, TakeCountIn{bwt.sym.p, c_gp.p}, "stat.take_cells");
             I.Emerged = prim::reduce_sum<u64>(E, CellHeadIn{cells}, "stat.merged_cells");
         }
         {
             StageTimer st(&tm.ind_assemble);
-            DBuf<idx_t> PH(P + 1), nhb(P + 1), Hpos(E + 1), Tpos(R + 1);
-            prim::exclusive_scan_nosync<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code}, PH.p, true, "asm.PH");
-            u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.prebwt.sym.p, hocc_code}, nhb.p, true, "asm.nhb");
-            u64 Hsum = (u64)prim::exclusive_scan<idx_t>(E, CellLenIn{cells}, Hpos.p, true, "asm.Hpos");
-            u64 Tsum = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
-            u64 PHsum = (u64)PH.get(P);
-            if (Hsum != PHsum) throw prim::Error(-71, "induction: induced symbols do not match the pre-BWT (level " +
-                                                            std::to_string(r) + ": " + std::to_string(Hsum) + " vs " +
-                                                            std::to_string(PHsum) + ")");
-            const u64 G = NH + E;
-            I.G = G;
-            DBuf<u32> seg_sym(G);
-            DBuf<idx_t> seg_len(G);
-            prim::for_each(P, SegFromPreFn{L.prebwt.sym.p, L.prebwt.len.p, PH.p, nhb.p, Hpos.p, E, bwt_code, hocc_code,
-                                           take_code, seg_sym.p, seg_len.p}, "asm.seg_pre");
-            prim::for_each(E, SegFromCellFn{cells, L.u_to_p.p, nhb.p, seg_sym.p, seg_len.p}, "asm.seg_cell");
-            Hpos.release(); skey.release(); ssym.release(); slen.release(); spack.release(); sfused.release(); gp.release();
-            DBuf<idx_t> Toff(G + 1), abase(G + 1);      // only now: the cells are gone (this level's peak memory)
-            u64 Tused = (u64)prim::exclusive_scan<idx_t>(G, CondLenIn{seg_sym.p, seg_len.p, take_code}, Toff.p, true, "asm.Toff");
-            if (Tused != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) +
-                                                           ": " + std::to_string(Tused) + " vs " + std::to_string(Tsum) + ")");
-            RankBits tbits, abits;
-            build_rankbits(tbits, Tpos.p, R, Tsum + 1, "asm.tbits");        // run boundaries of BWT_{r+1} on the T axis
-            prim::for_each(G, StoreFn<AtomCountIn>{AtomCountIn{seg_sym.p, seg_len.p, Toff.p, tbits.words.p, tbits.base.p, take_code}, abase.p},
-                           "asm.atom_count");
-            u64 A = (u64)prim::exclusive_scan<idx_t>(G, IdxIn<idx_t>{abase.p}, abase.p, true, "asm.atom_scan");
-            I.A = A;
-            build_rankbits(abits, abase.p, G, A + 1, "asm.abits");          // first atom of every segment on the atom axis
-            DBuf<u32> osym(A);
-            DBuf<idx_t> olen(A);
-            prim::for_each(A, AtomFn{seg_sym.p, seg_len.p, Toff.p, Tpos.p, abase.p, term.p, tbits.words.p, tbits.base.p,
-                                     abits.words.p, abits.base.p, take_code, osym.p, olen.p}, "asm.atoms");
-            // everything but the atoms can go before the merge allocates its scan arrays (peak memory)
-            seg_sym.release(); seg_len.release(); Toff.release(); abase.release(); Tpos.release(); PH.release(); nhb.release();
-            tbits.words.release(); tbits.base.release(); abits.words.release(); abits.base.release();
-            term.release();
-            bwt.sym.release(); bwt.len.release();
-            bwt = merge_runs(osym.p, olen.p, A);
+            DBuf<idx_t> Tpos(R + 1);
+            const u64 Tsum = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
+            if (Tsum < 0xFFFFFFFFull) assemble_t<u32>(L, I, cells, E, Tpos, Tsum, term, r);      // the cells' TAKE prefix fits 32 bits
+            else assemble_t<u64>(L, I, cells, E, Tpos, Tsum, term, r);
         }
         bwt_level = r;
         I.R = bwt.R;
@@ -2081,6 +2184,69 @@ class Engine {
         // the level's grammar is no longer needed
         L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.prebwt.sym.release(); L.prebwt.len.release();
     }
+    // pass C (exact_ind_phase.cpp:287-361): BWT_r from the pre-BWT, the induced cells and the rewritten BWT_{r+1}
+    template <class TC>
+    void assemble_t(LevelData &L, LevelInfo &I, const CellView &cells, u64 E, DBuf<idx_t> &Tpos, u64 Tsum, DBuf<u32> &term, int r) {
+        const u32 bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
+        const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
+        // pre-BWT coordinates: (HOCC symbols, BWT-marker symbols) and the number of non-HOCC runs in front of every run
+        DBuf<HoccBwt> PHB(P + 1);
+        DBuf<idx_t> nhb(P + 1);
+        prim::exclusive_scan_nosync<HoccBwt>(P, PreScanIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code, bwt_code}, PHB.p, true, "asm.pre_scan");
+        const u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.prebwt.sym.p, hocc_code}, nhb.p, true, "asm.nhb");
+        const u64 PBsum = (u64)PHB.get(P).b;
+        // the cells' TAKE prefix
+        DBuf<TC> Tc(E + 1);
+        const u64 TCsum = (u64)prim::exclusive_scan<TC>(E, CellTakeIn<TC>{cells, take_code}, Tc.p, true, "asm.take_scan");
+        if (PBsum + TCsum != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
+                                                              std::to_string(PBsum + TCsum) + " vs " + std::to_string(Tsum) + ")");
+        const u64 G = NH + E;
+        I.G = G;
+        // bit-vectors over the T axis: run starts of BWT_{r+1}; TAKE segment starts -> coincidences
+        RankBits tbits, cbits;
+        build_rankbits(tbits, Tpos.p, R, Tsum + 1, "asm.tbits");
+        const u64 nw = Tsum / 64 + 2;
+        cbits.words.alloc(nw);
+        cbits.base.alloc(nw + 1);
+        cbits.words.zero();
+        DBuf<idx_t> pre_g(P), pre_x(P);
+        prim::for_each(P, PrePlaceFn<TC>{L.prebwt.sym.p, PHB.p, nhb.p, L.u_to_p.p, M, cells, E, Tc.p, hocc_code, bwt_code,
+                                         pre_g.p, pre_x.p, cbits.words.p}, "asm.pre_place");
+        prim::for_each((E + 15) / 16, CellTakeBitsFn<TC>{cells, L.u_to_p.p, PHB.p, Tc.p, E, take_code, cbits.words.p}, "asm.take_bits");
+        prim::for_each(nw, CoincFn{tbits.words.p, cbits.words.p}, "asm.coinc");
+        const u64 Ctot = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{cbits.words.p}, cbits.base.p, true, "asm.coinc_rank");
+        const u64 A = G + (R ? R - 1 : 0) - Ctot;           // every run start in (0, Tsum) that is no TAKE segment start cuts one atom
+        I.A = A;
+        DBuf<u32> osym(A);
+        DBuf<idx_t> olen(A);
+        const u32 big_cap = (u32)std::min<u64>(A / kInlineAtoms + 16, 0x7FFFFFFFull);
+        DBuf<BigSeg> big(big_cap);
+        DBuf<u32> big_n(1);
+        big_n.zero();
+        const AtomEmitter em{tbits.words.p, tbits.base.p, cbits.words.p, cbits.base.p, Tpos.p, term.p, osym.p, olen.p, big.p, big_n.p, big_cap};
+        prim::for_each(E, CellAtomsFn<TC>{cells, L.u_to_p.p, PHB.p, nhb.p, Tc.p, take_code, em}, "asm.cell_atoms");
+        prim::for_each(P, PreAtomsFn{L.prebwt.sym.p, L.prebwt.len.p, pre_g.p, pre_x.p, hocc_code, bwt_code, em}, "asm.pre_atoms");
+        const u64 nbig = (u64)big_n.get(0);
+        if (nbig > big_cap) throw prim::Error(-71, "induction: wide-segment queue overflow (level " + std::to_string(r) + ")");
+        if (nbig) {                                          // TAKE segments spanning many runs: one lane per atom
+            DBuf<u64> bbase(nbig + 1);
+            const u64 nb_atoms = prim::exclusive_scan<u64>(nbig, BigCountIn{big.p, tbits.words.p, tbits.base.p}, bbase.p, true, "asm.big_scan");
+            prim::for_each(nb_atoms, BigAtomsFn{big.p, bbase.p, nbig, Tpos.p, term.p, osym.p, olen.p}, "asm.big_atoms");
+        }
+        // everything but the atoms can go before the merge allocates its scan arrays (peak memory)
+        Tc.release(); pre_g.release(); pre_x.release(); PHB.release(); nhb.release(); big.release();
+        tbits.words.release(); tbits.base.release(); cbits.words.release(); cbits.base.release();
+        Tpos.release(); term.release();
+        release_cells();
+        bwt.sym.release(); bwt.len.release();
+        bwt = merge_runs(osym.p, olen.p, A);
+        if (bwt.n != L.info.n_in) throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(bwt.n) +
+                                                              " symbols, the level has " + std::to_string(L.info.n_in));
+    }
+    // the induced cells of the level being assembled (owned here so that pass C can drop them before the run merge)
+    DBuf<u32> c_skey, c_ssym; DBuf<idx_t> c_slen; DBuf<u64> c_spack, c_sfused, c_gp;
+    void release_cells() { c_skey.release(); c_ssym.release(); c_slen.release(); c_spack.release(); c_sfused.release(); c_gp.release(); }
+
     void induce_phase() {                                        // exact_ind_phase.cpp:674-697
         first_bwt();
         while (bwt_level > 0) induce_level();

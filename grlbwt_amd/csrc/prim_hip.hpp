@@ -219,6 +219,7 @@ struct Pool {
     std::map<void *, std::pair<int, size_t>> live;   // ptr -> (slab, length)
     size_t live_bytes = 0, peak_bytes = 0, slab_bytes = 0, next_slab = (size_t)1 << 30;
     int arena_state = 0;                      // 0 not tried, 1 in use, -1 unavailable / switched off
+    bool classic = false;                     // hipMalloc slabs only (GRLBWT_FLAG_CLASSIC_POOL)
 };
 inline Pool &pool() {
     static Pool p;
@@ -238,26 +239,21 @@ inline void pool_stage_end(u64 old_peak, const void *stage_id) {
                        P.peak_bytes / 1e9, P.live_bytes / 1e9);
     if (old_peak > P.peak_bytes) P.peak_bytes = old_peak;
 }
-inline void pool_classic() { if (pool().arena_state == 0) pool().arena_state = -1; }   // hipMalloc slabs only (before the first allocation)
+inline void pool_classic() { pool().classic = true; }    // hipMalloc slabs only (takes effect when no arena is live)
 inline u64 pool_peak_bytes() { return pool().peak_bytes; }
 inline u64 pool_reserved_bytes() { return pool().slab_bytes; }
 inline bool pool_disabled() {
     static int d = getenv("GRLBWT_NOPOOL") ? 1 : 0;
     return d != 0;
 }
-inline void pool_trim() {                    // give every fully free slab back to the runtime
+inline void pool_trim() {                    // give every fully free hipMalloc slab back to the runtime
     Pool &P = pool();
+    // The arena stays mapped for the life of the process and is reused by the next context.  Returning its backing
+    // (hipMemUnmap + hipMemRelease, with or without freeing the address range) and mapping new memory later was
+    // measured UNSAFE on this stack: the third context of a process read zeros where its kernels had just written
+    // (tests/test_consumers.py under -m gpu; the same tests pass with hipMalloc slabs).  Nothing is ever unmapped.
     for (auto &sl : P.slabs) {
-        if (sl.arena) {                      // unmap the backing, keep the (free) address range
-            if (sl.size && sl.free_list.size() == 1 && sl.free_list.begin()->second == sl.size) {
-                size_t off = 0;
-                for (auto &ch : sl.chunks) { (void)hipMemUnmap(sl.base + off, ch.second); (void)hipMemRelease(ch.first); off += ch.second; }
-                sl.chunks.clear();
-                P.slab_bytes -= sl.size;
-                sl.size = 0; sl.free_list.clear();
-            }
-            continue;
-        }
+        if (sl.arena) continue;
         if (sl.base && sl.free_list.size() == 1 && sl.free_list.begin()->second == sl.size) {
             (void)hipFree(sl.base);
             P.slab_bytes -= sl.size;
@@ -271,8 +267,8 @@ inline void pool_trim() {                    // give every fully free slab back 
 // ---- arena: reserve once, back on demand
 inline bool arena_create(Pool &P) {
     if (P.arena_state != 0) return P.arena_state > 0;
+    if (P.classic || getenv("GRLBWT_POOL_CLASSIC")) return false;
     P.arena_state = -1;
-    if (getenv("GRLBWT_POOL_CLASSIC")) return false;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) { (void)hipGetLastError(); return false; }
     const size_t gib = (size_t)1 << 30;
