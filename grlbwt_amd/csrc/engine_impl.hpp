@@ -122,7 +122,7 @@ struct PopcIn {
 };
 
 // ------------------------------------------------- a3: phrase hashing/count
-// phrase table: u64 keys (tag:12 | len:12 | pos+1:40, 0 = empty) and idx_t counts.  Struct-of-arrays when few phrases
+// phrase table: u64 keys (tag:11 | ends-a-string:1 | len:12 | pos+1:40, 0 = empty) and idx_t counts.  Struct-of-arrays when few phrases
 // are hot (level 0): the keys are written once and then read-mostly, so they stay cacheable, while the counts take
 // the atomic traffic (16-byte slots were measured 4x slower there: the atomics on a hot phrase's count kept
 // invalidating the line every probe of that phrase has to read).  16-byte (key, count) slots when most phrases are
@@ -131,6 +131,7 @@ static constexpr u64 kPosBits = 40;
 static constexpr u64 kPosMask = (1ull << kPosBits) - 1;
 static constexpr u64 kLenSat = 4095;               // lengths >= 4095 saturate; verified through the start bits
 GRL_HD u64 key_len(u64 k) { return (k >> kPosBits) & 0xFFFull; }
+GRL_HD bool key_lastT(u64 k) { return (k >> (kPosBits + 12)) & 1ull; }     // the phrase ends with a terminator (known to the inserting lane)
 GRL_HD u64 key_pos(u64 k) { return (k & kPosMask) - 1; }
 
 // Phrase hash: two 32-bit multiplicative lanes per symbol (the walk is instruction-bound: a 64-bit
@@ -216,14 +217,14 @@ struct HashInsertFn {
         }
         if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; return prim::kNoBucket; }
         u64 len = e - p + 1;
-        u32 found = find_or_insert(p, len, ph.finish(len));
+        u32 found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
         if (found != prim::kNoBucket) out_slot[ord] = found;
         return found;
     }
     // claim or find the table slot of the phrase t[p .. p+len) whose (finalised) hash is h
-    GRL_DEV u32 find_or_insert(u64 p, u64 len, u64 h) const {
+    GRL_DEV u32 find_or_insert(u64 p, u64 len, u64 h, bool lastT) const {
         u64 lsat = len < kLenSat ? len : kLenSat;
-        u64 hi = ((h >> 52) << 12) | lsat;          // tag:12 | len:12
+        u64 hi = ((h >> 53) << 13) | ((u64)lastT << 12) | lsat;          // tag:11 | ends-a-string:1 | len:12
         u64 mine = (hi << kPosBits) | (p + 1);
         u64 slot = h & mask;
         // NOTE: the result is carried in `found` and returned after the loop.  Returning from inside
@@ -279,7 +280,7 @@ struct CompactTableFn {
             len = e - pos + 1;
         }
         ph_pos[k] = pos; ph_freq[k] = counts[s * cs]; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
-        ph_lastT[k] = ops.isT(t[pos + len - 1]) ? 1 : 0;
+        ph_lastT[k] = key_lastT(k64) ? 1 : 0;          // carried in the key: no gather of the phrase's last cell
     }
 };
 struct LenIn {
@@ -567,11 +568,12 @@ struct FlagIn {
 struct GroupEmitFn {
     const u8 *gflag; const u32 *grank; const u32 *pidx; const u32 *gmin; const idx_t *gacc; const u32 *gstart; const u32 *perm;
     u32 bwt_code, hocc_code;
-    u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq; u32 *u_to_p0;
+    u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq; u32 *u_to_p0; u32 *pu0;
     GRL_DEV void operator()(u64 g) const {
         u8 f = gflag[g];
         if (!(f & GF_VALID)) return;
         u32 j = pidx[g];
+        pu0[j] = grank[g];           // metasymbols in front of this pre-BWT run (grank is the exclusive count of ranked groups)
         u32 s = gmin[g];
         if (f & GF_RANKED) {
             s = (f & GF_MULTI) ? hocc_code : bwt_code;
@@ -585,6 +587,10 @@ struct GroupEmitFn {
     }
 };
 
+struct PreToMetaFn {     // merged pre-BWT run -> number of metasymbols in front of it (the value of its first member)
+    const u32 *pu0; const u32 *merged; u32 *p_to_u;
+    GRL_DEV void operator()(u64 j) const { if (j == 0 || merged[j] != merged[j - 1]) p_to_u[merged[j]] = pu0[j]; }
+};
 struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
     const u32 *u_to_p0; const u32 *merged; u32 *u_to_p;
     GRL_DEV void operator()(u64 u) const { u_to_p[u] = merged[u_to_p0[u]]; }
@@ -592,20 +598,22 @@ struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
 
 // ------------------------------------------------------------- a8: grammar
 // meta[q] = metasymbol of the suffix at dictionary position q if its group is ranked and has > 1 member (the marked
-// positions, phr_marks, exact_par_phase.cpp:203-205), else 0 (metasymbols are >= sigma3 > 0).  By dictionary position:
-// rank[q] = head slot of q's group, gid[slot] = dense group id, ginfo[g] = grank<<1 | marked -- two dependent gathers and
-// a coalesced store, after which the grammar walk below reads meta[] sequentially and needs no further lookups.
+// positions, phr_marks, exact_par_phase.cpp:203-205), else 0 (metasymbols are >= sigma3 > 0), so that the grammar walk
+// below reads meta[] sequentially and needs no further lookups.  Filled from the SORTED side: slot t knows its dense
+// group gid[t] (non-decreasing: ginfo[] is read in order) and only the members of marked groups scatter through perm[]
+// (the earlier form, by dictionary position through rank[q] -> gid -> ginfo, was two dependent random gathers for
+// every position: 57 ms of the 10 GB build).
 struct PackGroupInfoFn {
     const u32 *grank; const u8 *gflag; u32 *ginfo;
     GRL_DEV void operator()(u64 g) const {       // grank < 2^30 (alphabet bound of the next level)
         ginfo[g] = (grank[g] << 1) | (((gflag[g] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1u : 0u);
     }
 };
-struct MetaPosFn {
-    const RankLen *rl; const u32 *gid; const u32 *ginfo; u32 sigma3; u32 *meta;
-    GRL_DEV void operator()(u64 q) const {
-        u32 gi = ginfo[gid[rl[q].rank]];
-        meta[q] = (gi & 1u) ? (gi >> 1) + sigma3 : 0u;
+struct MetaPosFn {         // by sorted slot t: gid[] and ginfo[] are read in order, only the marked suffixes scatter (meta[] zeroed before)
+    const u32 *perm; const u32 *gid; const u32 *ginfo; u32 sigma3; u32 *meta;
+    GRL_DEV void operator()(u64 t) const {
+        u32 gi = ginfo[gid[t]];
+        if (gi & 1u) meta[perm[t]] = (gi >> 1) + sigma3;
     }
 };
 struct GrammarFn {
@@ -960,41 +968,46 @@ GRL_DEV u64 cell_lower_bound(const CellView &c, u64 E, u32 u) {
     while (lo < hi) { u64 mid = (lo + hi) >> 1; if (c.key(mid) < u) lo = mid + 1; else hi = mid; }
     return lo;
 }
+GRL_DEV void mark_coincidence(const u64 *tw, u64 *cw, u64 x) {
+    if (x && ((tw[x >> 6] >> (x & 63)) & 1ull)) prim::atomic_or(&cw[x >> 6], 1ull << (x & 63));
+}
 template <class TC>
 struct PrePlaceFn {       // non-HOCC pre-BWT runs: segment index, T prefix; BWT-marker runs mark their T start
     const u32 *psym; const HoccBwt *PHB; const idx_t *nhb; const u32 *u_to_p; u64 M; CellView c; u64 E; const TC *Tc;
+    const u32 *p_to_u; const idx_t *first_cell;      // optional O(1) forms of the two searches (nullptr: search)
     u32 hocc_code, bwt_code;
-    idx_t *pre_g; idx_t *pre_x; u64 *sw;
+    idx_t *pre_g; idx_t *pre_x; const u64 *tw; u64 *cw;
     GRL_DEV void operator()(u64 j) const {
         u32 s = psym[j];
         if (s == hocc_code) return;
-        u64 ustar = lower_bound<u32>(u_to_p, M, (u32)j);           // metasymbols whose pre-BWT run lies in front of j
-        u64 cs = cell_lower_bound(c, E, (u32)ustar);                 // ... and their cells
+        u64 ustar = p_to_u ? (u64)p_to_u[j] : lower_bound<u32>(u_to_p, M, (u32)j);      // metasymbols whose pre-BWT run lies in front of j
+        u64 cs = first_cell ? (u64)first_cell[ustar] : cell_lower_bound(c, E, (u32)ustar);   // ... and their cells
         u64 x = (u64)PHB[j].b + (u64)Tc[cs];
         pre_g[j] = (idx_t)((u64)nhb[j] + cs);
         pre_x[j] = (idx_t)x;
-        if (s == bwt_code) prim::atomic_or(&sw[x >> 6], 1ull << (x & 63));
+        if (s == bwt_code) mark_coincidence(tw, cw, x);
     }
 };
+// Emit side of the TAKE-prefix scan over the cells: stores the prefix and marks, on the T axis, the TAKE cells whose
+// start is also a run start of BWT_{r+1} (the coincidences; a separate pass that marked every TAKE start and ANDed the
+// two bit-vectors afterwards cost 54 ms at level 0 of the 10 GB build, this costs one bit test per TAKE cell)
 template <class TC>
-struct CellTakeBitsFn {   // TAKE cells mark their T start; one lane per 16 consecutive cells (increasing positions: few words)
-    CellView c; const u32 *u_to_p; const HoccBwt *PHB; const TC *Tc; u64 E; u32 take_code; u64 *sw;
-    GRL_DEV void operator()(u64 q) const {
-        u64 t0 = q * 16, t1 = t0 + 16 < E ? t0 + 16 : E;
-        u64 cur = ~0ull, m = 0;
-        for (u64 t = t0; t < t1; t++) {
-            if (c.sym(t) != take_code) continue;
-            u64 x = (u64)Tc[t] + (u64)PHB[u_to_p[c.key(t)]].b;
-            u64 w = x >> 6;
-            if (w != cur) { if (m) prim::atomic_or(&sw[cur], m); m = 0; cur = w; }
-            m |= 1ull << (x & 63);
-        }
-        if (m) prim::atomic_or(&sw[cur], m);
+struct TakeScanEmitFn {
+    CellView c; const u32 *u_to_p; const HoccBwt *PHB; u32 take_code; u64 E; const u64 *tw; TC *Tc; u64 *cw;
+    GRL_DEV void operator()(u64 t, TC ex, TC v) const {
+        Tc[t] = ex;
+        if (t == E - 1) Tc[E] = ex + v;
+        if (c.sym(t) == take_code) mark_coincidence(tw, cw, (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b);
     }
 };
-struct CoincFn {          // sw &= tw, position 0 excluded: the positions that are a run start AND a TAKE segment start
-    const u64 *tw; u64 *sw;
-    GRL_DEV void operator()(u64 i) const { u64 v = sw[i] & tw[i]; if (i == 0) v &= ~1ull; sw[i] = v; }
+struct FirstCellFn {      // first_cell[m] = first cell whose bucket is >= m, for m in [0, M]: every bucket head fills the gap in front of it
+    CellView c; u64 E; u64 M; idx_t *first_cell;
+    GRL_DEV void operator()(u64 t) const {
+        const u32 k = c.key(t);
+        if (t == 0) { for (u64 m = 0; m <= k; m++) first_cell[m] = 0; }
+        else { const u32 pk = c.key(t - 1); for (u64 m = (u64)pk + 1; m <= k; m++) first_cell[m] = (idx_t)t; }
+        if (t == E - 1) for (u64 m = (u64)k + 1; m <= M; m++) first_cell[m] = (idx_t)E;
+    }
 };
 // atoms of one segment; a TAKE segment touching more than kInlineAtoms runs is queued for the wide kernel
 static constexpr u32 kInlineAtoms = 16;
@@ -1606,6 +1619,7 @@ struct LevelData {
     DBuf<u32> g0, g1;
     DBuf<u8> has_hocc;
     DBuf<u32> u_to_p;        // metasymbol -> index of the (merged) pre-BWT run emitted by its group
+    DBuf<u32> p_to_u;        // (merged) pre-BWT run -> number of metasymbols whose run lies in front of it (single-GPU dictionary stage)
     Runs prebwt;
     RoundInfo info;
 };
@@ -1943,19 +1957,22 @@ class Engine {
             L.has_hocc.alloc(M); repq.alloc(M);
             DBuf<u32> psym0(P0);
             DBuf<idx_t> plen0(P0);
-            DBuf<u32> u_to_p0(M), merged(P0);
+            DBuf<u32> u_to_p0(M), merged(P0), pu0(P0);
             prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code,
-                                          psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p}, "prebwt_emit");
+                                          psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p, pu0.p}, "prebwt_emit");
             L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
             L.u_to_p.alloc(M);
             prim::for_each(M, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
+            L.p_to_u.alloc(L.prebwt.R);
+            prim::for_each(P0, PreToMetaFn{pu0.p, merged.p, L.p_to_u.p}, "prebwt_map");
             // ---- a8: grammar ------------------------------------------------
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
             {
                 DBuf<u32> ginfo(G), meta(S);
                 prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, ginfo.p}, "grammar_ginfo");
-                prim::for_each(S, MetaPosFn{rl.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
+                meta.zero();
+                prim::for_each(S, MetaPosFn{perm.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
                 prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, meta.p, MD, L.g0.p, L.g1.p}, "grammar");
             }
             // ---- a9: metasymbol of every phrase --------------------------------
@@ -2182,7 +2199,7 @@ class Engine {
         I.n = L.info.n_in;
         if (keep_texts) keep_bwt(r);
         // the level's grammar is no longer needed
-        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.p_to_u.release(); L.prebwt.sym.release(); L.prebwt.len.release();
     }
     // pass C (exact_ind_phase.cpp:287-361): BWT_r from the pre-BWT, the induced cells and the rewritten BWT_{r+1}
     template <class TC>
@@ -2195,25 +2212,37 @@ class Engine {
         prim::exclusive_scan_nosync<HoccBwt>(P, PreScanIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code, bwt_code}, PHB.p, true, "asm.pre_scan");
         const u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.prebwt.sym.p, hocc_code}, nhb.p, true, "asm.nhb");
         const u64 PBsum = (u64)PHB.get(P).b;
-        // the cells' TAKE prefix
-        DBuf<TC> Tc(E + 1);
-        const u64 TCsum = (u64)prim::exclusive_scan<TC>(E, CellTakeIn<TC>{cells, take_code}, Tc.p, true, "asm.take_scan");
-        if (PBsum + TCsum != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
-                                                              std::to_string(PBsum + TCsum) + " vs " + std::to_string(Tsum) + ")");
-        const u64 G = NH + E;
-        I.G = G;
-        // bit-vectors over the T axis: run starts of BWT_{r+1}; TAKE segment starts -> coincidences
+        // bit-vectors over the T axis (n_{r+1} bits): run starts of BWT_{r+1}; TAKE segment starts that are run starts too
         RankBits tbits, cbits;
         build_rankbits(tbits, Tpos.p, R, Tsum + 1, "asm.tbits");
         const u64 nw = Tsum / 64 + 2;
         cbits.words.alloc(nw);
         cbits.base.alloc(nw + 1);
         cbits.words.zero();
+        // the cells' TAKE prefix (scan fused with the coincidence marks)
+        DBuf<TC> Tc(E + 1);
+        u64 TCsum = 0;
+        if (E) TCsum = (u64)prim::exclusive_scan_emit<TC>(E, CellTakeIn<TC>{cells, take_code},
+                                                           TakeScanEmitFn<TC>{cells, L.u_to_p.p, PHB.p, take_code, E, tbits.words.p, Tc.p, cbits.words.p},
+                                                           "asm.take_scan");
+        else Tc.zero();
+        if (PBsum + TCsum != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
+                                                              std::to_string(PBsum + TCsum) + " vs " + std::to_string(Tsum) + ")");
+        const u64 G = NH + E;
+        I.G = G;
         DBuf<idx_t> pre_g(P), pre_x(P);
-        prim::for_each(P, PrePlaceFn<TC>{L.prebwt.sym.p, PHB.p, nhb.p, L.u_to_p.p, M, cells, E, Tc.p, hocc_code, bwt_code,
-                                         pre_g.p, pre_x.p, cbits.words.p}, "asm.pre_place");
-        prim::for_each((E + 15) / 16, CellTakeBitsFn<TC>{cells, L.u_to_p.p, PHB.p, Tc.p, E, take_code, cbits.words.p}, "asm.take_bits");
-        prim::for_each(nw, CoincFn{tbits.words.p, cbits.words.p}, "asm.coinc");
+        {
+            // where the cells of the buckets in front of a pre-BWT run end: a table over the metasymbols when the runs are
+            // many (one pass over the cells), a binary search per run when they are few (level 0: 45 k runs, 2.6 G cells)
+            DBuf<idx_t> first_cell;
+            if (P * 32 > E && L.p_to_u.p && !getenv("GRLBWT_DBG_NOFIRSTCELL")) {
+                first_cell.alloc(M + 1);
+                if (E) prim::for_each(E, FirstCellFn{cells, E, M, first_cell.p}, "asm.first_cell");
+                else first_cell.zero();
+            }
+            prim::for_each(P, PrePlaceFn<TC>{L.prebwt.sym.p, PHB.p, nhb.p, L.u_to_p.p, M, cells, E, Tc.p, getenv("GRLBWT_DBG_NOPTOU") ? nullptr : L.p_to_u.p, first_cell.p,
+                                             hocc_code, bwt_code, pre_g.p, pre_x.p, tbits.words.p, cbits.words.p}, "asm.pre_place");
+        }
         const u64 Ctot = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{cbits.words.p}, cbits.base.p, true, "asm.coinc_rank");
         const u64 A = G + (R ? R - 1 : 0) - Ctot;           // every run start in (0, Tsum) that is no TAKE segment start cuts one atom
         I.A = A;
@@ -2784,7 +2813,7 @@ class Engine {
         if (got != hi - lo) throw prim::Error(-71, "dist induction: slice size mismatch (level " + std::to_string(r) + ")");
         bwt_level = r;
         I.R = bwt.R; I.n = n_r;
-        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.p_to_u.release(); L.prebwt.sym.release(); L.prebwt.len.release();
     }
 
     // gather the slices of BWT_0, restore maximal runs across rank boundaries, build the image
