@@ -122,7 +122,9 @@ struct PopcIn {
 };
 
 // ------------------------------------------------- a3: phrase hashing/count
-// phrase table: u64 keys (tag:11 | ends-a-string:1 | len:12 | pos+1:40, 0 = empty) and idx_t counts.  Struct-of-arrays when few phrases
+// phrase table: u64 keys and idx_t counts.  Two key forms (0 = empty):
+//   generic   0 | tag:10 | ends-a-string:1 | len:12 | pos+1:40      the phrase is compared through its representative occurrence
+//   exact     1 | len:3  | 0:4 | content:56                          byte cells, phrases of <= 7 cells: the key IS the phrase  Struct-of-arrays when few phrases
 // are hot (level 0): the keys are written once and then read-mostly, so they stay cacheable, while the counts take
 // the atomic traffic (16-byte slots were measured 4x slower there: the atomics on a hot phrase's count kept
 // invalidating the line every probe of that phrase has to read).  16-byte (key, count) slots when most phrases are
@@ -130,6 +132,7 @@ struct PopcIn {
 static constexpr u64 kPosBits = 40;
 static constexpr u64 kPosMask = (1ull << kPosBits) - 1;
 static constexpr u64 kLenSat = 4095;               // lengths >= 4095 saturate; verified through the start bits
+static constexpr u64 kExactKey = 1ull << 63;
 GRL_HD u64 key_len(u64 k) { return (k >> kPosBits) & 0xFFFull; }
 GRL_HD bool key_lastT(u64 k) { return (k >> (kPosBits + 12)) & 1ull; }     // the phrase ends with a terminator (known to the inserting lane)
 GRL_HD u64 key_pos(u64 k) { return (k & kPosMask) - 1; }
@@ -167,6 +170,16 @@ struct HashInsertFn {
     u32 *out_slot;    // [n_occ] slot of every phrase occurrence, text order
     u32 *scal;        // [1] error flag, [2..3] debug
     u64 n, n_occ;
+    u64 *rep_pos = nullptr;   // [capacity] exact keys: position of the occurrence that claimed the slot (the dictionary reads the phrase there)
+    // Byte cells: 4 phrases per lane at once through the exact-key path (process_batch).  A phrase of <= 7 cells is cut
+    // out of ONE unaligned 8-byte load with the start bits and a zero-byte test for the terminator -- no loop -- its
+    // bytes are the table key, so a probe that matches needs no look at a representative occurrence, and the text,
+    // start-bit and table loads of the 4 phrases are in flight together (the kernel waits on dependent gathers).
+    static constexpr bool kExact = FIRST && sizeof(cell_t) == 1;
+#ifndef GRL_HASH_BATCH
+#define GRL_HASH_BATCH 4
+#endif
+    static constexpr int kBatch = kExact ? GRL_HASH_BATCH : 1;
     static constexpr u64 kCh = 8 / sizeof(cell_t);    // cells per 8-byte chunk
     GRL_DEV static u64 load8(const cell_t *a) { u64 v; __builtin_memcpy(&v, a, 8); return v; }   // unaligned 8-byte load
     GRL_DEV bool same_phrase(u64 q, u64 p, u64 len, bool check_bits) const {
@@ -217,14 +230,98 @@ struct HashInsertFn {
         }
         if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; return prim::kNoBucket; }
         u64 len = e - p + 1;
-        u32 found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
+        u32 found;
+        if (kExact && len <= 7) {                  // same key form as process_batch: a phrase has ONE entry whichever path saw it
+            u64 content = 0;
+            for (u64 j = 0; j < len; j++) content |= (u64)t[p + j] << (8 * j);
+            const u64 mine = kExactKey | (len << 60) | content;
+            found = insert_exact(mine, p, exact_hash(mine) & mask, 0, false);
+        } else found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
         if (found != prim::kNoBucket) out_slot[ord] = found;
+        return found;
+    }
+    GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const {
+        constexpr int B = kBatch;
+        u64 chunk[B], wp[B], w0[B], w1[B], mine[B], idx[B], cur[B];
+        idx_t wb[B];
+        bool fast[B];
+        const bool can = n >= 8;
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            const u64 p = item[j];
+            fast[j] = valid[j] && can && p + 8 <= n;
+            const u64 pp = fast[j] ? p : 0;
+            chunk[j] = can ? load8(t + pp) : 0ull;
+            wp[j] = startbits[pp >> 6];
+            const u64 b1 = (pp + 1) >> 6;
+            w0[j] = startbits[b1];
+            w1[j] = startbits[b1 + 1];
+            wb[j] = wordbase[pp >> 6];
+        }
+        const u64 sepx = (u64)ops.sep * 0x0101010101010101ull;
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            const u64 p = item[j];
+            const u32 sh = (u32)((p + 1) & 63);
+            u64 bits = w0[j] >> sh;
+            if (sh) bits |= w1[j] << (64 - sh);
+            bits &= 0x7Full;                                            // start bits of cells p+1 .. p+7
+            const u64 x = chunk[j] ^ sepx;
+            const u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;     // lowest set bit: first terminator byte
+            const u32 tpos = z ? (u32)(__builtin_ctzll(z) >> 3) : 8u;  // cell index of the first terminator (8: none)
+            const u32 spos = bits ? (u32)__builtin_ctzll(bits) + 1u : 8u;
+            const u32 e = tpos == 0 ? 0u : (tpos < spos ? tpos : spos);  // last cell of the phrase
+            const u32 len = e + 1;
+            fast[j] = fast[j] && len <= 7;
+            const u64 content = chunk[j] & ((1ull << (8 * len)) - 1ull);
+            mine[j] = kExactKey | ((u64)len << 60) | content;
+            idx[j] = exact_hash(mine[j]) & mask;
+        }
+#pragma unroll
+        for (int j = 0; j < B; j++) cur[j] = prim::load_relaxed(&keys[(fast[j] ? idx[j] : 0) << ks]);
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            // (no continue/break/return inside divergent code here: see the note in find_or_insert)
+            const u64 p = item[j];
+            const bool ex = valid[j] && fast[j];
+            u32 found = prim::kNoBucket;
+            if (ex) found = insert_exact(mine[j], p, idx[j], cur[j], true);
+            if (ex && found != prim::kNoBucket) {
+                const u64 ord = (u64)wb[j] + (u64)__builtin_popcountll(wp[j] & ((1ull << (p & 63)) - 1ull));
+                if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; found = prim::kNoBucket; }
+                else out_slot[ord] = found;
+            }
+            if (valid[j] && !fast[j]) found = process(p);
+            slot[j] = found;
+        }
+    }
+    GRL_DEV static u64 exact_hash(u64 mine) {
+        u64 h = mine * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29;
+        return h;
+    }
+    // find or claim the slot of an exact key; (sl, c) = first slot and, if `have_first`, the key already loaded from it
+    GRL_DEV u32 insert_exact(u64 mine, u64 p, u64 sl, u64 c, bool have_first) const {
+        u32 found = prim::kNoBucket;
+        bool stop = false;                      // the table overflowed elsewhere: give up (the host re-runs the pass)
+        for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket && !stop; probes++) {
+            if (probes || !have_first) {
+                if (probes == 16 && prim::load_relaxed(&scal[1])) stop = true;
+                c = prim::load_relaxed(&keys[sl << ks]);
+            }
+            if (c == 0) {
+                u64 old = prim::atomic_cas(&keys[sl << ks], 0ull, mine);
+                if (old == 0) { c = mine; rep_pos[sl] = p; } else c = old;
+            }
+            if (c == mine) found = (u32)sl; else sl = (sl + 1) & mask;
+        }
+        if (found == prim::kNoBucket) scal[1] = 1;
         return found;
     }
     // claim or find the table slot of the phrase t[p .. p+len) whose (finalised) hash is h
     GRL_DEV u32 find_or_insert(u64 p, u64 len, u64 h, bool lastT) const {
         u64 lsat = len < kLenSat ? len : kLenSat;
-        u64 hi = ((h >> 53) << 13) | ((u64)lastT << 12) | lsat;          // tag:11 | ends-a-string:1 | len:12
+        u64 hi = ((h >> 54) << 13) | ((u64)lastT << 12) | lsat;          // tag:10 | ends-a-string:1 | len:12 (bit 63 of the key stays clear)
         u64 mine = (hi << kPosBits) | (p + 1);
         u64 slot = h & mask;
         // NOTE: the result is carried in `found` and returned after the loop.  Returning from inside
@@ -268,19 +365,31 @@ struct CompactTableFn {
     const u64 *startbits;
     const u64 *keys; const idx_t *counts; const u32 *slot_ph;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
-    int ks; u64 cs;
+    int ks; u64 cs; const u64 *rep_pos;
     GRL_DEV void operator()(u64 s) const {
         u64 k64 = keys[s << ks];
         if (!k64) return;
         u32 k = slot_ph[s];
-        u64 pos = key_pos(k64), len = key_len(k64);
-        if (len == kLenSat) {                      // saturated: walk to the phrase end
-            u64 e = pos;
-            for (;;) { if (ops.isT(t[e])) break; e++; if (bit_at(startbits, e)) break; }
-            len = e - pos + 1;
+        // (one exit: an early return from the first branch cost the ends-a-string flag of a few phrases in the 64-bit build
+        // -- the flag store of the second branch ran for lanes of the first; see the note in find_or_insert)
+        u64 pos, len;
+        bool lastT;
+        if (k64 & kExactKey) {                     // the key is the phrase: length and last cell come from the key, the position from rep_pos
+            len = (k64 >> 60) & 7ull;
+            pos = rep_pos[s];
+            lastT = ops.isT((cell_t)(k64 >> (8 * (len - 1))));
+        } else {
+            pos = key_pos(k64); len = key_len(k64);
+            lastT = key_lastT(k64);                // carried in the key: no gather of the phrase's last cell
+            if (len == kLenSat) {                  // saturated: walk to the phrase end
+                u64 e = pos;
+                bool more = true;
+                while (more) { if (ops.isT(t[e])) more = false; else { e++; if (bit_at(startbits, e)) more = false; } }
+                len = e - pos + 1;
+            }
         }
         ph_pos[k] = pos; ph_freq[k] = counts[s * cs]; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
-        ph_lastT[k] = key_lastT(k64) ? 1 : 0;          // carried in the key: no gather of the phrase's last cell
+        ph_lastT[k] = lastT ? 1 : 0;
     }
 };
 struct LenIn {
@@ -773,6 +882,38 @@ static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merg
     return out;
 }
 
+// the same over packed atoms  sym << lbits | len  (pass C writes 8 bytes per atom instead of 4 + sizeof(idx_t))
+struct AtomHeadLenIn {
+    const u64 *a; int lbits;
+    GRL_DEV HeadLen operator()(u64 t) const {
+        const u64 x = a[t];
+        return HeadLen((t == 0 || (x >> lbits) != (a[t - 1] >> lbits)) ? (idx_t)1 : (idx_t)0, (idx_t)(x & ((1ull << lbits) - 1ull)));
+    }
+};
+struct AtomMergeEmitFn {
+    const u64 *a; int lbits; u64 n;
+    u32 *osym; idx_t *ostart;
+    GRL_DEV void operator()(u64 t, HeadLen ex, HeadLen v) const {
+        if (v.a) { osym[ex.a] = (u32)(a[t] >> lbits); ostart[ex.a] = ex.b; }
+        if (t == n - 1) ostart[ex.a + v.a] = ex.b + v.b;
+    }
+};
+static inline Runs merge_atoms(const u64 *atoms, u64 n, int lbits) {
+    Runs out;
+    if (n == 0) { out.sym.alloc(0); out.len.alloc(0); return out; }
+    DBuf<u32> hsym(n);
+    DBuf<idx_t> ostart(n + 1);
+    HeadLen tot = prim::exclusive_scan_emit<HeadLen>(n, AtomHeadLenIn{atoms, lbits}, AtomMergeEmitFn{atoms, lbits, n, hsym.p, ostart.p}, "merge_runs.scan");
+    u64 R = (u64)tot.a;
+    out.n = (u64)tot.b;
+    out.len.alloc(R);
+    prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
+    if (R == n) out.sym = std::move(hsym);
+    else { out.sym.alloc(R); prim::d2d(out.sym.p, hsym.p, R * sizeof(u32)); }
+    out.R = R;
+    return out;
+}
+
 // --------------------------------------------------------- a12: parse2bwt
 struct CellSymFn {
     const u32 *t; u32 *sym; idx_t *len;
@@ -979,13 +1120,14 @@ struct PrePlaceFn {       // non-HOCC pre-BWT runs: segment index, T prefix; BWT
     idx_t *pre_g; idx_t *pre_x; const u64 *tw; u64 *cw;
     GRL_DEV void operator()(u64 j) const {
         u32 s = psym[j];
-        if (s == hocc_code) return;
-        u64 ustar = p_to_u ? (u64)p_to_u[j] : lower_bound<u32>(u_to_p, M, (u32)j);      // metasymbols whose pre-BWT run lies in front of j
-        u64 cs = first_cell ? (u64)first_cell[ustar] : cell_lower_bound(c, E, (u32)ustar);   // ... and their cells
-        u64 x = (u64)PHB[j].b + (u64)Tc[cs];
-        pre_g[j] = (idx_t)((u64)nhb[j] + cs);
-        pre_x[j] = (idx_t)x;
-        if (s == bwt_code) mark_coincidence(tw, cw, x);
+        if (s != hocc_code) {
+            u64 ustar = p_to_u ? (u64)p_to_u[j] : lower_bound<u32>(u_to_p, M, (u32)j);      // metasymbols whose pre-BWT run lies in front of j
+            u64 cs = first_cell ? (u64)first_cell[ustar] : cell_lower_bound(c, E, (u32)ustar);   // ... and their cells
+            u64 x = (u64)PHB[j].b + (u64)Tc[cs];
+            pre_g[j] = (idx_t)((u64)nhb[j] + cs);
+            pre_x[j] = (idx_t)x;
+            if (s == bwt_code) mark_coincidence(tw, cw, x);
+        }
     }
 };
 // Emit side of the TAKE-prefix scan over the cells: stores the prefix and marks, on the T axis, the TAKE cells whose
@@ -1000,43 +1142,53 @@ struct TakeScanEmitFn {
         if (c.sym(t) == take_code) mark_coincidence(tw, cw, (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b);
     }
 };
-struct FirstCellFn {      // first_cell[m] = first cell whose bucket is >= m, for m in [0, M]: every bucket head fills the gap in front of it
-    CellView c; u64 E; u64 M; idx_t *first_cell;
+// first_cell[m] = first cell whose bucket is >= m (m in [0, M]) = exclusive prefix of the bucket sizes.  The bucket heads
+// record where their bucket starts (+1: 0 = empty) and where the bucket in front of them ends; sizes -> one scan.
+// (Filling the gaps between heads by loops was quadratic at the deep levels: 24 cells, 65 M metasymbols.)
+struct BucketEdgesFn {
+    CellView c; u64 E; idx_t *bstart1; idx_t *bend;
     GRL_DEV void operator()(u64 t) const {
         const u32 k = c.key(t);
-        if (t == 0) { for (u64 m = 0; m <= k; m++) first_cell[m] = 0; }
-        else { const u32 pk = c.key(t - 1); for (u64 m = (u64)pk + 1; m <= k; m++) first_cell[m] = (idx_t)t; }
-        if (t == E - 1) for (u64 m = (u64)k + 1; m <= M; m++) first_cell[m] = (idx_t)E;
+        if (t == 0) bstart1[k] = 1;
+        else { const u32 pk = c.key(t - 1); if (pk != k) { bstart1[k] = (idx_t)(t + 1); bend[pk] = (idx_t)t; } }
+        if (t == E - 1) bend[k] = (idx_t)E;
     }
+};
+struct BucketSizeIn {
+    const idx_t *bstart1; const idx_t *bend;
+    GRL_DEV idx_t operator()(u64 m) const { return bstart1[m] ? bend[m] - (bstart1[m] - 1) : (idx_t)0; }
 };
 // atoms of one segment; a TAKE segment touching more than kInlineAtoms runs is queued for the wide kernel
 static constexpr u32 kInlineAtoms = 16;
 struct BigSeg { u64 abase, a, b, k0; };
 struct AtomEmitter {
     const u64 *tw; const idx_t *tb; const u64 *cw; const idx_t *cb; const idx_t *Tpos; const u32 *term;
-    u32 *osym; idx_t *olen; BigSeg *big; u32 *big_n; u32 big_cap;
+    u32 *osym; idx_t *olen; u64 *oatom; int lbits;      // oatom != nullptr: packed atoms sym << lbits | len
+    BigSeg *big; u32 *big_n; u32 big_cap;
     GRL_DEV u64 abase_of(u64 g, u64 x) const {
         return x ? g + (rank1(tw, tb, x) - 1) - rank1(cw, cb, x) : g;
     }
-    GRL_DEV void literal(u64 g, u64 x, u32 sym, idx_t len) const {
-        u64 o = abase_of(g, x);
-        osym[o] = sym; olen[o] = len;
+    GRL_DEV void put(u64 o, u32 sym, u64 len) const {
+        if (oatom) oatom[o] = ((u64)sym << lbits) | len;
+        else { osym[o] = sym; olen[o] = (idx_t)len; }
     }
+    GRL_DEV void literal(u64 g, u64 x, u32 sym, idx_t len) const { put(abase_of(g, x), sym, (u64)len); }
     GRL_DEV void take(u64 g, u64 a, u64 len) const {
         const u64 b = a + len, o = abase_of(g, a);
         const u64 k0 = rank1(tw, tb, a + 1) - 1;                     // run of BWT_{r+1} holding T position a
         const u64 cnt = rank1(tw, tb, b) - (k0 + 1) + 1;
+        // (if / else, no early return: hipcc 7.2 has let lanes of a branch that returned run the stores behind it)
         if (cnt > kInlineAtoms) {
             u32 slot = prim::atomic_add(big_n, 1u);
             if (slot < big_cap) big[slot] = BigSeg{o, a, b, k0};
-            return;
-        }
-        u64 s = a;
-        for (u64 x = 0; x < cnt; x++) {
-            u64 e = (u64)Tpos[k0 + x + 1];
-            if (e > b) e = b;
-            osym[o + x] = term[k0 + x]; olen[o + x] = (idx_t)(e - s);
-            s = e;
+        } else {
+            u64 s = a;
+            for (u64 x = 0; x < cnt; x++) {
+                u64 e = (u64)Tpos[k0 + x + 1];
+                if (e > b) e = b;
+                put(o + x, term[k0 + x], e - s);
+                s = e;
+            }
         }
     }
 };
@@ -1055,9 +1207,10 @@ struct PreAtomsFn {
     const u32 *psym; const idx_t *plen; const idx_t *pre_g; const idx_t *pre_x; u32 hocc_code, bwt_code; AtomEmitter em;
     GRL_DEV void operator()(u64 j) const {
         const u32 s = psym[j];
-        if (s == hocc_code) return;
-        if (s == bwt_code) em.take((u64)pre_g[j], (u64)pre_x[j], (u64)plen[j]);
-        else em.literal((u64)pre_g[j], (u64)pre_x[j], s, plen[j]);
+        if (s != hocc_code) {
+            if (s == bwt_code) em.take((u64)pre_g[j], (u64)pre_x[j], (u64)plen[j]);
+            else em.literal((u64)pre_g[j], (u64)pre_x[j], s, plen[j]);
+        }
     }
 };
 struct BigCountIn {
@@ -1065,7 +1218,7 @@ struct BigCountIn {
     GRL_DEV u64 operator()(u64 i) const { return rank1(tw, tb, big[i].b) - big[i].k0; }
 };
 struct BigAtomsFn {       // one lane per atom of the queued segments
-    const BigSeg *big; const u64 *bbase; u64 nbig; const idx_t *Tpos; const u32 *term; u32 *osym; idx_t *olen;
+    const BigSeg *big; const u64 *bbase; u64 nbig; const idx_t *Tpos; const u32 *term; AtomEmitter em;
     GRL_DEV void operator()(u64 y) const {
         const u64 i = upper_bound<u64>(bbase, nbig, y) - 1;
         const BigSeg sg = big[i];
@@ -1073,7 +1226,7 @@ struct BigAtomsFn {       // one lane per atom of the queued segments
         u64 s = (u64)Tpos[k], e = (u64)Tpos[k + 1];
         if (s < sg.a) s = sg.a;
         if (e > sg.b) e = sg.b;
-        osym[sg.abase + x] = term[k]; olen[sg.abase + x] = (idx_t)(e - s);
+        em.put(sg.abase + x, term[k], e - s);
     }
 };
 struct UnpackCellFn {   // (sym<<32 | len) payload carried through the radix split
@@ -1551,6 +1704,7 @@ struct SplitRunsFn {      // one lane per L-piece
     }
 };
 struct RunSymFn {         // for_each_agg protocol: every run is a work item, its bucket is its symbol
+    static constexpr int kBatch = 1;
     const u32 *rsym;
     GRL_DEV bool is_start(u64) const { return true; }
     GRL_DEV u32 process(u64 i) const { return rsym[i]; }
@@ -1770,11 +1924,12 @@ class Engine {
                 if (occ_s < 64) occ_s = 64;
                 u64 cap_s = 1024;
                 while (cap_s < 2 * occ_s) cap_s <<= 1;
-                DBuf<u64> tk(cap_s);
+                DBuf<u64> tk(cap_s), trep;
                 DBuf<idx_t> tc(cap_s);
+                if (HashInsertFn<cell_t, FIRST>::kExact) trep.alloc(cap_s);
                 tk.zero(); tc.zero(); scal.zero();
                 prim::for_each_agg(n_s, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0,
-                                                                    P.next_text.p, scal.p, n, n_occ},
+                                                                    P.next_text.p, scal.p, n, n_occ, trep.p},
                                    SlotCountAdd{tc.p, 1}, true, "hash_sample");
                 u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
                 frac = (double)d_s / (double)occ_s;
@@ -1785,7 +1940,7 @@ class Engine {
                 if (cap > cap_max) cap = cap_max;
             }
         }
-        DBuf<u64> keys;
+        DBuf<u64> keys, rep_pos;
         DBuf<idx_t> counts;
         // LDS pre-aggregation of the counts pays when few distinct phrases take most occurrences (level 0 of
         // DNA: 20 k phrases, 30 M occurrences); with mostly-distinct phrases the cache only thrashes.
@@ -1810,10 +1965,11 @@ class Engine {
                     cnt = counts.p;
                 }
                 counts_p = cnt;
+                if (HashInsertFn<cell_t, FIRST>::kExact) rep_pos.alloc(cap);          // (written by the lanes that claim a slot)
                 scal.zero();
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
                 launch_hash<cell_t, FIRST>(HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit, ks,
-                                                                     P.next_text.p, scal.p, n, n_occ}, cnt, cs, n, aggregate);
+                                                                     P.next_text.p, scal.p, n, n_occ, rep_pos.p}, cnt, cs, n, aggregate);
                 std::vector<u32> sc = scal.to_host(4);
                 if (sc[1] == 1) {
                     if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");
@@ -1837,7 +1993,7 @@ class Engine {
             P.D = D;
             P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
             prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, slot_ph.p, P.ph_pos.p,
-                                                              P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p, ks, cs}, "table_compact");
+                                                              P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p, ks, cs, rep_pos.p}, "table_compact");
             u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{P.ph_freq.p}, "dict_freq_check");
             if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
                                                            std::to_string(n_occ) + ")");
@@ -2237,8 +2393,10 @@ class Engine {
             DBuf<idx_t> first_cell;
             if (P * 32 > E && L.p_to_u.p && !getenv("GRLBWT_DBG_NOFIRSTCELL")) {
                 first_cell.alloc(M + 1);
-                if (E) prim::for_each(E, FirstCellFn{cells, E, M, first_cell.p}, "asm.first_cell");
-                else first_cell.zero();
+                DBuf<idx_t> bstart1(M), bend(M);
+                bstart1.zero(); bend.zero();
+                prim::for_each(E, BucketEdgesFn{cells, E, bstart1.p, bend.p}, "asm.first_cell");
+                prim::exclusive_scan_nosync<idx_t>(M, BucketSizeIn{bstart1.p, bend.p}, first_cell.p, true, "asm.first_cell");
             }
             prim::for_each(P, PrePlaceFn<TC>{L.prebwt.sym.p, PHB.p, nhb.p, L.u_to_p.p, M, cells, E, Tc.p, getenv("GRLBWT_DBG_NOPTOU") ? nullptr : L.p_to_u.p, first_cell.p,
                                              hocc_code, bwt_code, pre_g.p, pre_x.p, tbits.words.p, cbits.words.p}, "asm.pre_place");
@@ -2246,13 +2404,19 @@ class Engine {
         const u64 Ctot = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{cbits.words.p}, cbits.base.p, true, "asm.coinc_rank");
         const u64 A = G + (R ? R - 1 : 0) - Ctot;           // every run start in (0, Tsum) that is no TAKE segment start cuts one atom
         I.A = A;
-        DBuf<u32> osym(A);
-        DBuf<idx_t> olen(A);
+        // atoms: one packed word  sym << lbits | len  whenever a symbol and a length of this level fit 64 bits together
+        const int lbits = (int)bitlen64(L.info.n_in), sbits = (int)bitlen64((u64)L.sigma + 3);
+        const bool packed_atoms = lbits + sbits <= 64;
+        DBuf<u32> osym;
+        DBuf<idx_t> olen;
+        DBuf<u64> oatom;
+        if (packed_atoms) oatom.alloc(A); else { osym.alloc(A); olen.alloc(A); }
         const u32 big_cap = (u32)std::min<u64>(A / kInlineAtoms + 16, 0x7FFFFFFFull);
         DBuf<BigSeg> big(big_cap);
         DBuf<u32> big_n(1);
         big_n.zero();
-        const AtomEmitter em{tbits.words.p, tbits.base.p, cbits.words.p, cbits.base.p, Tpos.p, term.p, osym.p, olen.p, big.p, big_n.p, big_cap};
+        const AtomEmitter em{tbits.words.p, tbits.base.p, cbits.words.p, cbits.base.p, Tpos.p, term.p, osym.p, olen.p,
+                             packed_atoms ? oatom.p : nullptr, lbits, big.p, big_n.p, big_cap};
         prim::for_each(E, CellAtomsFn<TC>{cells, L.u_to_p.p, PHB.p, nhb.p, Tc.p, take_code, em}, "asm.cell_atoms");
         prim::for_each(P, PreAtomsFn{L.prebwt.sym.p, L.prebwt.len.p, pre_g.p, pre_x.p, hocc_code, bwt_code, em}, "asm.pre_atoms");
         const u64 nbig = (u64)big_n.get(0);
@@ -2260,7 +2424,7 @@ class Engine {
         if (nbig) {                                          // TAKE segments spanning many runs: one lane per atom
             DBuf<u64> bbase(nbig + 1);
             const u64 nb_atoms = prim::exclusive_scan<u64>(nbig, BigCountIn{big.p, tbits.words.p, tbits.base.p}, bbase.p, true, "asm.big_scan");
-            prim::for_each(nb_atoms, BigAtomsFn{big.p, bbase.p, nbig, Tpos.p, term.p, osym.p, olen.p}, "asm.big_atoms");
+            prim::for_each(nb_atoms, BigAtomsFn{big.p, bbase.p, nbig, Tpos.p, term.p, em}, "asm.big_atoms");
         }
         // everything but the atoms can go before the merge allocates its scan arrays (peak memory)
         Tc.release(); pre_g.release(); pre_x.release(); PHB.release(); nhb.release(); big.release();
@@ -2268,7 +2432,7 @@ class Engine {
         Tpos.release(); term.release();
         release_cells();
         bwt.sym.release(); bwt.len.release();
-        bwt = merge_runs(osym.p, olen.p, A);
+        bwt = packed_atoms ? merge_atoms(oatom.p, A, lbits) : merge_runs(osym.p, olen.p, A);
         if (bwt.n != L.info.n_in) throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(bwt.n) +
                                                               " symbols, the level has " + std::to_string(L.info.n_in));
     }

@@ -666,9 +666,8 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
             if (st) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)(i - base);
             qn += (u32)__popcll(m);
         }
-        for (u32 q = lane; q < qn; q += 64) {
-            u32 s = f.process(base + queue[q]);
-            if (s != kNoBucket) {
+        auto count = [&](u32 s) {
+            if (s != kNoBucket) {                 // (nested, no early return: see the compiler note in engine_impl.hpp)
                 if (AGG) {
                     u32 h = (s * 2654435761u) >> (32 - __builtin_ctz(SLOTS));
                     bool done = false;
@@ -680,6 +679,26 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                     if (!done) add(s, 1u);
                 } else add(s, 1u);
             }
+        };
+        if constexpr (F::kBatch > 1) {
+            // f.process_batch takes kBatch work items per lane at once (straight-line code: their loads are in flight
+            // together; the kernel waits on dependent gathers, not on issue slots)
+            for (u32 q0 = 0; q0 < qn; q0 += 64 * F::kBatch) {
+                u64 item[F::kBatch];
+                bool valid[F::kBatch];
+                u32 slot[F::kBatch];
+#pragma unroll
+                for (int j = 0; j < F::kBatch; j++) {
+                    const u32 q = q0 + (u32)j * 64 + lane;
+                    valid[j] = q < qn;
+                    item[j] = base + (valid[j] ? queue[q] : 0u);
+                }
+                f.process_batch(item, valid, slot);
+#pragma unroll
+                for (int j = 0; j < F::kBatch; j++) if (valid[j]) count(slot[j]);
+            }
+        } else {
+            for (u32 q = lane; q < qn; q += 64) count(f.process(base + queue[q]));
         }
     }
     if (AGG) {

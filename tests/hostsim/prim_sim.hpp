@@ -102,7 +102,23 @@ inline void start_bitvector(u64 n, const cell_t *, OPS, F pred, u64 *words, cons
 static constexpr u32 kNoBucket = 0xFFFFFFFFu;
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
-    for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
+    if constexpr (F::kBatch > 1) {       // the functor's batched form (what the HIP kernel calls), kBatch work items at a time
+        u64 item[F::kBatch];
+        bool valid[F::kBatch];
+        u32 slot[F::kBatch];
+        int k = 0;
+        auto flush = [&] {
+            for (int j = k; j < F::kBatch; j++) { item[j] = 0; valid[j] = false; }
+            f.process_batch(item, valid, slot);
+            for (int j = 0; j < k; j++) if (slot[j] != kNoBucket) add(slot[j], 1u);
+            k = 0;
+        };
+        for (u64 i = 0; i < n; i++)
+            if (f.is_start(i)) { item[k] = i; valid[k] = true; if (++k == F::kBatch) flush(); }
+        if (k) flush();
+    } else {
+        for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
+    }
 }
 // stage clocks: host wall time here (the HIP runtime uses event pairs on its stream)
 #include <time.h>
