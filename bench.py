@@ -84,16 +84,17 @@ def parse_bytes(rounds, cell_bytes):
 
 # launch sites (prim::prof names, "#<phase><level>" stripped) of each accounting group
 GROUP_SITES = {
-    "induce_AB": lambda s, ph: ph == "i" and (s.startswith("induce_") or s.startswith("induce.")),
+    "induce_AB": lambda s, ph: ph == "i" and (s == "induce" or s.startswith("induce_") or s.startswith("induce.")),
     "induce_C": lambda s, ph: ph == "i" and (s.startswith("asm.") or s.startswith("merge_runs")),
     "hash_emit": lambda s, ph: ph == "p" and s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases",
                                                     "slot_values", "emit_parse", "hash_prepare", "hash_lookup"),
 }
 # rocprofv3 kernel-name fragments of the kernels a group launches (PMC traffic lookup)
 GROUP_KERNELS = {
-    "induce_AB": ["ChainCount", "ChainExpand", "ChainSplit", "PackGrammar", "k_induce"],
-    "induce_C": ["Seg", "Atom", "MergeEmit", "BuildBits"],
-    "hash_emit": ["HashInsert", "k_start_bits", "MapFn", "k_hash"],
+    "induce_AB": ["k_xs_count", "k_xs_scatter", "PackGrammarFn", "ChainCountFn", "ChainExpandFn", "NoVal, 1>", "k_rs_hist<unsigned long, 1>"],
+    "induce_C": ["TakeScanEmitFn", "CellTakeIn", "PrePlaceFn", "BucketEdgesFn", "BucketSizeIn", "CellAtomsFn", "PreAtomsFn", "BigAtomsFn",
+                 "BigCountIn", "AtomHeadLenIn", "PreScanIn", "NotCodeIn"],
+    "hash_emit": ["HashInsertFn", "k_start_bits", "MapFn", "ScatterValFn"],
 }
 
 
@@ -114,7 +115,7 @@ def pmc_traffic(kernel_fragments):
             if any(f in name for f in kernel_fragments):
                 hit = True
                 tot += e.get("hbm_bytes_total", 0.0)
-        return round(tot / steps) if hit else None
+        return round(tot / steps) if (hit and tot > 0) else None
     except Exception:
         return None
 

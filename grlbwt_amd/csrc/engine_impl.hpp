@@ -529,6 +529,25 @@ struct SufLenPFn {        // suffix length of every dictionary position (coalesc
     const u32 *dict_phr; const u32 *ph_off; RankLen *rl;
     GRL_DEV void operator()(u64 q) const { rl[q].suflen = ph_off[dict_phr[q] + 1] - (u32)q; }
 };
+// Writing rank[perm[t]] for all t is the inverse of a permutation: S random 4-byte stores (14 G/s measured, 42 ms for
+// 617 M suffixes).  Partitioned instead: (position, rank) pairs, ONE stable radix pass on the top bits of the position
+// (sequential traffic), then the pairs are applied in that order -- the stores of one digit fall into 1/256 of the array,
+// a region the L2s and the memory-side cache hold while it is being written.
+struct RankPairFn {       // pair[t] = position << 32 | rank of slot t
+    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u64 *pairs;
+    GRL_DEV void operator()(u64 t) const { pairs[t] = ((u64)perm[t] << 32) | (u64)gstart[ex[t] + hflag[t] - 1]; }
+};
+struct RankHeadPairFn {   // the same for the suffixes a refinement pass re-sorted
+    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; u64 *pairs;
+    GRL_DEV void operator()(u64 i) const {
+        u32 head = (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
+        pairs[i] = ((u64)v[i] << 32) | (u64)hpos[hex[i] + head - 1];
+    }
+};
+struct RankApplyFn {
+    const u64 *pairs; RankLen *rl;
+    GRL_DEV void operator()(u64 i) const { const u64 x = pairs[i]; rl[x >> 32].rank = (u32)x; }
+};
 struct RankAllPFn {       // rank of every suffix after the first pass
     const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; RankLen *rl;
     GRL_DEV void operator()(u64 t) const { rl[perm[t]].rank = gstart[ex[t] + hflag[t] - 1]; }
@@ -2004,6 +2023,23 @@ class Engine {
         }
     }
 
+    // rank[position] = value for `count` (position, value) pairs over `S` positions: partitioned by the top 8 bits of the
+    // position when the array is too large for the caches to absorb random stores, directly otherwise
+    template <class MakePairs, class Direct>
+    void scatter_ranks(u64 count, u64 S, MakePairs make_pairs, Direct direct, RankLen *rl) {
+        static const bool off = getenv("GRLBWT_DIRECT_RANK_SCATTER") != nullptr;
+        const char *mn = getenv("GRLBWT_RANK_PART_MIN");                             // (tests lower the threshold to take this path on small inputs)
+        const u64 min_s = mn ? (u64)atoll(mn) : ((u64)8 << 20);                      // 64 MB of records or less: the memory-side cache copes
+        if (off || S < min_s || count < S / 16) { direct(); return; }
+        DBuf<u64> pa(count), pb(count);
+        make_pairs(pa.p);
+        const int pbits = (int)bitlen64(S - 1);
+        static const int part_bits = getenv("GRLBWT_RANK_PART_BITS") ? atoi(getenv("GRLBWT_RANK_PART_BITS")) : 16;
+        const int lo = 32 + (pbits > part_bits ? pbits - part_bits : 0);
+        int res = prim::sort_keys<u64>(pa.p, pb.p, count, lo, 32 + pbits, "suffix_ranks.part");
+        prim::for_each(count, RankApplyFn{res ? pb.p : pa.p, rl}, "suffix_ranks");
+    }
+
     // a5-a8 on D distinct phrases given as (position in t, length, frequency, ends-with-terminator);
     // fills L (grammar, has_hocc, pre-BWT, M) and phrase_val[k] = rank<<2 | (freq>1)<<1 | lastT.
     template <class cell_t, bool FIRST>
@@ -2048,7 +2084,8 @@ class Engine {
             }
             G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
             prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
-            prim::for_each(S, RankAllPFn{hflag.p, ex.p, gstart.p, perm.p, rl.p}, "suffix_ranks");
+            scatter_ranks(S, S, [&](u64 *pairs) { prim::for_each(S, RankPairFn{hflag.p, ex.p, gstart.p, perm.p, pairs}, "suffix_ranks"); },
+                          [&] { prim::for_each(S, RankAllPFn{hflag.p, ex.p, gstart.p, perm.p, rl.p}, "suffix_ranks"); }, rl.p);
             const int lowbits = (int)bitlen64(S);
             u64 Lres = (u64)K, iters = 1;
             DBuf<u32> act;                       // slots still unresolved after the previous pass (empty = all slots)
@@ -2070,7 +2107,8 @@ class Engine {
                 DBuf<u32> hex(U + 1), hpos(U);
                 prim::exclusive_scan_nosync<u32>(U, HeadKeyIn{sk}, hex.p, false, "suffix_heads");
                 prim::for_each(U, HeadSlotFn{sk, hex.p, uslot.p, hpos.p}, "suffix_gstart");
-                prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rl.p}, "suffix_ranks");
+                scatter_ranks(U, S, [&](u64 *pairs) { prim::for_each(U, RankHeadPairFn{sk, hex.p, hpos.p, sv, pairs}, "suffix_ranks"); },
+                              [&] { prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rl.p}, "suffix_ranks"); }, rl.p);
                 act = std::move(uslot);
                 A = U;
                 refined = true;
@@ -2300,7 +2338,7 @@ class Engine {
                                                                  nullptr, nullptr, nullptr, nullptr, ef.p, term.p, kb, lb}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
-                int res = prim::sort_keys<u64>(ef.p, ef2.p, E, 0, bits, "induce_split");
+                int res = prim::sort_keys<u64, 1>(ef.p, ef2.p, E, 0, bits, "induce_split");
                 sfused = std::move(res ? ef2 : ef);
                 prim::sync();
             } else if (packed) {

@@ -1094,7 +1094,9 @@ static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup
 // complements) selected by l's own bits, and the two high bits split that set four ways with wave-uniform masks.
 // (Measured equal to the form with one LDS atomic per key, and to 4/8-byte instead of 16-byte key loads, within 6 %:
 // 29 M 8-byte keys in 64 us either way.  Kept because its cost does not depend on how skewed the digits are.)
-template <class K>
+// (SITE: a tag that only names the instantiation -- the induction's bucket split gets kernels of its own in profiler
+// output, apart from the other keys-only 64-bit sorts)
+template <class K, int SITE = 0>
 __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 dmask, u32 *counts, u32 tiles) {
     __shared__ u32 s_h[kBlock / 64][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1193,7 +1195,7 @@ inline void rs_offsets(const u32 *counts, u32 tiles, u32 *chunk_sums, u64 *chunk
 // once the keys' registers are free; those loads overlap the key write-out.
 static constexpr int kRsKeys = kRsTile / kBlock;
 struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays are read or written
-template <class K, class V>
+template <class K, class V, int SITE = 0>
 __global__ void __launch_bounds__(kBlock)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
                         const u64 *offsets /*[tiles][256] exclusive*/, u32 tiles) {
@@ -1628,7 +1630,7 @@ inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char
 
 // Sorts n pairs by key bits [begin_bit, end_bit).  Buffers a/b ping-pong; returns
 // 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b).
-template <class K, class V>
+template <class K, class V, int SITE = 0>
 inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit,
                       const char *name = "radix_sort") {
     if (n == 0 || end_bit <= begin_bit) return 0;
@@ -1648,12 +1650,12 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         K *kout = cur ? keys_a : keys_b;
         V *vout = cur ? vals_a : vals_b;
         prof_begin(std::string(name) + ".hist", n * sizeof(K));
-        hipLaunchKernelGGL((k_rs_hist<K>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
+        hipLaunchKernelGGL((k_rs_hist<K, SITE>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
         prof_end();
         after_launch(name);
         rs_offsets<256>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
         prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
-        hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL((k_rs_scatter<K, V, SITE>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
                            shift, dmask, offsets, tiles);
         prof_end();
         after_launch(name);
@@ -1667,12 +1669,12 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
 }
 
 // keys only: returns 0 if the result is in keys_a, 1 if in keys_b
-template <class K>
+template <class K, int SITE = 0>
 inline int sort_keys(K *keys_a, K *keys_b, u64 n, int begin_bit, int end_bit, const char *name = "radix_sort") {
-    return sort_pairs<K, NoVal>(keys_a, (NoVal *)nullptr, keys_b, (NoVal *)nullptr, n, begin_bit, end_bit, name);
+    return sort_pairs<K, NoVal, SITE>(keys_a, (NoVal *)nullptr, keys_b, (NoVal *)nullptr, n, begin_bit, end_bit, name);
 }
 inline int sort_keys_fwd(u64 *a, u64 *b, u64 n, int begin_bit, int end_bit, const char *name) {
-    return sort_keys<u64>(a, b, n, begin_bit, end_bit, name);
+    return sort_keys<u64, 1>(a, b, n, begin_bit, end_bit, name);      // SITE 1: the passes behind the fused expand + first pass
 }
 
 }   // namespace prim

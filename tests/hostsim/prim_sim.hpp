@@ -185,7 +185,7 @@ inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
     std::memset(hist_host, 0, 256 * 8);
     for (u64 i = 0; i < n; i++) hist_host[p[i]]++;
 }
-template <class K, class V>
+template <class K, class V, int SITE = 0>
 inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit,
                       const char * = "") {
     if (n == 0 || end_bit <= begin_bit) return 0;
@@ -207,7 +207,7 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
     return 1;
 }
 
-template <class K>
+template <class K, int SITE = 0>
 inline int sort_keys(K *keys_a, K *keys_b, u64 n, int begin_bit, int end_bit, const char * = "") {
     if (n == 0 || end_bit <= begin_bit) return 0;
     int bits = end_bit - begin_bit;

@@ -155,3 +155,11 @@ def test_file_in_file_out(sim, oracle_mod, tmp_path):
             ctx.load_file(str(bad), 2)                # size not a multiple of the cell width
         with pytest.raises(engine.GrlbwtError):
             ctx.load_file(str(tmp_path / "missing.bin"), 1)
+
+
+def test_partitioned_rank_scatter_branch(sim, oracle_mod, monkeypatch):
+    """The inverse-permutation scatter of the suffix ranks goes through one radix pass on the position when the dictionary is
+    large; the threshold is lowered to take that branch here."""
+    monkeypatch.setenv("GRLBWT_RANK_PART_MIN", "1")
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=3).tobytes(), 1, engine.FLAG_FORCE_IDX64)
