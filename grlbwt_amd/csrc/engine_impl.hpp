@@ -179,19 +179,26 @@ struct HashInsertFn {
 #ifndef GRL_HASH_BATCH
 #define GRL_HASH_BATCH 4
 #endif
+    // (The same batching for the 4-byte cells of the levels above 0 -- phrases of <= 4 cells, generic keys, probe and
+    // representative compare 2-4 phrases wide -- was built and measured at 80 vs 77 ms on level 1 of the 10 GB build:
+    // there the two random HBM accesses per phrase run at the memory system's random-access rate, ~25 G/s, whatever
+    // the number in flight per lane.  Dropped.)
     static constexpr int kBatch = kExact ? GRL_HASH_BATCH : 1;
     static constexpr u64 kCh = 8 / sizeof(cell_t);    // cells per 8-byte chunk
     GRL_DEV static u64 load8(const cell_t *a) { u64 v; __builtin_memcpy(&v, a, 8); return v; }   // unaligned 8-byte load
+    // (single exit, loop flags instead of returns from inside the loops: these functions are inlined several times into
+    // unrolled batch code, where hipcc 7.2 has mishandled divergent early exits -- see find_or_insert)
     GRL_DEV bool same_phrase(u64 q, u64 p, u64 len, bool check_bits) const {
-        if (q + len > n) { scal[1] = 3; scal[2] = (u32)q; scal[3] = (u32)len; return false; }
+        bool same = true;
+        if (q + len > n) { scal[1] = 3; scal[2] = (u32)q; scal[3] = (u32)len; same = false; }
         u64 j = 0;
-        if (!check_bits)                                // 8 bytes per load: long phrases are latency-bound per load
-            for (; j + kCh <= len; j += kCh) if (load8(t + q + j) != load8(t + p + j)) return false;
-        for (; j < len; j++) {
-            if (t[q + j] != t[p + j]) return false;
-            if (check_bits && j > 0 && bit_at(startbits, q + j) != bit_at(startbits, p + j)) return false;
+        if (same && !check_bits)                        // 8 bytes per load: long phrases are latency-bound per load
+            for (; same && j + kCh <= len; j += kCh) if (load8(t + q + j) != load8(t + p + j)) same = false;
+        for (; same && j < len; j++) {
+            if (t[q + j] != t[p + j]) same = false;
+            else if (check_bits && j > 0 && bit_at(startbits, q + j) != bit_at(startbits, p + j)) same = false;
         }
-        return true;
+        return same;
     }
     GRL_DEV bool is_start(u64 p) const { return (startbits[p >> 6] >> (p & 63)) & 1ull; }
     GRL_DEV u32 operator()(u64 p) const { return is_start(p) ? process(p) : prim::kNoBucket; }
@@ -221,26 +228,32 @@ struct HashInsertFn {
                 }
             }
         }
+        bool ok = true;
         while (!done) {                           // tail of the text: cell by cell
             e++;
-            if (e >= n) { scal[1] = 4; scal[2] = (u32)p; return prim::kNoBucket; }
-            c = t[e];
-            ph.add(ops.sym(c));
-            done = bit_at(startbits, e) || ops.isT(c);
+            if (e >= n) { scal[1] = 4; scal[2] = (u32)p; ok = false; done = true; }
+            else {
+                c = t[e];
+                ph.add(ops.sym(c));
+                done = bit_at(startbits, e) || ops.isT(c);
+            }
         }
-        if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; return prim::kNoBucket; }
-        u64 len = e - p + 1;
-        u32 found;
-        if (kExact && len <= 7) {                  // same key form as process_batch: a phrase has ONE entry whichever path saw it
-            u64 content = 0;
-            for (u64 j = 0; j < len; j++) content |= (u64)t[p + j] << (8 * j);
-            const u64 mine = kExactKey | (len << 60) | content;
-            found = insert_exact(mine, p, exact_hash(mine) & mask, 0, false);
-        } else found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
-        if (found != prim::kNoBucket) out_slot[ord] = found;
+        if (ok && ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; ok = false; }
+        u32 found = prim::kNoBucket;
+        if (ok) {
+            u64 len = e - p + 1;
+            if (kExact && len <= 7) {              // same key form as process_batch: a phrase has ONE entry whichever path saw it
+                u64 content = 0;
+                for (u64 j = 0; j < len; j++) content |= (u64)t[p + j] << (8 * j);
+                const u64 mine = kExactKey | (len << 60) | content;
+                found = insert_exact(mine, p, exact_hash(mine) & mask, 0, false);
+            } else found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
+            if (found != prim::kNoBucket) out_slot[ord] = found;
+        }
         return found;
     }
-    GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const {
+    GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const { process_batch_exact(item, valid, slot); }
+    GRL_DEV void process_batch_exact(const u64 *item, const bool *valid, u32 *slot) const {
         constexpr int B = kBatch;
         u64 chunk[B], wp[B], w0[B], w1[B], mine[B], idx[B], cur[B];
         idx_t wb[B];
@@ -328,10 +341,11 @@ struct HashInsertFn {
         // the probe loop made hipcc 7.2 (gfx950) reuse the return register as a scratch under a
         // partial exec mask, so lanes that matched an existing key returned a stale value.
         u32 found = prim::kNoBucket;
-        for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket; probes++) {
+        bool stop = false;
+        for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket && !stop; probes++) {
             // once probing gets long, look at the overflow flag (L1-bypassing load; done rarely: a coherent load of one
             // address by every lane was measured to serialise and cost 20 ms per 10 M phrases)
-            if (probes == 16 && prim::load_relaxed(&scal[1])) return prim::kNoBucket;
+            if (probes == 16 && prim::load_relaxed(&scal[1])) stop = true;
             u64 cur = prim::load_relaxed(&keys[slot << ks]);   // L1-bypassing: a stale 0 from L1 would turn every later occurrence of a hot phrase into a CAS on one address
             if (cur == 0) {
                 u64 old = prim::atomic_cas(&keys[slot << ks], 0ull, mine);

@@ -45,6 +45,15 @@ def test_cli_end_to_end(cli, tmp_path):
     blob = open(tmp_path / "test_byte_alphabet.rl_bwt", "rb").read()
     assert hashlib.md5(blob).hexdigest() == tab["test_byte_alphabet.txt"]["md5"]
     assert "Parsing round 8" in out and "The resulting BCR BWT was stored in" in out
+    # the reference's stage labels (exact_par_phase.cpp:380,410,111,124,428,452; exact_ind_phase.cpp:121,141,270) and its
+    # report_time wording (utils.h:109-126): harnesses grep them
+    for label in ("Reading the file", "Computing the dictionary of LMS phrases", "Compacting the dictionary",
+                  "Sorting the dictionary and constructing the preliminary BWT", "Compressing the dictionary",
+                  "Assigning metasymbols to the LMS phrases", "Creating the parse of the text", "Inferring the BWT",
+                  "Computing the deepest recursive BWT", "Inducing the BWT for parse 8", "Computing the number of induced symbols",
+                  "Performing the induction from the previous BWT", "Assembling the new BWT", "Elapsed time ("):
+        assert label in out, label
+    assert "grlbwt-timing: read+upload" in out
     # -o with an extension: the last extension is replaced (main.cpp:112-113)
     rc, out, err = run(cli, os.path.join(GOLD, "test_2bytes_alphabet.txt"), "-a", "2", "-o", str(tmp_path / "x.y"))
     assert rc == 0, err

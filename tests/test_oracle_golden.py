@@ -1,11 +1,10 @@
 """Pins the CPU oracle (oracle/grlbwt_oracle.c) before anything trusts it.
 
-Golden vectors: the reference has no test suite; the only
-fixtures are its two test_data files and the table of reference outputs that
-SURVEY.md section 8c recorded from the reference (md5, size, header, run count,
-and byte-exact tiny cases).  The reference cannot be rebuilt in this image
-(needs SDSL-lite), so those recorded values + the textbook definition
-(naive sorter) + LF inversion are what pins parity.
+Golden vectors: the reference has no test suite; its builder (main.cpp) needs SDSL-lite and
+cannot be rebuilt in this image, its .rl_bwt consumer programs can (oracle/Makefile target `ref`).  The oracle is
+pinned by: the table of reference outputs SURVEY.md section 8c recorded (md5, size, header, run count, byte-exact tiny
+cases -- this file); what the reference's own reader and re-writer make of the oracle's bytes
+(tests/test_consumers.py, tests/golden/ref_consumers.json); the textbook definition (naive sorter) and LF inversion.
 """
 import hashlib
 import os

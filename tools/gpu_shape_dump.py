@@ -18,7 +18,7 @@ def main():
     reads = int(sys.argv[2]) if len(sys.argv) > 2 else 66225166
     tag = sys.argv[3] if len(sys.argv) > 3 else "%s_%d" % (kind, reads)
     dev = torch.device("cuda", 0)
-    lib = g.build_hip()
+    lib = os.environ.get("GRLBWT_HIP_LIB") or g.build_hip()
     t0 = time.time()
     if kind == "illumina":
         text = workloads.sampled_reads_torch(reads, 150, 330000000, seed=20260003, device=dev)
