@@ -410,16 +410,20 @@ struct LenIn {
     const u32 *l;
     GRL_DEV u32 operator()(u64 i) const { return l[i]; }
 };
+GRL_HD u64 rank1(const u64 *words, const idx_t *base, u64 x);      // (defined with the rank bit-vectors below)
 template <class cell_t, bool FIRST>
-struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: one phrase search, then a forward walk
+struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: one phrase lookup, then a forward walk
     const cell_t *t;
     CellOps<cell_t, FIRST> ops;
     const u32 *ph_off; u64 D; u64 S; const u64 *ph_pos;
     u32 *dict_sym; u32 *dict_phr;
+    const u64 *pw; const idx_t *pb;      // rank bit-vector of the phrase starts over the dictionary positions (nullptr: binary search)
     struct alignas(16) Quad { u32 v[4]; };
     GRL_DEV void operator()(u64 c) const {
         u64 q0 = c * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
-        u64 k = upper_bound<u32>(ph_off, D, (u32)q0) - 1;
+        // the phrase holding position q0: two loads through the bit-vector (a binary search over the phrase offsets was
+        // 27 dependent probes per lane)
+        u64 k = pw ? rank1(pw, pb, q0 + 1) - 1 : upper_bound<u32>(ph_off, D, (u32)q0) - 1;
         u64 nxt = ph_off[k + 1];
         u32 phr[16], sym[16];
 #pragma unroll
@@ -479,6 +483,14 @@ struct RankWriteFn {   // gid[t] = (#heads before t) + head(t) - 1 ; rank[perm[t
 struct HeadFlagFn {       // hflag[t] = 1 where the sorted key changes
     const u64 *k; u8 *hflag;
     GRL_DEV void operator()(u64 t) const { hflag[t] = (t == 0 || k[t] != k[t - 1]) ? 1 : 0; }
+};
+struct FirstUnresolvedFn { // after the first sort: member of a group of > 1 suffixes whose key holds no sentinel (the suffix is at
+                           // least K symbols long) -- the flag ActiveFlagFn would compute, from the sorted keys instead of a gather
+    const u64 *k; const u8 *hflag; u64 S; u64 sent; u8 *uflag;
+    GRL_DEV void operator()(u64 t) const {
+        bool multi = !hflag[t] || (t + 1 < S && !hflag[t + 1]);
+        uflag[t] = (multi && (k[t] & sent) != sent) ? 1 : 0;
+    }
 };
 struct ByteIn {
     const u8 *f;
@@ -844,6 +856,28 @@ static inline void build_rankbits(RankBits &rb, const idx_t *pos, u64 count, u64
     rb.base.alloc(nw + 1);
     rb.words.zero();
     prim::for_each((count + 15) / 16, BuildBitsFn{pos, count, rb.words.p}, name);
+    prim::exclusive_scan_nosync<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, name);
+}
+
+struct BuildBits32Fn {    // the same for 32-bit positions (phrase offsets of the dictionary)
+    const u32 *pos; u64 count; u64 *words;
+    GRL_DEV void operator()(u64 j) const {
+        u64 i0 = j * 16, i1 = i0 + 16 < count ? i0 + 16 : count;
+        u64 cur = (u64)pos[i0] >> 6, m = 0;
+        for (u64 i = i0; i < i1; i++) {
+            u64 x = pos[i], w = x >> 6;
+            if (w != cur) { prim::atomic_or(&words[cur], m); m = 0; cur = w; }
+            m |= 1ull << (x & 63);
+        }
+        prim::atomic_or(&words[cur], m);
+    }
+};
+static inline void build_rankbits32(RankBits &rb, const u32 *pos, u64 count, u64 nbits, const char *name) {
+    u64 nw = nbits / 64 + 2;
+    rb.words.alloc(nw);
+    rb.base.alloc(nw + 1);
+    rb.words.zero();
+    prim::for_each((count + 15) / 16, BuildBits32Fn{pos, count, rb.words.p}, name);
     prim::exclusive_scan_nosync<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, name);
 }
 
@@ -2063,7 +2097,9 @@ class Engine {
         DBuf<u32> dict_sym(S), dict_phr(S);
         {
             StageTimer st(&tm.dict_sort);
-            prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
+            RankBits pbits;
+            build_rankbits32(pbits, ph_off, D, S + 1, "dict_build");
+            prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p}, "dict_build");
         }
         // ---- a6: sort all phrase suffixes (radix + filtered prefix doubling) ----------
         DBuf<u32> perm(S), gid(S), gstart(S + 1);
@@ -2094,6 +2130,9 @@ class Engine {
                     ks = kb.p;
                 }
                 prim::for_each(S, HeadFlagFn{ks, hflag.p}, "suffix_heads");
+                // the last symbol of a key is the sentinel exactly when the suffix is shorter than K: the first refinement's
+                // "long enough" test comes from the sorted keys (streamed) instead of a random gather per slot
+                prim::for_each(S, FirstUnresolvedFn{ks, hflag.p, S, (1ull << b) - 1ull, uflag.p}, "suffix_unresolved");
                 prim::sync();
             }
             G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
@@ -2107,7 +2146,7 @@ class Engine {
             bool refined = false;
             while (Lres < maxlen) {              // Lres symbols (incl. a possible sentinel) resolved so far
                 const u32 *ap = refined ? act.p : nullptr;
-                prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, rl.p, S, Lres, uflag.p}, "suffix_unresolved");
+                if (refined) prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, rl.p, S, Lres, uflag.p}, "suffix_unresolved");
                 DBuf<u32> uex(A + 1);
                 u64 U = prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
                 if (U == 0) break;
@@ -2611,7 +2650,7 @@ class Engine {
         bool has_hi = false;
         {
             StageTimer st(&tm.dict_sort);
-            prim::for_each((S + 15) / 16, DictBuildFn<u32, false>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p}, "dict_build");
+            prim::for_each((S + 15) / 16, DictBuildFn<u32, false>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, nullptr, nullptr}, "dict_build");
             prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
             prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, key0.p, rank.p}, "suffix_keys0");   // rank used as scratch
             // splitters: quantiles of a strided sample of the keys (identical on every rank: replicated data)
