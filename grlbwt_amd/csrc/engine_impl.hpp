@@ -304,7 +304,7 @@ struct HashInsertFn {
                 if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; found = prim::kNoBucket; }
                 else out_slot[ord] = found;
             }
-            if (valid[j] && !fast[j]) found = process(p);
+            if (valid[j] && !fast[j]) found = prim::kDeferBucket;      // the long cases go through process() later, 64 at a time
             slot[j] = found;
         }
     }

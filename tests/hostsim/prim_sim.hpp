@@ -100,6 +100,7 @@ inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char * = "") {
 template <class cell_t, class OPS, class F>
 inline void start_bitvector(u64 n, const cell_t *, OPS, F pred, u64 *words, const char * = "") { bitvector_from_pred(n, pred, words); }
 static constexpr u32 kNoBucket = 0xFFFFFFFFu;
+static constexpr u32 kDeferBucket = 0xFFFFFFFEu;
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     if constexpr (F::kBatch > 1) {       // the functor's batched form (what the HIP kernel calls), kBatch work items at a time
@@ -110,7 +111,10 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
         auto flush = [&] {
             for (int j = k; j < F::kBatch; j++) { item[j] = 0; valid[j] = false; }
             f.process_batch(item, valid, slot);
-            for (int j = 0; j < k; j++) if (slot[j] != kNoBucket) add(slot[j], 1u);
+            for (int j = 0; j < k; j++) {
+                if (slot[j] == kDeferBucket) slot[j] = f.process(item[j]);       // (the HIP kernel queues these up)
+                if (slot[j] != kNoBucket) add(slot[j], 1u);
+            }
             k = 0;
         };
         for (u64 i = 0; i < n; i++)
