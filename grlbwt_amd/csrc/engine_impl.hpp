@@ -1241,9 +1241,12 @@ struct AtomEmitter {
     }
     GRL_DEV void literal(u64 g, u64 x, u32 sym, idx_t len) const { put(abase_of(g, x), sym, (u64)len); }
     GRL_DEV void take(u64 g, u64 a, u64 len) const {
-        const u64 b = a + len, o = abase_of(g, a);
         const u64 k0 = rank1(tw, tb, a + 1) - 1;                     // run of BWT_{r+1} holding T position a
-        const u64 cnt = rank1(tw, tb, b) - (k0 + 1) + 1;
+        take_at(abase_of(g, a), a, len, k0, rank1(tw, tb, a + len) - k0);
+    }
+    // TAKE segment [a, a+len) whose first atom is o, first run k0, number of runs touched cnt
+    GRL_DEV void take_at(u64 o, u64 a, u64 len, u64 k0, u64 cnt) const {
+        const u64 b = a + len;
         // (if / else, no early return: hipcc 7.2 has let lanes of a branch that returned run the stores behind it)
         if (cnt > kInlineAtoms) {
             u32 slot = prim::atomic_add(big_n, 1u);
@@ -1259,15 +1262,29 @@ struct AtomEmitter {
         }
     }
 };
+// Two cells per lane: the address chain of a cell (bucket -> pre-BWT run -> T prefix -> rank words -> run index) is five
+// dependent gathers deep and the kernel waits on them at full occupancy; taking two cells through the chain together
+// keeps twice the loads in flight.  (Straight-line up to the emission, which loops over the runs a TAKE cell spans.)
 template <class TC>
 struct CellAtomsFn {
-    CellView c; const u32 *u_to_p; const HoccBwt *PHB; const idx_t *nhb; const TC *Tc; u32 take_code; AtomEmitter em;
-    GRL_DEV void operator()(u64 t) const {
-        const u32 j = u_to_p[c.key(t)];
-        const u64 g = (u64)nhb[j] + t, x = (u64)Tc[t] + (u64)PHB[j].b;
-        const u32 sy = c.sym(t);
-        if (sy == take_code) em.take(g, x, (u64)c.len(t));
-        else em.literal(g, x, sy, c.len(t));
+    CellView c; const u32 *u_to_p; const HoccBwt *PHB; const idx_t *nhb; const TC *Tc; u32 take_code; AtomEmitter em; u64 E;
+    GRL_DEV void operator()(u64 h) const {
+        const u64 t0 = 2 * h, t1 = t0 + 1 < E ? t0 + 1 : t0;       // (an odd tail: the second slot repeats the first and is not emitted)
+        const u32 k0 = c.key(t0), k1 = c.key(t1);
+        const u32 j0 = u_to_p[k0], j1 = u_to_p[k1];
+        const u64 g0 = (u64)nhb[j0] + t0, g1 = (u64)nhb[j1] + t1;
+        const u64 x0 = (u64)Tc[t0] + (u64)PHB[j0].b, x1 = (u64)Tc[t1] + (u64)PHB[j1].b;
+        const u32 s0 = c.sym(t0), s1 = c.sym(t1);
+        const u64 l0 = (u64)c.len(t0), l1 = (u64)c.len(t1);
+        // ranks of both cells: the loads of the two chains are independent
+        const u64 r0 = x0 ? rank1(em.tw, em.tb, x0) : 0, r1 = x1 ? rank1(em.tw, em.tb, x1) : 0;
+        const u64 q0 = x0 ? rank1(em.cw, em.cb, x0) : 0, q1 = x1 ? rank1(em.cw, em.cb, x1) : 0;
+        const u64 o0 = x0 ? g0 + (r0 - 1) - q0 : g0, o1 = x1 ? g1 + (r1 - 1) - q1 : g1;
+        const bool tk0 = s0 == take_code, tk1 = s1 == take_code;
+        const u64 f0 = tk0 ? rank1(em.tw, em.tb, x0 + 1) - 1 : 0, f1 = tk1 ? rank1(em.tw, em.tb, x1 + 1) - 1 : 0;   // run holding the TAKE start
+        const u64 n0 = tk0 ? rank1(em.tw, em.tb, x0 + l0) - f0 : 0, n1 = tk1 ? rank1(em.tw, em.tb, x1 + l1) - f1 : 0;
+        if (tk0) em.take_at(o0, x0, l0, f0, n0); else em.put(o0, s0, l0);
+        if (t1 != t0) { if (tk1) em.take_at(o1, x1, l1, f1, n1); else em.put(o1, s1, l1); }
     }
 };
 struct PreAtomsFn {
@@ -2508,7 +2525,7 @@ class Engine {
         big_n.zero();
         const AtomEmitter em{tbits.words.p, tbits.base.p, cbits.words.p, cbits.base.p, Tpos.p, term.p, osym.p, olen.p,
                              packed_atoms ? oatom.p : nullptr, lbits, big.p, big_n.p, big_cap};
-        prim::for_each(E, CellAtomsFn<TC>{cells, L.u_to_p.p, PHB.p, nhb.p, Tc.p, take_code, em}, "asm.cell_atoms");
+        prim::for_each((E + 1) / 2, CellAtomsFn<TC>{cells, L.u_to_p.p, PHB.p, nhb.p, Tc.p, take_code, em, E}, "asm.cell_atoms");
         prim::for_each(P, PreAtomsFn{L.prebwt.sym.p, L.prebwt.len.p, pre_g.p, pre_x.p, hocc_code, bwt_code, em}, "asm.pre_atoms");
         const u64 nbig = (u64)big_n.get(0);
         if (nbig > big_cap) throw prim::Error(-71, "induction: wide-segment queue overflow (level " + std::to_string(r) + ")");
