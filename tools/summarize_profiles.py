@@ -16,7 +16,7 @@ import sys
 out, tag = sys.argv[1], sys.argv[2]
 builds = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 STREAMING = ("k_rs_scatter", "k_rs_hist", "k_scan_tiles", "k_scan_tile_sums", "k_start_bits", "k_byte_hist", "k_rs_chunk_sums",
-             "k_rs_tile_offsets", "k_reduce", "PackRunsFn", "DiffFn", "k_xs_scatter")
+             "k_rs_tile_offsets", "k_reduce", "PackRunsFn", "DiffFn")
 res = {"tag": tag, "builds_profiled": builds,
        "note": "per kernel over the whole PMC run (builds_profiled builds of the bench workload): FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 "
                "reports them; hbm_bytes_total = fetch_factor * FETCH * 1024 + WRITE * 1024 with fetch_factor 2 for streaming kernels "
@@ -48,6 +48,7 @@ for k, e in res["kernels"].items():
     f = 2 if any(s in k for s in STREAMING) else 1
     e["fetch_factor"] = f
     e["hbm_bytes_total"] = round((f * e.get("fetch_kib_total", 0.0) + e.get("write_kib_total", 0.0)) * 1024)
+res["kernels"] = {k: v for k, v in res["kernels"].items() if not k.startswith("void at::")}      # (the workload generator's torch kernels)
 top = sorted(res["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_total"])[:90]
 res["kernels"] = dict(top)
 json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
