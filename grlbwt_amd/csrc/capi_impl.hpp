@@ -84,8 +84,7 @@ template <class E>
 void text_download(const E &e, int level, uint64_t *out) {
     const auto &b = e.kept_texts[level - 1];
     std::vector<uint32_t> h = b.to_host(b.n);
-    const bool raw = getenv("GRLBWT_DBG_RAWCELLS") != nullptr;
-    for (uint64_t i = 0; i < b.n; i++) out[i] = raw ? (uint64_t)h[i] : (uint64_t)(h[i] >> 1);   // (rank<<2|rep<<1|T) -> (rank<<1|rep)
+    for (uint64_t i = 0; i < b.n; i++) out[i] = (uint64_t)(h[i] >> 1);   // (rank<<2|rep<<1|T) -> (rank<<1|rep)
 }
 template <class E>
 void bwt_download(const E &e, int level, uint64_t *sym, uint64_t *len) {

@@ -1098,7 +1098,8 @@ struct SegFromPreFn {   // non-HOCC pre-BWT runs -> segments
 struct CellView {
     const u64 *fused; int kb, lb;
     const u32 *skey; const u64 *packed; const u32 *ssym; const idx_t *slen;
-    GRL_DEV u32 key(u64 t) const { return fused ? (u32)(fused[t] & ((1ull << kb) - 1ull)) : skey[t]; }
+    u32 u0;                 // first bucket of the piece being assembled (collection-level mode: buckets are owned by ranges)
+    GRL_DEV u32 key(u64 t) const { return (fused ? (u32)(fused[t] & ((1ull << kb) - 1ull)) : skey[t]) - u0; }
     GRL_DEV u32 sym(u64 t) const { return fused ? (u32)(fused[t] >> (kb + lb)) : packed ? (u32)(packed[t] >> 32) : ssym[t]; }
     GRL_DEV idx_t len(u64 t) const {
         return fused ? (idx_t)((fused[t] >> kb) & ((1ull << lb) - 1ull)) : packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t];
@@ -1549,172 +1550,68 @@ struct PhraseValDistFn {
     }
 };
 
-// ---- distributed induction functors -------------------------------------------------
-struct BucketSumFn {      // per bucket u: my cells' symbol count, my TAKE symbol count, my first cell
-    const u32 *skey; u64 E; const idx_t *lH; const idx_t *lT;
-    u64 *cntpair /*[2M]*/; idx_t *lfirst;
-    GRL_DEV void operator()(u64 u) const {
-        u64 a = lower_bound<u32>(skey, E, (u32)u), b = lower_bound<u32>(skey, E, (u32)u + 1);
-        cntpair[2 * u] = (u64)lH[b] - (u64)lH[a];
-        cntpair[2 * u + 1] = (u64)lT[b] - (u64)lT[a];
-        lfirst[u] = (idx_t)a;
+// ---- collection-level induction functors ----------------------------------------------
+// The output of a level (BWT_r) is cut at pre-BWT run boundaries into one contiguous piece per rank ("owner").  An owner
+// holds the buckets (metasymbols) whose HOCC runs lie in its piece, so it receives exactly those cells from every rank,
+// and the stretch of the rewritten BWT_{r+1} its piece consumes (consumption is monotone in output order).  With cells
+// and that stretch in hand a piece is an ordinary single-GPU pass C.
+struct OwnerSplitFn {     // lane d in [0, size]: first pre-BWT run of owner d, its first bucket, symbols and BWT-marker symbols in front
+    const idx_t *Ppos; const HoccBwt *PHB; const u32 *u_to_p; u64 P, M, n_r; int size;
+    u64 *out /*[size+1][4]*/;
+    GRL_DEV void operator()(u64 d) const {
+        const u64 chunk = (n_r + (u64)size - 1) / (u64)size;
+        const u64 target = d * chunk < n_r ? d * chunk : n_r;
+        const u64 p = (d == (u64)size) ? P : lower_bound<idx_t>(Ppos, P, (idx_t)target);
+        out[4 * d] = p;
+        out[4 * d + 1] = lower_bound<u32>(u_to_p, M, (u32)p);
+        out[4 * d + 2] = (u64)Ppos[p];
+        out[4 * d + 3] = (u64)PHB[p].b;
     }
 };
-struct BucketPrefixFn {   // totals over all ranks and the part held by ranks before me
-    const u64 *all /*[size][2M]*/; int size, me; u64 M;
-    idx_t *tot, *before, *totT, *beforeT;
-    GRL_DEV void operator()(u64 u) const {
-        u64 t = 0, b = 0, tT = 0, bT = 0;
-        for (int g = 0; g < size; g++) {
-            u64 c = all[(u64)g * 2 * M + 2 * u], cT = all[(u64)g * 2 * M + 2 * u + 1];
-            if (g < me) { b += c; bT += cT; }
-            t += c; tT += cT;
+struct CellBoundsFn {     // lane d: first of my cells whose bucket belongs to owner d or a later one
+    CellView c; u64 E; const u64 *split; u64 *out;
+    GRL_DEV void operator()(u64 d) const { out[d] = cell_lower_bound(c, E, (u32)split[4 * d + 1]); }
+};
+struct CellTakeOffIn {    // TAKE length of cell off + t
+    CellView c; u32 take_code; u64 off;
+    GRL_DEV u64 operator()(u64 t) const { return c.sym(off + t) == take_code ? (u64)c.len(off + t) : 0ull; }
+};
+struct WindowRunsFn {     // lane d: my runs of BWT_{r+1} that overlap [a, b) (local symbol coordinates): first run, count
+    const idx_t *Tpos; u64 R; const u64 *ab; u64 *out /*[size][2]*/;
+    GRL_DEV void operator()(u64 d) const {
+        const u64 a = ab[2 * d], b = ab[2 * d + 1];
+        u64 k0 = 0, cnt = 0;
+        if (a < b) {
+            k0 = upper_bound<idx_t>(Tpos, R, (idx_t)a) - 1;               // the run holding symbol a
+            cnt = lower_bound<idx_t>(Tpos, R, (idx_t)b) - k0;             // ... up to the run holding symbol b - 1
         }
-        tot[u] = (idx_t)t; before[u] = (idx_t)b; totT[u] = (idx_t)tT; beforeT[u] = (idx_t)bT;
+        out[2 * d] = k0; out[2 * d + 1] = cnt;
     }
 };
-struct PreClipFlagIn {    // 1 if the (non-HOCC) pre-BWT run overlaps my output range
-    const u32 *psym; const idx_t *Ppos; u32 hocc_code; u64 lo, hi;
-    GRL_DEV u32 operator()(u64 j) const {
-        if (psym[j] == hocc_code) return 0u;
-        u64 a = Ppos[j] > lo ? (u64)Ppos[j] : lo, b = Ppos[j + 1] < hi ? (u64)Ppos[j + 1] : hi;
-        return a < b ? 1u : 0u;
-    }
-};
-struct DistSegPreFn {
-    const u32 *psym; const idx_t *plen; const idx_t *Ppos; const idx_t *PB; const u32 *u_to_p; const idx_t *th_base;
-    const u32 *pidx; u64 M, lo, hi; u32 bwt_code, hocc_code, take_code;
-    u64 *seg_out; u32 *seg_sym; idx_t *seg_len; idx_t *seg_toff;
-    GRL_DEV void operator()(u64 j) const {
-        u32 s = psym[j];
-        if (s == hocc_code) return;
-        u64 a = Ppos[j] > lo ? (u64)Ppos[j] : lo, b = Ppos[j + 1] < hi ? (u64)Ppos[j + 1] : hi;
-        if (a >= b) return;
-        u64 g = pidx[j];
-        seg_out[g] = a; seg_len[g] = (idx_t)(b - a);
-        if (s == bwt_code) {
-            u64 ustar = lower_bound<u32>(u_to_p, M, (u32)j);       // buckets of earlier pre-BWT runs
-            seg_sym[g] = take_code;
-            seg_toff[g] = (idx_t)((u64)PB[j] + (u64)th_base[ustar] + (a - (u64)Ppos[j]));
-        } else { seg_sym[g] = s; seg_toff[g] = 0; }
-    }
-};
-struct DistSegCellFn {
-    const u32 *skey; const u32 *ssym; const idx_t *slen; const idx_t *lH; const idx_t *lT; const idx_t *lfirst;
-    const u32 *u_to_p; const idx_t *Ppos; const idx_t *PH; const idx_t *PB;
-    const idx_t *bucket_base; const idx_t *before; const idx_t *th_base; const idx_t *beforeT;
-    u64 seg0; u32 take_code;
-    u64 *seg_out; u32 *seg_sym; idx_t *seg_len; idx_t *seg_toff;
-    GRL_DEV void operator()(u64 t) const {
-        u32 u = skey[t];
-        u64 j = u_to_p[u], f = lfirst[u];
-        u64 hglob = (u64)bucket_base[u] + (u64)before[u] + ((u64)lH[t] - (u64)lH[f]);
-        u64 g = seg0 + t;
-        seg_out[g] = (u64)Ppos[j] + (hglob - (u64)PH[j]);
-        seg_sym[g] = ssym[t];
-        seg_len[g] = slen[t];
-        seg_toff[g] = (ssym[t] == take_code) ? (idx_t)((u64)PB[j] + (u64)th_base[u] + (u64)beforeT[u] + ((u64)lT[t] - (u64)lT[f])) : (idx_t)0;
-    }
-};
-struct DistAtomCountIn {
-    const u32 *seg_sym; const idx_t *seg_len; const idx_t *seg_toff; const u64 *tw; const idx_t *tb; u32 take_code;
-    GRL_DEV idx_t operator()(u64 g) const {
-        if (seg_sym[g] != take_code) return 1;
-        u64 a = seg_toff[g], b = a + seg_len[g];
-        return (idx_t)(rank1(tw, tb, b) - rank1(tw, tb, a + 1) + 1);
-    }
-};
-struct DistAtomFn {       // atoms with explicit global output positions
-    const u64 *seg_out; const u32 *seg_sym; const idx_t *seg_len; const idx_t *seg_toff; const idx_t *Tpos; const u32 *Tsym;
-    const idx_t *abase; const u64 *tw; const idx_t *tb; const u64 *aw; const idx_t *ab; u32 take_code;
-    u64 *a_out; u32 *a_sym; u64 *a_len;
-    GRL_DEV void operator()(u64 x) const {
-        u64 g = rank1(aw, ab, x + 1) - 1;
-        if (seg_sym[g] != take_code) { a_out[x] = seg_out[g]; a_sym[x] = seg_sym[g]; a_len[x] = seg_len[g]; return; }
-        u64 a = seg_toff[g], b = a + seg_len[g];
-        u64 kf = rank1(tw, tb, a + 1) - 1;
-        u64 k = kf + (x - abase[g]);
-        u64 s = Tpos[k] > a ? (u64)Tpos[k] : a;
-        u64 e = Tpos[k + 1] < b ? (u64)Tpos[k + 1] : b;
-        a_out[x] = seg_out[g] + (s - a); a_sym[x] = Tsym[k]; a_len[x] = e - s;
-    }
-};
-struct PieceCountIn {     // an atom is cut at the output-range boundaries of the ranks
-    const u64 *a_out; const u64 *a_len; u64 chunk;
-    GRL_DEV idx_t operator()(u64 x) const { return (idx_t)((a_out[x] + a_len[x] - 1) / chunk - a_out[x] / chunk + 1); }
-};
-struct PieceFn {
-    const u64 *a_out; const u32 *a_sym; const u64 *a_len; const idx_t *pbase; const u64 *pw; const idx_t *pb; u64 chunk;
-    u32 *p_owner; idx_t *p_idx; u64 *p_out; u32 *p_sym; u64 *p_len;
+struct WindowSendFn {     // the runs of every owner's window, clipped to the window, in owner order
+    const idx_t *Tpos; const u32 *term; const u64 *ab; const u64 *k0cnt; const u64 *soff /*[size+1]*/; int size;
+    u32 *ssym; idx_t *slen;
     GRL_DEV void operator()(u64 y) const {
-        u64 x = rank1(pw, pb, y + 1) - 1;
-        u64 o = a_out[x], l = a_len[x];
-        u64 d = o / chunk + (y - pbase[x]);
-        u64 s = d * chunk > o ? d * chunk : o;
-        u64 e = (d + 1) * chunk < o + l ? (d + 1) * chunk : o + l;
-        p_owner[y] = (u32)d; p_idx[y] = (idx_t)y; p_out[y] = s; p_sym[y] = a_sym[x]; p_len[y] = e - s;
+        int d = 0;
+        while (d + 1 < size && y >= soff[d + 1]) d++;
+        const u64 k = k0cnt[2 * d] + (y - soff[d]);
+        const u64 a = ab[2 * d], b = ab[2 * d + 1];
+        const u64 s = (u64)Tpos[k] > a ? (u64)Tpos[k] : a, e = (u64)Tpos[k + 1] < b ? (u64)Tpos[k + 1] : b;
+        ssym[y] = term[k];
+        slen[y] = (idx_t)(e - s);
     }
 };
-struct PermuteAtomsFn {
-    const idx_t *perm; const u64 *o; const u32 *s; const u64 *l; u64 *o2; u32 *s2; u64 *l2;
-    GRL_DEV void operator()(u64 i) const { u64 y = perm[i]; o2[i] = o[y]; s2[i] = s[y]; l2[i] = l[y]; }
+struct RebaseFn {         // out[i] = in[i] - sub
+    const u32 *in; u32 sub; u32 *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = in[i] - sub; }
 };
-// Received atoms tile the rank's output range, so "sort by output position" is a placement: mark every atom's start
-// in a bit-vector over the range, rank the bits, and drop each atom at the rank of its own start.
-struct RecvMarkFn {        // one lane per 16 consecutive atoms (each source's atoms arrive in position order: few words per lane)
-    const u64 *o; u64 n, lo, span; u64 *words; u32 *bad;
-    struct alignas(16) Two { u64 v[2]; };
-    GRL_DEV void operator()(u64 j) const {
-        u64 i0 = j * 16, i1 = i0 + 16 < n ? i0 + 16 : n;
-        u64 x16[16];
-        if (i1 - i0 == 16 && ((uintptr_t)o & 15) == 0) {      // 16-byte loads (see BuildBitsFn)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                Two t2 = *reinterpret_cast<const Two *>(o + i0 + 2 * c);
-                x16[2 * c] = t2.v[0]; x16[2 * c + 1] = t2.v[1];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) x16[k] = (i0 + k < i1) ? o[i0 + k] : lo;
-        }
-        u64 cur = ~0ull, m = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (i0 + k < i1) {
-                u64 x = x16[k] - lo;
-                if (x16[k] < lo || x >= span) { *bad = 1; continue; }
-                u64 w = x >> 6;
-                if (w != cur) { if (m) prim::atomic_or(&words[cur], m); m = 0; cur = w; }
-                m |= 1ull << (x & 63);
-            }
-        }
-        if (m) prim::atomic_or(&words[cur], m);
-    }
+struct PieceMetaFn {      // metasymbols in front of every pre-BWT run of my piece, relative to the piece (no p_to_u table at hand)
+    const u32 *u_to_p; u64 M; u32 p0, u0; u32 *out;
+    GRL_DEV void operator()(u64 j) const { out[j] = (u32)lower_bound<u32>(u_to_p, M, p0 + (u32)j) - u0; }
 };
-struct RecvPlaceFn {
-    const u64 *o; const u32 *s; const u64 *l; u64 lo, span; const u64 *words; const idx_t *base;
-    u64 *opos; u32 *os; idx_t *ol;
-    GRL_DEV void operator()(u64 i) const {
-        u64 x = o[i] - lo;
-        if (o[i] < lo || x >= span) return;
-        u64 j = rank1(words, base, x);
-        opos[j] = x; os[j] = s[i]; ol[j] = (idx_t)l[i];
-    }
-};
-struct CheckPlacedAtomsFn {   // every atom must start where the previous one ended (also catches two atoms on one start)
-    const u64 *opos; const idx_t *ol; u64 n; u32 *bad;
-    GRL_DEV void operator()(u64 i) const {
-        u64 expect = (i == 0) ? 0 : opos[i - 1] + (u64)ol[i - 1];
-        if (opos[i] != expect) *bad = 1;
-    }
-};
-struct OwnerBoundFn {     // first routed atom of every destination rank
-    const u32 *k; u64 n; idx_t *out;
-    GRL_DEV void operator()(u64 d) const { out[d] = (idx_t)lower_bound<u32>(k, n, (u32)d); }
-};
-struct NarrowFn {
-    const u64 *a; idx_t *b;
-    GRL_DEV void operator()(u64 i) const { b[i] = (idx_t)a[i]; }
+struct IotaIdxFn {
+    idx_t *v;
+    GRL_DEV void operator()(u64 i) const { v[i] = (idx_t)i; }
 };
 
 // ---- .rl_bwt consumers (scripts/grl2plain.cpp, scripts/reverse_bwt.cpp + fm_index.h:79-83) ------
@@ -2335,44 +2232,38 @@ class Engine {
     }
 
     // ---- a13-a15: BWT_r from BWT_{r+1} -------------------------------------
-    void induce_level() {
-        if (bwt_level <= 0) throw prim::Error(-22, "no level left to induce");
-        const int r = bwt_level - 1;
-        prim::rt().tag = r;
-        prim::rt().phase = 'i';
-        LevelData &L = levels[r];
+    // passes A+B (exact_ind_phase.cpp:42-109,143-258) over the runs this engine holds of BWT_{r+1}: chain walks through
+    // the level's grammar, cells split by bucket (stable).  The cells stay in c_* (bucket-major), term[i] = rewritten symbol
+    // of run i.  `maxrun` = longest run of BWT_{r+1} (of ALL shards in the collection-level mode: it fixes the cell layout).
+    u64 expand_split(LevelData &L, DBuf<u32> &term, u64 maxrun, int &kb, int &lb) {
         const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, take_code = bwt_code;
-        const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
-        LevelInfo &I = linfo[r];
-        I.R_next = R; I.P = P;
-
+        const u64 R = bwt.R, M = L.M;
         DBuf<idx_t> eoff;
-        DBuf<u32> term(R);
         DBuf<u32> ssym; DBuf<idx_t> slen;
         DBuf<u64> gp;                           // packed grammar cells (chain walks)
         u64 E = 0;
         DBuf<u32> skey;                         // bucket of every induced cell, bucket-major order
         DBuf<u64> spack;                        // (sym<<32 | len) of every induced cell, same order (packed path)
         DBuf<u64> sfused;                       // sym | len | bucket in one word per cell (fused path)
-        int kb = (int)bitlen64(L.M > 0 ? L.M - 1 : 0), lb = 0;
+        kb = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
         if (kb < 1) kb = 1;
+        lb = (int)bitlen64(maxrun);
+        if (lb < 1) lb = 1;
         {
             const int bits = kb;
-            u64 maxrun;
             {
                 StageTimer st(&tm.ind_expand);
                 gp.alloc(M);
                 prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
-                maxrun = prim::reduce_max<u64>(R, IdxIn64{bwt.len.p}, "induce_maxrun");
             }
-            lb = (int)bitlen64(maxrun);
-            if (lb < 1) lb = 1;
             const int sbits = (int)bitlen64((u64)sigma3);
             // Whenever bucket, run length and symbol fit 64 bits together (always at DNA scales), the cell IS the sort
             // key: the split moves 8 bytes per cell and pass instead of 12, and holds 16 instead of 24 bytes per cell.
-            const bool fused = kb + lb + sbits <= 64;
+            // (GRLBWT_CELL_LAYOUT=packed|separate: the tests take the wider layouts on inputs that would never need them)
+            const char *force = getenv("GRLBWT_CELL_LAYOUT");
+            const bool fused = kb + lb + sbits <= 64 && !force;
             // otherwise the payload (sym, len) rides through the split as one u64 whenever every run length fits 32 bits
-            const bool packed = !fused && maxrun < 0xFFFFFFFFull;
+            const bool packed = !fused && maxrun < 0xFFFFFFFFull && !(force && force[0] == 's');
             bool done = false;
             if (fused) {
                 // chain expansion fused with the first pass of the bucket split (prim::expand_*): the cells are never
@@ -2441,40 +2332,65 @@ class Engine {
                 prim::sync();
             }
         }
-        I.E = E;
         // the cells move to the engine: pass C drops them before its run merge (peak memory)
         c_skey = std::move(skey); c_ssym = std::move(ssym); c_slen = std::move(slen); c_spack = std::move(spack);
         c_sfused = std::move(sfused); c_gp = std::move(gp);
-        const CellView cells{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p};
-        eoff.release();
+        return E;
+    }
+    CellView cell_view(int kb, int lb, u32 u0 = 0) const { return CellView{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p, u0}; }
+    u64 level_maxrun() {
+        StageTimer st(&tm.ind_expand);
+        return prim::reduce_max<u64>(bwt.R, IdxIn64{bwt.len.p}, "induce_maxrun");
+    }
+    // what pass C assembles: a contiguous piece of the level's pre-BWT, the metasymbols (buckets) whose HOCC runs lie in it
+    // (indices relative to the piece), and the number of symbols the piece describes.  The whole level on one GPU.
+    struct AsmIn { const u32 *psym; const idx_t *plen; u64 P; const u32 *u_to_p; const u32 *p_to_u; u64 M; u32 sigma; u64 n_out; };
+    void assemble(const AsmIn &in, LevelInfo &I, const CellView &cells, u64 E, DBuf<u32> &term, int r) {
+        StageTimer st(&tm.ind_assemble);
+        DBuf<idx_t> Tpos(bwt.R + 1);
+        const u64 Tsum = (u64)prim::exclusive_scan<idx_t>(bwt.R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
+        if (Tsum < 0xFFFFFFFFull) assemble_t<u32>(in, I, cells, E, Tpos, Tsum, term, r);      // the cells' TAKE prefix fits 32 bits
+        else assemble_t<u64>(in, I, cells, E, Tpos, Tsum, term, r);
+    }
+    void release_level(LevelData &L) {           // the level's grammar is no longer needed
+        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.p_to_u.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+    }
+
+    void induce_level() {
+        if (bwt_level <= 0) throw prim::Error(-22, "no level left to induce");
+        const int r = bwt_level - 1;
+        prim::rt().tag = r;
+        prim::rt().phase = 'i';
+        LevelData &L = levels[r];
+        const u64 R = bwt.R;
+        LevelInfo &I = linfo[r];
+        I.R_next = R; I.P = L.prebwt.R;
+        DBuf<u32> term(R);
+        int kb, lb;
+        const u64 E = expand_split(L, term, level_maxrun(), kb, lb);
+        I.E = E;
+        const CellView cells = cell_view(kb, lb);
         if (prim::rt().profile) {              // SURVEY 8d's E'_r and E_r for the roofline accounting (bench.py)
             I.Esteps = E - prim::reduce_sum<u64>(R, TakeCountIn{bwt.sym.p, c_gp.p}, "stat.take_cells");
             I.Emerged = prim::reduce_sum<u64>(E, CellHeadIn{cells}, "stat.merged_cells");
         }
-        {
-            StageTimer st(&tm.ind_assemble);
-            DBuf<idx_t> Tpos(R + 1);
-            const u64 Tsum = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
-            if (Tsum < 0xFFFFFFFFull) assemble_t<u32>(L, I, cells, E, Tpos, Tsum, term, r);      // the cells' TAKE prefix fits 32 bits
-            else assemble_t<u64>(L, I, cells, E, Tpos, Tsum, term, r);
-        }
+        assemble(AsmIn{L.prebwt.sym.p, L.prebwt.len.p, L.prebwt.R, L.u_to_p.p, L.p_to_u.p, L.M, L.sigma, L.info.n_in}, I, cells, E, term, r);
         bwt_level = r;
         I.R = bwt.R;
         I.n = L.info.n_in;
         if (keep_texts) keep_bwt(r);
-        // the level's grammar is no longer needed
-        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.p_to_u.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+        release_level(L);
     }
     // pass C (exact_ind_phase.cpp:287-361): BWT_r from the pre-BWT, the induced cells and the rewritten BWT_{r+1}
     template <class TC>
-    void assemble_t(LevelData &L, LevelInfo &I, const CellView &cells, u64 E, DBuf<idx_t> &Tpos, u64 Tsum, DBuf<u32> &term, int r) {
+    void assemble_t(const AsmIn &L, LevelInfo &I, const CellView &cells, u64 E, DBuf<idx_t> &Tpos, u64 Tsum, DBuf<u32> &term, int r) {
         const u32 bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
-        const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
+        const u64 R = bwt.R, P = L.P, M = L.M;
         // pre-BWT coordinates: (HOCC symbols, BWT-marker symbols) and the number of non-HOCC runs in front of every run
         DBuf<HoccBwt> PHB(P + 1);
         DBuf<idx_t> nhb(P + 1);
-        prim::exclusive_scan_nosync<HoccBwt>(P, PreScanIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code, bwt_code}, PHB.p, true, "asm.pre_scan");
-        const u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.prebwt.sym.p, hocc_code}, nhb.p, true, "asm.nhb");
+        prim::exclusive_scan_nosync<HoccBwt>(P, PreScanIn{L.psym, L.plen, hocc_code, bwt_code}, PHB.p, true, "asm.pre_scan");
+        const u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.psym, hocc_code}, nhb.p, true, "asm.nhb");
         const u64 PBsum = (u64)PHB.get(P).b;
         // bit-vectors over the T axis (n_{r+1} bits): run starts of BWT_{r+1}; TAKE segment starts that are run starts too
         RankBits tbits, cbits;
@@ -2487,7 +2403,7 @@ class Engine {
         DBuf<TC> Tc(E + 1);
         u64 TCsum = 0;
         if (E) TCsum = (u64)prim::exclusive_scan_emit<TC>(E, CellTakeIn<TC>{cells, take_code},
-                                                           TakeScanEmitFn<TC>{cells, L.u_to_p.p, PHB.p, take_code, E, tbits.words.p, Tc.p, cbits.words.p},
+                                                           TakeScanEmitFn<TC>{cells, L.u_to_p, PHB.p, take_code, E, tbits.words.p, Tc.p, cbits.words.p},
                                                            "asm.take_scan");
         else Tc.zero();
         if (PBsum + TCsum != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
@@ -2499,21 +2415,21 @@ class Engine {
             // where the cells of the buckets in front of a pre-BWT run end: a table over the metasymbols when the runs are
             // many (one pass over the cells), a binary search per run when they are few (level 0: 45 k runs, 2.6 G cells)
             DBuf<idx_t> first_cell;
-            if (P * 32 > E && L.p_to_u.p && !getenv("GRLBWT_DBG_NOFIRSTCELL")) {
+            if (P * 32 > E && L.p_to_u) {
                 first_cell.alloc(M + 1);
                 DBuf<idx_t> bstart1(M), bend(M);
                 bstart1.zero(); bend.zero();
                 prim::for_each(E, BucketEdgesFn{cells, E, bstart1.p, bend.p}, "asm.first_cell");
                 prim::exclusive_scan_nosync<idx_t>(M, BucketSizeIn{bstart1.p, bend.p}, first_cell.p, true, "asm.first_cell");
             }
-            prim::for_each(P, PrePlaceFn<TC>{L.prebwt.sym.p, PHB.p, nhb.p, L.u_to_p.p, M, cells, E, Tc.p, getenv("GRLBWT_DBG_NOPTOU") ? nullptr : L.p_to_u.p, first_cell.p,
+            prim::for_each(P, PrePlaceFn<TC>{L.psym, PHB.p, nhb.p, L.u_to_p, M, cells, E, Tc.p, L.p_to_u, first_cell.p,
                                              hocc_code, bwt_code, pre_g.p, pre_x.p, tbits.words.p, cbits.words.p}, "asm.pre_place");
         }
         const u64 Ctot = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{cbits.words.p}, cbits.base.p, true, "asm.coinc_rank");
         const u64 A = G + (R ? R - 1 : 0) - Ctot;           // every run start in (0, Tsum) that is no TAKE segment start cuts one atom
         I.A = A;
         // atoms: one packed word  sym << lbits | len  whenever a symbol and a length of this level fit 64 bits together
-        const int lbits = (int)bitlen64(L.info.n_in), sbits = (int)bitlen64((u64)L.sigma + 3);
+        const int lbits = (int)bitlen64(L.n_out), sbits = (int)bitlen64((u64)L.sigma + 3);
         const bool packed_atoms = lbits + sbits <= 64;
         DBuf<u32> osym;
         DBuf<idx_t> olen;
@@ -2525,8 +2441,8 @@ class Engine {
         big_n.zero();
         const AtomEmitter em{tbits.words.p, tbits.base.p, cbits.words.p, cbits.base.p, Tpos.p, term.p, osym.p, olen.p,
                              packed_atoms ? oatom.p : nullptr, lbits, big.p, big_n.p, big_cap};
-        prim::for_each((E + 1) / 2, CellAtomsFn<TC>{cells, L.u_to_p.p, PHB.p, nhb.p, Tc.p, take_code, em, E}, "asm.cell_atoms");
-        prim::for_each(P, PreAtomsFn{L.prebwt.sym.p, L.prebwt.len.p, pre_g.p, pre_x.p, hocc_code, bwt_code, em}, "asm.pre_atoms");
+        prim::for_each((E + 1) / 2, CellAtomsFn<TC>{cells, L.u_to_p, PHB.p, nhb.p, Tc.p, take_code, em, E}, "asm.cell_atoms");
+        prim::for_each(P, PreAtomsFn{L.psym, L.plen, pre_g.p, pre_x.p, hocc_code, bwt_code, em}, "asm.pre_atoms");
         const u64 nbig = (u64)big_n.get(0);
         if (nbig > big_cap) throw prim::Error(-71, "induction: wide-segment queue overflow (level " + std::to_string(r) + ")");
         if (nbig) {                                          // TAKE segments spanning many runs: one lane per atom
@@ -2541,8 +2457,8 @@ class Engine {
         release_cells();
         bwt.sym.release(); bwt.len.release();
         bwt = packed_atoms ? merge_atoms(oatom.p, A, lbits) : merge_runs(osym.p, olen.p, A);
-        if (bwt.n != L.info.n_in) throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(bwt.n) +
-                                                              " symbols, the level has " + std::to_string(L.info.n_in));
+        if (bwt.n != L.n_out) throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(bwt.n) +
+                                                              " symbols, the level has " + std::to_string(L.n_out));
     }
     // the induced cells of the level being assembled (owned here so that pass C can drop them before the run merge)
     DBuf<u32> c_skey, c_ssym; DBuf<idx_t> c_slen; DBuf<u64> c_spack, c_sfused, c_gp;
@@ -2576,7 +2492,7 @@ class Engine {
         int rank = 0, size = 1;
         void *user = nullptr;
         int (*ag)(void *, const void *, void *, u64) = nullptr;
-        int (*a2a)(void *, const void *, const u64 *, void *, const u64 *) = nullptr;
+        int (*a2a)(void *, const void *, const u64 *, const u64 *, void *, const u64 *, const u64 *) = nullptr;
         bool stream_ordered = false;      // callbacks enqueue on the engine's stream: no host synchronisation around them
         void allgather(const void *send, void *recv, u64 bytes) const {
             if (!stream_ordered) prim::sync();
@@ -2588,6 +2504,27 @@ class Engine {
             prim::h2d(s.p, mine.data(), c * 8);
             allgather(s.p, r.p, c * 8);
             return r.to_host(c * size);
+        }
+        // counts in elements of `elem` bytes; send blocks packed in destination order, receive blocks in source order.
+        // `max_block` = the largest block of the whole exchange in elements (all ranks pass the same value: they hold the
+        // count matrix): blocks above the limit go in several rounds, the same number on every rank.  (torch 2.10 + RCCL
+        // 2.26 delivers HALF of an all-to-all block of 2 GB, silently, and is fine at 1 GiB: tools/gpu_rccl_sizes.py.)
+        void alltoall(const void *send, const std::vector<u64> &scnt, void *recv, const std::vector<u64> &rcnt, u64 elem, u64 max_block) const {
+            static const u64 limit = getenv("GRLBWT_A2A_BLOCK") ? (u64)atoll(getenv("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
+            const u64 per = std::max<u64>(limit / elem, 1);
+            const u64 rounds = std::max<u64>((max_block + per - 1) / per, 1);
+            std::vector<u64> sb(size), so(size), rb(size), ro(size), sbase(size + 1, 0), rbase(size + 1, 0);
+            for (int g = 0; g < size; g++) { sbase[g + 1] = sbase[g] + scnt[g]; rbase[g + 1] = rbase[g] + rcnt[g]; }
+            if (!stream_ordered) prim::sync();
+            for (u64 k = 0; k < rounds; k++) {
+                for (int g = 0; g < size; g++) {
+                    const u64 s0 = std::min(k * per, scnt[g]), s1 = std::min((k + 1) * per, scnt[g]);
+                    const u64 r0 = std::min(k * per, rcnt[g]), r1 = std::min((k + 1) * per, rcnt[g]);
+                    sb[g] = (s1 - s0) * elem; so[g] = (sbase[g] + s0) * elem;
+                    rb[g] = (r1 - r0) * elem; ro[g] = (rbase[g] + r0) * elem;
+                }
+                if (a2a(user, send, sb.data(), so.data(), recv, rb.data(), ro.data()) != 0) throw prim::Error(-5, "alltoallv callback failed");
+            }
         }
         // variable-length all-gather of a typed device array -> dense concatenation in rank order.
         // same_counts: `base` already holds the prefix of every rank's count (an earlier call with the same counts)
@@ -2897,13 +2834,14 @@ class Engine {
 
     // ---- distributed induction --------------------------------------------------------------
     // Invariant: every rank holds a contiguous slice of BWT_{level} (runs), slices in rank order.
-    // Per level: (1) local chain expansion + stable bucket split of the slice (same kernels as the
-    // single-GPU path); (2) the rewritten run symbols of BWT_{r+1} are all-gathered (every rank can
-    // then resolve its own TAKE cells); (3) per-bucket symbol counts are exchanged ("rank counts":
-    // totals give the bucket starts, the part of earlier ranks the offset of my cells inside each
-    // bucket); (4) every rank turns its cells, and the part of the replicated pre-BWT that falls in
-    // its own output range, into atoms with explicit output positions; (5) atoms are routed to the
-    // rank that owns their output range (all-to-all), sorted by position and merged into runs.
+    // Per level: (1) the shards agree on the cell layout (longest run) and every rank runs passes A+B over its slice: chain
+    // expansion + stable bucket split, the single-GPU kernels; (2) the level's output is cut into one piece per rank at
+    // pre-BWT run boundaries; a piece owns the buckets inside it; (3) all-to-all #1: every rank sends each owner the part of
+    // the rewritten BWT_{r+1} (runs, clipped) that the owner's piece consumes and that lies in its slice -- consumption is
+    // monotone in output order, so a piece needs ONE contiguous window; (4) all-to-all #2: the cells, already bucket-major,
+    // go to the owners of their buckets (8 bytes per cell in the usual layout) and are merged by one stable split on the
+    // bucket bits (rank order inside a bucket = slice order); (5) every rank runs the single-GPU pass C on its piece and
+    // ends up holding its slice of BWT_r.  Nothing is replicated and no symbol crosses the fabric more than once per level.
     void dist_first_bwt() {
         first_bwt();     // local: my strings' final symbols, in collection order
     }
@@ -2914,178 +2852,169 @@ class Engine {
         prim::rt().tag = r;
         prim::rt().phase = 'i';
         LevelData &L = levels[r];
-        const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
-        const u64 R = bwt.R, P = L.prebwt.R, M = L.M;
+        const u32 bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
+        const u64 P = L.prebwt.R, M = L.M, R = bwt.R;
+        const int N = C.size, me = C.rank;
         LevelInfo &I = linfo[r];
         I.R_next = R; I.P = P;
-        // (1) local expansion and stable split by bucket
-        DBuf<idx_t> eoff(R + 1);
-        DBuf<u32> term(R);
-        DBuf<u64> gp;                           // packed grammar cells (chain walks)
-        u64 E;
+        // (1) one cell layout for all shards, then passes A+B over my slice (the single-GPU kernels)
+        DBuf<idx_t> Tpos(R + 1);
+        u64 Tlocal, maxrun = 0, Toff = 0, Ttotal = 0;
         {
             StageTimer st(&tm.ind_expand);
-            gp.alloc(M);
-            prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
-            prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, gp.p, sigma3}, eoff.p}, "induce_count");
-            E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
+            Tlocal = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "dist.Tpos");
         }
-        I.E = E;
-        DBuf<u32> skey, ssym(E);
-        DBuf<idx_t> slen(E);
         {
-            DBuf<u32> ekey(E), ekey2(E);
-            int bits = (int)bitlen64(M > 0 ? M - 1 : 0);
-            if (bits < 1) bits = 1;
-            bool packed = sizeof(idx_t) == 4;
-            if (!packed) packed = prim::reduce_max<u64>(R, IdxIn<idx_t>{bwt.len.p}, "induce_maxrun") < 0xFFFFFFFFull;
-            if (packed) {
-                DBuf<u64> ep(E), ep2(E);
-                {
-                    StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<CELLS_PACKED>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
-                                                          ekey.p, nullptr, nullptr, nullptr, ep.p, term.p, 0, 0}, "induce_expand");
-                }
-                StageTimer st(&tm.ind_sort);
-                int res = prim::sort_pairs<u32, u64>(ekey.p, ep.p, ekey2.p, ep2.p, E, 0, bits, "induce_split");
-                prim::for_each(E, UnpackCellFn{res ? ep2.p : ep.p, ssym.p, slen.p}, "induce_unpack");
-                skey = std::move(res ? ekey2 : ekey);
-                prim::sync();
-            } else {
-                DBuf<u32> esym(E);
-                DBuf<idx_t> eidx(E), eidx2(E), elen(E);
-                {
-                    StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<CELLS_SEPARATE>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
-                                                           ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p, 0, 0}, "induce_expand");
-                }
-                StageTimer st(&tm.ind_sort);
-                int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
-                prim::for_each(E, GatherCellFn{res ? eidx2.p : eidx.p, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
-                skey = std::move(res ? ekey2 : ekey);
-                prim::sync();
+            const u64 mr = level_maxrun();
+            std::vector<u64> g1 = C.allgather_u64({mr, Tlocal});
+            for (int g = 0; g < N; g++) {
+                if (g1[2 * g] > maxrun) maxrun = g1[2 * g];
+                if (g < me) Toff += g1[2 * g + 1];
+                Ttotal += g1[2 * g + 1];
             }
         }
-        eoff.release();
-        StageTimer st(&tm.ind_assemble);
-        // (2) replicate the rewritten BWT_{r+1} (run symbols + lengths)
-        std::vector<u64> rbase, rbase2;
-        DBuf<u32> Tsym = C.allgather_v<u32>(term.p, R, rbase);
-        DBuf<idx_t> Tlen = C.allgather_v<idx_t>(bwt.len.p, R, rbase, true);
-        const u64 Rt = rbase[C.size];
-        DBuf<idx_t> Tpos(Rt + 1);
-        u64 Tsum = (u64)prim::exclusive_scan<idx_t>(Rt, IdxIn<idx_t>{Tlen.p}, Tpos.p, true, "dist.Tpos");
-        term.release(); Tlen.release();
-        // (3) per-bucket rank counts
-        DBuf<idx_t> lH(E + 1), lT(E + 1), lfirst(M + 1);
-        prim::exclusive_scan_nosync<idx_t>(E, IdxIn<idx_t>{slen.p}, lH.p, true, "dist.lH");
-        prim::exclusive_scan_nosync<idx_t>(E, CondLenIn{ssym.p, slen.p, take_code}, lT.p, true, "dist.lT");
-        DBuf<u64> cntpair(2 * M + 2), allcnt((2 * M + 2) * (u64)C.size);
-        prim::for_each(M, BucketSumFn{skey.p, E, lH.p, lT.p, cntpair.p, lfirst.p}, "dist.bucket_counts");
-        C.allgather(cntpair.p, allcnt.p, (2 * M + 2) * 8);
-        DBuf<idx_t> tot(M + 1), before(M + 1), totT(M + 1), beforeT(M + 1), bucket_base(M + 1), th_base(M + 1);
-        // note: rows of allcnt have stride 2M+2; BucketPrefixFn is told that stride through M' = M+1
-        prim::for_each(M, BucketPrefixFn{allcnt.p, C.size, C.rank, M + 1, tot.p, before.p, totT.p, beforeT.p}, "dist.bucket_prefix");
-        u64 Hsum = (u64)prim::exclusive_scan<idx_t>(M, IdxIn<idx_t>{tot.p}, bucket_base.p, true, "dist.bucket_base");
-        u64 THsum = (u64)prim::exclusive_scan<idx_t>(M, IdxIn<idx_t>{totT.p}, th_base.p, true, "dist.th_base");
-        allcnt.release(); cntpair.release();
-        // replicated pre-BWT coordinates
-        DBuf<idx_t> PH(P + 1), PB(P + 1), Ppos(P + 1);
-        u64 PHsum = (u64)prim::exclusive_scan<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code}, PH.p, true, "dist.PH");
-        u64 PBsum = (u64)prim::exclusive_scan<idx_t>(P, CondLenIn{L.prebwt.sym.p, L.prebwt.len.p, bwt_code}, PB.p, true, "dist.PB");
-        u64 n_r = (u64)prim::exclusive_scan<idx_t>(P, IdxIn<idx_t>{L.prebwt.len.p}, Ppos.p, true, "dist.Ppos");
-        if (Hsum != PHsum) throw prim::Error(-71, "dist induction: induced symbols do not match the pre-BWT (level " + std::to_string(r) + ")");
-        if (PBsum + THsum != Tsum) throw prim::Error(-71, "dist induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ")");
-        // (4) my output range and my segments
-        const u64 chunk = (n_r + C.size - 1) / C.size > 0 ? (n_r + C.size - 1) / C.size : 1;
-        const u64 lo = std::min<u64>(n_r, (u64)C.rank * chunk), hi = std::min<u64>(n_r, lo + chunk);
-        DBuf<u32> pidx(P + 1);
-        u64 Pc = prim::exclusive_scan<u32>(P, PreClipFlagIn{L.prebwt.sym.p, Ppos.p, hocc_code, lo, hi}, pidx.p, false, "dist.clip");
-        const u64 G = Pc + E;
-        I.G = G;
-        DBuf<u64> seg_out(G);
-        DBuf<u32> seg_sym(G);
-        DBuf<idx_t> seg_len(G), seg_toff(G), abase(G + 1);
-        prim::for_each(P, DistSegPreFn{L.prebwt.sym.p, L.prebwt.len.p, Ppos.p, PB.p, L.u_to_p.p, th_base.p, pidx.p, M, lo, hi,
-                                       bwt_code, hocc_code, take_code, seg_out.p, seg_sym.p, seg_len.p, seg_toff.p}, "dist.seg_pre");
-        prim::for_each(E, DistSegCellFn{skey.p, ssym.p, slen.p, lH.p, lT.p, lfirst.p, L.u_to_p.p, Ppos.p, PH.p, PB.p, bucket_base.p,
-                                        before.p, th_base.p, beforeT.p, Pc, take_code, seg_out.p, seg_sym.p, seg_len.p, seg_toff.p},
-                       "dist.seg_cell");
-        skey.release(); ssym.release(); slen.release(); lH.release(); lT.release();
-        RankBits tbits, abits, pbits;
-        build_rankbits(tbits, Tpos.p, Rt, Tsum + 1, "dist.tbits");
-        prim::for_each(G, StoreFn<DistAtomCountIn>{DistAtomCountIn{seg_sym.p, seg_len.p, seg_toff.p, tbits.words.p, tbits.base.p, take_code}, abase.p},
-                       "dist.atom_count");
-        u64 A = (u64)prim::exclusive_scan<idx_t>(G, IdxIn<idx_t>{abase.p}, abase.p, true, "dist.atom_scan");
-        I.A = A;
-        build_rankbits(abits, abase.p, G, A + 1, "dist.abits");
-        DBuf<u64> a_out(A), a_len(A);
-        DBuf<u32> a_sym(A);
-        prim::for_each(A, DistAtomFn{seg_out.p, seg_sym.p, seg_len.p, seg_toff.p, Tpos.p, Tsym.p, abase.p, tbits.words.p, tbits.base.p,
-                                     abits.words.p, abits.base.p, take_code, a_out.p, a_sym.p, a_len.p}, "dist.atoms");
-        seg_out.release(); seg_sym.release(); seg_len.release(); seg_toff.release(); Tsym.release(); Tpos.release();
-        // (5) route the atoms to the owners of their output ranges
-        DBuf<idx_t> pbase(A + 1);
-        u64 Np = (u64)prim::exclusive_scan<idx_t>(A, PieceCountIn{a_out.p, a_len.p, chunk}, pbase.p, true, "dist.piece_count");
-        build_rankbits(pbits, pbase.p, A, Np + 1, "dist.pbits");
-        DBuf<u32> p_owner(Np), p_owner2(Np), p_sym(Np), s_sym(Np);
-        DBuf<idx_t> p_idx(Np), p_idx2(Np);
-        DBuf<u64> p_out(Np), p_len(Np), s_out(Np), s_len(Np);
-        prim::for_each(Np, PieceFn{a_out.p, a_sym.p, a_len.p, pbase.p, pbits.words.p, pbits.base.p, chunk, p_owner.p, p_idx.p, p_out.p,
-                                   p_sym.p, p_len.p}, "dist.pieces");
-        int obits = (int)bitlen64((u64)C.size - 1);
-        if (obits < 1) obits = 1;
-        int res = prim::sort_pairs<u32, idx_t>(p_owner.p, p_idx.p, p_owner2.p, p_idx2.p, Np, 0, obits, "dist.route_sort");
-        const u32 *okey = res ? p_owner2.p : p_owner.p;
-        prim::for_each(Np, PermuteAtomsFn{res ? p_idx2.p : p_idx.p, p_out.p, p_sym.p, p_len.p, s_out.p, s_sym.p, s_len.p}, "dist.route_pack");
-        std::vector<u64> send_cnt(C.size, 0);
+        DBuf<u32> term(R);
+        int kb, lb;
+        u64 E = expand_split(L, term, maxrun, kb, lb);
+        I.E = E;
+        u32 p0, p1, u0, u1;
+        u64 n_out, n_r;
         {
-            // counts per owner from the sorted owner keys (binary search on the host copy of a small prefix array)
-            DBuf<idx_t> ocount(C.size + 1);
-            prim::for_each((u64)C.size + 1, OwnerBoundFn{okey, Np, ocount.p}, "dist.route_counts");
-            std::vector<idx_t> oc = ocount.to_host(C.size + 1);
-            for (int d = 0; d < C.size; d++) send_cnt[d] = (u64)oc[d + 1] - (u64)oc[d];
+            StageTimer st(&tm.ind_assemble);
+            // (2) owners of the output: pre-BWT run ranges of about n_r / size symbols, and the buckets inside them
+            std::vector<u64> sp;
+            DBuf<u64> split(4 * ((u64)N + 1));
+            {
+                DBuf<idx_t> Ppos(P + 1);
+                DBuf<HoccBwt> PHB(P + 1);
+                n_r = (u64)prim::exclusive_scan<idx_t>(P, IdxIn<idx_t>{L.prebwt.len.p}, Ppos.p, true, "dist.Ppos");
+                prim::exclusive_scan_nosync<HoccBwt>(P, PreScanIn{L.prebwt.sym.p, L.prebwt.len.p, hocc_code, bwt_code}, PHB.p, true, "dist.pre_scan");
+                if (n_r != L.info.n_in) throw prim::Error(-71, "dist induction: the pre-BWT of level " + std::to_string(r) + " does not describe the level");
+                prim::for_each((u64)N + 1, OwnerSplitFn{Ppos.p, PHB.p, L.u_to_p.p, P, M, n_r, N, split.p}, "dist.owners");
+                sp = split.to_host(4 * ((u64)N + 1));
+            }
+            // my cells and my TAKE symbols per owner
+            std::vector<u64> cbh, v(2 * (u64)N, 0);
+            {
+                const CellView mine = cell_view(kb, lb);
+                DBuf<u64> cb((u64)N + 1);
+                prim::for_each((u64)N + 1, CellBoundsFn{mine, E, split.p, cb.p}, "dist.cell_bounds");
+                cbh = cb.to_host((u64)N + 1);
+                for (int d = 0; d < N; d++) {
+                    const u64 cnt = cbh[d + 1] - cbh[d];
+                    v[d] = cnt;
+                    v[N + d] = cnt ? prim::reduce_sum<u64>(cnt, CellTakeOffIn{mine, take_code, cbh[d]}, "dist.take_sums") : 0;
+                }
+            }
+            std::vector<u64> mat = C.allgather_u64(v);           // mat[s*2N + d] cells, mat[s*2N + N + d] TAKE symbols of rank s for owner d
+            // symbols of the rewritten BWT_{r+1} consumed in front of every owner's piece (output order = consumption order)
+            std::vector<u64> Tc((u64)N + 1);
+            {
+                u64 acc = 0;
+                for (int d = 0; d <= N; d++) {
+                    Tc[d] = sp[4 * d + 3] + acc;
+                    if (d < N) for (int g = 0; g < N; g++) acc += mat[(u64)g * 2 * N + N + d];
+                }
+            }
+            if (Tc[N] != Ttotal) throw prim::Error(-71, "dist induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
+                                                            std::to_string(Tc[N]) + " vs " + std::to_string(Ttotal) + ")");
+            // (3) every owner's window of the rewritten BWT_{r+1}: I send the part of it that lies in my slice
+            DBuf<u32> wsym; DBuf<idx_t> wlen;
+            u64 Rw = 0;
+            {
+                std::vector<u64> ab(2 * (u64)N), scnt(N), soff((u64)N + 1, 0), rcnt(N);
+                for (int d = 0; d < N; d++) {
+                    const u64 lo = Tc[d] > Toff ? Tc[d] - Toff : 0, hi = Tc[d + 1] > Toff ? Tc[d + 1] - Toff : 0;
+                    ab[2 * d] = lo < Tlocal ? lo : Tlocal;
+                    ab[2 * d + 1] = hi < Tlocal ? hi : Tlocal;
+                }
+                DBuf<u64> abd(2 * (u64)N), kc(2 * (u64)N), sod((u64)N + 1);
+                prim::h2d(abd.p, ab.data(), 2 * (u64)N * 8);
+                prim::for_each((u64)N, WindowRunsFn{Tpos.p, R, abd.p, kc.p}, "dist.window_runs");
+                std::vector<u64> kch = kc.to_host(2 * (u64)N);
+                for (int d = 0; d < N; d++) { scnt[d] = kch[2 * d + 1]; soff[d + 1] = soff[d] + scnt[d]; }
+                std::vector<u64> rc = C.allgather_u64(scnt);     // rc[s*N + d]
+                for (int g = 0; g < N; g++) { rcnt[g] = rc[(u64)g * N + me]; Rw += rcnt[g]; }
+                const u64 maxw = *std::max_element(rc.begin(), rc.end());
+                DBuf<u32> ssym(soff[N]); DBuf<idx_t> slen(soff[N]);
+                prim::h2d(sod.p, soff.data(), ((u64)N + 1) * 8);
+                prim::for_each(soff[N], WindowSendFn{Tpos.p, term.p, abd.p, kc.p, sod.p, N, ssym.p, slen.p}, "dist.window_send");
+                wsym.alloc(Rw); wlen.alloc(Rw);
+                C.alltoall(ssym.p, scnt, wsym.p, rcnt, sizeof(u32), maxw);
+                C.alltoall(slen.p, scnt, wlen.p, rcnt, sizeof(idx_t), maxw);
+            }
+            Tpos.release(); term.release();
+            bwt.sym.release(); bwt.len.release();
+            // (4) the cells of my buckets, from every rank; rank order inside a bucket = order of the slices
+            {
+                std::vector<u64> scnt(N), rcnt(N);
+                u64 Er = 0;
+                for (int d = 0; d < N; d++) scnt[d] = v[d];
+                for (int g = 0; g < N; g++) { rcnt[g] = mat[(u64)g * 2 * N + me]; Er += rcnt[g]; }
+                u64 maxc = 0;
+                for (int g = 0; g < N; g++) for (int d = 0; d < N; d++) maxc = std::max(maxc, mat[(u64)g * 2 * N + d]);
+                const int bits = kb;
+                if (c_sfused.p) {
+                    DBuf<u64> rf(Er);
+                    C.alltoall(c_sfused.p, scnt, rf.p, rcnt, 8, maxc);
+                    c_sfused = std::move(rf);
+                    if (N > 1 && Er) {
+                        DBuf<u64> tmp(Er);
+                        if (prim::sort_keys<u64, 1>(c_sfused.p, tmp.p, Er, 0, bits, "dist.merge_cells")) c_sfused = std::move(tmp);
+                    }
+                } else if (c_spack.p) {
+                    DBuf<u32> rk(Er); DBuf<u64> rp(Er);
+                    C.alltoall(c_skey.p, scnt, rk.p, rcnt, 4, maxc);
+                    C.alltoall(c_spack.p, scnt, rp.p, rcnt, 8, maxc);
+                    c_skey = std::move(rk); c_spack = std::move(rp);
+                    if (N > 1 && Er) {
+                        DBuf<u32> k2(Er); DBuf<u64> p2(Er);
+                        if (prim::sort_pairs<u32, u64>(c_skey.p, c_spack.p, k2.p, p2.p, Er, 0, bits, "dist.merge_cells")) { c_skey = std::move(k2); c_spack = std::move(p2); }
+                    }
+                } else {
+                    DBuf<u32> rk(Er), rs(Er); DBuf<idx_t> rl(Er);
+                    C.alltoall(c_skey.p, scnt, rk.p, rcnt, 4, maxc);
+                    C.alltoall(c_ssym.p, scnt, rs.p, rcnt, 4, maxc);
+                    C.alltoall(c_slen.p, scnt, rl.p, rcnt, sizeof(idx_t), maxc);
+                    c_skey = std::move(rk);
+                    if (N > 1 && Er) {
+                        DBuf<u32> k2(Er); DBuf<idx_t> ix(Er), ix2(Er);
+                        prim::for_each(Er, IotaIdxFn{ix.p}, "dist.merge_cells");
+                        int res = prim::sort_pairs<u32, idx_t>(c_skey.p, ix.p, k2.p, ix2.p, Er, 0, bits, "dist.merge_cells");
+                        c_ssym.alloc(Er); c_slen.alloc(Er);
+                        prim::for_each(Er, GatherCellFn{res ? ix2.p : ix.p, rs.p, rl.p, c_ssym.p, c_slen.p}, "dist.merge_cells");
+                        if (res) c_skey = std::move(k2);
+                    } else { c_ssym = std::move(rs); c_slen = std::move(rl); }
+                }
+                E = Er;
+            }
+            p0 = (u32)sp[4 * me]; p1 = (u32)sp[4 * (me + 1)];
+            u0 = (u32)sp[4 * me + 1]; u1 = (u32)sp[4 * (me + 1) + 1];
+            n_out = sp[4 * (me + 1) + 2] - sp[4 * me + 2];
+            // my window becomes "the BWT_{r+1}" of my piece
+            bwt.sym.alloc(0);
+            bwt.len = std::move(wlen);
+            bwt.R = Rw;
+            bwt.n = Tc[me + 1] - Tc[me];
+            term = std::move(wsym);
         }
-        std::vector<u64> mat = C.allgather_u64(send_cnt);       // mat[g*size + d] = atoms g sends to d
-        std::vector<u64> recv_cnt(C.size);
-        u64 Nr = 0;
-        for (int g = 0; g < C.size; g++) { recv_cnt[g] = mat[(u64)g * C.size + C.rank]; Nr += recv_cnt[g]; }
-        DBuf<u64> r_out(Nr), r_len(Nr);
-        DBuf<u32> r_sym(Nr);
-        auto a2a = [&](const void *sp, void *rp, u64 elem) {
-            std::vector<u64> sb(C.size), rb(C.size);
-            for (int g = 0; g < C.size; g++) { sb[g] = send_cnt[g] * elem; rb[g] = recv_cnt[g] * elem; }
-            if (!C.stream_ordered) prim::sync();
-            if (C.a2a(C.user, sp, sb.data(), rp, rb.data()) != 0) throw prim::Error(-5, "alltoallv callback failed");
-        };
-        a2a(s_out.p, r_out.p, 8); a2a(s_len.p, r_len.p, 8); a2a(s_sym.p, r_sym.p, 4);
-        // place what I received in output order and merge into runs: my slice of BWT_r
-        DBuf<u32> bad(1);
-        bad.zero();
-        DBuf<u32> osym(Nr);
-        DBuf<idx_t> olen(Nr);
-        {
-            const u64 span = hi - lo;
-            RankBits rb;
-            const u64 nw = span / 64 + 2;
-            rb.words.alloc(nw);
-            rb.base.alloc(nw + 1);
-            rb.words.zero();
-            prim::for_each((Nr + 15) / 16, RecvMarkFn{r_out.p, Nr, lo, span, rb.words.p, bad.p}, "dist.recv_mark");
-            u64 marked = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{rb.words.p}, rb.base.p, true, "dist.recv_rank");
-            if (marked != Nr || bad.get(0))
-                throw prim::Error(-71, "dist induction: received atoms do not tile my output range (level " + std::to_string(r) + ")");
-            DBuf<u64> opos(Nr);
-            prim::for_each(Nr, RecvPlaceFn{r_out.p, r_sym.p, r_len.p, lo, span, rb.words.p, rb.base.p, opos.p, osym.p, olen.p}, "dist.recv_place");
-            prim::for_each(Nr, CheckPlacedAtomsFn{opos.p, olen.p, Nr, bad.p}, "dist.recv_check");
+        // (5) pass C on my piece (the single-GPU kernels)
+        if (n_out == 0) {
+            if (E || bwt.R) throw prim::Error(-71, "dist induction: cells or BWT_{r+1} symbols for an empty piece (level " + std::to_string(r) + ")");
+            release_cells();
+            bwt = Runs();
+            bwt.sym.alloc(0); bwt.len.alloc(0);
+        } else {
+            const u64 Pm = p1 - p0, Mm = u1 - u0;
+            DBuf<u32> u2p(Mm), p2u(Pm);
+            prim::for_each(Mm, RebaseFn{L.u_to_p.p + u0, p0, u2p.p}, "dist.piece_maps");
+            if (L.p_to_u.p) prim::for_each(Pm, RebaseFn{L.p_to_u.p + p0, u0, p2u.p}, "dist.piece_maps");
+            else prim::for_each(Pm, PieceMetaFn{L.u_to_p.p, M, p0, u0, p2u.p}, "dist.piece_maps");
+            assemble(AsmIn{L.prebwt.sym.p + p0, L.prebwt.len.p + p0, Pm, u2p.p, p2u.p, Mm, L.sigma, n_out}, I, cell_view(kb, lb, u0), E, term, r);
         }
-        if (bad.get(0)) throw prim::Error(-71, "dist induction: received atoms do not tile my output range (level " + std::to_string(r) + ")");
-        bwt = merge_runs(osym.p, olen.p, Nr);
-        u64 got = prim::reduce_sum<u64>(bwt.R, IdxIn<idx_t>{bwt.len.p}, "dist.slice_check");
-        if (got != hi - lo) throw prim::Error(-71, "dist induction: slice size mismatch (level " + std::to_string(r) + ")");
         bwt_level = r;
         I.R = bwt.R; I.n = n_r;
-        L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.p_to_u.release(); L.prebwt.sym.release(); L.prebwt.len.release();
+        release_level(L);
     }
 
     // gather the slices of BWT_0, restore maximal runs across rank boundaries, build the image

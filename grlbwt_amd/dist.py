@@ -16,7 +16,8 @@ import torch.distributed as dist
 from . import engine
 
 _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
-_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                   C.POINTER(C.c_uint64))
 
 
 class CommStruct(C.Structure):
@@ -104,22 +105,33 @@ class Communicator:
             print("grlbwt allgather callback failed:", repr(e), flush=True)
             return 1
 
-    def _alltoallv(self, user, send, send_bytes, recv, recv_bytes):
+    def _alltoallv(self, user, send, send_bytes, send_off, recv, recv_bytes, recv_off):
+        """MPI_Alltoallv shape: block g = send_bytes[g] bytes at send + send_off[g] (the engine keeps blocks <= 256 MiB)."""
         t0 = time.perf_counter()
         try:
-            sb = [int(send_bytes[i]) for i in range(self.size)]
-            rb = [int(recv_bytes[i]) for i in range(self.size)]
-            s = _view(send, sum(sb), self.device)
-            r = _view(recv, sum(rb), self.device)
-            if self.stage:
-                hs, hr = s.cpu(), torch.empty(sum(rb), dtype=torch.uint8)
+            n = self.size
+            send, recv = send or 0, recv or 0
+            sb = [int(send_bytes[i]) for i in range(n)]
+            rb = [int(recv_bytes[i]) for i in range(n)]
+            so = [int(send_off[i]) for i in range(n)]
+            ro = [int(recv_off[i]) for i in range(n)]
+            ins = [_view(send + so[g], sb[g], self.device) for g in range(n)]
+            outs = [_view(recv + ro[g], rb[g], self.device) for g in range(n)]
+            if self.stage or self.device.type == "cpu":
+                # gloo has the single-buffer form only: pack on the host, exchange, unpack
+                hs = torch.cat([t.cpu() for t in ins]) if sum(sb) else torch.empty(0, dtype=torch.uint8)
+                hr = torch.empty(sum(rb), dtype=torch.uint8)
                 dist.all_to_all_single(hr, hs, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
-                r.copy_(hr)
+                pos = 0
+                for g in range(n):
+                    if rb[g]:
+                        outs[g].copy_(hr[pos:pos + rb[g]])
+                    pos += rb[g]
             elif self.stream is not None:
                 with torch.cuda.stream(self.stream):
-                    dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+                    dist.all_to_all(outs, ins, group=self.group)             # grouped send/recv on the views
             else:
-                dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+                dist.all_to_all(outs, ins, group=self.group)
             self._sync()
             self.bytes_moved += sum(sb)
             self.n_alltoall += 1

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GRLBWT_ABI_VERSION 2
+#define GRLBWT_ABI_VERSION 3
 
 #define GRLBWT_OK 0
 #define GRLBWT_EINVAL (-22)     /* bad argument / call out of order                                  */
@@ -226,8 +226,11 @@ typedef struct grlbwt_comm {
     void *user;
     /* every rank contributes `bytes` bytes at `send`; `recv` gets size*bytes in rank order; 0 = ok */
     int (*allgather)(void *user, const void *send, void *recv, uint64_t bytes);
-    /* variable all-to-all: send_bytes[size]/recv_bytes[size] (host arrays), blocks contiguous in rank order */
-    int (*alltoallv)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+    /* variable all-to-all (MPI_Alltoallv shape, byte units, host arrays of `size` entries): send_bytes[g] bytes at
+     * send + send_off[g] go to rank g; recv_bytes[g] bytes from rank g land at recv + recv_off[g].  The engine keeps every
+     * block at or below 256 MiB (larger exchanges arrive as several calls; GRLBWT_A2A_BLOCK overrides the limit). */
+    int (*alltoallv)(void *user, const void *send, const uint64_t *send_bytes, const uint64_t *send_off,
+                     void *recv, const uint64_t *recv_bytes, const uint64_t *recv_off);
     /* GRLBWT_COMM_STREAM_ORDERED: the callbacks enqueue the exchange on the context's stream
      * (grlbwt_ctx_set_stream) and return without waiting; the engine then neither drains its stream
      * before a callback nor expects the data to be complete when it returns -- later work on the same

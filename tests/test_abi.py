@@ -27,7 +27,7 @@ def test_header_symbols_exported(hip_lib):
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "missing export %s" % n
-    assert lib.grlbwt_abi_version() == 2
+    assert lib.grlbwt_abi_version() == 3
 
 
 def test_python_binding_covers_header():

@@ -47,6 +47,27 @@ def test_sharded_collection_matches_oracle(sim, oracle_mod, tmp_path, world, cas
         assert n_ag > 0 and n_a2a > 0 and nbytes > 0
 
 
+@pytest.mark.parametrize("layout", ["packed", "separate"])
+def test_sharded_wider_cell_layouts(sim, oracle_mod, tmp_path, monkeypatch, layout):
+    """The cell exchange of the collection-level induction in the two wider cell layouts (several arrays per cell)."""
+    monkeypatch.setenv("GRLBWT_CELL_LAYOUT", layout)
+    _run(3, sim, "reads", tmp_path, 29571 if layout == "packed" else 29572)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+
+
+def test_large_exchanges_go_in_rounds(sim, oracle_mod, tmp_path, monkeypatch):
+    """All-to-all blocks above the engine's limit are sent in several rounds (the limit is lowered to 4 KiB here)."""
+    monkeypatch.setenv("GRLBWT_A2A_BLOCK", "4096")
+    _run(3, sim, "reads", tmp_path, 29573)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+    n_a2a = int(open(tmp_path / "reads.rank0.comm").read().split()[1])
+    monkeypatch.delenv("GRLBWT_A2A_BLOCK")
+    _run(3, sim, "reads", tmp_path, 29574)
+    assert n_a2a > int(open(tmp_path / "reads.rank0.comm").read().split()[1])
+
+
 def test_replicated_induction_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
     monkeypatch.setenv("GRLBWT_DIST_REPLICATED_INDUCTION", "1")
     _run(2, sim, "reads", tmp_path, 29590)

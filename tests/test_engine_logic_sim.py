@@ -135,6 +135,15 @@ def test_unfused_expansion_branch(sim, oracle_mod, monkeypatch):
     parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
+@pytest.mark.parametrize("layout", ["packed", "separate"])
+def test_wider_cell_layouts(sim, oracle_mod, monkeypatch, layout):
+    """Induced cells that do not fit one 64-bit word (bucket + run length + symbol > 64 bits) travel as bucket + packed
+    payload, or as three arrays when a run length needs more than 32 bits; forced here on ordinary inputs."""
+    monkeypatch.setenv("GRLBWT_CELL_LAYOUT", layout)
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+
+
 def test_file_in_file_out(sim, oracle_mod, tmp_path):
     """grlbwt_text_load_file / grlbwt_result_write_file (the CLI's path): chunked staging, histogram taken per chunk."""
     for data, w in ((workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1),

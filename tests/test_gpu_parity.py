@@ -298,3 +298,12 @@ def test_sharded_equals_single_gpu_image(hip, tmp_path):
     want = "%s %d" % (hashlib.md5(single).hexdigest(), len(single))
     for r in range(2):
         assert open(tmp_path / ("illumina_dev.rank%d.md5" % r)).read() == want
+    # the same collection through RCCL (one rank: all this box has).  Its level-0 cell exchange is a 2.1 GB block, the size
+    # at which torch 2.10 / RCCL 2.26 deliver half of an all-to-all silently: the engine sends such blocks in rounds
+    os.remove(tmp_path / "illumina_dev.rank0.md5")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29672",
+           os.path.join(here, "dist_worker.py"), hip, "nccl", "illumina_dev:%d:%d" % (reads, genome), str(tmp_path)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert open(tmp_path / "illumina_dev.rank0.md5").read() == want
