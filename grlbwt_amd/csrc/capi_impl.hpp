@@ -526,7 +526,7 @@ int grlbwt_build(grlbwt_ctx *ctx) {
 int grlbwt_result_size(const grlbwt_ctx *ctx, uint64_t *image_bytes, uint64_t *n_runs) {
     if (!HAS_ENG(ctx) || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
     if (image_bytes) *image_bytes = ENG(ctx, image_bytes);
-    if (n_runs) *n_runs = ENG(ctx, bwt.R);
+    if (n_runs) *n_runs = ENG(ctx, image_runs);
     return GRLBWT_OK;
 }
 int grlbwt_result_device_ptr(const grlbwt_ctx *ctx, const void **dev_ptr) {
@@ -668,7 +668,7 @@ int grlbwt_memory_usage(const grlbwt_ctx *ctx, uint64_t *peak_live_bytes, uint64
 }
 
 int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm) {
-    if (!HAS_ENG(ctx) || !comm || !comm->allgather || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size) return GRLBWT_EINVAL;
+    if (!HAS_ENG(ctx) || !comm || !comm->allgather || !comm->alltoallv || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size) return GRLBWT_EINVAL;
     return guarded(ctx, [&] {
         if (ctx->e32) {
             grl32::Engine::Comm C;

@@ -461,21 +461,12 @@ struct Key0Fn {        // first K symbols packed b bits each
         u64 sent = (1ull << b) - 1, key = 0;
         for (int j = 0; j < K; j++) key = (key << b) | ((q + j < end) ? (u64)dict_sym[q + j] : sent);
         keys[q] = key;
-        vals[q] = (u32)q;
+        if (vals) vals[q] = (u32)q;
     }
 };
 struct HeadKeyIn {     // 1 where the sorted key changes
     const u64 *k;
     GRL_DEV u32 operator()(u64 t) const { return (t == 0 || k[t] != k[t - 1]) ? 1u : 0u; }
-};
-struct RankWriteFn {   // gid[t] = (#heads before t) + head(t) - 1 ; rank[perm[t]] = gid[t]
-    const u64 *k; const u32 *ex; const u32 *perm; u32 *gid; u32 *rank;
-    GRL_DEV void operator()(u64 t) const {
-        u32 head = (t == 0 || k[t] != k[t - 1]) ? 1u : 0u;
-        u32 g = ex[t] + head - 1;
-        gid[t] = g;
-        rank[perm[t]] = g;
-    }
 };
 // prefix doubling with filtering: after every pass only the suffixes that sit in a group of equal
 // keys whose key did not yet reach the phrase end ("unresolved") are re-sorted, by
@@ -498,39 +489,11 @@ struct ByteIn {
 };
 // Ranks are POSITIONAL: rank[q] = first slot of q's group in the sorted order, so refining one
 // group never renumbers the others and only the re-sorted suffixes get their rank rewritten.
-struct SufLenFn {         // suffix length of every dictionary position (coalesced)
-    const u32 *dict_phr; const u32 *ph_off; u32 *suflen;
-    GRL_DEV void operator()(u64 q) const { suflen[q] = ph_off[dict_phr[q] + 1] - (u32)q; }
-};
 struct GroupStartsFn {    // gstart[dense group id] = head slot ; gstart[G] = S
     const u8 *hflag; const u32 *ex; u64 S; u32 *gstart;
     GRL_DEV void operator()(u64 t) const {
         if (hflag[t]) gstart[ex[t]] = (u32)t;
         if (t == S - 1) gstart[ex[t] + hflag[t]] = (u32)S;
-    }
-};
-struct UnresolvedFlagFn { // member of a group of >1 suffixes that are all at least as long as the resolved prefix
-    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; const u32 *suflen; u64 Lres; u8 *uflag;
-    GRL_DEV void operator()(u64 t) const {
-        u32 g = ex[t] + hflag[t] - 1;
-        u8 f = 0;
-        if (gstart[g + 1] - gstart[g] >= 2) f = (suflen[perm[t]] >= Lres) ? 1 : 0;
-        uflag[t] = f;
-    }
-};
-struct UnresolvedKeyFn {  // compact the unresolved slots and build their refinement keys
-    const u8 *uflag; const u32 *uex; const u32 *perm; const u32 *rank; const u32 *suflen;
-    u64 h; int lowbits;
-    u64 *keys; u32 *vals; u32 *uslot;
-    GRL_DEV void operator()(u64 t) const {
-        if (!uflag[t]) return;
-        u64 q = perm[t];
-        u64 sent = (1ull << lowbits) - 1;
-        u64 low = (h < suflen[q]) ? (u64)rank[q + h] : sent;
-        u32 i = uex[t];
-        keys[i] = ((u64)rank[q] << lowbits) | low;
-        vals[i] = (u32)q;
-        uslot[i] = (u32)t;
     }
 };
 struct RefineWriteFn {    // sorted unresolved suffixes go back into their slots; new heads where the key changes
@@ -539,13 +502,6 @@ struct RefineWriteFn {    // sorted unresolved suffixes go back into their slots
         u32 t = uslot[i];
         perm[t] = v[i];
         if (i > 0 && k[i] != k[i - 1]) hflag[t] = 1;
-    }
-};
-struct RankRefinedFn {    // new positional rank of the re-sorted suffixes only
-    const u32 *uslot; const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 *rank;
-    GRL_DEV void operator()(u64 i) const {
-        u32 t = uslot[i];
-        rank[perm[t]] = gstart[ex[t] + hflag[t] - 1];
     }
 };
 // Positional rank and suffix length of a dictionary position in ONE 8-byte record: the refinement looks both up at the
@@ -559,15 +515,16 @@ struct SufLenPFn {        // suffix length of every dictionary position (coalesc
 // 617 M suffixes).  Partitioned instead: (position, rank) pairs, ONE stable radix pass on the top bits of the position
 // (sequential traffic), then the pairs are applied in that order -- the stores of one digit fall into 1/256 of the array,
 // a region the L2s and the memory-side cache hold while it is being written.
+// (`base` = global slot of my first slot: the sorted order may be sharded over ranks by key range, see below)
 struct RankPairFn {       // pair[t] = position << 32 | rank of slot t
-    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u64 *pairs;
-    GRL_DEV void operator()(u64 t) const { pairs[t] = ((u64)perm[t] << 32) | (u64)gstart[ex[t] + hflag[t] - 1]; }
+    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 base; u64 *pairs;
+    GRL_DEV void operator()(u64 t) const { pairs[t] = ((u64)perm[t] << 32) | (u64)(base + gstart[ex[t] + hflag[t] - 1]); }
 };
 struct RankHeadPairFn {   // the same for the suffixes a refinement pass re-sorted
-    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; u64 *pairs;
+    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; u32 base; u64 *pairs;
     GRL_DEV void operator()(u64 i) const {
         u32 head = (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
-        pairs[i] = ((u64)v[i] << 32) | (u64)hpos[hex[i] + head - 1];
+        pairs[i] = ((u64)v[i] << 32) | (u64)(base + hpos[hex[i] + head - 1]);
     }
 };
 struct RankApplyFn {
@@ -719,25 +676,26 @@ struct FlagIn {
     const u8 *f; u8 m;
     GRL_DEV u32 operator()(u64 i) const { return (f[i] & m) ? 1u : 0u; }
 };
-struct GroupEmitFn {
+struct GroupEmitFn {      // (m_off, p_off: metasymbols / pre-BWT entries of the ranks in front of me when the groups are sharded)
     const u8 *gflag; const u32 *grank; const u32 *pidx; const u32 *gmin; const idx_t *gacc; const u32 *gstart; const u32 *perm;
-    u32 bwt_code, hocc_code;
+    u32 bwt_code, hocc_code, m_off, p_off;
     u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq; u32 *u_to_p0; u32 *pu0;
     GRL_DEV void operator()(u64 g) const {
         u8 f = gflag[g];
-        if (!(f & GF_VALID)) return;
-        u32 j = pidx[g];
-        pu0[j] = grank[g];           // metasymbols in front of this pre-BWT run (grank is the exclusive count of ranked groups)
-        u32 s = gmin[g];
-        if (f & GF_RANKED) {
-            s = (f & GF_MULTI) ? hocc_code : bwt_code;
-            u32 u = grank[g];
-            has_hocc[u] = (f & GF_MULTI) ? 1 : 0;
-            repq[u] = perm[gstart[g]];
-            u_to_p0[u] = j;
+        if (f & GF_VALID) {
+            u32 j = pidx[g];
+            pu0[j] = m_off + grank[g];   // metasymbols in front of this pre-BWT run (grank is the exclusive count of ranked groups)
+            u32 s = gmin[g];
+            if (f & GF_RANKED) {
+                s = (f & GF_MULTI) ? hocc_code : bwt_code;
+                u32 u = grank[g];
+                has_hocc[u] = (f & GF_MULTI) ? 1 : 0;
+                repq[u] = perm[gstart[g]];
+                u_to_p0[u] = p_off + j;
+            }
+            psym[j] = s;
+            plen[j] = gacc[g];
         }
-        psym[j] = s;
-        plen[j] = gacc[g];
     }
 };
 
@@ -758,9 +716,20 @@ struct ComposeMapFn {    // metasymbol -> merged pre-BWT run
 // (the earlier form, by dictionary position through rank[q] -> gid -> ginfo, was two dependent random gathers for
 // every position: 57 ms of the 10 GB build).
 struct PackGroupInfoFn {
-    const u32 *grank; const u8 *gflag; u32 *ginfo;
-    GRL_DEV void operator()(u64 g) const {       // grank < 2^30 (alphabet bound of the next level)
-        ginfo[g] = (grank[g] << 1) | (((gflag[g] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1u : 0u);
+    const u32 *grank; const u8 *gflag; u32 m_off; u32 *ginfo;
+    GRL_DEV void operator()(u64 g) const {       // rank < 2^30 (alphabet bound of the next level)
+        ginfo[g] = ((m_off + grank[g]) << 1) | (((gflag[g] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1u : 0u);
+    }
+};
+struct MarkedIn {          // 1 for the slots MetaPosFn would write (members of marked groups)
+    const u32 *gid; const u32 *ginfo;
+    GRL_DEV u32 operator()(u64 t) const { return ginfo[gid[t]] & 1u; }
+};
+struct MetaPairFn {        // (position << 32 | metasymbol) of the marked slots, compacted: what a rank tells the others
+    const u32 *perm; const u32 *gid; const u32 *ginfo; const u32 *ex; u32 sigma3; u64 *pairs;
+    GRL_DEV void operator()(u64 t) const {
+        u32 gi = ginfo[gid[t]];
+        if (gi & 1u) pairs[ex[t]] = ((u64)perm[t] << 32) | (u64)((gi >> 1) + sigma3);
     }
 };
 struct MetaPosFn {         // by sorted slot t: gid[] and ginfo[] are read in order, only the marked suffixes scatter (meta[] zeroed before)
@@ -1321,10 +1290,10 @@ struct UnpackCellFn {   // (sym<<32 | len) payload carried through the radix spl
 
 // ------------------------------------------------------- a16: .rl_bwt image
 struct PackRunsFn {
-    const u32 *sym; const idx_t *len; u32 sb, fb; u8 *out;
+    const u32 *sym; const idx_t *len; u32 sb, fb; u8 *out; u32 hdr;      // hdr: bytes in front of the first record (16, or 0 for a part)
     GRL_DEV void operator()(u64 i) const {
         const u32 rec = sb + fb;
-        u8 *p = out + 16 + i * (u64)rec;
+        u8 *p = out + hdr + i * (u64)rec;
         u64 s = sym[i], l = len[i];
         // records of 4 or 8 bytes (DNA: 1+3; tokens: 2+2 ... ) are one aligned store, not `rec` byte stores
         if (rec == 4 && ((uintptr_t)out & 3) == 0) { *reinterpret_cast<u32 *>(p) = (u32)(s | (l << (8 * sb))); return; }
@@ -1371,18 +1340,70 @@ struct UnpadFn {          // dense[i] = padded[g*stride + (i - base[g])], g = ra
         dense[i] = padded[(u64)g * stride + (i - base[g])];
     }
 };
-// phrases given as a list (offset, length, weight) over a cell buffer: the merged dictionary
+// The per-round dictionary merge (join_thread_phrases, parsing_strategies.h:277-386) is partitioned by content: a hash of
+// a phrase names the rank that merges it, so the same phrase from every shard meets on ONE rank and every rank inserts
+// about its own share of the phrases (an all-gather of the lists made every rank insert all of them).
+struct PhraseOwnerFn {
+    const u32 *cells; const u32 *off; const u32 *len; u32 size; u32 *owner; u32 *idx;
+    GRL_DEV void operator()(u64 k) const {
+        const u64 o = off[k], l = len[k];
+        PhraseHash ph = PhraseHash::init();
+        for (u64 j = 0; j < l; j++) ph.add(cells[o + j] >> 2);
+        const u64 h = ph.finish(l) * 0x9E3779B97F4A7C15ull;        // remixed: the table below takes its slot and tag from the plain hash
+        owner[k] = (u32)(((h >> 32) * (u64)size) >> 32);
+        idx[k] = (u32)k;
+    }
+};
+struct KeyBoundFn {       // first element of every key value in a sorted key array; with `pre`, the prefix value there too
+    const u32 *k; u64 n; const u64 *pre; u64 *out;
+    GRL_DEV void operator()(u64 d) const {
+        const u64 i = lower_bound<u32>(k, n, (u32)d);
+        out[2 * d] = i;
+        out[2 * d + 1] = pre ? pre[i] : 0ull;
+    }
+};
+struct SendPhraseFn {     // my phrases in owner order: length and frequency
+    const u32 *order; const u32 *len; const idx_t *freq; u32 *slen; u64 *sfreq;
+    GRL_DEV void operator()(u64 i) const { const u32 k = order[i]; slen[i] = len[k]; sfreq[i] = (u64)freq[k]; }
+};
+struct SendCellsFn {      // ... and their cells
+    const u32 *order; const u32 *off; const u64 *soff; u64 D; const u32 *cells; u32 *out;
+    GRL_DEV void operator()(u64 q) const {
+        const u64 i = upper_bound<u64>(soff, D, q) - 1;
+        out[q] = cells[(u64)off[order[i]] + (q - soff[i])];
+    }
+};
+struct ListCellsFn {      // cells of the phrases a list names, packed in list order
+    const u64 *pos; const u32 *off; u64 D; const u32 *cells; u32 *out;
+    GRL_DEV void operator()(u64 q) const {
+        const u64 k = upper_bound<u32>(off, D, (u32)q) - 1;
+        out[q] = cells[pos[k] + (q - off[k])];
+    }
+};
+struct AddLenFn {
+    idx_t *len; u64 add;
+    GRL_DEV void operator()(u64) const { *len = (idx_t)((u64)*len + add); }
+};
+struct OffToPosFn {
+    const u32 *off; u64 *pos;
+    GRL_DEV void operator()(u64 k) const { pos[k] = off[k]; }
+};
+struct ScatterU32Fn {     // out[order[i]] = v[i]
+    const u32 *order; const u32 *v; u32 *out;
+    GRL_DEV void operator()(u64 i) const { out[order[i]] = v[i]; }
+};
+// phrases given as a list (offset, length, weight) over a cell buffer
 struct ListInsertFn {
     const u32 *cells; const u64 *off; const u32 *len; const u64 *weight;
     u64 *keys; idx_t *counts; u64 mask;      // key = tag:24 | (list index + 1):40
     u32 *list_slot; u32 *scal;
     GRL_DEV void operator()(u64 i) const {
-        u64 o = off[i], l = len[i];
+        const u64 o = off[i], l = len[i];
         PhraseHash ph = PhraseHash::init();
         for (u64 j = 0; j < l; j++) ph.add(cells[o + j] >> 2);
-        u64 h = ph.finish(l);
-        u64 tag = h >> kPosBits;
-        u64 mine = (tag << kPosBits) | (i + 1);
+        const u64 h = ph.finish(l);
+        const u64 tag = h >> kPosBits;
+        const u64 mine = (tag << kPosBits) | (i + 1);
         u64 slot = h & mask;
         u32 found = prim::kNoBucket;
         for (u64 probes = 0; probes <= mask && found == prim::kNoBucket; probes++) {
@@ -1393,23 +1414,26 @@ struct ListInsertFn {
             }
             bool hit = (cur == mine);
             if (!hit && (cur >> kPosBits) == tag) {
-                u64 i2 = (cur & kPosMask) - 1;
+                const u64 i2 = (cur & kPosMask) - 1;
                 if (len[i2] == l) {
-                    u64 o2 = off[i2];
-                    hit = true;
-                    for (u64 j = 0; j < l; j++) if (cells[o2 + j] != cells[o + j]) { hit = false; break; }
+                    const u64 o2 = off[i2];
+                    u32 diff = 0;
+                    for (u64 j = 0; j < l; j++) diff |= cells[o2 + j] ^ cells[o + j];
+                    hit = diff == 0;
                 }
             }
             if (hit) found = (u32)slot; else slot = (slot + 1) & mask;
         }
-        if (found == prim::kNoBucket) { scal[1] = 1; return; }
-        prim::atomic_add(&counts[found], (idx_t)weight[i]);
-        list_slot[i] = found;
+        if (found == prim::kNoBucket) scal[1] = 1;
+        else {
+            prim::atomic_add(&counts[found], (idx_t)weight[i]);
+            list_slot[i] = found;
+        }
     }
 };
 // The merged dictionary must have the SAME layout on every rank (the sharded dictionary stage exchanges
 // dictionary positions): which duplicate wins a table slot is a race, so the representative of a phrase is
-// defined as its smallest list index and the phrases are numbered in the order of their representatives.
+// defined as its smallest list index and an owner numbers its phrases in the order of their representatives.
 struct SlotMinFn {        // slot_min[slot] = smallest list index mapped to the slot
     const u32 *list_slot; u32 *slot_min;
     GRL_DEV void operator()(u64 i) const { prim::atomic_min(&slot_min[list_slot[i]], (u32)i); }
@@ -1423,16 +1447,17 @@ struct ListPhraseFn {     // phrase k = rank of its representative among the rep
     const idx_t *counts;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u8 *ph_lastT;
     GRL_DEV void operator()(u64 i) const {
-        u32 s = list_slot[i];
-        if (slot_min[s] != (u32)i) return;
-        u32 k = rep_ex[i];
-        ph_pos[k] = off[i]; ph_freq[k] = counts[s]; ph_len[k] = len[i];
-        ph_lastT[k] = (u8)(cells[off[i] + len[i] - 1] & 1u);
+        const u32 s = list_slot[i];
+        if (slot_min[s] == (u32)i) {
+            const u32 k = rep_ex[i];
+            ph_pos[k] = off[i]; ph_freq[k] = counts[s]; ph_len[k] = len[i];
+            ph_lastT[k] = (u8)(cells[off[i] + len[i] - 1] & 1u);
+        }
     }
 };
-struct LocalValFn {       // metasymbol of my k-th local phrase through the merged dictionary
+struct ListValFn {        // value of the i-th phrase of the lists I merged: through its representative's number in the merged dictionary
     const u32 *list_slot; const u32 *slot_min; const u32 *rep_ex; const u32 *gval; u64 my_first; u32 *val;
-    GRL_DEV void operator()(u64 k) const { val[k] = gval[rep_ex[slot_min[list_slot[my_first + k]]]]; }
+    GRL_DEV void operator()(u64 i) const { val[i] = gval[my_first + rep_ex[slot_min[list_slot[i]]]]; }
 };
 
 // ---- distributed dictionary stage functors ---------------------------------------------
@@ -1459,57 +1484,9 @@ struct SampleKeysFn {
     const u64 *key0; u64 stride; u64 *out;
     GRL_DEV void operator()(u64 i) const { out[i] = key0[i * stride]; }
 };
-struct RankAllBaseFn {
-    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 base; u32 *rank; u64 *pairs;
-    GRL_DEV void operator()(u64 t) const {
-        u32 q = perm[t], r = base + gstart[ex[t] + hflag[t] - 1];
-        rank[q] = r;
-        pairs[t] = ((u64)q << 32) | r;
-    }
-};
-struct RankRefinedBaseFn {
-    const u32 *uslot; const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 base; u32 *rank; u64 *pairs;
-    GRL_DEV void operator()(u64 i) const {
-        u32 t = uslot[i], q = perm[t], r = base + gstart[ex[t] + hflag[t] - 1];
-        rank[q] = r;
-        pairs[i] = ((u64)q << 32) | r;
-    }
-};
 struct ApplyPairsFn {     // value[pair >> 32] = low 32 bits
     const u64 *pairs; u32 *value;
     GRL_DEV void operator()(u64 i) const { u64 p = pairs[i]; value[p >> 32] = (u32)p; }
-};
-struct GroupEmitDistFn {  // like GroupEmitFn, local outputs; pre-BWT indices become global through p_off
-    const u8 *gflag; const u32 *grank; const u32 *pidx; const u32 *gmin; const idx_t *gacc; const u32 *gstart; const u32 *perm;
-    u32 bwt_code, hocc_code, p_off;
-    u32 *psym; idx_t *plen; u8 *has_hocc; u32 *repq; u32 *u_to_p0;
-    GRL_DEV void operator()(u64 g) const {
-        u8 f = gflag[g];
-        if (!(f & GF_VALID)) return;
-        u32 j = pidx[g];
-        u32 s = gmin[g];
-        if (f & GF_RANKED) {
-            s = (f & GF_MULTI) ? hocc_code : bwt_code;
-            u32 u = grank[g];
-            has_hocc[u] = (f & GF_MULTI) ? 1 : 0;
-            repq[u] = perm[gstart[g]];
-            u_to_p0[u] = j + p_off;
-        }
-        psym[j] = s;
-        plen[j] = gacc[g];
-    }
-};
-struct MarkFlagIn {       // slot belongs to a ranked group with > 1 member
-    const u32 *gid; const u8 *gflag;
-    GRL_DEV u32 operator()(u64 t) const { return ((gflag[gid[t]] & (GF_RANKED | GF_MULTI)) == (GF_RANKED | GF_MULTI)) ? 1u : 0u; }
-};
-struct MarkPairFn {
-    const u32 *gid; const u8 *gflag; const u32 *ex; const u32 *perm; const u32 *grank; u32 m_off; u64 *pairs;
-    GRL_DEV void operator()(u64 t) const {
-        u32 g = gid[t];
-        if ((gflag[g] & (GF_RANKED | GF_MULTI)) != (GF_RANKED | GF_MULTI)) return;
-        pairs[ex[t]] = ((u64)perm[t] << 32) | (u64)(m_off + grank[g]);
-    }
 };
 struct FullFlagIn {       // slot is the whole-phrase suffix of its phrase
     const u32 *perm; const u32 *dict_phr; const u32 *ph_off;
@@ -1523,24 +1500,6 @@ struct FullPairFn {
         if (!fflag[t]) return;                   // FullFlagIn, evaluated once: only whole-phrase slots pay the gathers again
         u32 k = dict_phr[perm[t]];
         pairs[ex[t]] = ((u64)k << 32) | (u64)(m_off + grank[gid[t]]);
-    }
-};
-struct GrammarDistFn {    // GrammarFn over the replicated position -> metasymbol map of the marked positions
-    const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT; const u32 *mark_rank;
-    u32 sigma3, MD;
-    u32 *g0; u32 *g1;
-    GRL_DEV void operator()(u64 u) const {
-        u64 q = repq[u];
-        u32 k = dict_phr[q];
-        u64 e = (u64)ph_off[k + 1] - 1;
-        if (q == e) { g0[u] = MD; g1[u] = dict_sym[q]; return; }
-        u64 x = q + 1;
-        for (;;) {
-            u32 mr = mark_rank[x];
-            if (mr != 0xFFFFFFFFu) { g0[u] = dict_sym[x - 1]; g1[u] = mr + sigma3; return; }
-            if (x == e) { g0[u] = MD; g1[u] = ph_lastT[k] ? dict_sym[e] : dict_sym[e - 1]; return; }
-            x++;
-        }
     }
 };
 struct PhraseValDistFn {
@@ -1793,6 +1752,7 @@ class Engine {
     int bwt_level = -1;
     DBuf<u8> image;                   // .rl_bwt bytes (device)
     u64 image_bytes = 0;
+    u64 image_runs = 0;
     bool keep_texts = false;          // debug/parity: keep every level's text
     std::vector<DBuf<u32>> kept_texts;
     std::vector<Runs> kept_bwts;      // debug/parity: BWT of every level (index = level)
@@ -1985,27 +1945,125 @@ class Engine {
         }
     }
 
-    // rank[position] = value for `count` (position, value) pairs over `S` positions: partitioned by the top 8 bits of the
+    // the exchanges of the collection-level mode; nullptr = this engine holds the whole collection
+    struct Comm {
+        int rank = 0, size = 1;
+        void *user = nullptr;
+        int (*ag)(void *, const void *, void *, u64) = nullptr;
+        int (*a2a)(void *, const void *, const u64 *, const u64 *, void *, const u64 *, const u64 *) = nullptr;
+        bool stream_ordered = false;      // callbacks enqueue on the engine's stream: no host synchronisation around them
+        void allgather(const void *send, void *recv, u64 bytes) const {
+            if (!stream_ordered) prim::sync();
+            if (ag(user, send, recv, bytes) != 0) throw prim::Error(-5, "allgather callback failed");
+        }
+        std::vector<u64> allgather_u64(const std::vector<u64> &mine) const {
+            u64 c = mine.size();
+            DBuf<u64> s(c), r(c * size);
+            prim::h2d(s.p, mine.data(), c * 8);
+            allgather(s.p, r.p, c * 8);
+            return r.to_host(c * size);
+        }
+        // counts in elements of `elem` bytes; send blocks packed in destination order, receive blocks in source order.
+        // `max_block` = the largest block of the whole exchange in elements (all ranks pass the same value: they hold the
+        // count matrix): blocks above the limit go in several rounds, the same number on every rank.  (torch 2.10 + RCCL
+        // 2.26 delivers HALF of an all-to-all block of 2 GB, silently, and is fine at 1 GiB: tools/gpu_rccl_sizes.py.)
+        void alltoall(const void *send, const std::vector<u64> &scnt, void *recv, const std::vector<u64> &rcnt, u64 elem, u64 max_block) const {
+            static const u64 limit = getenv("GRLBWT_A2A_BLOCK") ? (u64)atoll(getenv("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
+            const u64 per = std::max<u64>(limit / elem, 1);
+            const u64 rounds = std::max<u64>((max_block + per - 1) / per, 1);
+            std::vector<u64> sb(size), so(size), rb(size), ro(size), sbase(size + 1, 0), rbase(size + 1, 0);
+            for (int g = 0; g < size; g++) { sbase[g + 1] = sbase[g] + scnt[g]; rbase[g + 1] = rbase[g] + rcnt[g]; }
+            // my own block never leaves the device: a plain copy (GRLBWT_A2A_SELF_VIA_COMM=1: through the callback like the
+            // others -- the tests do that so that a one-rank RCCL run still moves data through RCCL)
+            static const bool self_via_comm = getenv("GRLBWT_A2A_SELF_VIA_COMM") != nullptr;
+            if (!self_via_comm) {
+                if (scnt[rank] != rcnt[rank]) throw prim::Error(-71, "alltoallv: my own block has two sizes");
+                prim::d2d((char *)recv + rbase[rank] * elem, (const char *)send + sbase[rank] * elem, scnt[rank] * elem);
+                if (size == 1) return;
+            }
+            if (!stream_ordered) prim::sync();
+            for (u64 k = 0; k < rounds; k++) {
+                for (int g = 0; g < size; g++) {
+                    const bool skip = !self_via_comm && g == rank;
+                    const u64 s0 = std::min(k * per, scnt[g]), s1 = skip ? s0 : std::min((k + 1) * per, scnt[g]);
+                    const u64 r0 = std::min(k * per, rcnt[g]), r1 = skip ? r0 : std::min((k + 1) * per, rcnt[g]);
+                    sb[g] = (s1 - s0) * elem; so[g] = (sbase[g] + s0) * elem;
+                    rb[g] = (r1 - r0) * elem; ro[g] = (rbase[g] + r0) * elem;
+                }
+                if (a2a(user, send, sb.data(), so.data(), recv, rb.data(), ro.data()) != 0) throw prim::Error(-5, "alltoallv callback failed");
+            }
+        }
+        // variable-length all-gather of a typed device array -> dense concatenation in rank order.
+        // same_counts: `base` already holds the prefix of every rank's count (an earlier call with the same counts)
+        template <class T>
+        DBuf<T> allgather_v(const T *send, u64 count, std::vector<u64> &base, bool same_counts = false, T *dest = nullptr) const {
+            if (!same_counts || base.size() != (size_t)size + 1) {
+                std::vector<u64> cnt = allgather_u64({count});
+                base.assign(size + 1, 0);
+                for (int g = 0; g < size; g++) base[g + 1] = base[g] + cnt[g];
+            }
+            if (base[rank + 1] - base[rank] != count) throw prim::Error(-71, "allgather_v: counts changed between calls");
+            u64 mx = 1;
+            for (int g = 0; g < size; g++) if (base[g + 1] - base[g] > mx) mx = base[g + 1] - base[g];
+            DBuf<T> sp(mx), rp(mx * size);
+            prim::dev_memset(sp.p, 0, mx * sizeof(T));
+            prim::d2d(sp.p, send, count * sizeof(T));
+            allgather(sp.p, rp.p, mx * sizeof(T));
+            DBuf<T> dense;
+            if (!dest) dense.alloc(base[size]);             // (dest: the caller's own array of base[size] elements)
+            DBuf<u64> dbase(size + 1);
+            prim::h2d(dbase.p, base.data(), (size + 1) * 8);
+            prim::for_each(base[size], UnpadFn<T>{rp.p, dbase.p, size, mx, dest ? dest : dense.p}, "dist.unpad");
+            return dense;       // scratch goes back to the pool in stream order
+        }
+    };
+
+    // rank[position] = value for `count` (position, value) pairs over `S` positions: partitioned by the top 16 bits of the
     // position when the array is too large for the caches to absorb random stores, directly otherwise
-    template <class MakePairs, class Direct>
-    void scatter_ranks(u64 count, u64 S, MakePairs make_pairs, Direct direct, RankLen *rl) {
+    static bool rank_scatter_partitioned(u64 count, u64 S) {
         static const bool off = getenv("GRLBWT_DIRECT_RANK_SCATTER") != nullptr;
         const char *mn = getenv("GRLBWT_RANK_PART_MIN");                             // (tests lower the threshold to take this path on small inputs)
         const u64 min_s = mn ? (u64)atoll(mn) : ((u64)8 << 20);                      // 64 MB of records or less: the memory-side cache copes
-        if (off || S < min_s || count < S / 16) { direct(); return; }
-        DBuf<u64> pa(count), pb(count);
+        return !(off || S < min_s || count < S / 16);
+    }
+    void apply_rank_pairs(u64 *pairs, u64 count, u64 S, RankLen *rl) {
+        if (rank_scatter_partitioned(count, S)) {
+            DBuf<u64> pb(count);
+            const int pbits = (int)bitlen64(S - 1);
+            static const int part_bits = getenv("GRLBWT_RANK_PART_BITS") ? atoi(getenv("GRLBWT_RANK_PART_BITS")) : 16;
+            const int lo = 32 + (pbits > part_bits ? pbits - part_bits : 0);
+            int res = prim::sort_keys<u64>(pairs, pb.p, count, lo, 32 + pbits, "suffix_ranks.part");
+            prim::for_each(count, RankApplyFn{res ? pb.p : pairs, rl}, "suffix_ranks");
+        } else prim::for_each(count, RankApplyFn{pairs, rl}, "suffix_ranks");
+    }
+    template <class MakePairs, class Direct>
+    void scatter_ranks(const Comm *C, u64 count, u64 S, MakePairs make_pairs, Direct direct, RankLen *rl, u64 *total = nullptr) {
+        if (C) {                 // sharded sort: every rank learns the new ranks of every other rank's suffixes
+            DBuf<u64> pa(count);
+            make_pairs(pa.p);
+            std::vector<u64> pb;
+            DBuf<u64> all = C->template allgather_v<u64>(pa.p, count, pb);
+            pa.release();
+            if (total) *total = pb[C->size];
+            apply_rank_pairs(all.p, pb[C->size], S, rl);
+            return;
+        }
+        if (total) *total = count;
+        if (!rank_scatter_partitioned(count, S)) { direct(); return; }
+        DBuf<u64> pa(count);
         make_pairs(pa.p);
-        const int pbits = (int)bitlen64(S - 1);
-        static const int part_bits = getenv("GRLBWT_RANK_PART_BITS") ? atoi(getenv("GRLBWT_RANK_PART_BITS")) : 16;
-        const int lo = 32 + (pbits > part_bits ? pbits - part_bits : 0);
-        int res = prim::sort_keys<u64>(pa.p, pb.p, count, lo, 32 + pbits, "suffix_ranks.part");
-        prim::for_each(count, RankApplyFn{res ? pb.p : pa.p, rl}, "suffix_ranks");
+        apply_rank_pairs(pa.p, count, S, rl);
     }
 
     // a5-a8 on D distinct phrases given as (position in t, length, frequency, ends-with-terminator);
     // fills L (grammar, has_hocc, pre-BWT, M) and phrase_val[k] = rank<<2 | (freq>1)<<1 | lastT.
+    // With a communicator (collection-level mode: t, ph_* are the MERGED dictionary, identical on every rank) the suffix
+    // sort and the group stage are sharded over the ranks by ranges of the packed first-pass key: equal suffixes have equal
+    // keys, so a group never spans two ranks and rank order = sorted order.  Positional ranks are global slots (`base` of my
+    // range + local slot); after every pass the new ranks travel as (position, rank) pairs; the group stage's outputs are
+    // all-gathered.  The O(S) streaming passes (dictionary, grammar walk) stay replicated.  Same kernels in both modes.
     template <class cell_t, bool FIRST>
-    void dict_stage(const cell_t *t, CellOps<cell_t, FIRST> ops, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
+    void dict_stage(const Comm *C, const cell_t *t, CellOps<cell_t, FIRST> ops, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
                     const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val) {
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
         DBuf<u32> dict_sym(S), dict_phr(S);
@@ -2016,13 +2074,13 @@ class Engine {
             prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p}, "dict_build");
         }
         // ---- a6: sort all phrase suffixes (radix + filtered prefix doubling) ----------
-        DBuf<u32> perm(S), gid(S), gstart(S + 1);
+        u64 Sg = S;                              // my slots of the sorted order: [base, base + Sg)
+        u32 base = 0;
+        DBuf<u32> perm, gid, gstart;
         DBuf<RankLen> rl(S);                     // (positional rank, suffix length) of every dictionary position
         u64 G;
         {
             StageTimer st(&tm.dict_sort);
-            DBuf<u8> hflag(S), uflag(S);
-            DBuf<u32> ex(S + 1);
             prim::for_each(S, SufLenPFn{dict_phr.p, ph_off, rl.p}, "suffix_len");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
@@ -2034,48 +2092,79 @@ class Engine {
             if (K < 1) K = 1;
             if (K > 16) K = 16;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
-            {
-                DBuf<u64> ka(S), kb(S);
-                DBuf<u32> vb(S);
+            DBuf<u64> ka;
+            if (!C) {
+                ka.alloc(S); perm.alloc(S);
                 prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, ka.p, perm.p}, "suffix_keys0");
+            } else {
+                DBuf<u64> key0(S);
+                prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, key0.p, nullptr}, "suffix_keys0");
+                // splitters: quantiles of a strided sample of the keys (identical on every rank: replicated data)
+                u64 lo = 0, hi = 0;
+                bool has_hi = false;
+                const u64 ns = S < 8192 ? S : 8192, stride = S / ns;
+                DBuf<u64> samp(ns);
+                prim::for_each(ns, SampleKeysFn{key0.p, stride, samp.p}, "dist.sample_keys");
+                std::vector<u64> hs = samp.to_host(ns);
+                std::sort(hs.begin(), hs.end());
+                if (C->rank > 0) lo = hs[(u64)C->rank * ns / C->size];
+                if (C->rank + 1 < C->size) { hi = hs[(u64)(C->rank + 1) * ns / C->size]; has_hi = true; }
+                if (has_hi && hi < lo) hi = lo;
+                DBuf<u32> oex(S + 1);
+                Sg = prim::exclusive_scan<u32>(S, OwnFlagIn{key0.p, lo, hi, has_hi}, oex.p, false, "dist.own_scan");
+                base = (u32)prim::reduce_sum<u64>(S, LessIn{key0.p, lo}, "dist.base");
+                ka.alloc(Sg); perm.alloc(Sg);
+                prim::for_each(S, OwnCompactFn{key0.p, oex.p, lo, hi, has_hi, ka.p, perm.p}, "dist.own_compact");
+            }
+            gid.alloc(Sg); gstart.alloc(Sg + 1);
+            DBuf<u8> hflag(Sg), uflag(Sg);
+            DBuf<u32> ex(Sg + 1);
+            {
+                DBuf<u64> kb(Sg);
+                DBuf<u32> vb(Sg);
                 const u64 *ks = ka.p;
-                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, S, 0, K * b, "suffix_sort0")) {
+                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, Sg, 0, K * b, "suffix_sort0")) {
                     std::swap(perm, vb);         // the result sits in the second buffer: take it, no copy
                     ks = kb.p;
                 }
-                prim::for_each(S, HeadFlagFn{ks, hflag.p}, "suffix_heads");
+                prim::for_each(Sg, HeadFlagFn{ks, hflag.p}, "suffix_heads");
                 // the last symbol of a key is the sentinel exactly when the suffix is shorter than K: the first refinement's
                 // "long enough" test comes from the sorted keys (streamed) instead of a random gather per slot
-                prim::for_each(S, FirstUnresolvedFn{ks, hflag.p, S, (1ull << b) - 1ull, uflag.p}, "suffix_unresolved");
+                prim::for_each(Sg, FirstUnresolvedFn{ks, hflag.p, Sg, (1ull << b) - 1ull, uflag.p}, "suffix_unresolved");
                 prim::sync();
             }
-            G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-            prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
-            scatter_ranks(S, S, [&](u64 *pairs) { prim::for_each(S, RankPairFn{hflag.p, ex.p, gstart.p, perm.p, pairs}, "suffix_ranks"); },
-                          [&] { prim::for_each(S, RankAllPFn{hflag.p, ex.p, gstart.p, perm.p, rl.p}, "suffix_ranks"); }, rl.p);
+            ka.release();
+            G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+            prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
+            scatter_ranks(C, Sg, S, [&](u64 *pairs) { prim::for_each(Sg, RankPairFn{hflag.p, ex.p, gstart.p, perm.p, base, pairs}, "suffix_ranks"); },
+                          [&] { prim::for_each(Sg, RankAllPFn{hflag.p, ex.p, gstart.p, perm.p, rl.p}, "suffix_ranks"); }, rl.p);
             const int lowbits = (int)bitlen64(S);
             u64 Lres = (u64)K, iters = 1;
             DBuf<u32> act;                       // slots still unresolved after the previous pass (empty = all slots)
-            u64 A = S;
+            u64 A = Sg;
             bool refined = false;
             while (Lres < maxlen) {              // Lres symbols (incl. a possible sentinel) resolved so far
                 const u32 *ap = refined ? act.p : nullptr;
-                if (refined) prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, rl.p, S, Lres, uflag.p}, "suffix_unresolved");
+                if (refined) prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, rl.p, Sg, Lres, uflag.p}, "suffix_unresolved");
                 DBuf<u32> uex(A + 1);
-                u64 U = prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
-                if (U == 0) break;
+                const u64 U = prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
+                if (!C && U == 0) break;
                 DBuf<u64> ka(U), kb(U);
-                DBuf<u32> va(U), vb(U), uslot(U);
-                prim::for_each(A, ActiveKeyFn{ap, uflag.p, uex.p, perm.p, rl.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
-                int res = prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort");
-                const u64 *sk = res ? kb.p : ka.p;
-                const u32 *sv = res ? vb.p : va.p;
-                prim::for_each(U, RefineWriteFn{sk, sv, uslot.p, perm.p, hflag.p}, "suffix_refine");
-                DBuf<u32> hex(U + 1), hpos(U);
-                prim::exclusive_scan_nosync<u32>(U, HeadKeyIn{sk}, hex.p, false, "suffix_heads");
-                prim::for_each(U, HeadSlotFn{sk, hex.p, uslot.p, hpos.p}, "suffix_gstart");
-                scatter_ranks(U, S, [&](u64 *pairs) { prim::for_each(U, RankHeadPairFn{sk, hex.p, hpos.p, sv, pairs}, "suffix_ranks"); },
-                              [&] { prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rl.p}, "suffix_ranks"); }, rl.p);
+                DBuf<u32> va(U), vb(U), uslot(U), hex(U + 1), hpos(U);
+                const u64 *sk = ka.p;
+                const u32 *sv = va.p;
+                if (U) {
+                    prim::for_each(A, ActiveKeyFn{ap, uflag.p, uex.p, perm.p, rl.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
+                    if (prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort")) { sk = kb.p; sv = vb.p; }
+                    prim::for_each(U, RefineWriteFn{sk, sv, uslot.p, perm.p, hflag.p}, "suffix_refine");
+                    prim::exclusive_scan_nosync<u32>(U, HeadKeyIn{sk}, hex.p, false, "suffix_heads");
+                    prim::for_each(U, HeadSlotFn{sk, hex.p, uslot.p, hpos.p}, "suffix_gstart");
+                }
+                // (sharded: every rank takes part in the exchange of this pass, also with nothing to refine)
+                u64 total = 0;
+                scatter_ranks(C, U, S, [&](u64 *pairs) { prim::for_each(U, RankHeadPairFn{sk, hex.p, hpos.p, sv, base, pairs}, "suffix_ranks"); },
+                              [&] { prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rl.p}, "suffix_ranks"); }, rl.p, &total);
+                if (total == 0) break;           // nothing left anywhere (same decision on every rank)
                 act = std::move(uslot);
                 A = U;
                 refined = true;
@@ -2083,10 +2172,10 @@ class Engine {
                 iters++;
             }
             if (refined) {                       // group table of the final order
-                G = prim::exclusive_scan<u32>(S, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-                prim::for_each(S, GroupStartsFn{hflag.p, ex.p, S, gstart.p}, "suffix_gstart");
+                G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+                prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
             }
-            prim::for_each(S, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
+            prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
             prim::sync();
             L.info.sort_iters = iters;
         }
@@ -2106,21 +2195,40 @@ class Engine {
                 prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
                 prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code,
                                                     gmin.p, gmax.p, gacc.p, gfull.p, gflag.p}, "group_accum");
-                prim::for_each(S, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code,
-                                                    gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum_large");
+                prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code,
+                                                     gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum_large");
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
-            M = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
-            P0 = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
+            const u64 Ml = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
+            const u64 P0l = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
+            u64 Moff = 0, P0off = 0;
+            M = Ml; P0 = P0l;
+            std::vector<u64> bbM, bbP;
+            if (C) {
+                std::vector<u64> cnts = C->allgather_u64({Ml, P0l});
+                bbM.assign(C->size + 1, 0); bbP.assign(C->size + 1, 0);
+                for (int g = 0; g < C->size; g++) { bbM[g + 1] = bbM[g] + cnts[2 * g]; bbP[g + 1] = bbP[g] + cnts[2 * g + 1]; }
+                Moff = bbM[C->rank]; P0off = bbP[C->rank];
+                M = bbM[C->size]; P0 = bbP[C->size];
+            }
             if ((u64)sigma3 + M + 8 >= (1ull << 30)) throw prim::Error(-75, "alphabet of the next level >= 2^30");
             L.M = (u32)M;
-            L.has_hocc.alloc(M); repq.alloc(M);
-            DBuf<u32> psym0(P0);
-            DBuf<idx_t> plen0(P0);
-            DBuf<u32> u_to_p0(M), merged(P0), pu0(P0);
-            prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code,
+            L.has_hocc.alloc(Ml); repq.alloc(Ml);
+            DBuf<u32> psym0(P0l);
+            DBuf<idx_t> plen0(P0l);
+            DBuf<u32> u_to_p0(Ml), pu0(P0l);
+            prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code, (u32)Moff, (u32)P0off,
                                           psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p, pu0.p}, "prebwt_emit");
+            if (C) {                             // every rank's (Ml, P0l) is known: one exchange per array
+                psym0 = C->template allgather_v<u32>(psym0.p, P0l, bbP, true);
+                plen0 = C->template allgather_v<idx_t>(plen0.p, P0l, bbP, true);
+                pu0 = C->template allgather_v<u32>(pu0.p, P0l, bbP, true);
+                L.has_hocc = C->template allgather_v<u8>(L.has_hocc.p, Ml, bbM, true);
+                repq = C->template allgather_v<u32>(repq.p, Ml, bbM, true);
+                u_to_p0 = C->template allgather_v<u32>(u_to_p0.p, Ml, bbM, true);
+            }
+            DBuf<u32> merged(P0);
             L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
             L.u_to_p.alloc(M);
             prim::for_each(M, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
@@ -2131,14 +2239,36 @@ class Engine {
             u32 MD = sigma3 + (u32)M + 1;
             {
                 DBuf<u32> ginfo(G), meta(S);
-                prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, ginfo.p}, "grammar_ginfo");
+                prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, (u32)Moff, ginfo.p}, "grammar_ginfo");
                 meta.zero();
-                prim::for_each(S, MetaPosFn{perm.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
+                if (!C) prim::for_each(Sg, MetaPosFn{perm.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
+                else {                           // the marked positions of every rank's groups, as (position, metasymbol) pairs
+                    DBuf<u32> mex(Sg + 1);
+                    const u64 nm = prim::exclusive_scan<u32>(Sg, MarkedIn{gid.p, ginfo.p}, mex.p, false, "dist.mark_scan");
+                    DBuf<u64> mp(nm);
+                    prim::for_each(Sg, MetaPairFn{perm.p, gid.p, ginfo.p, mex.p, sigma3, mp.p}, "dist.mark_pairs");
+                    std::vector<u64> bb;
+                    DBuf<u64> all = C->template allgather_v<u64>(mp.p, nm, bb);
+                    prim::for_each(bb[C->size], ApplyPairsFn{all.p, meta.p}, "grammar_marks");
+                }
                 prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, meta.p, MD, L.g0.p, L.g1.p}, "grammar");
             }
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
-            prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rl.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
+            if (!C) prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rl.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
+            else {                               // whole-phrase suffixes sit on the rank that owns their key: (phrase, metasymbol) pairs
+                DBuf<u32> phrase_rank(D), fex(Sg + 1);
+                DBuf<u8> fflag(Sg);              // the flag costs two dependent gathers: evaluate it once, scan the bytes
+                prim::for_each(Sg, StoreByteFn<FullFlagIn>{FullFlagIn{perm.p, dict_phr.p, ph_off}, fflag.p}, "dist.full_flags");
+                const u64 nf = prim::exclusive_scan<u32>(Sg, ByteIn{fflag.p}, fex.p, false, "dist.full_scan");
+                DBuf<u64> fp(nf);
+                prim::for_each(Sg, FullPairFn{fflag.p, perm.p, dict_phr.p, fex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
+                std::vector<u64> bb;
+                DBuf<u64> allf = C->template allgather_v<u64>(fp.p, nf, bb);
+                if (bb[C->size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+                prim::for_each(D, ApplyPairsFn{allf.p, phrase_rank.p}, "dist.apply_phrase_ranks");
+                prim::for_each(D, PhraseValDistFn{phrase_rank.p, ph_freq, ph_lastT, phrase_val.p}, "phrase_values");
+            }
         }
         L.info.M = M;
     }
@@ -2178,7 +2308,7 @@ class Engine {
         LocalParse P;
         hash_local<cell_t, FIRST>(t, n, ops, P, L);
         DBuf<u32> phrase_val;
-        dict_stage<cell_t, FIRST>(t, ops, P.D, P.S, P.maxlen, P.ph_pos.p, P.ph_freq.p, P.ph_off.p, P.ph_lastT.p, sigma, L, phrase_val);
+        dict_stage<cell_t, FIRST>(nullptr, t, ops, P.D, P.S, P.maxlen, P.ph_pos.p, P.ph_freq.p, P.ph_off.p, P.ph_lastT.p, sigma, L, phrase_val);
         emit_local(P, phrase_val.p);
         finish_round(P, L, stats.n_strings, P.n_occ);
     }
@@ -2480,7 +2610,8 @@ class Engine {
         u8 hdr[16] = {0};
         for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
         prim::h2d(image.p, hdr, 16);
-        prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, bwt.len.p, sb, fb, image.p}, "pack_rl_bwt");
+        prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, bwt.len.p, sb, fb, image.p, 16u}, "pack_rl_bwt");
+        image_runs = bwt.R;
         // "results are complete when a call returns" (include/grlbwt_hip.h): the image pointer may be handed to another
         // stream (torch, a copy engine) right after the build, so the engine's stream is drained here
         prim::sync();
@@ -2488,68 +2619,6 @@ class Engine {
     // =====================================================================
     // collection-level multi-GPU: this engine holds one record shard
     // =====================================================================
-    struct Comm {
-        int rank = 0, size = 1;
-        void *user = nullptr;
-        int (*ag)(void *, const void *, void *, u64) = nullptr;
-        int (*a2a)(void *, const void *, const u64 *, const u64 *, void *, const u64 *, const u64 *) = nullptr;
-        bool stream_ordered = false;      // callbacks enqueue on the engine's stream: no host synchronisation around them
-        void allgather(const void *send, void *recv, u64 bytes) const {
-            if (!stream_ordered) prim::sync();
-            if (ag(user, send, recv, bytes) != 0) throw prim::Error(-5, "allgather callback failed");
-        }
-        std::vector<u64> allgather_u64(const std::vector<u64> &mine) const {
-            u64 c = mine.size();
-            DBuf<u64> s(c), r(c * size);
-            prim::h2d(s.p, mine.data(), c * 8);
-            allgather(s.p, r.p, c * 8);
-            return r.to_host(c * size);
-        }
-        // counts in elements of `elem` bytes; send blocks packed in destination order, receive blocks in source order.
-        // `max_block` = the largest block of the whole exchange in elements (all ranks pass the same value: they hold the
-        // count matrix): blocks above the limit go in several rounds, the same number on every rank.  (torch 2.10 + RCCL
-        // 2.26 delivers HALF of an all-to-all block of 2 GB, silently, and is fine at 1 GiB: tools/gpu_rccl_sizes.py.)
-        void alltoall(const void *send, const std::vector<u64> &scnt, void *recv, const std::vector<u64> &rcnt, u64 elem, u64 max_block) const {
-            static const u64 limit = getenv("GRLBWT_A2A_BLOCK") ? (u64)atoll(getenv("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
-            const u64 per = std::max<u64>(limit / elem, 1);
-            const u64 rounds = std::max<u64>((max_block + per - 1) / per, 1);
-            std::vector<u64> sb(size), so(size), rb(size), ro(size), sbase(size + 1, 0), rbase(size + 1, 0);
-            for (int g = 0; g < size; g++) { sbase[g + 1] = sbase[g] + scnt[g]; rbase[g + 1] = rbase[g] + rcnt[g]; }
-            if (!stream_ordered) prim::sync();
-            for (u64 k = 0; k < rounds; k++) {
-                for (int g = 0; g < size; g++) {
-                    const u64 s0 = std::min(k * per, scnt[g]), s1 = std::min((k + 1) * per, scnt[g]);
-                    const u64 r0 = std::min(k * per, rcnt[g]), r1 = std::min((k + 1) * per, rcnt[g]);
-                    sb[g] = (s1 - s0) * elem; so[g] = (sbase[g] + s0) * elem;
-                    rb[g] = (r1 - r0) * elem; ro[g] = (rbase[g] + r0) * elem;
-                }
-                if (a2a(user, send, sb.data(), so.data(), recv, rb.data(), ro.data()) != 0) throw prim::Error(-5, "alltoallv callback failed");
-            }
-        }
-        // variable-length all-gather of a typed device array -> dense concatenation in rank order.
-        // same_counts: `base` already holds the prefix of every rank's count (an earlier call with the same counts)
-        template <class T>
-        DBuf<T> allgather_v(const T *send, u64 count, std::vector<u64> &base, bool same_counts = false) const {
-            if (!same_counts || base.size() != (size_t)size + 1) {
-                std::vector<u64> cnt = allgather_u64({count});
-                base.assign(size + 1, 0);
-                for (int g = 0; g < size; g++) base[g + 1] = base[g] + cnt[g];
-            }
-            if (base[rank + 1] - base[rank] != count) throw prim::Error(-71, "allgather_v: counts changed between calls");
-            u64 mx = 1;
-            for (int g = 0; g < size; g++) if (base[g + 1] - base[g] > mx) mx = base[g + 1] - base[g];
-            DBuf<T> sp(mx), rp(mx * size);
-            prim::dev_memset(sp.p, 0, mx * sizeof(T));
-            prim::d2d(sp.p, send, count * sizeof(T));
-            allgather(sp.p, rp.p, mx * sizeof(T));
-            DBuf<T> dense(base[size]);
-            DBuf<u64> dbase(size + 1);
-            prim::h2d(dbase.p, base.data(), (size + 1) * 8);
-            prim::for_each(base[size], UnpadFn<T>{rp.p, dbase.p, size, mx, dense.p}, "dist.unpad");
-            return dense;       // scratch goes back to the pool in stream order
-        }
-    };
-
     u64 g_n_strings = 0, g_n_syms = 0;      // collection-wide totals (distributed mode)
 
     // collection_stats over all shards: separator, alphabet, header widths
@@ -2585,168 +2654,6 @@ class Engine {
         cur_sigma = (u32)(mx + 1);
     }
 
-    // a5-a8 over the merged dictionary with the suffix sort and the group stage SHARDED over the ranks
-    // (see the functor block above); grammar and the O(S) streaming passes stay replicated.
-    void dict_stage_dist(const Comm &C, const u32 *t, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
-                         const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val) {
-        CellOps<u32, false> ops{0u};
-        L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
-        const u32 bwt_code = sigma + 1, hocc_code = sigma + 2, sigma3 = sigma + 3;
-        DBuf<u32> dict_sym(S), dict_phr(S), suflen(S), rank(S);
-        DBuf<u64> key0(S);
-        int b = (int)bitlen64(sigma);
-        if (b < 1) b = 1;
-        int K = 64 / b;                          // as in the single-GPU stage
-        if (K < 1) K = 1;
-        if (K > 16) K = 16;
-        if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
-        u64 lo = 0, hi = 0;
-        bool has_hi = false;
-        {
-            StageTimer st(&tm.dict_sort);
-            prim::for_each((S + 15) / 16, DictBuildFn<u32, false>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, nullptr, nullptr}, "dict_build");
-            prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
-            prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, key0.p, rank.p}, "suffix_keys0");   // rank used as scratch
-            // splitters: quantiles of a strided sample of the keys (identical on every rank: replicated data)
-            u64 ns = S < 8192 ? S : 8192, stride = S / ns;
-            DBuf<u64> samp(ns);
-            prim::for_each(ns, SampleKeysFn{key0.p, stride, samp.p}, "dist.sample_keys");
-            std::vector<u64> hs = samp.to_host(ns);
-            std::sort(hs.begin(), hs.end());
-            if (C.rank > 0) lo = hs[(u64)C.rank * ns / C.size];
-            if (C.rank + 1 < C.size) { hi = hs[(u64)(C.rank + 1) * ns / C.size]; has_hi = true; }
-            if (has_hi && hi < lo) hi = lo;
-        }
-        // ---- my suffixes: compact, sort, first ranks ------------------------------------------
-        u64 Sg, base_g;
-        DBuf<u32> perm, gid, gstart;
-        u64 Gg = 0;
-        {
-            StageTimer st(&tm.dict_sort);
-            DBuf<u32> oex(S + 1);
-            Sg = prim::exclusive_scan<u32>(S, OwnFlagIn{key0.p, lo, hi, has_hi}, oex.p, false, "dist.own_scan");
-            base_g = prim::reduce_sum<u64>(S, LessIn{key0.p, lo}, "dist.base");
-            perm.alloc(Sg); gid.alloc(Sg); gstart.alloc(Sg + 1);
-            DBuf<u8> hflag(Sg), uflag(Sg);
-            DBuf<u32> ex(Sg + 1);
-            {
-                DBuf<u64> ka(Sg), kb(Sg);
-                DBuf<u32> vb(Sg);
-                prim::for_each(S, OwnCompactFn{key0.p, oex.p, lo, hi, has_hi, ka.p, perm.p}, "dist.own_compact");
-                const u64 *ks = ka.p;
-                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, Sg, 0, K * b, "suffix_sort0")) {
-                    prim::d2d(perm.p, vb.p, Sg * sizeof(u32));
-                    ks = kb.p;
-                }
-                prim::for_each(Sg, HeadFlagFn{ks, hflag.p}, "suffix_heads");
-                prim::sync();
-            }
-            oex.release(); key0.release();
-            Gg = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-            prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
-            {
-                DBuf<u64> pairs(Sg);
-                prim::for_each(Sg, RankAllBaseFn{hflag.p, ex.p, gstart.p, perm.p, (u32)base_g, rank.p, pairs.p}, "suffix_ranks");
-                std::vector<u64> pb;
-                DBuf<u64> all = C.allgather_v<u64>(pairs.p, Sg, pb);
-                prim::for_each(pb[C.size], ApplyPairsFn{all.p, rank.p}, "dist.apply_ranks");
-            }
-            const int lowbits = (int)bitlen64(S);
-            u64 Lres = (u64)K, iters = 1;
-            while (Lres < maxlen) {
-                prim::for_each(Sg, UnresolvedFlagFn{hflag.p, ex.p, gstart.p, perm.p, suflen.p, Lres, uflag.p}, "suffix_unresolved");
-                DBuf<u32> uex(Sg + 1);
-                u64 U = prim::exclusive_scan<u32>(Sg, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
-                DBuf<u64> pairs(U);
-                if (U > 0) {
-                    DBuf<u64> ka(U), kb(U);
-                    DBuf<u32> va(U), vb(U), uslot(U);
-                    prim::for_each(Sg, UnresolvedKeyFn{uflag.p, uex.p, perm.p, rank.p, suflen.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
-                    int res = prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort");
-                    prim::for_each(U, RefineWriteFn{res ? kb.p : ka.p, res ? vb.p : va.p, uslot.p, perm.p, hflag.p}, "suffix_refine");
-                    Gg = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-                    prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
-                    prim::for_each(U, RankRefinedBaseFn{uslot.p, hflag.p, ex.p, gstart.p, perm.p, (u32)base_g, rank.p, pairs.p}, "suffix_ranks");
-                }
-                // every rank takes part in the exchange of this pass, also with nothing to refine
-                std::vector<u64> pb;
-                DBuf<u64> all = C.allgather_v<u64>(pairs.p, U, pb);
-                if (pb[C.size] == 0) break;                 // nothing left anywhere (same decision on every rank)
-                prim::for_each(pb[C.size], ApplyPairsFn{all.p, rank.p}, "dist.apply_ranks");
-                Lres *= 2;
-                iters++;
-            }
-            prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
-            prim::sync();
-            L.info.sort_iters = iters;
-        }
-        // ---- my groups ----------------------------------------------------------------------------
-        StageTimer st(&tm.dict_groups);
-        DBuf<u32> grank(Gg + 1), pidx(Gg + 1), gmin(Gg), gmax(Gg);
-        DBuf<idx_t> gacc(Gg);
-        DBuf<u8> gfull(Gg), gflag(Gg);
-        gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
-        {
-            DBuf<SufRec> rec(S);
-            prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
-            prim::for_each(Gg, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p, gflag.p}, "group_accum");
-            prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p},
-                           "group_accum_large");
-        }
-        prim::for_each(Gg, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
-        u64 Mg = prim::exclusive_scan<u32>(Gg, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
-        u64 P0g = prim::exclusive_scan<u32>(Gg, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
-        std::vector<u64> cnts = C.allgather_u64({Mg, P0g});
-        u64 Moff = 0, P0off = 0, M = 0, P0 = 0;
-        for (int g = 0; g < C.size; g++) {
-            if (g < C.rank) { Moff += cnts[2 * g]; P0off += cnts[2 * g + 1]; }
-            M += cnts[2 * g]; P0 += cnts[2 * g + 1];
-        }
-        if ((u64)sigma3 + M + 8 >= (1ull << 30)) throw prim::Error(-75, "alphabet of the next level >= 2^30");
-        L.M = (u32)M;
-        DBuf<u32> psym0_l(P0g), repq_l(Mg), u2p0_l(Mg);
-        DBuf<idx_t> plen0_l(P0g);
-        DBuf<u8> hh_l(Mg);
-        prim::for_each(Gg, GroupEmitDistFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code, (u32)P0off,
-                                           psym0_l.p, plen0_l.p, hh_l.p, repq_l.p, u2p0_l.p}, "prebwt_emit");
-        std::vector<u64> bb, bbM(C.size + 1, 0), bbP(C.size + 1, 0);      // every rank's (Mg, P0g) is known from cnts
-        for (int g = 0; g < C.size; g++) { bbM[g + 1] = bbM[g] + cnts[2 * g]; bbP[g + 1] = bbP[g] + cnts[2 * g + 1]; }
-        DBuf<u32> psym0 = C.allgather_v<u32>(psym0_l.p, P0g, bbP, true);
-        DBuf<idx_t> plen0 = C.allgather_v<idx_t>(plen0_l.p, P0g, bbP, true);
-        L.has_hocc = C.allgather_v<u8>(hh_l.p, Mg, bbM, true);
-        DBuf<u32> repq = C.allgather_v<u32>(repq_l.p, Mg, bbM, true);
-        DBuf<u32> u_to_p0 = C.allgather_v<u32>(u2p0_l.p, Mg, bbM, true);
-        DBuf<u32> merged(P0);
-        L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
-        L.u_to_p.alloc(M);
-        prim::for_each(M, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
-        // marked positions -> metasymbol, whole phrases -> metasymbol (exchanged as pairs, applied on every rank)
-        DBuf<u32> mark_rank(S), phrase_rank(D);
-        mark_rank.fill_ff(); phrase_rank.fill_ff();
-        {
-            DBuf<u32> mex(Sg + 1);
-            u64 nm = prim::exclusive_scan<u32>(Sg, MarkFlagIn{gid.p, gflag.p}, mex.p, false, "dist.mark_scan");
-            DBuf<u64> mp(nm);
-            prim::for_each(Sg, MarkPairFn{gid.p, gflag.p, mex.p, perm.p, grank.p, (u32)Moff, mp.p}, "dist.mark_pairs");
-            DBuf<u64> all = C.allgather_v<u64>(mp.p, nm, bb);
-            prim::for_each(bb[C.size], ApplyPairsFn{all.p, mark_rank.p}, "dist.apply_marks");
-            DBuf<u8> fflag(Sg);                  // the flag costs two dependent gathers: evaluate it once, scan the bytes
-            prim::for_each(Sg, StoreByteFn<FullFlagIn>{FullFlagIn{perm.p, dict_phr.p, ph_off}, fflag.p}, "dist.full_flags");
-            u64 nf = prim::exclusive_scan<u32>(Sg, ByteIn{fflag.p}, mex.p, false, "dist.full_scan");
-            DBuf<u64> fp(nf);
-            prim::for_each(Sg, FullPairFn{fflag.p, perm.p, dict_phr.p, mex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
-            DBuf<u64> allf = C.allgather_v<u64>(fp.p, nf, bb);
-            if (bb[C.size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
-            prim::for_each(D, ApplyPairsFn{allf.p, phrase_rank.p}, "dist.apply_phrase_ranks");
-        }
-        L.g0.alloc(M); L.g1.alloc(M);
-        u32 MD = sigma3 + (u32)M + 1;
-        prim::for_each(M, GrammarDistFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, mark_rank.p, sigma3, MD, L.g0.p, L.g1.p}, "grammar");
-        phrase_val.alloc(D);
-        prim::for_each(D, PhraseValDistFn{phrase_rank.p, ph_freq, ph_lastT, phrase_val.p}, "phrase_values");
-        L.info.M = M;
-    }
-
     template <class cell_t, bool FIRST>
     void dist_round_t(const Comm &C, const cell_t *t, u64 n, u32 sigma, cell_t sep) {
         CellOps<cell_t, FIRST> ops{sep};
@@ -2757,60 +2664,118 @@ class Engine {
         L.info.sigma = sigma;
         LocalParse P;
         hash_local<cell_t, FIRST>(t, n, ops, P, L);
-        // ---- exchange: distinct phrases of every shard (cells, lengths, frequencies) -------------
-        DBuf<u32> lcells(P.S);
-        DBuf<u64> lfreq(P.D);
-        prim::for_each(P.S, ExportCellsFn<cell_t, FIRST>{t, ops, P.ph_off.p, P.D, P.ph_pos.p, lcells.p}, "dist.export_cells");
-        prim::for_each(P.D, WidenFn{P.ph_freq.p, lfreq.p}, "dist.export_freq");
-        std::vector<u64> sbase, dbase, dbase2;
-        DBuf<u32> gcells = C.allgather_v<u32>(lcells.p, P.S, sbase);
-        DBuf<u32> glen = C.allgather_v<u32>(P.ph_len.p, P.D, dbase);
-        DBuf<u64> gfreq = C.allgather_v<u64>(lfreq.p, P.D, dbase, true);
-        lcells.release(); lfreq.release();
-        const u64 Dl = dbase[C.size], Sl = sbase[C.size];
-        std::vector<u64> tot = C.allgather_u64({P.n_occ, n});
-        u64 occ_total = 0, n_total = 0;
-        for (int g = 0; g < C.size; g++) { occ_total += tot[2 * g]; n_total += tot[2 * g + 1]; }
+        const int N = C.size, me = C.rank;
+        // ---- my distinct phrases go to the ranks that merge them (owner = hash of the content) ---------------------
+        DBuf<u32> order;                         // my phrases in owner order
+        std::vector<u64> pc(N), cc(N), rpc(N), rcc(N);      // phrases / cells I send to every owner, and receive from every shard
+        DBuf<u32> rlen, rcells;
+        DBuf<u64> rfreq;
+        u64 Dr = 0, Sr = 0, occ_total = 0, n_total = 0, maxp = 0;     // maxp: largest phrase block of the exchange (all ranks agree)
+        {
+            StageTimer st(&tm.hash);
+            DBuf<u32> lcells(P.S);
+            prim::for_each(P.S, ExportCellsFn<cell_t, FIRST>{t, ops, P.ph_off.p, P.D, P.ph_pos.p, lcells.p}, "dist.export_cells");
+            DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D);
+            prim::for_each(P.D, PhraseOwnerFn{lcells.p, P.ph_off.p, P.ph_len.p, (u32)N, owner.p, idx.p}, "dist.phrase_owner");
+            int obits = (int)bitlen64((u64)N - 1);
+            if (obits < 1) obits = 1;
+            const int res = prim::sort_pairs<u32, u32>(owner.p, idx.p, owner2.p, idx2.p, P.D, 0, obits, "dist.owner_sort");
+            order = std::move(res ? idx2 : idx);
+            const u32 *okey = res ? owner2.p : owner.p;
+            DBuf<u32> slen(P.D);
+            DBuf<u64> sfreq(P.D), soff(P.D + 1), bound(2 * ((u64)N + 1));
+            prim::for_each(P.D, SendPhraseFn{order.p, P.ph_len.p, P.ph_freq.p, slen.p, sfreq.p}, "dist.send_phrases");
+            const u64 chk = prim::exclusive_scan<u64>(P.D, LenIn{slen.p}, soff.p, true, "dist.send_offsets");
+            if (chk != P.S) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
+            DBuf<u32> scells(P.S);
+            prim::for_each(P.S, SendCellsFn{order.p, P.ph_off.p, soff.p, P.D, lcells.p, scells.p}, "dist.send_cells");
+            prim::for_each((u64)N + 1, KeyBoundFn{okey, P.D, soff.p, bound.p}, "dist.owner_bounds");
+            std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
+            std::vector<u64> mine(2 * (u64)N + 2);
+            for (int d = 0; d < N; d++) { pc[d] = bh[2 * (d + 1)] - bh[2 * d]; cc[d] = bh[2 * (d + 1) + 1] - bh[2 * d + 1]; mine[d] = pc[d]; mine[N + d] = cc[d]; }
+            mine[2 * N] = P.n_occ; mine[2 * N + 1] = n;
+            const u64 w = mine.size();
+            std::vector<u64> mat = C.allgather_u64(mine);
+            u64 maxc = 0;
+            for (int g = 0; g < N; g++) {
+                rpc[g] = mat[g * w + me]; rcc[g] = mat[g * w + N + me];
+                Dr += rpc[g]; Sr += rcc[g];
+                occ_total += mat[g * w + 2 * N]; n_total += mat[g * w + 2 * N + 1];
+                for (int d = 0; d < N; d++) { maxp = std::max(maxp, mat[g * w + d]); maxc = std::max(maxc, mat[g * w + N + d]); }
+            }
+            rlen.alloc(Dr); rfreq.alloc(Dr); rcells.alloc(Sr);
+            C.alltoall(slen.p, pc, rlen.p, rpc, 4, maxp);
+            C.alltoall(sfreq.p, pc, rfreq.p, rpc, 8, maxp);
+            C.alltoall(scells.p, cc, rcells.p, rcc, 4, maxc);
+        }
         L.info.n_in = n_total;
         L.info.parse_size = occ_total;
-        // ---- merge: one table over the concatenated lists (join_thread_phrases, parsing_strategies.h:277-386) ----
-        DBuf<u64> goff(Dl + 1);
+        // ---- merge what I own: one table over the received lists --------------------------------------------------
+        DBuf<u32> list_slot(Dr), slot_min, rep_ex(Dr + 1);
+        DBuf<u32> gcells, ph_len, ph_off;
+        DBuf<idx_t> ph_freq;
+        DBuf<u8> ph_lastT;
+        DBuf<u64> ph_pos;
+        std::vector<u64> dbase(N + 1, 0), sbase(N + 1, 0);
+        u64 D, S;
+        u32 maxlen;
         {
-            u64 chk = prim::exclusive_scan<u64>(Dl, LenIn{glen.p}, goff.p, true, "dist.list_offsets");
-            if (chk != Sl) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
+            StageTimer st(&tm.hash);
+            DBuf<u64> goff(Dr + 1);
+            const u64 chk = prim::exclusive_scan<u64>(Dr, LenIn{rlen.p}, goff.p, true, "dist.list_offsets");
+            if (chk != Sr) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
+            u64 cap = 1024;
+            while (cap < 2 * Dr) cap <<= 1;
+            DBuf<u64> keys(cap);
+            DBuf<idx_t> counts(cap);
+            DBuf<u32> scal(4);
+            keys.zero(); counts.zero(); scal.zero();
+            prim::for_each(Dr, ListInsertFn{rcells.p, goff.p, rlen.p, rfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p}, "dist.merge_phrases");
+            if (scal.to_host(2)[1]) throw prim::Error(-28, "merged phrase table overflow");
+            keys.release();
+            // deterministic layout: representatives = smallest list index per slot, phrases in representative order
+            slot_min.alloc(cap);
+            slot_min.fill_ff();
+            prim::for_each(Dr, SlotMinFn{list_slot.p, slot_min.p}, "dist.slot_min");
+            const u64 Do = prim::exclusive_scan<u32>(Dr, IsRepIn{list_slot.p, slot_min.p}, rep_ex.p, false, "dist.merge_compact");
+            DBuf<u64> o_pos(Do); DBuf<idx_t> o_freq(Do); DBuf<u32> o_len(Do), o_off(Do + 1); DBuf<u8> o_lastT(Do);
+            prim::for_each(Dr, ListPhraseFn{rcells.p, goff.p, rlen.p, list_slot.p, slot_min.p, rep_ex.p, counts.p, o_pos.p, o_freq.p,
+                                            o_len.p, o_lastT.p}, "dist.merge_compact");
+            const u64 So64 = prim::reduce_sum<u64>(Do, LenIn{o_len.p}, "dist.dict_syms");
+            // ---- the merged dictionary, replicated: owner parts in rank order -----------------------------------
+            std::vector<u64> cnt = C.allgather_u64({Do, So64});
+            for (int g = 0; g < N; g++) { dbase[g + 1] = dbase[g] + cnt[2 * g]; sbase[g + 1] = sbase[g] + cnt[2 * g + 1]; }
+            D = dbase[N];
+            if (sbase[N] >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
+            prim::exclusive_scan_nosync<u32>(Do, LenIn{o_len.p}, o_off.p, true, "dist.dict_offsets");
+            DBuf<u32> ocells(So64);
+            prim::for_each(So64, ListCellsFn{o_pos.p, o_off.p, Do, rcells.p, ocells.p}, "dist.owner_cells");
+            rcells.release(); rlen.release(); rfreq.release();
+            gcells = C.allgather_v<u32>(ocells.p, So64, sbase, true);
+            ph_len = C.allgather_v<u32>(o_len.p, Do, dbase, true);
+            ph_freq = C.allgather_v<idx_t>(o_freq.p, Do, dbase, true);
+            ph_lastT = C.allgather_v<u8>(o_lastT.p, Do, dbase, true);
+            const u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dist.freq_check");
+            if (fsum != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
+            maxlen = prim::reduce_max<u32>(D, LenIn{ph_len.p}, "dist.maxlen");
+            ph_off.alloc(D + 1); ph_pos.alloc(D);
+            S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dist.dict_offsets");
+            if (S != sbase[N]) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
+            prim::for_each(D, OffToPosFn{ph_off.p, ph_pos.p}, "dist.dict_offsets");
         }
-        u64 cap = 1024;
-        while (cap < 2 * Dl) cap <<= 1;
-        DBuf<u64> keys(cap);
-        DBuf<idx_t> counts(cap);
-        DBuf<u32> list_slot(Dl), scal(4), slot_ph(cap);
-        keys.zero(); counts.zero(); scal.zero();
-        prim::for_each(Dl, ListInsertFn{gcells.p, goff.p, glen.p, gfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p}, "dist.merge_phrases");
-        if (scal.to_host(2)[1]) throw prim::Error(-28, "merged phrase table overflow");
-        // deterministic layout: representatives = smallest list index per slot, phrases in representative order
-        DBuf<u32> &slot_min = slot_ph;           // [cap]
-        slot_min.fill_ff();
-        prim::for_each(Dl, SlotMinFn{list_slot.p, slot_min.p}, "dist.slot_min");
-        DBuf<u32> rep_ex(Dl + 1);
-        u64 D = prim::exclusive_scan<u32>(Dl, IsRepIn{list_slot.p, slot_min.p}, rep_ex.p, false, "dist.merge_compact");
-        DBuf<u64> ph_pos(D); DBuf<idx_t> ph_freq(D); DBuf<u32> ph_len(D), ph_off(D + 1); DBuf<u8> ph_lastT(D);
-        prim::for_each(Dl, ListPhraseFn{gcells.p, goff.p, glen.p, list_slot.p, slot_min.p, rep_ex.p, counts.p, ph_pos.p, ph_freq.p,
-                                        ph_len.p, ph_lastT.p}, "dist.merge_compact");
-        u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dist.freq_check");
-        if (fsum != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
-        u32 maxlen = prim::reduce_max<u32>(D, LenIn{ph_len.p}, "dist.maxlen");
-        u64 S64 = prim::reduce_sum<u64>(D, LenIn{ph_len.p}, "dist.dict_syms");
-        if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
-        u64 S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dist.dict_offsets");
         // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar replicated ----
         DBuf<u32> gval;
-        if (getenv("GRLBWT_DIST_REPLICATED_DICT"))
-            dict_stage<u32, false>(gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p, ph_off.p, ph_lastT.p, sigma, L, gval);
-        else
-            dict_stage_dist(C, gcells.p, D, S, maxlen, ph_pos.p, ph_freq.p, ph_off.p, ph_lastT.p, sigma, L, gval);
-        // ---- back to the local parse ---------------------------------------------------------
+        dict_stage<u32, false>(getenv("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
+                               ph_off.p, ph_lastT.p, sigma, L, gval);
+        // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
-        prim::for_each(P.D, LocalValFn{list_slot.p, slot_min.p, rep_ex.p, gval.p, dbase[C.rank], lval.p}, "dist.local_values");
+        {
+            StageTimer st(&tm.emit);
+            DBuf<u32> rval(Dr), sval(P.D);
+            prim::for_each(Dr, ListValFn{list_slot.p, slot_min.p, rep_ex.p, gval.p, dbase[me], rval.p}, "dist.list_values");
+            C.alltoall(rval.p, rpc, sval.p, pc, 4, maxp);
+            prim::for_each(P.D, ScatterU32Fn{order.p, sval.p, lval.p}, "dist.local_values");
+        }
         emit_local(P, lval.p);
         finish_round(P, L, g_n_strings, occ_total);
     }
@@ -3017,15 +2982,52 @@ class Engine {
         release_level(L);
     }
 
-    // gather the slices of BWT_0, restore maximal runs across rank boundaries, build the image
+    // the image from the slices of BWT_0: every rank packs the records of its own slice, the packed parts are all-gathered
+    // behind the header.  Maximal runs across slice boundaries: a first run that continues the last run of the slices in
+    // front is dropped and its length goes to the slice where that run began (decided from every slice's two edge runs).
     void dist_finish(const Comm &C) {
-        std::vector<u64> b1, b2;
-        DBuf<u32> gs = C.allgather_v<u32>(bwt.sym.p, bwt.R, b1);
-        DBuf<idx_t> gl = C.allgather_v<idx_t>(bwt.len.p, bwt.R, b1, true);
-        bwt = merge_runs(gs.p, gl.p, b1[C.size]);
+        if (bwt_level != 0) throw prim::Error(-22, "induction not finished");
+        prim::rt().tag = -1; prim::rt().phase = 0;
+        StageTimer st(&tm.finish);
+        const int N = C.size, me = C.rank;
+        const u64 R = bwt.R;
+        std::vector<u64> mine(5, 0);             // runs, first (sym, len), last (sym, len)
+        mine[0] = R;
+        if (R) { mine[1] = bwt.sym.get(0); mine[2] = (u64)bwt.len.get(0); mine[3] = bwt.sym.get(R - 1); mine[4] = (u64)bwt.len.get(R - 1); }
+        std::vector<u64> all = C.allgather_u64(mine);
+        std::vector<u64> extra(N, 0);
+        std::vector<int> drop(N, 0);
+        int open = -1;
+        u64 open_sym = 0;
+        for (int g = 0; g < N; g++) {
+            const u64 Rg = all[5 * g];
+            if (!Rg) continue;
+            if (open >= 0 && all[5 * g + 1] == open_sym) {
+                drop[g] = 1;
+                extra[open] += all[5 * g + 2];
+                if (Rg == 1) continue;           // the whole slice was the tail of that run
+            }
+            open = g;
+            open_sym = all[5 * g + 3];
+        }
+        const u64 first = drop[me], Rm = R - first;
+        if (extra[me]) prim::for_each(1, AddLenFn{bwt.len.p + (R - 1), extra[me]}, "pack_rl_bwt");
+        const u32 sb = (u32)stats.sb, fb = (u32)stats.fb, rec = sb + fb;
+        DBuf<u8> part(Rm * rec);
+        prim::for_each(Rm, PackRunsFn{bwt.sym.p + first, bwt.len.p + first, sb, fb, part.p, 0u}, "pack_rl_bwt");
+        std::vector<u64> cnt = C.allgather_u64({Rm * rec}), base(N + 1, 0);
+        for (int g = 0; g < N; g++) base[g + 1] = base[g] + cnt[g];
+        image_bytes = 16 + base[N];
+        image_runs = base[N] / rec;
+        image.alloc(image_bytes);
+        u8 hdr[16] = {0};
+        for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
+        prim::h2d(image.p, hdr, 16);
+        C.allgather_v<u8>(part.p, Rm * rec, base, true, image.p + 16);
         stats.n_strings = g_n_strings;
         stats.n_syms = g_n_syms;
-        finish();
+        linfo[0].R = image_runs;
+        prim::sync();
     }
 
     void dist_induce(const Comm &C) {
@@ -3051,7 +3053,7 @@ class Engine {
     void dist_build(const Comm &C) {
         dist_stats(C);
         while (!dist_parse_round(C)) {}
-        if (getenv("GRLBWT_DIST_REPLICATED_INDUCTION") || !C.a2a) dist_induce_replicated(C);
+        if (getenv("GRLBWT_DIST_REPLICATED_INDUCTION")) dist_induce_replicated(C);
         else dist_induce(C);
     }
 

@@ -79,6 +79,8 @@ def main():
         parts = [b"A" * 3000 + b"C" * 2000 + b"\n", b"ACGT" * 900 + b"\n", b"\n" * 40, b"T" * 5000 + b"\n",
                  b"A" * 3000 + b"C" * 2000 + b"\n", b"G" * 100 + b"ACGT" * 50 + b"\n"] * 3
         data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    elif case == "samechar":       # two runs in the whole BWT: slices that are a single run continuing the previous slice's run
+        data = np.frombuffer(b"A\n" * 12, dtype=np.uint8)
     elif case == "tiny":
         data = np.frombuffer(b"A\n\nA\nGATTACA\nGATTACA\nT\n", dtype=np.uint8)
     else:

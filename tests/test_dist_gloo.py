@@ -31,9 +31,9 @@ def _run(world, lib, case, out_dir, port):
 
 
 @pytest.mark.parametrize("world,case", [(2, "reads"), (2, "tokens"), (3, "uniform"), (2, "repetitive"), (3, "tiny"),
-                                        (4, "reads"), (3, "longruns")])
+                                        (4, "reads"), (3, "longruns"), (4, "samechar")])
 def test_sharded_collection_matches_oracle(sim, oracle_mod, tmp_path, world, case):
-    port = 29500 + 7 * world + ['reads', 'tokens', 'uniform', 'repetitive', 'tiny', 'longruns'].index(case)
+    port = 29500 + 7 * world + ['reads', 'tokens', 'uniform', 'repetitive', 'tiny', 'longruns', 'samechar'].index(case)
     _run(world, sim, case, tmp_path, port)
     data = open(tmp_path / (case + ".input"), "rb").read()
     out = open(tmp_path / (case + ".rl_bwt"), "rb").read()
@@ -73,8 +73,18 @@ def test_replicated_induction_fallback_agrees(sim, oracle_mod, tmp_path, monkeyp
     _run(2, sim, "reads", tmp_path, 29590)
     data = open(tmp_path / "reads.input", "rb").read()
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
-    n_ag, n_a2a, _ = map(int, open(tmp_path / "reads.rank0.comm").read().split())
-    assert n_ag > 0 and n_a2a == 0
+    n_a2a = int(open(tmp_path / "reads.rank0.comm").read().split()[1])
+    monkeypatch.delenv("GRLBWT_DIST_REPLICATED_INDUCTION")
+    _run(2, sim, "reads", tmp_path, 29592)           # (the parse rounds exchange all-to-all in both modes; the induction adds its own)
+    assert n_a2a < int(open(tmp_path / "reads.rank0.comm").read().split()[1])
+
+
+def test_sharded_partitioned_rank_scatter(sim, oracle_mod, tmp_path, monkeypatch):
+    """The exchanged (position, rank) pairs applied through the partitioned scatter (threshold lowered)."""
+    monkeypatch.setenv("GRLBWT_RANK_PART_MIN", "1")
+    _run(2, sim, "tokens", tmp_path, 29594)
+    data = open(tmp_path / "tokens.input", "rb").read()
+    assert open(tmp_path / "tokens.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 2)
 
 
 def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):

@@ -165,7 +165,9 @@ def test_dist_path_single_rank_rccl(hip, oracle_mod, tmp_path):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                "--master-addr", "127.0.0.1", "--master-port", "29611",
                os.path.join(here, "dist_worker.py"), hip, "nccl", case, str(tmp_path)]
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
+        # (with one rank every all-to-all block is the rank's own: route it through RCCL anyway)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here),
+                           env=dict(os.environ, GRLBWT_A2A_SELF_VIA_COMM="1"))
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
         data = open(tmp_path / (case + ".input"), "rb").read()
         assert open(tmp_path / (case + ".rl_bwt"), "rb").read() == oracle_mod.rl_bwt(data, w)
@@ -304,6 +306,7 @@ def test_sharded_equals_single_gpu_image(hip, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29672",
            os.path.join(here, "dist_worker.py"), hip, "nccl", "illumina_dev:%d:%d" % (reads, genome), str(tmp_path)]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here),
+                       env=dict(os.environ, GRLBWT_A2A_SELF_VIA_COMM="1"))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert open(tmp_path / "illumina_dev.rank0.md5").read() == want
