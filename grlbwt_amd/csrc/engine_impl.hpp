@@ -1316,39 +1316,16 @@ struct CellIn {
 };
 
 // ------------------------------------------- collection-level multi-GPU pieces
-// exchange format of a phrase cell on every level: u32  sym<<2 | rep<<1 | is_terminator
-template <class cell_t, bool FIRST>
-struct ExportCellsFn {
-    const cell_t *t; CellOps<cell_t, FIRST> ops; const u32 *ph_off; u64 D; const u64 *ph_pos;
-    u32 *out;
-    GRL_DEV void operator()(u64 q) const {
-        u64 k = upper_bound<u32>(ph_off, D, (u32)q) - 1;
-        cell_t c = t[ph_pos[k] + (q - ph_off[k])];
-        out[q] = (ops.sym(c) << 2) | (ops.rep(c) ? 2u : 0u) | (ops.isT(c) ? 1u : 0u);
-    }
-};
-struct WidenFn {          // idx_t -> u64
-    const idx_t *a; u64 *b;
-    GRL_DEV void operator()(u64 i) const { b[i] = (u64)a[i]; }
-};
-template <class T>
-struct UnpadFn {          // dense[i] = padded[g*stride + (i - base[g])], g = rank owning i
-    const T *padded; const u64 *base; int size; u64 stride; T *dense;
-    GRL_DEV void operator()(u64 i) const {
-        int g = 0;
-        while (g + 1 < size && base[g + 1] <= i) g++;
-        dense[i] = padded[(u64)g * stride + (i - base[g])];
-    }
-};
 // The per-round dictionary merge (join_thread_phrases, parsing_strategies.h:277-386) is partitioned by content: a hash of
 // a phrase names the rank that merges it, so the same phrase from every shard meets on ONE rank and every rank inserts
 // about its own share of the phrases (an all-gather of the lists made every rank insert all of them).
+template <class cell_t, bool FIRST>
 struct PhraseOwnerFn {
-    const u32 *cells; const u32 *off; const u32 *len; u32 size; u32 *owner; u32 *idx;
+    const cell_t *t; CellOps<cell_t, FIRST> ops; const u64 *pos; const u32 *len; u32 size; u32 *owner; u32 *idx;
     GRL_DEV void operator()(u64 k) const {
-        const u64 o = off[k], l = len[k];
+        const u64 o = pos[k], l = len[k];
         PhraseHash ph = PhraseHash::init();
-        for (u64 j = 0; j < l; j++) ph.add(cells[o + j] >> 2);
+        for (u64 j = 0; j < l; j++) ph.add((u32)ops.sym(t[o + j]));
         const u64 h = ph.finish(l) * 0x9E3779B97F4A7C15ull;        // remixed: the table below takes its slot and tag from the plain hash
         owner[k] = (u32)(((h >> 32) * (u64)size) >> 32);
         idx[k] = (u32)k;
@@ -1366,18 +1343,32 @@ struct SendPhraseFn {     // my phrases in owner order: length and frequency
     const u32 *order; const u32 *len; const idx_t *freq; u32 *slen; u64 *sfreq;
     GRL_DEV void operator()(u64 i) const { const u32 k = order[i]; slen[i] = len[k]; sfreq[i] = (u64)freq[k]; }
 };
-struct SendCellsFn {      // ... and their cells
-    const u32 *order; const u32 *off; const u64 *soff; u64 D; const u32 *cells; u32 *out;
-    GRL_DEV void operator()(u64 q) const {
-        const u64 i = upper_bound<u64>(soff, D, q) - 1;
-        out[q] = cells[(u64)off[order[i]] + (q - soff[i])];
+// ... and their cells in the exchange format (u32  sym<<2 | rep<<1 | is_terminator on every level), straight from the text.
+// One lane per 16 consecutive output cells: one search for the phrase of the first cell, then a forward walk.
+template <class cell_t, bool FIRST>
+struct SendCellsFn {
+    const cell_t *t; CellOps<cell_t, FIRST> ops; const u32 *order; const u64 *pos; const u64 *soff; u64 D, S; u32 *out;
+    GRL_DEV void operator()(u64 j) const {
+        const u64 q0 = j * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
+        u64 i = upper_bound<u64>(soff, D, q0) - 1;
+        u64 nxt = soff[i + 1], src = pos[order[i]] + (q0 - soff[i]);
+        for (u64 q = q0; q < q1; q++) {
+            while (q >= nxt) { i++; nxt = soff[i + 1]; src = pos[order[i]]; }
+            const cell_t c = t[src++];
+            out[q] = ((u32)ops.sym(c) << 2) | (ops.rep(c) ? 2u : 0u) | (ops.isT(c) ? 1u : 0u);
+        }
     }
 };
-struct ListCellsFn {      // cells of the phrases a list names, packed in list order
-    const u64 *pos; const u32 *off; u64 D; const u32 *cells; u32 *out;
-    GRL_DEV void operator()(u64 q) const {
-        const u64 k = upper_bound<u32>(off, D, (u32)q) - 1;
-        out[q] = cells[pos[k] + (q - off[k])];
+struct ListCellsFn {      // cells of the phrases a list names, packed in list order (16 consecutive cells per lane)
+    const u64 *pos; const u32 *off; u64 D, S; const u32 *cells; u32 *out;
+    GRL_DEV void operator()(u64 j) const {
+        const u64 q0 = j * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
+        u64 k = upper_bound<u32>(off, D, (u32)q0) - 1;
+        u64 nxt = off[k + 1], src = pos[k] + (q0 - off[k]);
+        for (u64 q = q0; q < q1; q++) {
+            while (q >= nxt) { k++; nxt = off[k + 1]; src = pos[k]; }
+            out[q] = cells[src++];
+        }
     }
 };
 struct AddLenFn {
@@ -1488,18 +1479,15 @@ struct ApplyPairsFn {     // value[pair >> 32] = low 32 bits
     const u64 *pairs; u32 *value;
     GRL_DEV void operator()(u64 i) const { u64 p = pairs[i]; value[p >> 32] = (u32)p; }
 };
-struct FullFlagIn {       // slot is the whole-phrase suffix of its phrase
-    const u32 *perm; const u32 *dict_phr; const u32 *ph_off;
-    // q starts its phrase <=> the position before it belongs to another phrase (two reads of one cache line
-    // instead of the dependent gather ph_off[dict_phr[q]])
-    GRL_DEV u32 operator()(u64 t) const { u32 q = perm[t]; return (q == 0 || dict_phr[q] != dict_phr[q - 1]) ? 1u : 0u; }
+struct OwnPhraseIn {      // 1 if the whole-phrase suffix of phrase k sorted into my slots
+    const RankLen *rl; const u32 *ph_off; u32 base; u64 Sg;
+    GRL_DEV u32 operator()(u64 k) const { const u32 r = rl[ph_off[k]].rank; return (r >= base && (u64)(r - base) < Sg) ? 1u : 0u; }
 };
-struct FullPairFn {
-    const u8 *fflag; const u32 *perm; const u32 *dict_phr; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
-    GRL_DEV void operator()(u64 t) const {
-        if (!fflag[t]) return;                   // FullFlagIn, evaluated once: only whole-phrase slots pay the gathers again
-        u32 k = dict_phr[perm[t]];
-        pairs[ex[t]] = ((u64)k << 32) | (u64)(m_off + grank[gid[t]]);
+struct OwnPhrasePairFn {  // (phrase << 32 | metasymbol rank) for those
+    const RankLen *rl; const u32 *ph_off; u32 base; u64 Sg; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
+    GRL_DEV void operator()(u64 k) const {
+        const u32 r = rl[ph_off[k]].rank;
+        if (r >= base && (u64)(r - base) < Sg) pairs[ex[k]] = ((u64)k << 32) | (u64)(m_off + grank[gid[r - base]]);
     }
 };
 struct PhraseValDistFn {
@@ -1994,7 +1982,10 @@ class Engine {
             }
         }
         // variable-length all-gather of a typed device array -> dense concatenation in rank order.
-        // same_counts: `base` already holds the prefix of every rank's count (an earlier call with the same counts)
+        // same_counts: `base` already holds the prefix of every rank's count (an earlier call with the same counts).
+        // Every rank sends its block straight to its place in every peer's result through the all-to-all callback (xGMI is
+        // point to point: N - 1 direct writes per block); no padding to the longest block, no staging copy, no unpacking
+        // pass.  dest: the caller's own array of base[size] elements (then the returned buffer is empty).
         template <class T>
         DBuf<T> allgather_v(const T *send, u64 count, std::vector<u64> &base, bool same_counts = false, T *dest = nullptr) const {
             if (!same_counts || base.size() != (size_t)size + 1) {
@@ -2003,18 +1994,29 @@ class Engine {
                 for (int g = 0; g < size; g++) base[g + 1] = base[g] + cnt[g];
             }
             if (base[rank + 1] - base[rank] != count) throw prim::Error(-71, "allgather_v: counts changed between calls");
-            u64 mx = 1;
-            for (int g = 0; g < size; g++) if (base[g + 1] - base[g] > mx) mx = base[g + 1] - base[g];
-            DBuf<T> sp(mx), rp(mx * size);
-            prim::dev_memset(sp.p, 0, mx * sizeof(T));
-            prim::d2d(sp.p, send, count * sizeof(T));
-            allgather(sp.p, rp.p, mx * sizeof(T));
             DBuf<T> dense;
-            if (!dest) dense.alloc(base[size]);             // (dest: the caller's own array of base[size] elements)
-            DBuf<u64> dbase(size + 1);
-            prim::h2d(dbase.p, base.data(), (size + 1) * 8);
-            prim::for_each(base[size], UnpadFn<T>{rp.p, dbase.p, size, mx, dest ? dest : dense.p}, "dist.unpad");
-            return dense;       // scratch goes back to the pool in stream order
+            if (!dest) { dense.alloc(base[size]); dest = dense.p; }
+            static const bool self_via_comm = getenv("GRLBWT_A2A_SELF_VIA_COMM") != nullptr;
+            if (!self_via_comm || !a2a) prim::d2d(dest + base[rank], send, count * sizeof(T));
+            if ((size == 1 && !self_via_comm) || !a2a) return dense;
+            static const u64 limit = getenv("GRLBWT_A2A_BLOCK") ? (u64)atoll(getenv("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
+            const u64 per = std::max<u64>(limit / sizeof(T), 1);
+            u64 mx = 0;
+            for (int g = 0; g < size; g++) mx = std::max(mx, base[g + 1] - base[g]);
+            const u64 rounds = std::max<u64>((mx + per - 1) / per, 1);
+            std::vector<u64> sb(size), so(size), rb(size), ro(size);
+            if (!stream_ordered) prim::sync();
+            for (u64 k = 0; k < rounds; k++) {
+                const u64 s0 = std::min(k * per, count), s1 = std::min((k + 1) * per, count);
+                for (int g = 0; g < size; g++) {
+                    const bool skip = !self_via_comm && g == rank;
+                    const u64 cg = base[g + 1] - base[g], r0 = std::min(k * per, cg), r1 = skip ? r0 : std::min((k + 1) * per, cg);
+                    sb[g] = skip ? 0 : (s1 - s0) * sizeof(T); so[g] = s0 * sizeof(T);
+                    rb[g] = (r1 - r0) * sizeof(T); ro[g] = (base[g] + r0) * sizeof(T);
+                }
+                if (a2a(user, send, sb.data(), so.data(), dest, rb.data(), ro.data()) != 0) throw prim::Error(-5, "alltoallv callback failed");
+            }
+            return dense;
         }
     };
 
@@ -2256,13 +2258,11 @@ class Engine {
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
             if (!C) prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rl.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
-            else {                               // whole-phrase suffixes sit on the rank that owns their key: (phrase, metasymbol) pairs
-                DBuf<u32> phrase_rank(D), fex(Sg + 1);
-                DBuf<u8> fflag(Sg);              // the flag costs two dependent gathers: evaluate it once, scan the bytes
-                prim::for_each(Sg, StoreByteFn<FullFlagIn>{FullFlagIn{perm.p, dict_phr.p, ph_off}, fflag.p}, "dist.full_flags");
-                const u64 nf = prim::exclusive_scan<u32>(Sg, ByteIn{fflag.p}, fex.p, false, "dist.full_scan");
+            else {                               // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
+                DBuf<u32> phrase_rank(D), fex(D + 1);
+                const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{rl.p, ph_off, base, Sg}, fex.p, false, "dist.full_scan");
                 DBuf<u64> fp(nf);
-                prim::for_each(Sg, FullPairFn{fflag.p, perm.p, dict_phr.p, fex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
+                prim::for_each(D, OwnPhrasePairFn{rl.p, ph_off, base, Sg, fex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
                 std::vector<u64> bb;
                 DBuf<u64> allf = C->template allgather_v<u64>(fp.p, nf, bb);
                 if (bb[C->size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
@@ -2673,10 +2673,8 @@ class Engine {
         u64 Dr = 0, Sr = 0, occ_total = 0, n_total = 0, maxp = 0;     // maxp: largest phrase block of the exchange (all ranks agree)
         {
             StageTimer st(&tm.hash);
-            DBuf<u32> lcells(P.S);
-            prim::for_each(P.S, ExportCellsFn<cell_t, FIRST>{t, ops, P.ph_off.p, P.D, P.ph_pos.p, lcells.p}, "dist.export_cells");
             DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D);
-            prim::for_each(P.D, PhraseOwnerFn{lcells.p, P.ph_off.p, P.ph_len.p, (u32)N, owner.p, idx.p}, "dist.phrase_owner");
+            prim::for_each(P.D, PhraseOwnerFn<cell_t, FIRST>{t, ops, P.ph_pos.p, P.ph_len.p, (u32)N, owner.p, idx.p}, "dist.phrase_owner");
             int obits = (int)bitlen64((u64)N - 1);
             if (obits < 1) obits = 1;
             const int res = prim::sort_pairs<u32, u32>(owner.p, idx.p, owner2.p, idx2.p, P.D, 0, obits, "dist.owner_sort");
@@ -2688,7 +2686,7 @@ class Engine {
             const u64 chk = prim::exclusive_scan<u64>(P.D, LenIn{slen.p}, soff.p, true, "dist.send_offsets");
             if (chk != P.S) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
             DBuf<u32> scells(P.S);
-            prim::for_each(P.S, SendCellsFn{order.p, P.ph_off.p, soff.p, P.D, lcells.p, scells.p}, "dist.send_cells");
+            prim::for_each((P.S + 15) / 16, SendCellsFn<cell_t, FIRST>{t, ops, order.p, P.ph_pos.p, soff.p, P.D, P.S, scells.p}, "dist.send_cells");
             prim::for_each((u64)N + 1, KeyBoundFn{okey, P.D, soff.p, bound.p}, "dist.owner_bounds");
             std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
             std::vector<u64> mine(2 * (u64)N + 2);
@@ -2749,7 +2747,7 @@ class Engine {
             if (sbase[N] >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
             prim::exclusive_scan_nosync<u32>(Do, LenIn{o_len.p}, o_off.p, true, "dist.dict_offsets");
             DBuf<u32> ocells(So64);
-            prim::for_each(So64, ListCellsFn{o_pos.p, o_off.p, Do, rcells.p, ocells.p}, "dist.owner_cells");
+            prim::for_each((So64 + 15) / 16, ListCellsFn{o_pos.p, o_off.p, Do, So64, rcells.p, ocells.p}, "dist.owner_cells");
             rcells.release(); rlen.release(); rfreq.release();
             gcells = C.allgather_v<u32>(ocells.p, So64, sbase, true);
             ph_len = C.allgather_v<u32>(o_len.p, Do, dbase, true);
