@@ -1332,11 +1332,11 @@ struct PhraseOwnerFn {
     }
 };
 struct KeyBoundFn {       // first element of every key value in a sorted key array; with `pre`, the prefix value there too
-    const u32 *k; u64 n; const u64 *pre; u64 *out;
+    const u32 *k; u64 n; const u32 *pre; u64 *out;
     GRL_DEV void operator()(u64 d) const {
         const u64 i = lower_bound<u32>(k, n, (u32)d);
         out[2 * d] = i;
-        out[2 * d + 1] = pre ? pre[i] : 0ull;
+        out[2 * d + 1] = pre ? (u64)pre[i] : 0ull;
     }
 };
 struct SendPhraseFn {     // my phrases in owner order: length and frequency
@@ -1347,27 +1347,55 @@ struct SendPhraseFn {     // my phrases in owner order: length and frequency
 // One lane per 16 consecutive output cells: one search for the phrase of the first cell, then a forward walk.
 template <class cell_t, bool FIRST>
 struct SendCellsFn {
-    const cell_t *t; CellOps<cell_t, FIRST> ops; const u32 *order; const u64 *pos; const u64 *soff; u64 D, S; u32 *out;
+    const cell_t *t; CellOps<cell_t, FIRST> ops; const u32 *order; const u64 *pos; const u32 *soff; u64 D, S; u32 *out;
+    const u64 *pw; const idx_t *pb;      // rank bit-vector of the phrase starts over the output positions
+    struct alignas(16) Quad { u32 v[4]; };
     GRL_DEV void operator()(u64 j) const {
         const u64 q0 = j * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
-        u64 i = upper_bound<u64>(soff, D, q0) - 1;
+        u64 i = rank1(pw, pb, q0 + 1) - 1;
         u64 nxt = soff[i + 1], src = pos[order[i]] + (q0 - soff[i]);
-        for (u64 q = q0; q < q1; q++) {
-            while (q >= nxt) { i++; nxt = soff[i + 1]; src = pos[order[i]]; }
-            const cell_t c = t[src++];
-            out[q] = ((u32)ops.sym(c) << 2) | (ops.rep(c) ? 2u : 0u) | (ops.isT(c) ? 1u : 0u);
+        u32 v[16];
+#pragma unroll
+        for (int x = 0; x < 16; x++) {
+            const u64 q = q0 + x;
+            if (q < q1) {
+                while (q >= nxt) { i++; nxt = soff[i + 1]; src = pos[order[i]]; }
+                const cell_t c = t[src++];
+                v[x] = ((u32)ops.sym(c) << 2) | (ops.rep(c) ? 2u : 0u) | (ops.isT(c) ? 1u : 0u);
+            }
+        }
+        if (q1 - q0 == 16) {
+#pragma unroll
+            for (int x = 0; x < 16; x += 4) *reinterpret_cast<Quad *>(out + q0 + x) = Quad{{v[x], v[x + 1], v[x + 2], v[x + 3]}};
+        } else {
+#pragma unroll
+            for (int x = 0; x < 16; x++) if (q0 + x < q1) out[q0 + x] = v[x];
         }
     }
 };
 struct ListCellsFn {      // cells of the phrases a list names, packed in list order (16 consecutive cells per lane)
     const u64 *pos; const u32 *off; u64 D, S; const u32 *cells; u32 *out;
+    const u64 *pw; const idx_t *pb;
+    struct alignas(16) Quad { u32 v[4]; };
     GRL_DEV void operator()(u64 j) const {
         const u64 q0 = j * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
-        u64 k = upper_bound<u32>(off, D, (u32)q0) - 1;
+        u64 k = rank1(pw, pb, q0 + 1) - 1;
         u64 nxt = off[k + 1], src = pos[k] + (q0 - off[k]);
-        for (u64 q = q0; q < q1; q++) {
-            while (q >= nxt) { k++; nxt = off[k + 1]; src = pos[k]; }
-            out[q] = cells[src++];
+        u32 v[16];
+#pragma unroll
+        for (int x = 0; x < 16; x++) {
+            const u64 q = q0 + x;
+            if (q < q1) {
+                while (q >= nxt) { k++; nxt = off[k + 1]; src = pos[k]; }
+                v[x] = cells[src++];
+            }
+        }
+        if (q1 - q0 == 16) {
+#pragma unroll
+            for (int x = 0; x < 16; x += 4) *reinterpret_cast<Quad *>(out + q0 + x) = Quad{{v[x], v[x + 1], v[x + 2], v[x + 3]}};
+        } else {
+#pragma unroll
+            for (int x = 0; x < 16; x++) if (q0 + x < q1) out[q0 + x] = v[x];
         }
     }
 };
@@ -2680,13 +2708,18 @@ class Engine {
             const int res = prim::sort_pairs<u32, u32>(owner.p, idx.p, owner2.p, idx2.p, P.D, 0, obits, "dist.owner_sort");
             order = std::move(res ? idx2 : idx);
             const u32 *okey = res ? owner2.p : owner.p;
-            DBuf<u32> slen(P.D);
-            DBuf<u64> sfreq(P.D), soff(P.D + 1), bound(2 * ((u64)N + 1));
+            DBuf<u32> slen(P.D), soff(P.D + 1);
+            DBuf<u64> sfreq(P.D), bound(2 * ((u64)N + 1));
             prim::for_each(P.D, SendPhraseFn{order.p, P.ph_len.p, P.ph_freq.p, slen.p, sfreq.p}, "dist.send_phrases");
-            const u64 chk = prim::exclusive_scan<u64>(P.D, LenIn{slen.p}, soff.p, true, "dist.send_offsets");
+            const u64 chk = prim::exclusive_scan<u32>(P.D, LenIn{slen.p}, soff.p, true, "dist.send_offsets");
             if (chk != P.S) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
             DBuf<u32> scells(P.S);
-            prim::for_each((P.S + 15) / 16, SendCellsFn<cell_t, FIRST>{t, ops, order.p, P.ph_pos.p, soff.p, P.D, P.S, scells.p}, "dist.send_cells");
+            {
+                RankBits sbits;
+                build_rankbits32(sbits, soff.p, P.D, P.S + 1, "dist.send_cells");
+                prim::for_each((P.S + 15) / 16, SendCellsFn<cell_t, FIRST>{t, ops, order.p, P.ph_pos.p, soff.p, P.D, P.S, scells.p, sbits.words.p, sbits.base.p},
+                               "dist.send_cells");
+            }
             prim::for_each((u64)N + 1, KeyBoundFn{okey, P.D, soff.p, bound.p}, "dist.owner_bounds");
             std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
             std::vector<u64> mine(2 * (u64)N + 2);
@@ -2747,7 +2780,11 @@ class Engine {
             if (sbase[N] >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
             prim::exclusive_scan_nosync<u32>(Do, LenIn{o_len.p}, o_off.p, true, "dist.dict_offsets");
             DBuf<u32> ocells(So64);
-            prim::for_each((So64 + 15) / 16, ListCellsFn{o_pos.p, o_off.p, Do, So64, rcells.p, ocells.p}, "dist.owner_cells");
+            {
+                RankBits obits;
+                build_rankbits32(obits, o_off.p, Do, So64 + 1, "dist.owner_cells");
+                prim::for_each((So64 + 15) / 16, ListCellsFn{o_pos.p, o_off.p, Do, So64, rcells.p, ocells.p, obits.words.p, obits.base.p}, "dist.owner_cells");
+            }
             rcells.release(); rlen.release(); rfreq.release();
             gcells = C.allgather_v<u32>(ocells.p, So64, sbase, true);
             ph_len = C.allgather_v<u32>(o_len.p, Do, dbase, true);
@@ -3223,7 +3260,7 @@ class Engine {
         u8 hdr[16] = {0};
         for (int i = 0; i < 8; i++) { hdr[i] = (u8)(h.sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb2 >> (8 * i)); }
         prim::h2d(dev_out, hdr, 16);
-        prim::for_each(si.runs_after, PackRunsFn{osym.p, olen.p, (u32)h.sb, fb2, dev_out}, "split.pack");
+        prim::for_each(si.runs_after, PackRunsFn{osym.p, olen.p, (u32)h.sb, fb2, dev_out, 16u}, "split.pack");
         prim::sync();
         return si;
     }
