@@ -6,7 +6,13 @@
 // C-ABI of include/grlbwt_hip.h.  Own argument parser (CLI11 is third-party).
 // -t/-f/-b/-T are accepted and validated as in the reference; they are tuning knobs of
 // the reference's CPU tables/tmp files and never change the output.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <atomic>
 
 #include <chrono>
 #include <cstdio>
@@ -28,6 +34,7 @@ struct arguments {
     bool ver = false;
     int alph_bytes = 1;
     int device = 0;
+    int gpus = 1;                           // --gpus N: one process per GPU, record shards, RCCL (collection-level mode)
     std::string version = "v1.0.1 alpha";   // main.cpp:20 (reference version string)
 };
 
@@ -45,7 +52,9 @@ static void usage(const char *prog) {
               << "  -b,--run-len-bytes     Max. number of bytes to encode the run lengths in the recursive BWTs (def. 1)\n"
               << "  -T,--tmp               Temporary folder (def. /tmp/grl.bwt.xxxx)\n"
               << "  -v,--version           Print the software version and exit\n"
-              << "  -g,--gpu               HIP device ordinal (def. 0)\n";
+              << "  -g,--gpu               HIP device ordinal (def. 0; with --gpus: the first of N consecutive devices)\n"
+              << "  --gpus                 Number of GPUs: the collection is sharded by record, one process per GPU,\n"
+              << "                         exchanges over RCCL; the output does not depend on it (def. 1)\n";
 }
 [[noreturn]] static void fail(int code, const std::string &msg) {
     std::cerr << msg << "\nRun with --help for more information.\n";
@@ -67,6 +76,173 @@ static void report_ms(double seconds, int pad) {
 }
 static void report_time(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b, int pad) {
     report_ms(std::chrono::duration<double>(b - a).count(), pad);
+}
+
+// ---- --gpus N: the collection-level mode from the command line -------------------------------------------------------
+// The parent cuts the file into N record shards (byte ranges ending on a separator) and starts one process per GPU BEFORE
+// anything touches the HIP runtime; rank 0 makes the RCCL id and publishes it through a shared page; every rank loads its
+// shard, joins the communicator (grlbwt_rccl_comm_create) and runs grlbwt_dist_build; rank 0 reports and writes the file.
+struct SharedPage {
+    std::atomic<int> id_ready;
+    char id[GRLBWT_RCCL_ID_BYTES];
+    std::atomic<int> loaded[64];            // 0 = not yet, 1 = shard loaded, < 0 = the error code of the load
+};
+static bool read_cell(int fd, uint64_t idx, int w, uint64_t *out) {
+    unsigned char b[8] = {0};
+    if (pread(fd, b, (size_t)w, (off_t)(idx * (uint64_t)w)) != (ssize_t)w) return false;
+    uint64_t v = 0;
+    for (int i = 0; i < w; i++) v |= (uint64_t)b[i] << (8 * i);
+    *out = v;
+    return true;
+}
+// first cell index > from whose predecessor is the separator (= start of the next record), or n
+static uint64_t next_record_start(int fd, uint64_t from, uint64_t n, int w, uint64_t sep) {
+    std::vector<unsigned char> buf((size_t)1 << 20);
+    uint64_t i = from > 0 ? from - 1 : 0;
+    while (i < n) {
+        const uint64_t cells = std::min<uint64_t>(buf.size() / (size_t)w, n - i);
+        const ssize_t got = pread(fd, buf.data(), (size_t)(cells * (uint64_t)w), (off_t)(i * (uint64_t)w));
+        if (got <= 0) return n;
+        for (uint64_t k = 0; k < (uint64_t)got / (uint64_t)w; k++) {
+            uint64_t v = 0;
+            for (int b = 0; b < w; b++) v |= (uint64_t)buf[k * w + b] << (8 * b);
+            if (v == sep) return i + k + 1;
+        }
+        i += (uint64_t)got / (uint64_t)w;
+    }
+    return n;
+}
+static int rank_main(const arguments &args, int rank, int size, uint64_t off_bytes, uint64_t n_bytes, SharedPage *sh) {
+    const bool root = rank == 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    grlbwt_ctx *ctx = nullptr;
+    // (GRLBWT_CLI_SAME_DEVICE=1: every rank on --gpu's device, for boxes with fewer GPUs than ranks -- if the RCCL build allows it)
+    const int dev = std::getenv("GRLBWT_CLI_SAME_DEVICE") ? args.device : args.device + rank;
+    int rc = grlbwt_ctx_create(dev, GRLBWT_FLAG_CLASSIC_POOL, &ctx);                      // buffers are handed to RCCL
+    if (rc == GRLBWT_OK) rc = grlbwt_text_load_file_range(ctx, args.input_file.c_str(), off_bytes, n_bytes, args.alph_bytes);
+    // every rank learns whether every shard loaded before the first collective (nobody may be left waiting in one)
+    sh->loaded[rank].store(rc == GRLBWT_OK ? 1 : (rc < 0 ? rc : -1));
+    int worst = 1;
+    for (int g = 0; g < size; g++) {
+        int v;
+        while ((v = sh->loaded[g].load()) == 0) usleep(200);
+        if (v < 0 && worst == 1) worst = v;
+    }
+    if (worst < 0) {
+        if (root) {
+            if (worst == GRLBWT_EILLFORMED) std::cout << "Error: the file is ill formed" << std::endl;
+            else std::cerr << "grlbwt: a rank could not load its shard (" << grlbwt_strerror(worst) << ")" << std::endl;
+        }
+        if (ctx) grlbwt_ctx_destroy(ctx);
+        return worst == GRLBWT_EILLFORMED ? 1 : (worst == GRLBWT_EDEVICE ? 3 : 2);
+    }
+    const auto t_loaded = std::chrono::steady_clock::now();
+    auto die = [&](int code, const char *what) -> int {
+        std::cerr << "grlbwt[rank " << rank << "]: " << what << ": " << grlbwt_last_error(ctx) << " (" << grlbwt_strerror(code) << ")" << std::endl;
+        return code == GRLBWT_EILLFORMED ? 1 : 2;      // (no destroy: peers may be inside a collective; the process ends)
+    };
+    if (root) {
+        rc = grlbwt_rccl_unique_id(sh->id);
+        sh->id_ready.store(rc == GRLBWT_OK ? 1 : -1);
+    }
+    int ready;
+    while ((ready = sh->id_ready.load()) == 0) usleep(200);
+    if (ready < 0) { if (root) std::cerr << "grlbwt: RCCL is not available" << std::endl; return 3; }
+    grlbwt_comm comm;
+    std::memset(&comm, 0, sizeof comm);
+    rc = grlbwt_rccl_comm_create(ctx, sh->id, rank, size, &comm);
+    if (rc != GRLBWT_OK) return die(rc, "joining the communicator");
+    if (root) std::cout << "Parsing the text and inferring the BWT on " << size << " GPUs (record shards, RCCL)" << std::endl;
+    rc = grlbwt_dist_build(ctx, &comm);
+    if (rc != GRLBWT_OK) {
+        if (rc == GRLBWT_EILLFORMED && root) std::cout << "Error: the file is ill formed" << std::endl;
+        return die(rc, "collection-level build");
+    }
+    const auto t_built = std::chrono::steady_clock::now();
+    int code = 0;
+    if (root) {
+        // the reference's per-round / per-level statistics (exact_par_phase.cpp:484-488, exact_ind_phase.cpp:372-378)
+        grlbwt_stats st;
+        grlbwt_get_stats(ctx, &st);
+        std::cout << "Stats: " << std::endl;
+        std::cout << "  Smallest symbol               : " << st.min_sym << std::endl;
+        std::cout << "  Greatest symbol               : " << st.max_sym << std::endl;
+        std::cout << "  Number of symbols in the file : " << st.n_syms << std::endl;
+        std::cout << "  Number of strings             : " << st.n_strings << std::endl;
+        std::cout << "Parsing the text:    " << std::endl;
+        int rounds = 0;
+        grlbwt_round_info ri;
+        while (grlbwt_round_info_get(ctx, rounds, &ri) == GRLBWT_OK) {
+            std::cout << "  Parsing round " << ++rounds << std::endl;
+            std::cout << "    Stats:" << std::endl;
+            std::cout << "      Parsing phrases:                  " << ri.n_phrases << std::endl;
+            std::cout << "      Number of symbols in the phrases: " << ri.dict_syms << std::endl;
+            std::cout << "      Number of unsolved BWT blocks:    " << ri.n_metasyms << std::endl;
+            std::cout << "      Parse size:                       " << ri.parse_size << std::endl;
+        }
+        std::cout << "Inferring the BWT" << std::endl;
+        grlbwt_counters c;
+        grlbwt_get_counters(ctx, &c);
+        std::cout << "  Stage seconds of rank 0: dictionary of LMS phrases " << c.t_classify + c.t_hash << ", sorting + preliminary BWT " << c.t_dict_sort
+                  << ", compressing " << c.t_dict_groups << ", parse " << c.t_emit << ", induced symbols " << c.t_ind_expand << ", induction "
+                  << c.t_ind_split << ", assembling " << c.t_ind_assemble << std::endl;
+        rc = grlbwt_result_write_file(ctx, args.output_file.c_str());
+        if (rc != GRLBWT_OK) code = die(rc, "writing the output");
+        else {
+            const auto t_written = std::chrono::steady_clock::now();
+            std::cout << "The resulting BCR BWT was stored in " << args.output_file << std::endl;
+            auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+            const double tr = sec(t_start, t_loaded), tb = sec(t_loaded, t_built), tw = sec(t_built, t_written), tt = sec(t_start, t_written);
+            std::printf("grlbwt-timing: read+upload %.3f s, build %.3f s, write %.3f s, total %.3f s, %.1f MB/s (input bytes / total), %d GPUs\n", tr, tb, tw, tt,
+                        (double)st.n_syms * args.alph_bytes / 1e6 / (tt > 0 ? tt : 1e-9), size);
+        }
+    }
+    grlbwt_rccl_comm_destroy(&comm);
+    grlbwt_ctx_destroy(ctx);
+    return code;
+}
+static int run_multi_gpu(const arguments &args) {
+    const int N = args.gpus, w = args.alph_bytes;
+    int fd = open(args.input_file.c_str(), O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) fail(105, "TEXT: File does not exist: " + args.input_file);
+    const uint64_t bytes = (uint64_t)st.st_size;
+    if (bytes == 0 || bytes % (uint64_t)w) { std::cout << "Error: the file is ill formed" << std::endl; return 1; }
+    const uint64_t n = bytes / (uint64_t)w;
+    uint64_t sep = 0;
+    if (!read_cell(fd, n - 1, w, &sep)) fail(105, "TEXT: cannot read " + args.input_file);
+    // record shards: cut g at the first record start at or after cell g*n/N (the separator is the file's last cell)
+    std::vector<uint64_t> cut(N + 1, 0);
+    cut[N] = n;
+    for (int g = 1; g < N; g++) cut[g] = std::max(cut[g - 1], next_record_start(fd, (uint64_t)g * (n / (uint64_t)N), n, w, sep));
+    close(fd);
+    for (int g = 0; g < N; g++)
+        if (cut[g + 1] <= cut[g]) fail(105, "--gpus: the collection has too few strings for " + std::to_string(N) + " record shards");
+    SharedPage *sh = (SharedPage *)mmap(nullptr, sizeof(SharedPage), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (sh == MAP_FAILED) fail(2, "grlbwt: cannot map the rendezvous page");
+    new (sh) SharedPage();
+    sh->id_ready.store(0);
+    for (int g = 0; g < 64; g++) sh->loaded[g].store(0);
+    std::cout << std::flush;
+    std::vector<pid_t> kids;
+    for (int g = 0; g < N; g++) {
+        pid_t pid = fork();                  // (this process has not touched the GPU: the children initialise HIP themselves)
+        if (pid < 0) fail(2, "grlbwt: fork failed");
+        if (pid == 0) {
+            int rc = rank_main(args, g, N, cut[g] * (uint64_t)w, (cut[g + 1] - cut[g]) * (uint64_t)w, sh);
+            std::cout << std::flush;
+            _exit(rc);
+        }
+        kids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t pid : kids) {
+        int status = 0;
+        waitpid(pid, &status, 0);
+        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 2;
+        if (code > worst) worst = code;
+    }
+    return worst;
 }
 
 int main(int argc, char **argv) {
@@ -97,6 +273,10 @@ int main(int argc, char **argv) {
             args.tmp_dir = need("--tmp");
             if (!is_dir(args.tmp_dir)) fail(105, "--tmp: Directory does not exist: " + args.tmp_dir);
         } else if (a == "-g" || a == "--gpu") args.device = std::atoi(need("--gpu").c_str());
+        else if (a == "--gpus") {
+            args.gpus = std::atoi(need("--gpus").c_str());
+            if (args.gpus < 1 || args.gpus > 64) fail(105, "--gpus: Value not in range 1 to 64");
+        }
         else if (!a.empty() && a[0] == '-' && a.size() > 1) fail(109, "The following argument was not expected: " + a);
         else if (!have_text) { args.input_file = a; have_text = true; }
         else fail(109, "The following argument was not expected: " + a);
@@ -111,6 +291,8 @@ int main(int argc, char **argv) {
     std::cout << (args.alph_bytes > 1 ? "Alphabet type:    integer" : "Alphabet type:    byte") << std::endl;
     std::cout << "Temporary folder: (none: all levels stay resident in HBM)" << std::endl;
     std::cout << "BWT type:         BCR exact" << std::endl;
+    // GRLBWT_CLI_FORCE_RCCL=1: the collection-level path also with one GPU (that is all a single-GPU box can test)
+    if (args.gpus > 1 || std::getenv("GRLBWT_CLI_FORCE_RCCL")) return run_multi_gpu(args);
 
     const auto t_start = std::chrono::steady_clock::now();
     grlbwt_ctx *ctx = nullptr;

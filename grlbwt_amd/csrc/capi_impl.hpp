@@ -156,7 +156,7 @@ constexpr int kIoBufs = 3, kIoThreads = 4;
 // file -> HBM: chunk k+1 is read from the file while chunk k travels over PCIe; for byte cells the histogram of
 // collection_stats is taken from every chunk on the device as soon as it has landed (no second pass over the text)
 template <class E>
-void load_file_into(E &e, int fd, uint64_t bytes, int w) {
+void load_file_into(E &e, int fd, uint64_t base, uint64_t bytes, int w) {      // bytes [base, base + bytes) of the file
     e.own0.alloc(bytes + 16);
     char *bufs[kIoBufs] = {nullptr, nullptr, nullptr};
     prim::Fence fences[kIoBufs];
@@ -174,7 +174,7 @@ void load_file_into(E &e, int fd, uint64_t bytes, int w) {
         for (uint64_t off = 0; off < bytes; off += chunk, k = (k + 1) % kIoBufs) {
             const uint64_t len = bytes - off < chunk ? bytes - off : chunk;
             prim::fence_wait(fences[k]);                                // the copy that last used this buffer is done
-            if (!par_io(fd, bufs[k], off, len, false, kIoThreads)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+            if (!par_io(fd, bufs[k], base + off, len, false, kIoThreads)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
             prim::h2d_async(e.own0.p + off, bufs[k], len);
             if (d_hist) prim::byte_histogram_accumulate(e.own0.p + off, len, d_hist);
             prim::fence_record(fences[k]);
@@ -189,7 +189,7 @@ void load_file_into(E &e, int fd, uint64_t bytes, int w) {
         throw;
     }
 }
-void load_file(grlbwt_ctx *ctx, const char *path, int w) {
+void load_file(grlbwt_ctx *ctx, const char *path, int w, uint64_t base = 0, uint64_t range_bytes = ~0ull) {
     ctx->e32.reset();
     ctx->e64.reset();
     if (!(w == 1 || w == 2 || w == 4 || w == 8)) throw prim::Error(GRLBWT_EINVAL, "bad cell width");
@@ -197,21 +197,27 @@ void load_file(grlbwt_ctx *ctx, const char *path, int w) {
     if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); throw prim::Error(GRLBWT_EINVAL, std::string("cannot stat ") + path); }
-    const uint64_t bytes = (uint64_t)st.st_size;
+    uint64_t bytes = (uint64_t)st.st_size;
     try {
         if (bytes == 0 || bytes % (uint64_t)w) throw prim::Error(GRLBWT_EILLFORMED, "Error: the file is ill formed");
+        if (range_bytes != ~0ull) {               // a record shard of the file
+            if (base % (uint64_t)w || range_bytes % (uint64_t)w || base > bytes || range_bytes > bytes - base)
+                throw prim::Error(GRLBWT_EINVAL, "file range outside the file or not on cell boundaries");
+            if (range_bytes == 0) throw prim::Error(GRLBWT_EILLFORMED, "Error: the file is ill formed");
+            bytes = range_bytes;
+        } else base = 0;
         const uint64_t n = bytes / (uint64_t)w;
         bool big = (n >= 0xFFFFFF00ull) || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
         bool keep = ctx->flags & GRLBWT_FLAG_KEEP_LEVELS;
         if (big) {
             std::unique_ptr<grl64::Engine> e(new grl64::Engine());
             e->keep_texts = keep;
-            load_file_into(*e, fd, bytes, w);
+            load_file_into(*e, fd, base, bytes, w);
             ctx->e64 = std::move(e);
         } else {
             std::unique_ptr<grl32::Engine> e(new grl32::Engine());
             e->keep_texts = keep;
-            load_file_into(*e, fd, bytes, w);
+            load_file_into(*e, fd, base, bytes, w);
             ctx->e32 = std::move(e);
         }
     } catch (...) { close(fd); throw; }
@@ -467,6 +473,10 @@ int grlbwt_text_load_file(grlbwt_ctx *ctx, const char *path, int cell_bytes) {
     if (!ctx || !path) return GRLBWT_EINVAL;
     return guarded(ctx, [&] { load_file(ctx, path, cell_bytes); });
 }
+int grlbwt_text_load_file_range(grlbwt_ctx *ctx, const char *path, uint64_t offset_bytes, uint64_t n_bytes, int cell_bytes) {
+    if (!ctx || !path) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { load_file(ctx, path, cell_bytes, offset_bytes, n_bytes); });
+}
 int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes) {
     if (!ctx || !dev_cells || ((uintptr_t)dev_cells & 15)) return GRLBWT_EINVAL;
     return guarded(ctx, [&] { load(ctx, dev_cells, n_cells, cell_bytes, false); });
@@ -683,6 +693,101 @@ int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm) {
         }
     });
 }
+
+// ---- grlbwt_comm over RCCL, inside the library ---------------------------------------------------------------------
+#ifdef GRLBWT_PRIM_HIP
+}   // extern "C"
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl (573 MB) is loaded on first use, not linked
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        // a librccl already mapped into the process (torch brings its own) is found by its soname
+        for (const char *name : {"librccl.so.1", "librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!err.empty()) { dlclose(lib); lib = nullptr; return false; }
+        return true;
+    }
+};
+RcclApi &rccl() { static RcclApi a; return a; }
+struct RcclState { ncclComm_t comm = nullptr; int rank = 0, size = 1; };
+// stream-ordered callbacks: everything is enqueued on the engine's stream and nobody waits on the host
+int rccl_allgather(void *user, const void *send, void *recv, uint64_t bytes) {
+    RcclState *S = (RcclState *)user;
+    return rccl().AllGather(send, recv, (size_t)bytes, ncclUint8, S->comm, prim::rt().stream) == ncclSuccess ? 0 : 1;
+}
+int rccl_alltoallv(void *user, const void *send, const uint64_t *sb, const uint64_t *so, void *recv, const uint64_t *rb, const uint64_t *ro) {
+    RcclState *S = (RcclState *)user;
+    RcclApi &A = rccl();
+    bool ok = A.GroupStart() == ncclSuccess;
+    for (int g = 0; g < S->size && ok; g++) {        // one grouped send/recv per peer: direct xGMI writes, no staging
+        if (sb[g]) ok = A.Send((const char *)send + so[g], (size_t)sb[g], ncclUint8, g, S->comm, prim::rt().stream) == ncclSuccess;
+        if (ok && rb[g]) ok = A.Recv((char *)recv + ro[g], (size_t)rb[g], ncclUint8, g, S->comm, prim::rt().stream) == ncclSuccess;
+    }
+    return (A.GroupEnd() == ncclSuccess && ok) ? 0 : 1;
+}
+}   // namespace
+extern "C" {
+int grlbwt_rccl_unique_id(void *id128) {
+    if (!id128) return GRLBWT_EINVAL;
+    if (!rccl().load()) return GRLBWT_EDEVICE;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return GRLBWT_EINTERNAL;
+    static_assert(sizeof id == GRLBWT_RCCL_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof id);
+    return GRLBWT_OK;
+}
+int grlbwt_rccl_comm_create(grlbwt_ctx *ctx, const void *id128, int rank, int size, grlbwt_comm *comm) {
+    if (!ctx || !id128 || !comm || size < 1 || rank < 0 || rank >= size) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        if (!rccl().load()) throw prim::Error(GRLBWT_EDEVICE, rccl().err);
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof id);
+        std::unique_ptr<RcclState> S(new RcclState());
+        S->rank = rank; S->size = size;
+        ncclResult_t r = rccl().CommInitRank(&S->comm, size, id, rank);          // collective over all ranks; uses the current device
+        if (r != ncclSuccess) throw prim::Error(GRLBWT_EINTERNAL, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+        comm->rank = rank; comm->size = size; comm->user = S.release();
+        comm->allgather = rccl_allgather; comm->alltoallv = rccl_alltoallv;
+        comm->flags = GRLBWT_COMM_STREAM_ORDERED;
+    });
+}
+int grlbwt_rccl_comm_destroy(grlbwt_comm *comm) {
+    if (!comm || comm->allgather != rccl_allgather || !comm->user) return GRLBWT_EINVAL;
+    RcclState *S = (RcclState *)comm->user;
+    try { prim::sync(); } catch (...) {}
+    if (S->comm) rccl().CommDestroy(S->comm);
+    delete S;
+    comm->user = nullptr; comm->allgather = nullptr; comm->alltoallv = nullptr;
+    return GRLBWT_OK;
+}
+#else   // the tests' serial stand-in has no device and no RCCL
+int grlbwt_rccl_unique_id(void *) { return GRLBWT_EDEVICE; }
+int grlbwt_rccl_comm_create(grlbwt_ctx *, const void *, int, int, grlbwt_comm *) { return GRLBWT_EDEVICE; }
+int grlbwt_rccl_comm_destroy(grlbwt_comm *) { return GRLBWT_EDEVICE; }
+#endif
 
 int grlbwt_profile_enable(grlbwt_ctx *ctx, int on) {
     if (!ctx) return GRLBWT_EINVAL;

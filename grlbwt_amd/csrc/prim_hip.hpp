@@ -31,6 +31,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 static constexpr bool kIsDevice = true;
+#define GRLBWT_PRIM_HIP 1        // (capi_impl.hpp: the in-library RCCL transport exists in this build only)
 
 struct Error : std::runtime_error {
     int code;

@@ -22,7 +22,8 @@ EILLFORMED = -84
 # every symbol include/grlbwt_hip.h declares
 ABI_SYMBOLS = [
     "grlbwt_abi_version", "grlbwt_backend_name", "grlbwt_strerror", "grlbwt_last_error", "grlbwt_ctx_create", "grlbwt_ctx_destroy",
-    "grlbwt_ctx_set_stream", "grlbwt_text_upload", "grlbwt_text_load_file", "grlbwt_text_attach_device", "grlbwt_get_stats",
+    "grlbwt_ctx_set_stream", "grlbwt_text_upload", "grlbwt_text_load_file", "grlbwt_text_load_file_range", "grlbwt_rccl_unique_id", "grlbwt_rccl_comm_create",
+    "grlbwt_rccl_comm_destroy", "grlbwt_text_attach_device", "grlbwt_get_stats",
     "grlbwt_parse_round", "grlbwt_parse_phase", "grlbwt_round_info_get", "grlbwt_induce_first",
     "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
     "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",

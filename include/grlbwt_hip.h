@@ -117,6 +117,9 @@ int grlbwt_text_upload(grlbwt_ctx *ctx, const void *host_cells, uint64_t n_cells
  * chunk is read; for byte cells the symbol histogram is taken per chunk on the device behind the copies.  A file whose
  * size is 0 or not a multiple of cell_bytes is ill formed (GRLBWT_EILLFORMED). */
 int grlbwt_text_load_file(grlbwt_ctx *ctx, const char *path, int cell_bytes);
+/* the same for bytes [offset_bytes, offset_bytes + n_bytes) of the file: a record shard of the collection-level mode
+ * (the caller cuts at record boundaries; both numbers are multiples of cell_bytes) */
+int grlbwt_text_load_file_range(grlbwt_ctx *ctx, const char *path, uint64_t offset_bytes, uint64_t n_bytes, int cell_bytes);
 /* use cells already resident in HBM (borrowed until the context is reset/destroyed; 16-byte aligned) */
 int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes);
 int grlbwt_get_stats(const grlbwt_ctx *ctx, grlbwt_stats *out);
@@ -242,6 +245,17 @@ typedef struct grlbwt_comm {
 #define GRLBWT_COMM_STREAM_ORDERED 1u
 /* grl_bwt_algo over the sharded collection: par_phase with a dictionary merge per round, ind_phase, image */
 int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm);
+
+/* The two callbacks over RCCL inside the library, for hosts without a communication framework of their own (the grlbwt
+ * executable's --gpus N: one process per GPU, the counterpart of `-t N` reaching mt_parse_strat_t in the reference,
+ * main.cpp:62, parsing_strategies.h:200-275).  librccl is loaded on first use.  ONE rank makes the 128-byte id and the
+ * host hands it to the others (shared memory, a pipe, a file); comm_create is collective over all `size` ranks, each
+ * with its own device, and fills *comm with stream-ordered callbacks: ncclAllGather, and one grouped ncclSend/ncclRecv
+ * per peer for the all-to-all, enqueued on the context's stream. */
+#define GRLBWT_RCCL_ID_BYTES 128
+int grlbwt_rccl_unique_id(void *id128);
+int grlbwt_rccl_comm_create(grlbwt_ctx *ctx, const void *id128, int rank, int size, grlbwt_comm *comm);
+int grlbwt_rccl_comm_destroy(grlbwt_comm *comm);
 
 /* per-kernel timing with HIP events on the engine's stream (bench.py's roofline leg).
  * enable(1) clears the table and starts recording; dump writes one line per kernel name:

@@ -33,7 +33,9 @@ def test_cli_argument_contract(cli, tmp_path):
     assert run(cli, f, "-b", "6")[0] == 105
     assert run(cli, f, "-f", "1.5")[0] == 105
     assert run(cli, f, "-T", str(tmp_path / "nodir"))[0] == 105
-    assert run(cli, "--help")[0] == 0
+    assert run(cli, f, "--gpus", "0")[0] == 105
+    rc, out, _ = run(cli, "--help")
+    assert rc == 0 and "--gpus" in out
 
 
 @pytest.mark.gpu
@@ -64,3 +66,28 @@ def test_cli_end_to_end(cli, tmp_path):
     bad.write_bytes(b"AC\nGT")
     rc, out, _ = run(cli, str(bad), cwd=str(tmp_path))
     assert rc == 1 and "Error: the file is ill formed" in out
+
+
+@pytest.mark.gpu
+def test_cli_collection_level_mode_over_rccl(cli, tmp_path):
+    """`grlbwt --gpus N`: one process per GPU, record shards cut by the parent, the library's own RCCL transport
+    (grlbwt_rccl_comm_create) and grlbwt_dist_build.  This box has one GPU: the path runs with one rank
+    (GRLBWT_CLI_FORCE_RCCL=1), and a request for two GPUs must end on every rank with an error instead of hanging."""
+    tab = json.load(open(os.path.join(GOLD, "golden_table.json")))
+    env = dict(os.environ, GRLBWT_CLI_FORCE_RCCL="1", GRLBWT_A2A_SELF_VIA_COMM="1")
+    p = subprocess.run([cli, os.path.join(GOLD, "test_byte_alphabet.txt"), "-o", str(tmp_path / "one")], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert hashlib.md5(open(tmp_path / "one.rl_bwt", "rb").read()).hexdigest() == tab["test_byte_alphabet.txt"]["md5"]
+    assert "Parsing round 8" in p.stdout and "on 1 GPUs (record shards, RCCL)" in p.stdout and "grlbwt-timing:" in p.stdout
+    p = subprocess.run([cli, os.path.join(GOLD, "test_2bytes_alphabet.txt"), "-a", "2", "-o", str(tmp_path / "two")], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert hashlib.md5(open(tmp_path / "two.rl_bwt", "rb").read()).hexdigest() == tab["test_2bytes_alphabet.txt"]["md5"]
+    bad = tmp_path / "bad.txt"
+    bad.write_bytes(b"AC\nGT")
+    p = subprocess.run([cli, str(bad)], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert p.returncode == 1 and "Error: the file is ill formed" in p.stdout
+    import torch
+    if torch.cuda.device_count() == 1:
+        p = subprocess.run([cli, os.path.join(GOLD, "test_byte_alphabet.txt"), "--gpus", "2", "-o", str(tmp_path / "x")], capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 3 and "could not load its shard" in p.stderr
