@@ -34,6 +34,7 @@ struct arguments {
     bool ver = false;
     int alph_bytes = 1;
     int device = 0;
+    bool rev_comp = false;                  // -R (main.cpp:17,75): also the DNA reverse complements, FASTA/Q inputs
     int gpus = 1;                           // --gpus N: one process per GPU, record shards, RCCL (collection-level mode)
     std::string version = "v1.0.1 alpha";   // main.cpp:20 (reference version string)
 };
@@ -52,6 +53,7 @@ static void usage(const char *prog) {
               << "  -b,--run-len-bytes     Max. number of bytes to encode the run lengths in the recursive BWTs (def. 1)\n"
               << "  -T,--tmp               Temporary folder (def. /tmp/grl.bwt.xxxx)\n"
               << "  -v,--version           Print the software version and exit\n"
+              << "  -R,--rev-comp          Also consider the DNA reverse complements of the strings in TEXT (FASTA/Q input)\n"
               << "  -g,--gpu               HIP device ordinal (def. 0; with --gpus: the first of N consecutive devices)\n"
               << "  --gpus                 Number of GPUs: the collection is sharded by record, one process per GPU,\n"
               << "                         exchanges over RCCL; the output does not depend on it (def. 1)\n";
@@ -273,6 +275,7 @@ int main(int argc, char **argv) {
             args.tmp_dir = need("--tmp");
             if (!is_dir(args.tmp_dir)) fail(105, "--tmp: Directory does not exist: " + args.tmp_dir);
         } else if (a == "-g" || a == "--gpu") args.device = std::atoi(need("--gpu").c_str());
+        else if (a == "-R" || a == "--rev-comp") args.rev_comp = true;
         else if (a == "--gpus") {
             args.gpus = std::atoi(need("--gpus").c_str());
             if (args.gpus < 1 || args.gpus > 64) fail(105, "--gpus: Value not in range 1 to 64");
@@ -291,6 +294,14 @@ int main(int argc, char **argv) {
     std::cout << (args.alph_bytes > 1 ? "Alphabet type:    integer" : "Alphabet type:    byte") << std::endl;
     std::cout << "Temporary folder: (none: all levels stay resident in HBM)" << std::endl;
     std::cout << "BWT type:         BCR exact" << std::endl;
+    // is_fastx (external/cdt/lib/utils.cpp:13-30): first (decompressed) byte '>' or '@'
+    int fastx = 0, is_gz = 0;
+    if (grlbwt_fastx_probe(args.input_file.c_str(), &fastx, &is_gz) != GRLBWT_OK) fastx = 0;
+    if (fastx) {
+        if (args.alph_bytes != 1) fail(105, "--alphabet: a FASTA/Q input has a byte alphabet");
+        if (args.gpus > 1) fail(105, "--gpus: FASTA/Q inputs are converted on one GPU; convert first or use one GPU");
+        std::cout << "The input is in FASTA/Q format" << (is_gz ? " (gzip)" : "") << std::endl;          // main.cpp:120
+    } else if (args.rev_comp) fail(105, "--rev-comp: TEXT is not in FASTA/Q format (the reference has no reverse complements for plain inputs either, main.cpp:126-134)");
     // GRLBWT_CLI_FORCE_RCCL=1: the collection-level path also with one GPU (that is all a single-GPU box can test)
     if (args.gpus > 1 || std::getenv("GRLBWT_CLI_FORCE_RCCL")) return run_multi_gpu(args);
 
@@ -312,7 +323,13 @@ int main(int argc, char **argv) {
     // statistics of collection_stats are taken on the device behind the copies (the reference streams the file
     // through i_file_stream twice: once for the statistics, once for the first parsing round)
     std::cout << "Reading the file" << std::endl;                                      // exact_par_phase.cpp:288
-    rc = grlbwt_text_load_file(ctx, args.input_file.c_str(), args.alph_bytes);
+    if (fastx) {
+        // main.cpp:118-124 (switched off upstream): FASTA/Q records -> one string per line, here on the device and in HBM
+        // instead of a temporary plain file
+        uint64_t n_strings = 0;
+        rc = grlbwt_text_load_fastx(ctx, args.input_file.c_str(), args.rev_comp ? GRLBWT_FASTX_REVCOMP : 0, &n_strings);
+        if (rc == GRLBWT_ENOTDNA) { std::cerr << grlbwt_last_error(ctx) << std::endl; grlbwt_ctx_destroy(ctx); return 1; }   // fastx_handler.cpp:30-33
+    } else rc = grlbwt_text_load_file(ctx, args.input_file.c_str(), args.alph_bytes);
     if (rc != GRLBWT_OK) return die(rc);
     const auto t_loaded = std::chrono::steady_clock::now();
     grlbwt_stats st;

@@ -3,6 +3,7 @@
 #include "../../include/grlbwt_hip.h"
 
 #include <fcntl.h>
+#include <zlib.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -223,6 +224,146 @@ void load_file(grlbwt_ctx *ctx, const char *path, int w, uint64_t base = 0, uint
     } catch (...) { close(fd); throw; }
     close(fd);
 }
+// ---- f3: FASTA/FASTQ files (optionally gzip) ------------------------------------------------------------------------
+// gzip iff the file starts with 1F 8B (gzopen's rule, which the reference's converter relies on: fastx_handler.cpp:10)
+bool file_magic(const char *path, unsigned char out[2]) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    out[0] = out[1] = 0;
+    ssize_t r = pread(fd, out, 2, 0);
+    close(fd);
+    return r >= 1;
+}
+struct RawText { grl64::DBuf<uint8_t> buf; uint64_t n = 0; };
+// the (decompressed) bytes of the file in device memory; plain files go through the pinned reader of load_file_into, gzip
+// members are inflated on the host (zlib, one stream: the format has no parallel entry points) chunk by chunk into pinned
+// buffers that are copied while the next chunk inflates
+void read_fastx_raw(const char *path, RawText &R) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw prim::Error(GRLBWT_EINVAL, std::string("cannot stat ") + path); }
+    const uint64_t bytes = (uint64_t)st.st_size;
+    unsigned char mg[2] = {0, 0};
+    if (bytes >= 2 && pread(fd, mg, 2, 0) != 2) { close(fd); throw prim::Error(GRLBWT_EINVAL, "cannot read the input file"); }
+    const bool gz = mg[0] == 0x1F && mg[1] == 0x8B;
+    constexpr int NB = 2;
+    char *bufs[NB] = {nullptr, nullptr};
+    prim::Fence fences[NB];
+    std::vector<unsigned char> cin;
+    z_stream zs;
+    bool z_open = false;
+    auto cleanup = [&] {
+        for (int k = 0; k < NB; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); bufs[k] = nullptr; }
+        if (z_open) inflateEnd(&zs);
+        z_open = false;
+        close(fd);
+    };
+    try {
+        const uint64_t chunk = kIoChunk;
+        for (int k = 0; k < NB; k++) bufs[k] = (char *)prim::pinned_alloc(chunk);
+        if (!gz) {
+            R.buf.alloc(bytes + 16);
+            int k = 0;
+            for (uint64_t off = 0; off < bytes; off += chunk, k = (k + 1) % NB) {
+                const uint64_t len = bytes - off < chunk ? bytes - off : chunk;
+                prim::fence_wait(fences[k]);
+                if (!par_io(fd, bufs[k], off, len, false, kIoThreads)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+                prim::h2d_async(R.buf.p + off, bufs[k], len);
+                prim::fence_record(fences[k]);
+            }
+            R.n = bytes;
+        } else {
+            uint64_t cap = bytes * 5 + (1 << 20);
+            R.buf.alloc(cap + 16);
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, 15 + 32) != Z_OK) throw prim::Error(GRLBWT_EINTERNAL, "zlib: inflateInit2 failed");
+            z_open = true;
+            cin.resize((size_t)8 << 20);
+            uint64_t in_off = 0, out_n = 0;
+            int k = 0;
+            prim::fence_wait(fences[k]);
+            zs.next_out = (Bytef *)bufs[k]; zs.avail_out = (uInt)chunk;
+            auto flush = [&](bool final) {
+                const uint64_t len = chunk - zs.avail_out;
+                if (len) {
+                    if (out_n + len > cap) {                         // grow the device buffer (copy on the engine's stream)
+                        const uint64_t ncap = (out_n + len) * 3 / 2 + (1 << 20);
+                        grl64::DBuf<uint8_t> nb(ncap + 16);
+                        prim::d2d(nb.p, R.buf.p, out_n);
+                        R.buf = std::move(nb);
+                        cap = ncap;
+                    }
+                    prim::h2d_async(R.buf.p + out_n, bufs[k], len);
+                    prim::fence_record(fences[k]);
+                    out_n += len;
+                }
+                if (!final) {
+                    k = (k + 1) % NB;
+                    prim::fence_wait(fences[k]);
+                    zs.next_out = (Bytef *)bufs[k]; zs.avail_out = (uInt)chunk;
+                }
+            };
+            bool done = false;
+            while (!done) {
+                if (zs.avail_in == 0) {
+                    if (in_off >= bytes) break;
+                    const uint64_t len = bytes - in_off < cin.size() ? bytes - in_off : cin.size();
+                    if (!par_io(fd, (char *)cin.data(), in_off, len, false, 1)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+                    in_off += len;
+                    zs.next_in = cin.data(); zs.avail_in = (uInt)len;
+                }
+                const int r = inflate(&zs, Z_NO_FLUSH);
+                if (r == Z_STREAM_END) {                             // next member of a multi-member file, if any
+                    if (zs.avail_in == 0 && in_off >= bytes) done = true;
+                    else if (inflateReset(&zs) != Z_OK) throw prim::Error(GRLBWT_EINTERNAL, "zlib: inflateReset failed");
+                } else if (r != Z_OK && r != Z_BUF_ERROR) {
+                    throw prim::Error(GRLBWT_EINVAL, std::string("the gzip stream is damaged (zlib: ") + (zs.msg ? zs.msg : "error") + ")");
+                } else if (r == Z_BUF_ERROR && zs.avail_in == 0 && in_off >= bytes) done = true;       // truncated file: take what there is (gzread does)
+                if (zs.avail_out == 0) flush(false);
+            }
+            flush(true);
+            R.n = out_n;
+        }
+        prim::sync();
+        cleanup();
+    } catch (...) {
+        try { prim::sync(); } catch (...) {}
+        cleanup();
+        throw;
+    }
+}
+void load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fx_flags, uint64_t *n_strings) {
+    ctx->e32.reset();
+    ctx->e64.reset();
+    RawText raw;
+    read_fastx_raw(path, raw);
+    const bool rc = (fx_flags & GRLBWT_FASTX_REVCOMP) != 0;
+    const uint64_t cap = (rc ? 2 : 1) * raw.n + 16;
+    grl64::DBuf<uint8_t> text(cap + 16);
+    grl64::Engine::FastxInfo info = grl64::Engine::fastx_to_text(raw.buf.p, raw.n, rc, text.p, cap);
+    raw.buf.release();
+    if (n_strings) *n_strings = info.n_strings;
+    if (info.n_out == 0) throw prim::Error(GRLBWT_EILLFORMED, "Error: the file is ill formed");      // no record at all
+    const uint64_t n = info.n_out;
+    bool big = (n >= 0xFFFFFF00ull) || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+    bool keep = ctx->flags & GRLBWT_FLAG_KEEP_LEVELS;
+    if (big) {
+        std::unique_ptr<grl64::Engine> e(new grl64::Engine());
+        e->keep_texts = keep;
+        e->own0 = std::move(text);
+        e->load_text(e->own0.p, n, 1);
+        ctx->e64 = std::move(e);
+    } else {
+        std::unique_ptr<grl32::Engine> e(new grl32::Engine());
+        e->keep_texts = keep;
+        e->own0.alloc(n + 16);                                        // (the two engines have their own buffer types)
+        prim::d2d(e->own0.p, text.p, n);
+        text.release();
+        e->load_text(e->own0.p, n, 1);
+        ctx->e32 = std::move(e);
+    }
+}
 // HBM image -> file: chunk k is written while chunk k+1 comes down
 void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
     int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -426,6 +567,7 @@ const char *grlbwt_strerror(int code) {
         case GRLBWT_ERANGE: return "input beyond the supported range";
         case GRLBWT_ENOSPC: return "phrase table overflow";
         case GRLBWT_EINTERNAL: return "internal consistency check failed";
+        case GRLBWT_ENOTDNA: return "The input seems not to be DNA";
         default: return "unknown error";
     }
 }
@@ -476,6 +618,39 @@ int grlbwt_text_load_file(grlbwt_ctx *ctx, const char *path, int cell_bytes) {
 int grlbwt_text_load_file_range(grlbwt_ctx *ctx, const char *path, uint64_t offset_bytes, uint64_t n_bytes, int cell_bytes) {
     if (!ctx || !path) return GRLBWT_EINVAL;
     return guarded(ctx, [&] { load_file(ctx, path, cell_bytes, offset_bytes, n_bytes); });
+}
+int grlbwt_fastx_probe(const char *path, int *is_fastx, int *is_gz) {
+    if (!path) return GRLBWT_EINVAL;
+    unsigned char mg[2];
+    if (!file_magic(path, mg)) return GRLBWT_EINVAL;
+    // check_gzip (external/cdt/lib/utils.cpp:53-60): extension ".gz" AND the magic number
+    const std::string p(path);
+    const bool gz = p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0 && mg[0] == 0x1F && mg[1] == 0x8B;
+    unsigned char first = mg[0];
+    if (gz) {                                                        // is_fastx (utils.cpp:13-30): first DEcompressed byte
+        gzFile z = gzopen(path, "rb");
+        if (!z) return GRLBWT_EINVAL;
+        first = 0;
+        gzread(z, &first, 1);
+        gzclose(z);
+    }
+    if (is_gz) *is_gz = gz ? 1 : 0;
+    if (is_fastx) *is_fastx = (first == '>' || first == '@') ? 1 : 0;
+    return GRLBWT_OK;
+}
+int grlbwt_fastx_convert_device(grlbwt_ctx *ctx, const void *dev_in, uint64_t n_in, uint32_t fx_flags, void *dev_out, uint64_t capacity,
+                                uint64_t *n_out, uint64_t *n_strings) {
+    if (!ctx || !dev_in || !dev_out) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        grl64::Engine::FastxInfo info = grl64::Engine::fastx_to_text((const uint8_t *)dev_in, n_in, (fx_flags & GRLBWT_FASTX_REVCOMP) != 0,
+                                                                     (uint8_t *)dev_out, capacity);
+        if (n_out) *n_out = info.n_out;
+        if (n_strings) *n_strings = info.n_strings;
+    });
+}
+int grlbwt_text_load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fx_flags, uint64_t *n_strings) {
+    if (!ctx || !path) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] { load_fastx(ctx, path, fx_flags, n_strings); });
 }
 int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes) {
     if (!ctx || !dev_cells || ((uintptr_t)dev_cells & 15)) return GRLBWT_EINVAL;

@@ -1589,6 +1589,178 @@ struct IotaIdxFn {
     GRL_DEV void operator()(u64 i) const { v[i] = (idx_t)i; }
 };
 
+// ---- f3 ingestion: FASTA/FASTQ -> one string per line (external/bioparsers/lib/fastx_handler.cpp:7-58 over kseq.h:179-220) ----
+// The reference reads records one by one through kseq; here the file is a table of lines.  Every line is a HEADER (starts a
+// record), a SEQUENCE line (its bytes belong to the record above) or SKIPPED ('+' and quality lines of FASTQ); a record's
+// string is the concatenation of its sequence lines, each without the "\r" kseq drops (kseq.h:141), followed by the
+// separator, and with FX_REVCOMP by its reverse complement and another separator.  Two layouts are taken: no '+' line
+// outside headers (FASTA, any wrapping, blank lines), or strict four-line FASTQ records, verified on the device; anything
+// else is refused (kseq would follow it line by line: multi-line FASTQ, truncated qualities).
+enum : u8 { FX_SKIP = 0, FX_HDR = 1, FX_SEQ = 2 };
+struct FxNlWordsFn {      // one lane per 64 input bytes: bit b of words[w] = (in[64w + b] == '\n')
+    const u8 *in; u64 n; u64 *words;
+    GRL_DEV void operator()(u64 w) const {
+        const u64 x0 = w * 64;
+        u64 m = 0;
+        if (x0 + 64 <= n && (((uintptr_t)in) & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                struct alignas(16) Quad { u32 v[4]; };
+                const Quad qd = *reinterpret_cast<const Quad *>(in + x0 + 16 * q);
+                const u32 *ws = qd.v;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (((ws[k] >> (8 * b)) & 0xFFu) == 10u) m |= 1ull << (16 * q + 4 * k + b);
+            }
+        } else {
+            for (u64 b = 0; b < 64 && x0 + b < n; b++) if (in[x0 + b] == 10) m |= 1ull << b;
+        }
+        words[w] = m;
+    }
+};
+struct FxNlPosFn {        // end of every line: position of its '\n'
+    const u64 *words; const idx_t *base; u64 *nlpos;
+    GRL_DEV void operator()(u64 w) const {
+        u64 m = words[w], k = (u64)base[w];
+        while (m) { const int b = __builtin_ctzll(m); nlpos[k++] = w * 64 + (u64)b; m &= m - 1; }
+    }
+};
+struct FxLine { u64 start; u64 len; u8 first, last; };
+GRL_DEV FxLine fx_line(const u8 *in, const u64 *nlpos, u64 i) {
+    FxLine L;
+    L.start = i ? nlpos[i - 1] + 1 : 0;
+    L.len = nlpos[i] - L.start;
+    L.first = L.len ? in[L.start] : 0;
+    L.last = L.len ? in[L.start + L.len - 1] : 0;
+    return L;
+}
+GRL_DEV bool fx_is_hdr(u8 c) { return c == '>' || c == '@'; }
+struct FxPlusIn {         // 1 for a line that starts with '+' (headers start with '>' or '@')
+    const u8 *in; const u64 *nlpos;
+    GRL_DEV u64 operator()(u64 i) const { return fx_line(in, nlpos, i).first == '+' ? 1ull : 0ull; }
+};
+struct FxLastNonEmptyIn { // (index + 1) of a non-empty line
+    const u64 *nlpos;
+    GRL_DEV u64 operator()(u64 i) const { const u64 s = i ? nlpos[i - 1] + 1 : 0; return nlpos[i] > s ? i + 1 : 0ull; }
+};
+GRL_DEV u64 fx_kept(const FxLine &L) { return L.len - ((L.len > 1 && L.last == '\r') ? 1 : 0); }     // kseq.h:141
+struct FxFastqBadIn {     // 1 if record k is not a strict four-line FASTQ record
+    const u8 *in; const u64 *nlpos;
+    GRL_DEV u64 operator()(u64 k) const {
+        const FxLine h = fx_line(in, nlpos, 4 * k), s = fx_line(in, nlpos, 4 * k + 1), p = fx_line(in, nlpos, 4 * k + 2),
+                     q = fx_line(in, nlpos, 4 * k + 3);
+        bool ok = fx_is_hdr(h.first) && h.len >= 1 && p.first == '+';
+        ok = ok && !(s.len && (fx_is_hdr(s.first) || s.first == '+'));
+        ok = ok && fx_kept(s) == fx_kept(q);
+        return ok ? 0ull : 1ull;
+    }
+};
+struct FxClassFn {        // class and provisional kept length of every line
+    const u8 *in; const u64 *nlpos; u64 fastq_lines;     // > 0: strict FASTQ over the first fastq_lines lines
+    bool fastq;
+    u8 *cls; u64 *raw;
+    GRL_DEV void operator()(u64 i) const {
+        const FxLine L = fx_line(in, nlpos, i);
+        u8 c;
+        if (fastq) c = (i < fastq_lines) ? ((i & 3) == 0 ? FX_HDR : (i & 3) == 1 ? FX_SEQ : FX_SKIP) : FX_SKIP;
+        else c = fx_is_hdr(L.first) ? FX_HDR : FX_SEQ;
+        cls[i] = c;
+        raw[i] = c == FX_SEQ ? fx_kept(L) : 0;
+    }
+};
+struct FxIsHdrIn {
+    const u8 *cls;
+    GRL_DEV u64 operator()(u64 i) const { return cls[i] == FX_HDR ? 1ull : 0ull; }
+};
+struct FxHdrLinesFn {     // hline[r] = line of the r-th header
+    const u8 *cls; const u64 *hrank; u64 m; u64 R; u64 *hline;
+    GRL_DEV void operator()(u64 i) const {
+        if (cls[i] == FX_HDR) hline[hrank[i]] = i;
+        if (i == 0) hline[R] = m;
+    }
+};
+// A line that is just "\r": kseq keeps the '\r' only when it is the first byte of the record's sequence (the string must be
+// longer than one byte for the strip, kseq.h:141)
+struct FxKeptFn {
+    const u8 *in; const u64 *nlpos; const u8 *cls; const u64 *hrank; const u64 *hline; const u64 *praw; u64 *kept;
+    GRL_DEV void operator()(u64 i) const {
+        u64 k = 0;
+        if (cls[i] == FX_SEQ) {
+            const FxLine L = fx_line(in, nlpos, i);
+            k = fx_kept(L);
+            if (L.len == 1 && L.last == '\r') {
+                const u64 r = hrank[i] - 1;                       // (a sequence line always has a header in front)
+                k = (praw[i] - praw[hline[r]] == 0) ? 1 : 0;
+            }
+        }
+        kept[i] = k;
+    }
+};
+struct FxLineRec { u64 start, out_base, rc_base, kept_cls; };      // kept << 2 | class
+struct FxLineRecFn {
+    const u64 *nlpos; const u8 *cls; const u64 *hrank; const u64 *hline; const u64 *kept; const u64 *pk; bool rc;
+    FxLineRec *rec;
+    GRL_DEV void operator()(u64 i) const {
+        FxLineRec L;
+        L.start = i ? nlpos[i - 1] + 1 : 0;
+        L.kept_cls = (kept[i] << 2) | cls[i];
+        L.out_base = 0; L.rc_base = 0;
+        if (cls[i] == FX_SEQ) {
+            const u64 r = hrank[i] - 1, b = pk[hline[r]], lr = pk[hline[r + 1]] - b, j = pk[i] - b;
+            if (!rc) L.out_base = pk[i] + r;
+            else { const u64 B = 2 * b + 2 * r; L.out_base = B + j; L.rc_base = B + 2 * lr - j; }
+        }
+        rec[i] = L;
+    }
+};
+GRL_DEV u8 fx_comp(u8 c) {   // dna_string::comp (external/bioparsers/lib/dna_string.cpp:6-14); 0 = no complement
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == 10 ? 10 : c == 149 ? 168 : c == 151 ? 155 :
+           c == 155 ? 151 : c == 168 ? 149 : 0;
+}
+struct FxCopyFn {         // one lane per input byte
+    const u8 *in; u64 n; const u64 *words; const idx_t *base; const FxLineRec *rec; const u64 *hrank; bool rc;
+    u8 *out; u64 *bad_rec;
+    GRL_DEV void operator()(u64 x) const {
+        const u8 c = in[x];
+        if (c != 10) {
+            const u64 i = rank1(words, base, x);
+            const FxLineRec L = rec[i];
+            const u64 t = x - L.start;
+            if ((L.kept_cls & 3) == FX_SEQ && t < (L.kept_cls >> 2)) {
+                out[L.out_base + t] = c;
+                if (rc) {
+                    const u8 cc = fx_comp(c);
+                    if (cc) out[L.rc_base - t] = cc;
+                    else prim::atomic_min(bad_rec, hrank[i] - 1);
+                }
+            }
+        }
+    }
+};
+struct FxBadPosFn {       // the last byte without complement of record `r` (the first the reference meets: it walks a record backwards)
+    const u8 *in; const u64 *words; const idx_t *base; const FxLineRec *rec; const u64 *hrank; u64 r; u64 x0; u64 *bad_pos;
+    GRL_DEV void operator()(u64 d) const {
+        const u64 x = x0 + d;
+        const u8 c = in[x];
+        if (c != 10) {
+            const u64 i = rank1(words, base, x);
+            const FxLineRec L = rec[i];
+            if ((L.kept_cls & 3) == FX_SEQ && x - L.start < (L.kept_cls >> 2) && hrank[i] - 1 == r && fx_comp(c) == 0)
+                prim::atomic_max(bad_pos, x + 1);
+        }
+    }
+};
+struct FxSepFn {          // the separator(s) of every record
+    const u64 *hline; const u64 *pk; bool rc; u8 sep; u8 *out;
+    GRL_DEV void operator()(u64 r) const {
+        const u64 b = pk[hline[r]], lr = pk[hline[r + 1]] - b;
+        if (!rc) out[b + lr + r] = sep;
+        else { const u64 B = 2 * b + 2 * r; out[B + lr] = sep; out[B + 2 * lr + 1] = sep; }
+    }
+};
+
 // ---- .rl_bwt consumers (scripts/grl2plain.cpp, scripts/reverse_bwt.cpp + fm_index.h:79-83) ------
 struct PtrU32In {
     const u32 *p;
@@ -3157,6 +3329,78 @@ class Engine {
             throw prim::Error(-22, "bad .rl_bwt header");
         return ImageHeader{hdr[0], hdr[1], (image_bytes - 16) / (hdr[0] + hdr[1])};
     }
+    // ---- f3: FASTA/FASTQ text in device memory -> one string per line (see the functor block) ------------------------
+    struct FastxInfo { u64 n_out, n_strings; int fastq; };
+    static constexpr int kErrNotFastx = -22, kErrNotDna = -86;
+    static FastxInfo fastx_to_text(const u8 *in, u64 n, bool rc, u8 *out, u64 capacity) {
+        if (n == 0) throw prim::Error(kErrNotFastx, "FASTA/Q input is empty");
+        u8 first, lastb;
+        prim::d2h(&first, in, 1);
+        prim::d2h(&lastb, in + n - 1, 1);
+        if (first != '>' && first != '@') throw prim::Error(kErrNotFastx, "the input is not in FASTA/Q format (first byte is neither '>' nor '@')");
+        // line table
+        const u64 nw = n / 64 + 2;
+        DBuf<u64> words(nw);
+        DBuf<idx_t> base(nw + 1);
+        words.zero();
+        prim::for_each((n + 63) / 64, FxNlWordsFn{in, n, words.p}, "fastx.newlines");
+        const u64 n_nl = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{words.p}, base.p, true, "fastx.newlines");
+        const bool tail = lastb != 10;                               // a last line without '\n'
+        const u64 m = n_nl + (tail ? 1 : 0);
+        DBuf<u64> nlpos(m);
+        prim::for_each((n + 63) / 64, FxNlPosFn{words.p, base.p, nlpos.p}, "fastx.line_ends");
+        if (tail) prim::h2d(nlpos.p + (m - 1), &n, 8);
+        // layout: FASTA (no '+' line) or strict four-line FASTQ
+        const bool fastq = prim::reduce_sum<u64>(m, FxPlusIn{in, nlpos.p}, "fastx.plus_lines") != 0;
+        u64 fq_lines = 0;
+        if (fastq) {
+            fq_lines = prim::reduce_max<u64>(m, FxLastNonEmptyIn{nlpos.p}, "fastx.last_line");
+            const bool ok = fq_lines % 4 == 0 && prim::reduce_sum<u64>(fq_lines / 4, FxFastqBadIn{in, nlpos.p}, "fastx.fastq_check") == 0;
+            if (!ok) throw prim::Error(kErrNotFastx, "FASTQ records are not in the four-line layout (or lines starting with '+' in a FASTA file): not supported");
+        }
+        DBuf<u8> cls(m);
+        DBuf<u64> raw(m), hrank(m + 1), praw(m + 1);
+        prim::for_each(m, FxClassFn{in, nlpos.p, fq_lines, fastq, cls.p, raw.p}, "fastx.classify");
+        u64 R = prim::exclusive_scan<u64>(m, FxIsHdrIn{cls.p}, hrank.p, true, "fastx.records");
+        prim::exclusive_scan_nosync<u64>(m, IdxIn<u64>{raw.p}, praw.p, true, "fastx.raw_offsets");
+        DBuf<u64> hline(R + 1), kept(m), pk(m + 1);
+        prim::for_each(m, FxHdrLinesFn{cls.p, hrank.p, m, R, hline.p}, "fastx.header_lines");
+        prim::for_each(m, FxKeptFn{in, nlpos.p, cls.p, hrank.p, hline.p, praw.p, kept.p}, "fastx.kept");
+        const u64 K = prim::exclusive_scan<u64>(m, IdxIn<u64>{kept.p}, pk.p, true, "fastx.offsets");
+        raw.release(); praw.release();
+        // a header character that ends the input ("...\n>") opens no record (kseq.h:188: nothing to read after it)
+        if (R && tail) {
+            const u64 hl = hline.get(R - 1);
+            if (hl == m - 1 && n - (hl ? nlpos.get(hl - 1) + 1 : 0) == 1) R--;
+        }
+        FastxInfo info;
+        info.fastq = fastq ? 1 : 0;
+        info.n_strings = rc ? 2 * R : R;
+        info.n_out = rc ? 2 * K + 2 * R : K + R;
+        if (info.n_out > capacity) throw prim::Error(-22, "fastx: output buffer too small");
+        DBuf<FxLineRec> rec(m);
+        prim::for_each(m, FxLineRecFn{nlpos.p, cls.p, hrank.p, hline.p, kept.p, pk.p, rc, rec.p}, "fastx.line_records");
+        DBuf<u64> bad(2);
+        const u64 none[2] = {~0ull, 0};
+        prim::h2d(bad.p, none, 16);
+        prim::for_each(n, FxCopyFn{in, n, words.p, base.p, rec.p, hrank.p, rc, out, bad.p}, "fastx.copy");
+        prim::for_each(R, FxSepFn{hline.p, pk.p, rc, (u8)10, out}, "fastx.separators");
+        if (rc) {
+            const u64 br = bad.get(0);
+            if (br != ~0ull) {
+                const u64 l0 = hline.get(br), l1 = hline.get(br + 1);
+                const u64 x0 = l0 ? nlpos.get(l0 - 1) + 1 : 0, x1 = l1 < m ? nlpos.get(l1 - 1) + 1 : n;
+                prim::for_each(x1 - x0, FxBadPosFn{in, words.p, base.p, rec.p, hrank.p, br, x0, bad.p + 1}, "fastx.bad_symbol");
+                const u64 bp = bad.get(1);
+                u8 c = '?';
+                if (bp) prim::d2h(&c, in + (bp - 1), 1);
+                throw prim::Error(kErrNotDna, std::string("The input seems not to be DNA (invalid symbol:") + (char)c + ")");
+            }
+        }
+        prim::sync();
+        return info;
+    }
+
     // number of symbols an image describes, summed in 64 bits whatever the index width of the caller
     static u64 image_total_symbols(const void *dev_image, u64 image_bytes) {
         ImageHeader h = image_header(dev_image, image_bytes);

@@ -480,6 +480,8 @@ GRL_DEV void atomic_or(u64 *p, u64 v) {
 }
 GRL_DEV u32 atomic_min(u32 *p, u32 v) { return atomicMin(p, v); }
 GRL_DEV u32 atomic_max(u32 *p, u32 v) { return atomicMax(p, v); }
+GRL_DEV u64 atomic_min(u64 *p, u64 v) { return (u64)atomicMin(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
+GRL_DEV u64 atomic_max(u64 *p, u64 v) { return (u64)atomicMax(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 GRL_DEV u64 atomic_cas(u64 *p, u64 expect, u64 desired) {
     return (u64)atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)expect,
                           (unsigned long long)desired);

@@ -18,12 +18,13 @@ FLAG_CLASSIC_POOL = 8
 
 OK = 0
 EILLFORMED = -84
+ENOTDNA = -86
 
 # every symbol include/grlbwt_hip.h declares
 ABI_SYMBOLS = [
     "grlbwt_abi_version", "grlbwt_backend_name", "grlbwt_strerror", "grlbwt_last_error", "grlbwt_ctx_create", "grlbwt_ctx_destroy",
     "grlbwt_ctx_set_stream", "grlbwt_text_upload", "grlbwt_text_load_file", "grlbwt_text_load_file_range", "grlbwt_rccl_unique_id", "grlbwt_rccl_comm_create",
-    "grlbwt_rccl_comm_destroy", "grlbwt_text_attach_device", "grlbwt_get_stats",
+    "grlbwt_rccl_comm_destroy", "grlbwt_fastx_probe", "grlbwt_text_load_fastx", "grlbwt_fastx_convert_device", "grlbwt_text_attach_device", "grlbwt_get_stats",
     "grlbwt_parse_round", "grlbwt_parse_phase", "grlbwt_round_info_get", "grlbwt_induce_first",
     "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
     "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
@@ -72,6 +73,23 @@ class GrlbwtError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("grlbwt error %d: %s" % (code, msg))
         self.code = code
+
+
+class NotDNA(GrlbwtError):
+    """The reference's "The input seems not to be DNA (invalid symbol:X)", exit(1) (fastx_handler.cpp:30-33)."""
+
+
+FASTX_REVCOMP = 1
+
+
+def fastx_probe(path, lib=None):
+    """(is_fastx, is_gz) as the reference's is_fastx / check_gzip decide them (host only: no device is touched)."""
+    L = load_library(lib, allow_test_standin=os.environ.get("GRLBWT_ALLOW_TEST_STANDIN") == "1")
+    a, b = C.c_int(0), C.c_int(0)
+    rc = L.grlbwt_fastx_probe(os.fsencode(path), C.byref(a), C.byref(b))
+    if rc != 0:
+        raise GrlbwtError(rc, "cannot probe " + str(path))
+    return bool(a.value), bool(b.value)
 
 
 class IllFormedInput(GrlbwtError):
@@ -168,6 +186,8 @@ class Context:
             msg = self.L.grlbwt_last_error(self._h).decode() or self.L.grlbwt_strerror(rc).decode()
             if rc == EILLFORMED:
                 raise IllFormedInput(rc, msg)
+            if rc == ENOTDNA:
+                raise NotDNA(rc, msg)
             raise GrlbwtError(rc, msg)
 
     def close(self):
@@ -203,6 +223,21 @@ class Context:
         """collection_stats + first-round input straight from a file of raw cells (pinned, overlapped upload)."""
         self._keep = None
         self._ck(self.L.grlbwt_text_load_file(self._h, os.fsencode(path), cell_bytes))
+
+    def load_fastx(self, path, rev_comp=False):
+        """FASTA/FASTQ (optionally gzip) -> the one-string-per-line text in HBM (fastx2plain_format of the reference);
+        returns the number of strings."""
+        self._keep = None
+        n = C.c_uint64(0)
+        self._ck(self.L.grlbwt_text_load_fastx(self._h, os.fsencode(path), FASTX_REVCOMP if rev_comp else 0, C.byref(n)))
+        return n.value
+
+    def fastx_convert(self, src_ptr, n_in, rev_comp, dst_ptr, capacity):
+        """The conversion alone, device buffer to device buffer: (bytes written, n_strings)."""
+        n_out, n_str = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.grlbwt_fastx_convert_device(self._h, C.c_void_p(src_ptr), n_in, FASTX_REVCOMP if rev_comp else 0, C.c_void_p(dst_ptr),
+                                                    capacity, C.byref(n_out), C.byref(n_str)))
+        return n_out.value, n_str.value
 
     def attach_device(self, dev_ptr, n_cells, cell_bytes=1, keepalive=None):
         """Use cells already resident in HBM (e.g. a torch tensor's data_ptr())."""

@@ -43,6 +43,7 @@ extern "C" {
 #define GRLBWT_ERANGE (-75)     /* input beyond what this build supports (symbols >= 2^30, ...)      */
 #define GRLBWT_ENOSPC (-28)     /* phrase table overflow                                              */
 #define GRLBWT_EINTERNAL (-71)  /* internal consistency check failed                                  */
+#define GRLBWT_ENOTDNA (-86)    /* reference: "The input seems not to be DNA (invalid symbol:X)", exit(1) (fastx_handler.cpp:30-33) */
 
 /* ctx flags */
 #define GRLBWT_FLAG_KEEP_LEVELS 1u   /* keep every level's text and BWT for parity inspection        */
@@ -123,6 +124,20 @@ int grlbwt_text_load_file_range(grlbwt_ctx *ctx, const char *path, uint64_t offs
 /* use cells already resident in HBM (borrowed until the context is reset/destroyed; 16-byte aligned) */
 int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes);
 int grlbwt_get_stats(const grlbwt_ctx *ctx, grlbwt_stats *out);
+
+/* ---- FASTA/FASTQ ingestion: replaces is_fastx / check_gzip (external/cdt/lib/utils.cpp:13-30,53-60)
+ * and fastx2plain_format (external/bioparsers/lib/fastx_handler.cpp:7-58, kseq.h:179-220), which the reference's
+ * main.cpp:118-136 has switched off.  The file (gzip members are inflated on the host) goes to HBM as it is; the records
+ * become the one-string-per-line text on the device: every record's sequence lines joined, '\n' behind it, and with
+ * GRLBWT_FASTX_REVCOMP its reverse complement + '\n' as a second string (a symbol outside ACGT: GRLBWT_ENOTDNA, with the
+ * reference's message naming the symbol).  Supported layouts: FASTA with any line wrapping, blank and CRLF lines;
+ * FASTQ with four lines per record.  Multi-line FASTQ and damaged records are refused (GRLBWT_EINVAL), not guessed at. */
+#define GRLBWT_FASTX_REVCOMP 1u
+int grlbwt_fastx_probe(const char *path, int *is_fastx, int *is_gz);
+int grlbwt_text_load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fastx_flags, uint64_t *n_strings);
+/* the conversion alone, device buffer to device buffer (capacity >= n_in, or 2 * n_in with reverse complements) */
+int grlbwt_fastx_convert_device(grlbwt_ctx *ctx, const void *dev_in, uint64_t n_in, uint32_t fastx_flags, void *dev_out,
+                                uint64_t capacity, uint64_t *n_out, uint64_t *n_strings);
 
 /* ---- parsing phase ------------------------------------------------------- */
 /* one par_round (exact_par_phase.cpp:374-497): LMS breaks, phrase hashing, dictionary

@@ -32,6 +32,11 @@ uint64_t oracle_level_grammar(const oracle_result *R, int level, const uint64_t 
                               const uint8_t **has_hocc);
 void oracle_free(oracle_result *R);
 
+/* FASTA/FASTQ text (decompressed) -> one string per line, optionally with the reverse complements: the reference's
+ * fastx2plain_format over kseq (fastx_oracle.c).  0 ok; 1 = a symbol without complement (*bad_sym); ORACLE_ERR_ARG = cap */
+int oracle_fastx2plain(const uint8_t *in, uint64_t n, int rc, uint8_t sep, uint8_t *out, uint64_t cap, uint64_t *n_out,
+                       uint64_t *n_strings, uint8_t *bad_sym);
+
 #ifdef __cplusplus
 }
 #endif

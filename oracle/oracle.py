@@ -19,13 +19,13 @@ ORACLE_ERR_ILLFORMED = -84
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not (os.path.exists(_LIB) and os.path.exists(CLI)):
-        subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
+    # (make decides what is stale: the library has several sources)
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return _LIB
 
 
 REF_DIR = os.path.join(_HERE, "_ref")
-REF_PROGS = ("bwt_stats", "grl2plain", "grlbwt2rle", "split_runs")
+REF_PROGS = ("bwt_stats", "grl2plain", "grlbwt2rle", "split_runs", "fastx2plain")
 REFERENCE_ROOT = "/root/reference"
 
 
@@ -72,6 +72,8 @@ def _load():
         L.oracle_level_grammar.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p)]
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_fastx2plain.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint8, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
         _lib = L
     return _lib
 
@@ -156,3 +158,22 @@ def rl_bwt(data, cell_bytes=1):
     out = r.rl_bwt
     r.close()
     return out
+
+
+class NotDNA(Exception):
+    """The reference's "The input seems not to be DNA (invalid symbol:X)", exit(1)."""
+
+
+def fastx2plain(data, rev_comp=False):
+    """(plain text bytes, n_strings) of a decompressed FASTA/FASTQ buffer, as the reference's fastx2plain_format."""
+    L = _load()
+    data = bytes(data)
+    cap = 2 * len(data) + 16
+    out = (C.c_uint8 * cap)()
+    n_out, n_str, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint8(0)
+    rc = L.oracle_fastx2plain(data, len(data), 1 if rev_comp else 0, 10, out, cap, C.byref(n_out), C.byref(n_str), C.byref(bad))
+    if rc == 1:
+        raise NotDNA(chr(bad.value))
+    if rc != 0:
+        raise RuntimeError("oracle_fastx2plain failed: %d" % rc)
+    return bytes(out[:n_out.value]), n_str.value

@@ -79,6 +79,8 @@ inline u64 atomic_add(u64 *p, u64 v) { u64 o = *p; *p += v; return o; }
 inline void atomic_or(u64 *p, u64 v) { *p |= v; }
 inline u32 atomic_min(u32 *p, u32 v) { u32 o = *p; if (v < o) *p = v; return o; }
 inline u32 atomic_max(u32 *p, u32 v) { u32 o = *p; if (v > o) *p = v; return o; }
+inline u64 atomic_min(u64 *p, u64 v) { u64 o = *p; if (v < o) *p = v; return o; }
+inline u64 atomic_max(u64 *p, u64 v) { u64 o = *p; if (v > o) *p = v; return o; }
 inline u64 atomic_cas(u64 *p, u64 expect, u64 desired) { u64 o = *p; if (o == expect) *p = desired; return o; }
 inline u64 load_relaxed(const u64 *p) { return *p; }
 inline u32 load_relaxed(const u32 *p) { return *p; }

@@ -35,7 +35,9 @@ def test_cli_argument_contract(cli, tmp_path):
     assert run(cli, f, "-T", str(tmp_path / "nodir"))[0] == 105
     assert run(cli, f, "--gpus", "0")[0] == 105
     rc, out, _ = run(cli, "--help")
-    assert rc == 0 and "--gpus" in out
+    assert rc == 0 and "--gpus" in out and "--rev-comp" in out
+    assert run(cli, f, "-a", "2", "-R")[0] == 105                 # reverse complements need a FASTA/Q input
+    assert run(cli, os.path.join(GOLD, "fastx", "fq_regular.fq"), "-a", "2")[0] == 105
 
 
 @pytest.mark.gpu
@@ -91,3 +93,19 @@ def test_cli_collection_level_mode_over_rccl(cli, tmp_path):
         p = subprocess.run([cli, os.path.join(GOLD, "test_byte_alphabet.txt"), "--gpus", "2", "-o", str(tmp_path / "x")], capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 3 and "could not load its shard" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_fasta_fastq_inputs(cli, tmp_path, oracle_mod):
+    """FASTA/FASTQ (gzip) inputs from the command line, with and without -R: the .rl_bwt of the converted collection."""
+    import zlib
+    for name, flags in (("fa_wrapped60.fa", []), ("fq_gz.fq.gz", ["-R"]), ("fa_gz.fa.gz", ["--rev-comp"])):
+        raw = open(os.path.join(GOLD, "fastx", name), "rb").read()
+        if raw[:2] == b"\x1f\x8b":
+            raw = zlib.decompress(raw, 31)
+        text, _ = oracle_mod.fastx2plain(raw, bool(flags))
+        p = subprocess.run([cli, os.path.join(GOLD, "fastx", name), "-o", str(tmp_path / "fx")] + flags, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "The input is in FASTA/Q format" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+        assert open(tmp_path / "fx.rl_bwt", "rb").read() == oracle_mod.rl_bwt(text, 1)
+    p = subprocess.run([cli, os.path.join(GOLD, "fastx", "fq_with_N.fq"), "-R", "-o", str(tmp_path / "n")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and "The input seems not to be DNA (invalid symbol:N)" in p.stderr
