@@ -7,8 +7,9 @@ workload, input cells already resident in HBM, output .rl_bwt image left in HBM.
 Workload (default): BASELINE.json's metric configuration -- configs[3], 66,225,166 x 150 bp Illumina-style
 reads from a 330 Mbp genome, 0.5 % substitutions, 10,000,000,066 bytes.  At N = 1 the whole collection is on
 one GPU.  At N > 1 the SAME collection is sharded by record (rank g holds reads [g*R/N, (g+1)*R/N)), one
-process per GPU, and the ranks build ONE BWT of the whole collection (grlbwt_amd/dist.py: RCCL all-gather
-dictionary merge per round, per-bucket rank-count exchange + all-to-all per induction level): strong scaling,
+process per GPU, and the ranks build ONE BWT of the whole collection (grlbwt_dist_build with grlbwt_amd/dist.py's
+RCCL callbacks: hash-partitioned dictionary merge + key-range-sharded dictionary stage per round; per induction level
+the cells and the BWT_{r+1} windows go once to the owners of the output pieces): strong scaling,
 value = collection bytes / time.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
@@ -407,8 +408,8 @@ def main():
             "config": {"workload": wl, "input_resident": "HBM", "output": ".rl_bwt image in HBM",
                        "parallelism": ("1 GPU" if world == 1 else
                                        "the ONE collection sharded by record over %d GPUs (%d reads each): local LMS parsing/hashing/emission, "
-                                       "RCCL all-gather dictionary merge + key-range-sharded dictionary stage per round, induction sharded by "
-                                       "BWT position (per-bucket rank-count exchange, all-to-all atom routing)" % (world, hi - lo))},
+                                       "hash-partitioned dictionary merge (all-to-all) + key-range-sharded dictionary stage per round, induction "
+                                       "sharded by output piece (cells and BWT_{r+1} windows cross the fabric once per level), RCCL" % (world, hi - lo))},
             "roofline": roofline, "cpu_baseline": cpu,
             "roofline_groups": groups, "pass_efficiency": pass_eff[:12],
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
