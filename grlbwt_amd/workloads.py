@@ -166,3 +166,50 @@ def sampled_reads_torch(n_reads, read_len, genome_len, seed=20260003, err=0.005,
         view[r0 - read_lo:r1 - read_lo, read_len] = 10
         del z, hi, lo, starts, bases
     return out
+
+
+def repetitive_copies_torch(n_copies, length, seed=20260002, rate=1e-3, device="cuda"):
+    """Same bytes as repetitive_copies() (config 3: n_copies of a pseudo-chromosome with substitutions), on `device`."""
+    import torch
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    g = torch.empty(length, dtype=torch.uint8, device=device)
+    step = 1 << 26
+    for a in range(0, length, step):
+        b = min(length, a + step)
+        g[a:b] = acgt[(_splitmix64_torch(seed, a, b, device) >> 62) & 3]
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    code[acgt.long()] = torch.arange(4, device=device)
+    out = torch.empty(n_copies * (length + 1), dtype=torch.uint8, device=device)
+    view = out.view(n_copies, length + 1)
+    for k in range(n_copies):
+        for a in range(0, length, step):
+            b = min(length, a + step)
+            e = _splitmix64_torch(seed + 1 + k, a, b, device)
+            hit = ((e >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / (1 << 53)) < rate
+            shift = (e & 3) % 3 + 1
+            gs = g[a:b]
+            view[k, a:b] = torch.where(hit, acgt[(code[gs.long()] + shift) % 4], gs)
+            del e, hit, shift
+        view[k, length] = 10
+    return out
+
+
+def zipf_tokens_torch(n_cells, doc_len=1000, vocab=65000, s=1.1, seed=20260005, device="cuda", chunk_docs=20000):
+    """Same cells as zipf_tokens() (config 5: uint16 Zipf documents, separator 0), as an int16 tensor on `device`
+    (torch has no uint16 arithmetic; the bit patterns are the uint16 values)."""
+    import torch
+    n_docs = n_cells // (doc_len + 1)
+    w = np.arange(1, vocab + 1, dtype=np.float64) ** (-s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    cdf_t = torch.from_numpy(cdf).to(device)
+    out = torch.zeros(n_docs * (doc_len + 1), dtype=torch.int16, device=device)
+    view = out.view(n_docs, doc_len + 1)
+    for d0 in range(0, n_docs, chunk_docs):
+        d1 = min(n_docs, d0 + chunk_docs)
+        z = _splitmix64_torch(seed, d0 * doc_len, d1 * doc_len, device)
+        u = ((z >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / (1 << 53))
+        tok = torch.searchsorted(cdf_t, u) + 1                     # np.searchsorted(side="left") semantics
+        view[d0:d1, :doc_len] = tok.view(d1 - d0, doc_len).to(torch.int16)     # wraps to the uint16 bit pattern
+        del z, u, tok
+    return out

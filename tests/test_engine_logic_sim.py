@@ -144,6 +144,14 @@ def test_wider_cell_layouts(sim, oracle_mod, monkeypatch, layout):
     parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
+def test_device_side_generators_match_host():
+    """The torch generators of the large test inputs (run on the GPU there) produce the host generators' bytes."""
+    a = workloads.repetitive_copies(5, 30011)
+    assert np.array_equal(a, workloads.repetitive_copies_torch(5, 30011, device="cpu").numpy())
+    a = workloads.zipf_tokens(50000, doc_len=100, vocab=3000)
+    assert np.array_equal(a, workloads.zipf_tokens_torch(50000, doc_len=100, vocab=3000, device="cpu", chunk_docs=37).numpy().view(np.uint16))
+
+
 def test_file_in_file_out(sim, oracle_mod, tmp_path):
     """grlbwt_text_load_file / grlbwt_result_write_file (the CLI's path): chunked staging, histogram taken per chunk."""
     for data, w in ((workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1),

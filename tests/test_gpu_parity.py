@@ -229,6 +229,31 @@ def test_dist_kernels_multi_rank_on_one_gpu(hip, oracle_mod, tmp_path, world, ca
     assert open(tmp_path / (case + ".rl_bwt"), "rb").read() == oracle_mod.rl_bwt(data, w)
 
 
+@pytest.mark.parametrize("config", ["configs2_repetitive_2.4GB", "configs4_u16_tokens_1GB"])
+def test_baseline_configs_at_stated_size_round_trip(hip, config):
+    """BASELINE.json configs[2] (100 copies x 24 Mbp pseudo-chromosome, 1e-3 substitutions, 2,400,000,100 bytes) and
+    configs[4] (499,999,500 uint16 cells of Zipf tokens, 1 GB, -a 2) at FULL size: built, inverted on the device (grl2plain +
+    reverse_bwt kernels) and compared with the input cell for cell.  (configs[2]: 100 strings of 24 M symbols, the
+    inversion walks each of them sequentially: about 50 s.)"""
+    import torch
+    if config.startswith("configs2"):
+        text, w = workloads.repetitive_copies_torch(100, 24000000, device="cuda:0"), 1
+    else:
+        text, w = workloads.zipf_tokens_torch(500000000, device="cuda:0"), 2
+    back = torch.zeros_like(text)
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), w, keepalive=text)
+        ctx.build()
+        st = ctx.stats()
+        assert st["n_syms"] == text.numel() and st["n_strings"] == (100 if w == 1 else 499500)
+        nb, nr = ctx.result_size()
+        assert nb == 16 + nr * (st["sb"] + st["fb"])
+        n = ctx.invert_image(ctx.result_device_ptr(), nb, w, back.data_ptr(), back.numel())
+    torch.cuda.synchronize()
+    assert n == text.numel() and torch.equal(back, text)
+
+
 def test_result_pointer_is_complete_when_build_returns(hip, oracle_mod):
     """include/grlbwt_hip.h: "results are complete when a call returns" -- the image is read from ANOTHER stream (torch's
     default stream) right after build(), with no synchronisation of the engine's stream by the caller."""
