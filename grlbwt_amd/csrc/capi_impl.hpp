@@ -152,7 +152,16 @@ bool par_io(int fd, char *buf, uint64_t off, uint64_t len, bool write, int nthr)
     return true;
 }
 constexpr uint64_t kIoChunk = (uint64_t)64 << 20;
-constexpr int kIoBufs = 3, kIoThreads = 4;
+constexpr int kIoBufs = 3;
+// reader / writer threads per chunk: page-cache copies run at about 2 GB/s per thread (GRLBWT_IO_THREADS overrides)
+int io_threads() {
+    static const int n = [] {
+        if (const char *e = getenv("GRLBWT_IO_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(std::max<unsigned>(hc / 2, 4u), 8u);       // (8 and 16 measured alike on a 256-core host, 4 a little slower)
+    }();
+    return n;
+}
 
 // file -> HBM: chunk k+1 is read from the file while chunk k travels over PCIe; for byte cells the histogram of
 // collection_stats is taken from every chunk on the device as soon as it has landed (no second pass over the text)
@@ -175,7 +184,7 @@ void load_file_into(E &e, int fd, uint64_t base, uint64_t bytes, int w) {      /
         for (uint64_t off = 0; off < bytes; off += chunk, k = (k + 1) % kIoBufs) {
             const uint64_t len = bytes - off < chunk ? bytes - off : chunk;
             prim::fence_wait(fences[k]);                                // the copy that last used this buffer is done
-            if (!par_io(fd, bufs[k], base + off, len, false, kIoThreads)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+            if (!par_io(fd, bufs[k], base + off, len, false, io_threads())) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
             prim::h2d_async(e.own0.p + off, bufs[k], len);
             if (d_hist) prim::byte_histogram_accumulate(e.own0.p + off, len, d_hist);
             prim::fence_record(fences[k]);
@@ -268,7 +277,7 @@ void read_fastx_raw(const char *path, RawText &R) {
             for (uint64_t off = 0; off < bytes; off += chunk, k = (k + 1) % NB) {
                 const uint64_t len = bytes - off < chunk ? bytes - off : chunk;
                 prim::fence_wait(fences[k]);
-                if (!par_io(fd, bufs[k], off, len, false, kIoThreads)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+                if (!par_io(fd, bufs[k], off, len, false, io_threads())) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
                 prim::h2d_async(R.buf.p + off, bufs[k], len);
                 prim::fence_record(fences[k]);
             }
@@ -366,6 +375,9 @@ void load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fx_flags, uint64_t *
 }
 // HBM image -> file: chunk k is written while chunk k+1 comes down
 void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
+    // a fresh file: rewriting an existing 6.7 GB output in place (O_TRUNC) took 2.3 s against 0.9 s for a new one
+    struct stat st0;
+    if (stat(path, &st0) == 0 && S_ISREG(st0.st_mode)) unlink(path);
     int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
     char *bufs[2] = {nullptr, nullptr};
@@ -385,7 +397,7 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
             if (writer.joinable()) writer.join();
             prim::fence_wait(fences[k]);
             poff = off; plen = len; pk = k;
-            writer = std::thread([&, poff, plen, pk] { if (!par_io(fd, bufs[pk], poff, plen, true, kIoThreads)) ok = false; });
+            writer = std::thread([&, poff, plen, pk] { if (!par_io(fd, bufs[pk], poff, plen, true, io_threads())) ok = false; });
         }
         if (writer.joinable()) writer.join();
     } catch (...) {
