@@ -464,19 +464,12 @@ struct Key0Fn {        // first K symbols packed b bits each
         if (vals) vals[q] = (u32)q;
     }
 };
-struct HeadKeyIn {     // 1 where the sorted key changes
-    const u64 *k;
-    GRL_DEV u32 operator()(u64 t) const { return (t == 0 || k[t] != k[t - 1]) ? 1u : 0u; }
-};
-// prefix doubling with filtering: after every pass only the suffixes that sit in a group of equal
-// keys whose key did not yet reach the phrase end ("unresolved") are re-sorted, by
-// (group id, rank of the suffix h symbols further or +inf).
 struct HeadFlagFn {       // hflag[t] = 1 where the sorted key changes
     const u64 *k; u8 *hflag;
     GRL_DEV void operator()(u64 t) const { hflag[t] = (t == 0 || k[t] != k[t - 1]) ? 1 : 0; }
 };
 struct FirstUnresolvedFn { // after the first sort: member of a group of > 1 suffixes whose key holds no sentinel (the suffix is at
-                           // least K symbols long) -- the flag ActiveFlagFn would compute, from the sorted keys instead of a gather
+                           // least K symbols long): what the refinement below has to look at again
     const u64 *k; const u8 *hflag; u64 S; u64 sent; u8 *uflag;
     GRL_DEV void operator()(u64 t) const {
         bool multi = !hflag[t] || (t + 1 < S && !hflag[t + 1]);
@@ -487,8 +480,20 @@ struct ByteIn {
     const u8 *f;
     GRL_DEV u32 operator()(u64 i) const { return f[i]; }
 };
-// Ranks are POSITIONAL: rank[q] = first slot of q's group in the sorted order, so refining one
-// group never renumbers the others and only the re-sorted suffixes get their rank rewritten.
+// Refinement by SYMBOL EXTENSION.  After the first pass a group of equal keys whose suffixes have not ended is re-sorted,
+// inside the group, by the next K symbols of its members (read straight from the dictionary: one contiguous gather), and so
+// on K symbols at a time until every group has ended or is a singleton.  Groups are contiguous slot ranges and homogeneous
+// (equal keys end at the same place), so a round works on the list of still-unresolved slots only: no rank array over the
+// dictionary, no inverse-permutation scatter, no rank gathers -- and nothing to exchange between ranks that own different
+// key ranges.  (Rounds 1 and 2 used prefix doubling over positional ranks: every pass scattered the ranks of the re-sorted
+// suffixes to their dictionary positions -- 85 ms of the 10 GB build -- and in the collection-level mode all-gathered them.)
+// A group of at most kSegCap members is ordered by counting (every member counts the smaller keys of its group: the keys sit
+// in neighbouring words); larger groups take two stable radix sorts together, by key and then by group.
+static constexpr u32 kSegCap = 64;
+struct SufLenFn {         // suffix length of every dictionary position (coalesced)
+    const u32 *dict_phr; const u32 *ph_off; u32 *suflen;
+    GRL_DEV void operator()(u64 q) const { suflen[q] = ph_off[dict_phr[q] + 1] - (u32)q; }
+};
 struct GroupStartsFn {    // gstart[dense group id] = head slot ; gstart[G] = S
     const u8 *hflag; const u32 *ex; u64 S; u32 *gstart;
     GRL_DEV void operator()(u64 t) const {
@@ -496,82 +501,80 @@ struct GroupStartsFn {    // gstart[dense group id] = head slot ; gstart[G] = S
         if (t == S - 1) gstart[ex[t] + hflag[t]] = (u32)S;
     }
 };
-struct RefineWriteFn {    // sorted unresolved suffixes go back into their slots; new heads where the key changes
-    const u64 *k; const u32 *v; const u32 *uslot; u32 *perm; u8 *hflag;
+struct ExtKeyFn {         // compact the unresolved slots; key = the next K symbols of each (sentinel behind the phrase end)
+    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag; const u32 *dict_sym; const u32 *suflen;
+    u64 Lres; int K, b;
+    u32 *uslot; u32 *uq; u64 *ukey; u8 *uhead;
     GRL_DEV void operator()(u64 i) const {
-        u32 t = uslot[i];
-        perm[t] = v[i];
-        if (i > 0 && k[i] != k[i - 1]) hflag[t] = 1;
+        if (uflag[i]) {
+            const u64 t = act ? (u64)act[i] : i;
+            const u64 q = perm[t], len = suflen[q];
+            const u64 sent = (1ull << b) - 1;
+            u64 key = 0;
+            for (int j = 0; j < K; j++) key = (key << b) | ((Lres + (u64)j < len) ? (u64)dict_sym[q + Lres + (u64)j] : sent);
+            const u32 o = uex[i];
+            uslot[o] = (u32)t; uq[o] = (u32)q; ukey[o] = key; uhead[o] = hflag[t];
+        }
     }
 };
-// Positional rank and suffix length of a dictionary position in ONE 8-byte record: the refinement looks both up at the
-// same random position q (and the rank again at q+h, usually in the same cache line).
-struct RankLen { u32 rank; u32 suflen; };
-struct SufLenPFn {        // suffix length of every dictionary position (coalesced)
-    const u32 *dict_phr; const u32 *ph_off; RankLen *rl;
-    GRL_DEV void operator()(u64 q) const { rl[q].suflen = ph_off[dict_phr[q] + 1] - (u32)q; }
-};
-// Writing rank[perm[t]] for all t is the inverse of a permutation: S random 4-byte stores (14 G/s measured, 42 ms for
-// 617 M suffixes).  Partitioned instead: (position, rank) pairs, ONE stable radix pass on the top bits of the position
-// (sequential traffic), then the pairs are applied in that order -- the stores of one digit fall into 1/256 of the array,
-// a region the L2s and the memory-side cache hold while it is being written.
-// (`base` = global slot of my first slot: the sorted order may be sharded over ranks by key range, see below)
-struct RankPairFn {       // pair[t] = position << 32 | rank of slot t
-    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; u32 base; u64 *pairs;
-    GRL_DEV void operator()(u64 t) const { pairs[t] = ((u64)perm[t] << 32) | (u64)(base + gstart[ex[t] + hflag[t] - 1]); }
-};
-struct RankHeadPairFn {   // the same for the suffixes a refinement pass re-sorted
-    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; u32 base; u64 *pairs;
-    GRL_DEV void operator()(u64 i) const {
-        u32 head = (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
-        pairs[i] = ((u64)v[i] << 32) | (u64)(base + hpos[hex[i] + head - 1]);
+struct SegStartFn {       // seg_start[k] = item of the k-th group head among the unresolved items ; seg_start[nseg] = U
+    const u8 *uhead; const u32 *hex; u64 U; u32 *seg_start;
+    GRL_DEV void operator()(u64 j) const {
+        if (uhead[j]) seg_start[hex[j]] = (u32)j;
+        if (j == U - 1) seg_start[hex[j] + uhead[j]] = (u32)U;
     }
 };
-struct RankApplyFn {
-    const u64 *pairs; RankLen *rl;
-    GRL_DEV void operator()(u64 i) const { const u64 x = pairs[i]; rl[x >> 32].rank = (u32)x; }
-};
-struct RankAllPFn {       // rank of every suffix after the first pass
-    const u8 *hflag; const u32 *ex; const u32 *gstart; const u32 *perm; RankLen *rl;
-    GRL_DEV void operator()(u64 t) const { rl[perm[t]].rank = gstart[ex[t] + hflag[t] - 1]; }
-};
-// The same refinement driven by the list of still-unresolved slots (ascending; nullptr = all slots): a suffix that is
-// resolved stays resolved, so every pass after the first touches only the previous pass's unresolved slots.
-// "My group has >= 2 members" needs no group table: slot t is not a head, or slot t+1 is not one either.
-struct ActiveFlagFn {
-    const u32 *act; const u8 *hflag; const u32 *perm; const RankLen *rl; u64 S; u64 Lres; u8 *uflag;
-    GRL_DEV void operator()(u64 i) const {
-        u64 t = act ? (u64)act[i] : i;
-        bool multi = !hflag[t] || (t + 1 < S && !hflag[t + 1]);
-        uflag[i] = (multi && rl[perm[t]].suflen >= Lres) ? 1 : 0;
+struct SegSortSmallFn {   // one lane per item of a group of at most kSegCap items: stable rank among the group's keys
+    const u8 *uhead; const u32 *hex; const u32 *seg_start; const u32 *uslot; const u32 *uq; const u64 *ukey; u64 sent; u32 cap;
+    u32 *perm; u8 *hflag; u8 *unext;       // unext[position] = the item now at that position is still unresolved
+    GRL_DEV void operator()(u64 j) const {
+        const u32 s = hex[j] + uhead[j] - 1;
+        const u32 a = seg_start[s], e = seg_start[s + 1];
+        if (e - a <= cap) {
+            const u64 k = ukey[j];
+            u32 less = 0, eq_before = 0, eq_total = 0;
+            for (u32 x = a; x < e; x++) {
+                const u64 kx = ukey[x];
+                less += kx < k ? 1u : 0u;
+                const u32 same = kx == k ? 1u : 0u;
+                eq_total += same;
+                eq_before += (same && x < (u32)j) ? 1u : 0u;
+            }
+            const u32 pos = a + less + eq_before;
+            const u32 dst = uslot[pos];
+            perm[dst] = uq[j];
+            if (eq_before == 0 && pos != a) hflag[dst] = 1;           // first of its key (the group's first slot is a head already)
+            unext[pos] = (eq_total >= 2 && (k & sent) != sent) ? 1 : 0;
+        }
     }
 };
-struct ActiveKeyFn {      // compact the unresolved slots and build their refinement keys
-    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const RankLen *rl;
-    u64 h; int lowbits;
-    u64 *keys; u32 *vals; u32 *uslot;
-    GRL_DEV void operator()(u64 i) const {
-        if (!uflag[i]) return;
-        u64 t = act ? (u64)act[i] : i;
-        u64 q = perm[t];
-        u64 sent = (1ull << lowbits) - 1;
-        RankLen me = rl[q];
-        u64 low = (h < me.suflen) ? (u64)rl[q + h].rank : sent;
-        u32 j = uex[i];
-        keys[j] = ((u64)me.rank << lowbits) | low;
-        vals[j] = (u32)q;
-        uslot[j] = (u32)t;
+struct SegBigIn {         // 1 for the items of groups above kSegCap
+    const u8 *uhead; const u32 *hex; const u32 *seg_start; u32 cap;
+    GRL_DEV u32 operator()(u64 j) const { const u32 s = hex[j] + uhead[j] - 1; return (seg_start[s + 1] - seg_start[s] > cap) ? 1u : 0u; }
+};
+struct SegBigGatherFn {
+    const u8 *uhead; const u32 *hex; const u32 *seg_start; const u32 *bex; const u64 *ukey; u32 cap; u32 *bitem; u64 *bkey; u32 *bidx;
+    GRL_DEV void operator()(u64 j) const {
+        const u32 s = hex[j] + uhead[j] - 1;
+        if (seg_start[s + 1] - seg_start[s] > cap) { const u32 p = bex[j]; bitem[p] = (u32)j; bkey[p] = ukey[j]; bidx[p] = p; }
     }
 };
-struct HeadSlotFn {       // hpos[k] = slot of the k-th group head among the re-sorted suffixes
-    const u64 *k; const u32 *hex; const u32 *uslot; u32 *hpos;
-    GRL_DEV void operator()(u64 i) const { if (i == 0 || k[i] != k[i - 1]) hpos[hex[i]] = uslot[i]; }
+struct SegBigSegKeyFn {   // second sort key of the key-sorted large items: their group
+    const u32 *i1; const u32 *bitem; const u8 *uhead; const u32 *hex; u32 *key2;
+    GRL_DEV void operator()(u64 p) const { const u32 j = bitem[i1[p]]; key2[p] = hex[j] + uhead[j] - 1; }
 };
-struct RankFromHeadsFn {  // positional rank = slot of my group's head
-    const u64 *k; const u32 *hex; const u32 *hpos; const u32 *v; RankLen *rl;
-    GRL_DEV void operator()(u64 i) const {
-        u32 head = (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
-        rl[v[i]].rank = hpos[hex[i] + head - 1];
+struct SegBigWriteFn {    // large items now ordered by (group, key): back into the groups' slots
+    const u32 *s2; const u32 *i2; const u32 *bitem; const u64 *ukey; const u32 *uq; const u32 *uslot; u64 n; u64 sent;
+    u32 *perm; u8 *hflag; u8 *unext;
+    GRL_DEV void operator()(u64 p) const {
+        const u32 src = bitem[i2[p]], seg = s2[p];
+        const u64 k = ukey[src];
+        const bool first = p == 0 || s2[p - 1] != seg, last = p + 1 == n || s2[p + 1] != seg;
+        const bool eq_prev = !first && ukey[bitem[i2[p - 1]]] == k, eq_next = !last && ukey[bitem[i2[p + 1]]] == k;
+        const u32 jt = bitem[p], dst = uslot[jt];                     // the p-th large item's place: same groups, same sizes, same order
+        perm[dst] = uq[src];
+        if (!first && !eq_prev) hflag[dst] = 1;
+        unext[jt] = ((eq_prev || eq_next) && (k & sent) != sent) ? 1 : 0;
     }
 };
 struct DenseGidFn {       // final dense group id of every slot
@@ -589,7 +592,11 @@ struct GroupStartFn {
 };
 // Per dictionary position q (coalesced pass): left symbol (or the BWT marker for a whole phrase)
 // and the frequency of its phrase, so that the pass over the sorted suffixes needs ONE gather.
-struct alignas(sizeof(idx_t) == 4 ? 8 : 16) SufRec { idx_t freq; u32 left; };   // one 8/16-byte gather per sorted suffix
+// (the 64-bit build's record has four spare bytes: they carry the phrase, which the whole-phrase suffixes need)
+template <int IB> struct SufRecT;
+template <> struct alignas(8) SufRecT<4> { u32 freq; u32 left; GRL_HD void set_phr(u32) {} GRL_HD u32 phr(const u32 *dict_phr, u32 q) const { return dict_phr[q]; } };
+template <> struct alignas(16) SufRecT<8> { u64 freq; u32 left; u32 k; GRL_HD void set_phr(u32 v) { k = v; } GRL_HD u32 phr(const u32 *, u32) const { return k; } };
+typedef SufRecT<sizeof(idx_t)> SufRec;      // one 8/16-byte gather per sorted suffix
 // left carries two flags above the symbol (symbols are < 2^30): the suffix is the last cell of its phrase, and that
 // phrase ends a string -- what the group decision needs from the group's first member.
 static constexpr u32 kRecSym = 0x3FFFFFFFu, kRecFinal = 0x40000000u, kRecLastT = 0x80000000u;
@@ -601,6 +608,7 @@ struct SuffixRecFn {
         SufRec r;
         r.freq = ph_freq[k];
         r.left = ((q == ph_off[k]) ? bwt_code : dict_sym[q - 1]) | ((q + 1 == ph_off[k + 1]) ? kRecFinal : 0u) | (ph_lastT[k] ? kRecLastT : 0u);
+        r.set_phr(k);
         rec[q] = r;
     }
 };
@@ -611,20 +619,21 @@ struct SuffixRecFn {
 // atomics per chunk (GroupAccumLargeFn; 32x fewer same-address atomics than one per member).
 static constexpr u32 kGroupChunk = 32;
 struct GroupAccumSmallFn {
-    const u32 *perm; const u32 *gstart; const SufRec *rec;
+    const u32 *perm; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
     u32 bwt_code;
-    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag;
+    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag; u32 *pslot;
     GRL_DEV void operator()(u64 g) const {
         u32 t0 = gstart[g], t1 = gstart[g + 1];
         if (t1 - t0 > kGroupChunk) return;
         u32 mn = 0xFFFFFFFFu, mx = 0, first = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = t0; j < t1; j++) {
-            SufRec r = rec[perm[j]];
+            const u32 q = perm[j];
+            SufRec r = rec[q];
             if (j == t0) first = r.left;
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
-            fl |= (left == bwt_code) ? 1 : 0;
+            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = j; }      // a whole phrase: where its metasymbol will be read
         }
         gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
         // the group decision (GroupDecideFn) from what is already in registers
@@ -634,9 +643,9 @@ struct GroupAccumSmallFn {
     }
 };
 struct GroupAccumLargeFn {
-    const u32 *perm; const u32 *gid; const u32 *gstart; const SufRec *rec;
+    const u32 *perm; const u32 *gid; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
     u32 bwt_code;
-    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull;
+    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u32 *pslot;
     GRL_DEV void operator()(u64 t) const {
         u32 g = gid[t];
         u32 t0 = gstart[g], t1 = gstart[g + 1];
@@ -644,11 +653,12 @@ struct GroupAccumLargeFn {
         u32 te = (u32)t + kGroupChunk < t1 ? (u32)t + kGroupChunk : t1;
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = (u32)t; j < te; j++) {
-            SufRec r = rec[perm[j]];
+            const u32 q = perm[j];
+            SufRec r = rec[q];
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
-            fl |= (left == bwt_code) ? 1 : 0;
+            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = j; }
         }
         prim::atomic_min(&gmin[g], mn);
         prim::atomic_max(&gmax[g], mx);
@@ -760,11 +770,11 @@ struct GrammarFn {
 };
 
 // ------------------------------------------- a9 + a10: ranks -> next text
-struct PhraseValFn {
-    const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; const RankLen *rl; const u32 *gid; const u32 *grank;
+struct PhraseValFn {      // pslot[k] = sorted slot of phrase k's whole-phrase suffix (recorded by the group accumulation)
+    const u32 *pslot; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *gid; const u32 *grank;
     u32 *phrase_val;
     GRL_DEV void operator()(u64 k) const {
-        u32 r = grank[gid[rl[ph_off[k]].rank]];
+        u32 r = grank[gid[pslot[k]]];
         phrase_val[k] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
     }
 };
@@ -1508,14 +1518,14 @@ struct ApplyPairsFn {     // value[pair >> 32] = low 32 bits
     GRL_DEV void operator()(u64 i) const { u64 p = pairs[i]; value[p >> 32] = (u32)p; }
 };
 struct OwnPhraseIn {      // 1 if the whole-phrase suffix of phrase k sorted into my slots
-    const RankLen *rl; const u32 *ph_off; u32 base; u64 Sg;
-    GRL_DEV u32 operator()(u64 k) const { const u32 r = rl[ph_off[k]].rank; return (r >= base && (u64)(r - base) < Sg) ? 1u : 0u; }
+    const u32 *pslot;
+    GRL_DEV u32 operator()(u64 k) const { return pslot[k] != 0xFFFFFFFFu ? 1u : 0u; }
 };
 struct OwnPhrasePairFn {  // (phrase << 32 | metasymbol rank) for those
-    const RankLen *rl; const u32 *ph_off; u32 base; u64 Sg; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
+    const u32 *pslot; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
     GRL_DEV void operator()(u64 k) const {
-        const u32 r = rl[ph_off[k]].rank;
-        if (r >= base && (u64)(r - base) < Sg) pairs[ex[k]] = ((u64)k << 32) | (u64)(m_off + grank[gid[r - base]]);
+        const u32 t = pslot[k];
+        if (t != 0xFFFFFFFFu) pairs[ex[k]] = ((u64)k << 32) | (u64)(m_off + grank[gid[t]]);
     }
 };
 struct PhraseValDistFn {
@@ -2220,50 +2230,13 @@ class Engine {
         }
     };
 
-    // rank[position] = value for `count` (position, value) pairs over `S` positions: partitioned by the top 16 bits of the
-    // position when the array is too large for the caches to absorb random stores, directly otherwise
-    static bool rank_scatter_partitioned(u64 count, u64 S) {
-        static const bool off = getenv("GRLBWT_DIRECT_RANK_SCATTER") != nullptr;
-        const char *mn = getenv("GRLBWT_RANK_PART_MIN");                             // (tests lower the threshold to take this path on small inputs)
-        const u64 min_s = mn ? (u64)atoll(mn) : ((u64)8 << 20);                      // 64 MB of records or less: the memory-side cache copes
-        return !(off || S < min_s || count < S / 16);
-    }
-    void apply_rank_pairs(u64 *pairs, u64 count, u64 S, RankLen *rl) {
-        if (rank_scatter_partitioned(count, S)) {
-            DBuf<u64> pb(count);
-            const int pbits = (int)bitlen64(S - 1);
-            static const int part_bits = getenv("GRLBWT_RANK_PART_BITS") ? atoi(getenv("GRLBWT_RANK_PART_BITS")) : 16;
-            const int lo = 32 + (pbits > part_bits ? pbits - part_bits : 0);
-            int res = prim::sort_keys<u64>(pairs, pb.p, count, lo, 32 + pbits, "suffix_ranks.part");
-            prim::for_each(count, RankApplyFn{res ? pb.p : pairs, rl}, "suffix_ranks");
-        } else prim::for_each(count, RankApplyFn{pairs, rl}, "suffix_ranks");
-    }
-    template <class MakePairs, class Direct>
-    void scatter_ranks(const Comm *C, u64 count, u64 S, MakePairs make_pairs, Direct direct, RankLen *rl, u64 *total = nullptr) {
-        if (C) {                 // sharded sort: every rank learns the new ranks of every other rank's suffixes
-            DBuf<u64> pa(count);
-            make_pairs(pa.p);
-            std::vector<u64> pb;
-            DBuf<u64> all = C->template allgather_v<u64>(pa.p, count, pb);
-            pa.release();
-            if (total) *total = pb[C->size];
-            apply_rank_pairs(all.p, pb[C->size], S, rl);
-            return;
-        }
-        if (total) *total = count;
-        if (!rank_scatter_partitioned(count, S)) { direct(); return; }
-        DBuf<u64> pa(count);
-        make_pairs(pa.p);
-        apply_rank_pairs(pa.p, count, S, rl);
-    }
-
     // a5-a8 on D distinct phrases given as (position in t, length, frequency, ends-with-terminator);
     // fills L (grammar, has_hocc, pre-BWT, M) and phrase_val[k] = rank<<2 | (freq>1)<<1 | lastT.
     // With a communicator (collection-level mode: t, ph_* are the MERGED dictionary, identical on every rank) the suffix
     // sort and the group stage are sharded over the ranks by ranges of the packed first-pass key: equal suffixes have equal
-    // keys, so a group never spans two ranks and rank order = sorted order.  Positional ranks are global slots (`base` of my
-    // range + local slot); after every pass the new ranks travel as (position, rank) pairs; the group stage's outputs are
-    // all-gathered.  The O(S) streaming passes (dictionary, grammar walk) stay replicated.  Same kernels in both modes.
+    // keys, so a group never spans two ranks and rank order = sorted order; the refinement reads only the dictionary, so every
+    // rank finishes its own key range without talking to the others; the group stage's outputs are all-gathered.  The O(S)
+    // streaming passes (dictionary, grammar walk) stay replicated.  Same kernels in both modes.
     template <class cell_t, bool FIRST>
     void dict_stage(const Comm *C, const cell_t *t, CellOps<cell_t, FIRST> ops, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
                     const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val) {
@@ -2275,25 +2248,24 @@ class Engine {
             build_rankbits32(pbits, ph_off, D, S + 1, "dict_build");
             prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p}, "dict_build");
         }
-        // ---- a6: sort all phrase suffixes (radix + filtered prefix doubling) ----------
-        u64 Sg = S;                              // my slots of the sorted order: [base, base + Sg)
-        u32 base = 0;
+        // ---- a6: sort all phrase suffixes (radix on the first K symbols + refinement by symbol extension) ----------
+        u64 Sg = S;                              // my slots of the sorted order (all of them without a communicator)
         DBuf<u32> perm, gid, gstart;
-        DBuf<RankLen> rl(S);                     // (positional rank, suffix length) of every dictionary position
         u64 G;
         {
             StageTimer st(&tm.dict_sort);
-            prim::for_each(S, SufLenPFn{dict_phr.p, ph_off, rl.p}, "suffix_len");
+            DBuf<u32> suflen(S);
+            prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
-            // first pass: as many symbols as fit 64 key bits (up to 8 radix passes over all suffixes).  A refinement
-            // pass gathers two ranks per unresolved suffix at random and sorts 2*bitlen(S) key bits, so symbols taken
-            // here are the cheaper ones: 48-bit keys were 7 % slower on the 10 GB build (levels with alphabets above
-            // 2^24 got a single symbol and left nearly every suffix to the first refinement).
+            // as many symbols as fit 64 key bits per pass (up to 8 radix passes over all suffixes in the first one)
             int K = 64 / b;
             if (K < 1) K = 1;
             if (K > 16) K = 16;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
+            const u64 sent = (1ull << b) - 1ull;
+            // (GRLBWT_SEG_CAP: the tests lower the limit so that ordinary inputs take the large-group path too)
+            static const u32 cap = getenv("GRLBWT_SEG_CAP") ? (u32)atoi(getenv("GRLBWT_SEG_CAP")) : kSegCap;
             DBuf<u64> ka;
             if (!C) {
                 ka.alloc(S); perm.alloc(S);
@@ -2314,7 +2286,6 @@ class Engine {
                 if (has_hi && hi < lo) hi = lo;
                 DBuf<u32> oex(S + 1);
                 Sg = prim::exclusive_scan<u32>(S, OwnFlagIn{key0.p, lo, hi, has_hi}, oex.p, false, "dist.own_scan");
-                base = (u32)prim::reduce_sum<u64>(S, LessIn{key0.p, lo}, "dist.base");
                 ka.alloc(Sg); perm.alloc(Sg);
                 prim::for_each(S, OwnCompactFn{key0.p, oex.p, lo, hi, has_hi, ka.p, perm.p}, "dist.own_compact");
             }
@@ -2330,53 +2301,51 @@ class Engine {
                     ks = kb.p;
                 }
                 prim::for_each(Sg, HeadFlagFn{ks, hflag.p}, "suffix_heads");
-                // the last symbol of a key is the sentinel exactly when the suffix is shorter than K: the first refinement's
-                // "long enough" test comes from the sorted keys (streamed) instead of a random gather per slot
-                prim::for_each(Sg, FirstUnresolvedFn{ks, hflag.p, Sg, (1ull << b) - 1ull, uflag.p}, "suffix_unresolved");
+                prim::for_each(Sg, FirstUnresolvedFn{ks, hflag.p, Sg, sent, uflag.p}, "suffix_unresolved");
                 prim::sync();
             }
             ka.release();
-            G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-            prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
-            scatter_ranks(C, Sg, S, [&](u64 *pairs) { prim::for_each(Sg, RankPairFn{hflag.p, ex.p, gstart.p, perm.p, base, pairs}, "suffix_ranks"); },
-                          [&] { prim::for_each(Sg, RankAllPFn{hflag.p, ex.p, gstart.p, perm.p, rl.p}, "suffix_ranks"); }, rl.p);
-            const int lowbits = (int)bitlen64(S);
-            u64 Lres = (u64)K, iters = 1;
-            DBuf<u32> act;                       // slots still unresolved after the previous pass (empty = all slots)
+            u64 Lres = (u64)K, iters = 1;        // Lres symbols (incl. a possible sentinel) resolved so far
+            DBuf<u32> act;                       // slots still unresolved (empty = all slots), ascending
             u64 A = Sg;
             bool refined = false;
-            while (Lres < maxlen) {              // Lres symbols (incl. a possible sentinel) resolved so far
-                const u32 *ap = refined ? act.p : nullptr;
-                if (refined) prim::for_each(A, ActiveFlagFn{ap, hflag.p, perm.p, rl.p, Sg, Lres, uflag.p}, "suffix_unresolved");
+            for (;;) {
                 DBuf<u32> uex(A + 1);
                 const u64 U = prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
-                if (!C && U == 0) break;
-                DBuf<u64> ka(U), kb(U);
-                DBuf<u32> va(U), vb(U), uslot(U), hex(U + 1), hpos(U);
-                const u64 *sk = ka.p;
-                const u32 *sv = va.p;
-                if (U) {
-                    prim::for_each(A, ActiveKeyFn{ap, uflag.p, uex.p, perm.p, rl.p, Lres, lowbits, ka.p, va.p, uslot.p}, "suffix_keys");
-                    if (prim::sort_pairs<u64, u32>(ka.p, va.p, kb.p, vb.p, U, 0, 2 * lowbits, "suffix_sort")) { sk = kb.p; sv = vb.p; }
-                    prim::for_each(U, RefineWriteFn{sk, sv, uslot.p, perm.p, hflag.p}, "suffix_refine");
-                    prim::exclusive_scan_nosync<u32>(U, HeadKeyIn{sk}, hex.p, false, "suffix_heads");
-                    prim::for_each(U, HeadSlotFn{sk, hex.p, uslot.p, hpos.p}, "suffix_gstart");
+                if (U == 0) break;
+                if (Lres > (u64)maxlen + (u64)K) throw prim::Error(-71, "suffix refinement does not terminate");
+                DBuf<u32> uslot(U), uq(U), hex(U + 1);
+                DBuf<u64> ukey(U);
+                DBuf<u8> uhead(U), unext(U);
+                prim::for_each(A, ExtKeyFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, dict_sym.p, suflen.p, Lres, K, b,
+                                           uslot.p, uq.p, ukey.p, uhead.p}, "suffix_keys");
+                const u64 nseg = prim::exclusive_scan<u32>(U, ByteIn{uhead.p}, hex.p, false, "suffix_heads");
+                DBuf<u32> seg_start(nseg + 1), bex(U + 1);
+                prim::for_each(U, SegStartFn{uhead.p, hex.p, U, seg_start.p}, "suffix_gstart");
+                prim::for_each(U, SegSortSmallFn{uhead.p, hex.p, seg_start.p, uslot.p, uq.p, ukey.p, sent, cap, perm.p, hflag.p, unext.p}, "suffix_sort.small");
+                const u64 NB = prim::exclusive_scan<u32>(U, SegBigIn{uhead.p, hex.p, seg_start.p, cap}, bex.p, false, "suffix_sort.big_scan");
+                if (NB) {                        // groups above kSegCap: by key, then (stable) by group
+                    DBuf<u32> bitem(NB), bidx(NB), bidx2(NB), key2(NB), key2b(NB);
+                    DBuf<u64> bkey(NB), bkey2(NB);
+                    prim::for_each(U, SegBigGatherFn{uhead.p, hex.p, seg_start.p, bex.p, ukey.p, cap, bitem.p, bkey.p, bidx.p}, "suffix_sort.big_gather");
+                    const u32 *i1 = prim::sort_pairs<u64, u32>(bkey.p, bidx.p, bkey2.p, bidx2.p, NB, 0, K * b, "suffix_sort") ? bidx2.p : bidx.p;
+                    u32 *i1o = (i1 == bidx.p) ? bidx2.p : bidx.p;
+                    prim::for_each(NB, SegBigSegKeyFn{i1, bitem.p, uhead.p, hex.p, key2.p}, "suffix_sort.big_groups");
+                    int sbits = (int)bitlen64(nseg);
+                    if (sbits < 1) sbits = 1;
+                    const int res = prim::sort_pairs<u32, u32>(key2.p, (u32 *)i1, key2b.p, i1o, NB, 0, sbits, "suffix_sort");
+                    prim::for_each(NB, SegBigWriteFn{res ? key2b.p : key2.p, res ? i1o : i1, bitem.p, ukey.p, uq.p, uslot.p, NB, sent,
+                                                     perm.p, hflag.p, unext.p}, "suffix_refine");
                 }
-                // (sharded: every rank takes part in the exchange of this pass, also with nothing to refine)
-                u64 total = 0;
-                scatter_ranks(C, U, S, [&](u64 *pairs) { prim::for_each(U, RankHeadPairFn{sk, hex.p, hpos.p, sv, base, pairs}, "suffix_ranks"); },
-                              [&] { prim::for_each(U, RankFromHeadsFn{sk, hex.p, hpos.p, sv, rl.p}, "suffix_ranks"); }, rl.p, &total);
-                if (total == 0) break;           // nothing left anywhere (same decision on every rank)
                 act = std::move(uslot);
+                uflag = std::move(unext);
                 A = U;
                 refined = true;
-                Lres *= 2;
+                Lres += (u64)K;
                 iters++;
             }
-            if (refined) {                       // group table of the final order
-                G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
-                prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
-            }
+            G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+            prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
             prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
             prim::sync();
             L.info.sort_iters = iters;
@@ -2387,18 +2356,20 @@ class Engine {
         DBuf<u32> grank(G + 1), pidx(G + 1), gmin(G), gmax(G);
         DBuf<idx_t> gacc(G);
         DBuf<u8> gfull(G), gflag(G);
-        DBuf<u32> repq;
+        DBuf<u32> repq, pslot;                   // pslot[k] = my sorted slot of phrase k's whole-phrase suffix (all ones: not mine)
         u64 M, P0;
         {
             StageTimer st(&tm.dict_groups);
             gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
+            pslot.alloc(D);
+            pslot.fill_ff();
             {
                 DBuf<SufRec> rec(S);
                 prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
-                prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, bwt_code,
-                                                    gmin.p, gmax.p, gacc.p, gfull.p, gflag.p}, "group_accum");
-                prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, bwt_code,
-                                                     gmin.p, gmax.p, gacc.p, gfull.p}, "group_accum_large");
+                prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, dict_phr.p, bwt_code,
+                                                    gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p}, "group_accum");
+                prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, dict_phr.p, bwt_code,
+                                                     gmin.p, gmax.p, gacc.p, gfull.p, pslot.p}, "group_accum_large");
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
@@ -2457,12 +2428,12 @@ class Engine {
             }
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
-            if (!C) prim::for_each(D, PhraseValFn{ph_off, ph_freq, ph_lastT, rl.p, gid.p, grank.p, phrase_val.p}, "phrase_values");
+            if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, gid.p, grank.p, phrase_val.p}, "phrase_values");
             else {                               // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
                 DBuf<u32> phrase_rank(D), fex(D + 1);
-                const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{rl.p, ph_off, base, Sg}, fex.p, false, "dist.full_scan");
+                const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{pslot.p}, fex.p, false, "dist.full_scan");
                 DBuf<u64> fp(nf);
-                prim::for_each(D, OwnPhrasePairFn{rl.p, ph_off, base, Sg, fex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
+                prim::for_each(D, OwnPhrasePairFn{pslot.p, fex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
                 std::vector<u64> bb;
                 DBuf<u64> allf = C->template allgather_v<u64>(fp.p, nf, bb);
                 if (bb[C->size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");

@@ -79,9 +79,9 @@ def test_replicated_induction_fallback_agrees(sim, oracle_mod, tmp_path, monkeyp
     assert n_a2a < int(open(tmp_path / "reads.rank0.comm").read().split()[1])
 
 
-def test_sharded_partitioned_rank_scatter(sim, oracle_mod, tmp_path, monkeypatch):
-    """The exchanged (position, rank) pairs applied through the partitioned scatter (threshold lowered)."""
-    monkeypatch.setenv("GRLBWT_RANK_PART_MIN", "1")
+def test_sharded_large_group_refinement(sim, oracle_mod, tmp_path, monkeypatch):
+    """The key-range-sharded suffix refinement with every group on the large-group path (limit lowered)."""
+    monkeypatch.setenv("GRLBWT_SEG_CAP", "1")
     _run(2, sim, "tokens", tmp_path, 29594)
     data = open(tmp_path / "tokens.input", "rb").read()
     assert open(tmp_path / "tokens.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 2)

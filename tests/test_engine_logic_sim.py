@@ -174,9 +174,11 @@ def test_file_in_file_out(sim, oracle_mod, tmp_path):
             ctx.load_file(str(tmp_path / "missing.bin"), 1)
 
 
-def test_partitioned_rank_scatter_branch(sim, oracle_mod, monkeypatch):
-    """The inverse-permutation scatter of the suffix ranks goes through one radix pass on the position when the dictionary is
-    large; the threshold is lowered to take that branch here."""
-    monkeypatch.setenv("GRLBWT_RANK_PART_MIN", "1")
+@pytest.mark.parametrize("cap", ["1", "3"])
+def test_large_group_refinement_branch(sim, oracle_mod, monkeypatch, cap):
+    """Suffix refinement: groups above the counting limit are re-sorted by two radix sorts (key, then group); the limit is
+    lowered so that ordinary inputs take that path (cap 1: every group; cap 3: both paths in one round)."""
+    monkeypatch.setenv("GRLBWT_SEG_CAP", cap)
     parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
     parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=3).tobytes(), 1, engine.FLAG_FORCE_IDX64)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2)
