@@ -490,10 +490,6 @@ struct ByteIn {
 // A group of at most kSegCap members is ordered by counting (every member counts the smaller keys of its group: the keys sit
 // in neighbouring words); larger groups take two stable radix sorts together, by key and then by group.
 static constexpr u32 kSegCap = 64;
-struct SufLenFn {         // suffix length of every dictionary position (coalesced)
-    const u32 *dict_phr; const u32 *ph_off; u32 *suflen;
-    GRL_DEV void operator()(u64 q) const { suflen[q] = ph_off[dict_phr[q] + 1] - (u32)q; }
-};
 struct GroupStartsFn {    // gstart[dense group id] = head slot ; gstart[G] = S
     const u8 *hflag; const u32 *ex; u64 S; u32 *gstart;
     GRL_DEV void operator()(u64 t) const {
@@ -502,16 +498,29 @@ struct GroupStartsFn {    // gstart[dense group id] = head slot ; gstart[G] = S
     }
 };
 struct ExtKeyFn {         // compact the unresolved slots; key = the next K symbols of each (sentinel behind the phrase end)
-    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag; const u32 *dict_sym; const u32 *suflen;
+    // Where the phrase ends comes from the phrase-start bit-vector of the dictionary (S/8 bytes: it stays in the caches),
+    // not from a per-position length array: an unresolved suffix has not ended within its first Lres symbols, so it ends
+    // at the first phrase start in [q + Lres, q + Lres + K].
+    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag; const u32 *dict_sym; const u64 *pw; u64 S;
     u64 Lres; int K, b;
     u32 *uslot; u32 *uq; u64 *ukey; u8 *uhead;
     GRL_DEV void operator()(u64 i) const {
         if (uflag[i]) {
             const u64 t = act ? (u64)act[i] : i;
-            const u64 q = perm[t], len = suflen[q];
+            const u64 q = perm[t], x = q + Lres;
+            // bits x .. x+K-1 of the start vector (K <= 16; the vector has a spare word behind position S)
+            u64 w = 0;
+            if (x < S) {
+                w = pw[x >> 6] >> (x & 63);
+                if ((x & 63) + (u64)K > 64) w |= pw[(x >> 6) + 1] << (64 - (x & 63));
+            }
+            u32 valid = x >= S ? 0u : (u32)K;                      // symbols of the key that lie inside the phrase
+            const u32 starts = (u32)(w & ((1ull << K) - 1ull));
+            if (x < S && starts) valid = (u32)__builtin_ctz(starts);
+            if (x < S && x + valid > S) valid = (u32)(S - x);
             const u64 sent = (1ull << b) - 1;
             u64 key = 0;
-            for (int j = 0; j < K; j++) key = (key << b) | ((Lres + (u64)j < len) ? (u64)dict_sym[q + Lres + (u64)j] : sent);
+            for (int j = 0; j < K; j++) key = (key << b) | (((u32)j < valid) ? (u64)dict_sym[x + (u64)j] : sent);
             const u32 o = uex[i];
             uslot[o] = (u32)t; uq[o] = (u32)q; ukey[o] = key; uhead[o] = hflag[t];
         }
@@ -2242,9 +2251,9 @@ class Engine {
                     const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val) {
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
         DBuf<u32> dict_sym(S), dict_phr(S);
+        RankBits pbits;                          // phrase starts over the dictionary positions (dictionary build, suffix refinement)
         {
             StageTimer st(&tm.dict_sort);
-            RankBits pbits;
             build_rankbits32(pbits, ph_off, D, S + 1, "dict_build");
             prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p}, "dict_build");
         }
@@ -2254,8 +2263,6 @@ class Engine {
         u64 G;
         {
             StageTimer st(&tm.dict_sort);
-            DBuf<u32> suflen(S);
-            prim::for_each(S, SufLenFn{dict_phr.p, ph_off, suflen.p}, "suffix_len");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
             // as many symbols as fit 64 key bits per pass (up to 8 radix passes over all suffixes in the first one)
@@ -2317,7 +2324,7 @@ class Engine {
                 DBuf<u32> uslot(U), uq(U), hex(U + 1);
                 DBuf<u64> ukey(U);
                 DBuf<u8> uhead(U), unext(U);
-                prim::for_each(A, ExtKeyFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, dict_sym.p, suflen.p, Lres, K, b,
+                prim::for_each(A, ExtKeyFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, dict_sym.p, pbits.words.p, S, Lres, K, b,
                                            uslot.p, uq.p, ukey.p, uhead.p}, "suffix_keys");
                 const u64 nseg = prim::exclusive_scan<u32>(U, ByteIn{uhead.p}, hex.p, false, "suffix_heads");
                 DBuf<u32> seg_start(nseg + 1), bex(U + 1);
@@ -2344,6 +2351,7 @@ class Engine {
                 Lres += (u64)K;
                 iters++;
             }
+            pbits.words.release(); pbits.base.release();
             G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
             prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
             prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
