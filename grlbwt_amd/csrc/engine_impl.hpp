@@ -2846,7 +2846,6 @@ class Engine {
         L.sigma = sigma;
         L.info.sigma = sigma;
         LocalParse P;
-        hash_local<cell_t, FIRST>(t, n, ops, P, L);
         const int N = C.size, me = C.rank;
         // ---- my distinct phrases go to the ranks that merge them (owner = hash of the content) ---------------------
         DBuf<u32> order;                         // my phrases in owner order
@@ -2856,32 +2855,51 @@ class Engine {
         u64 Dr = 0, Sr = 0, occ_total = 0, n_total = 0, maxp = 0;     // maxp: largest phrase block of the exchange (all ranks agree)
         {
             StageTimer st(&tm.hash);
-            DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D);
-            prim::for_each(P.D, PhraseOwnerFn<cell_t, FIRST>{t, ops, P.ph_pos.p, P.ph_len.p, (u32)N, owner.p, idx.p}, "dist.phrase_owner");
-            int obits = (int)bitlen64((u64)N - 1);
-            if (obits < 1) obits = 1;
-            const int res = prim::sort_pairs<u32, u32>(owner.p, idx.p, owner2.p, idx2.p, P.D, 0, obits, "dist.owner_sort");
-            order = std::move(res ? idx2 : idx);
-            const u32 *okey = res ? owner2.p : owner.p;
-            DBuf<u32> slen(P.D), soff(P.D + 1);
-            DBuf<u64> sfreq(P.D), bound(2 * ((u64)N + 1));
-            prim::for_each(P.D, SendPhraseFn{order.p, P.ph_len.p, P.ph_freq.p, slen.p, sfreq.p}, "dist.send_phrases");
-            const u64 chk = prim::exclusive_scan<u32>(P.D, LenIn{slen.p}, soff.p, true, "dist.send_offsets");
-            if (chk != P.S) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
-            DBuf<u32> scells(P.S);
-            {
-                RankBits sbits;
-                build_rankbits32(sbits, soff.p, P.D, P.S + 1, "dist.send_cells");
-                prim::for_each((P.S + 15) / 16, SendCellsFn<cell_t, FIRST>{t, ops, order.p, P.ph_pos.p, soff.p, P.D, P.S, scells.p, sbits.words.p, sbits.base.p},
-                               "dist.send_cells");
+            DBuf<u32> slen, scells;
+            DBuf<u64> sfreq;
+            std::vector<u64> mine(2 * (u64)N + 3, 0);
+            // A failure that only this shard can have (phrase table overflow, a parse beyond the supported range) must not leave
+            // the other ranks waiting in the exchange below: the verdict travels with the counts and every rank raises.
+            std::string local_err;
+            try {
+                // (GRLBWT_TEST_FAIL_RANK=<rank>: the tests make one rank fail here)
+                if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK")) if (atoi(fr) == me) throw prim::Error(-28, "phrase hash table overflow (injected by the test)");
+                hash_local<cell_t, FIRST>(t, n, ops, P, L);
+                DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D), soff(P.D + 1);
+                DBuf<u64> bound(2 * ((u64)N + 1));
+                prim::for_each(P.D, PhraseOwnerFn<cell_t, FIRST>{t, ops, P.ph_pos.p, P.ph_len.p, (u32)N, owner.p, idx.p}, "dist.phrase_owner");
+                int obits = (int)bitlen64((u64)N - 1);
+                if (obits < 1) obits = 1;
+                const int res = prim::sort_pairs<u32, u32>(owner.p, idx.p, owner2.p, idx2.p, P.D, 0, obits, "dist.owner_sort");
+                order = std::move(res ? idx2 : idx);
+                const u32 *okey = res ? owner2.p : owner.p;
+                slen.alloc(P.D); sfreq.alloc(P.D);
+                prim::for_each(P.D, SendPhraseFn{order.p, P.ph_len.p, P.ph_freq.p, slen.p, sfreq.p}, "dist.send_phrases");
+                const u64 chk = prim::exclusive_scan<u32>(P.D, LenIn{slen.p}, soff.p, true, "dist.send_offsets");
+                if (chk != P.S) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
+                scells.alloc(P.S);
+                {
+                    RankBits sbits;
+                    build_rankbits32(sbits, soff.p, P.D, P.S + 1, "dist.send_cells");
+                    prim::for_each((P.S + 15) / 16, SendCellsFn<cell_t, FIRST>{t, ops, order.p, P.ph_pos.p, soff.p, P.D, P.S, scells.p, sbits.words.p, sbits.base.p},
+                                   "dist.send_cells");
+                }
+                prim::for_each((u64)N + 1, KeyBoundFn{okey, P.D, soff.p, bound.p}, "dist.owner_bounds");
+                std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
+                for (int d = 0; d < N; d++) { pc[d] = bh[2 * (d + 1)] - bh[2 * d]; cc[d] = bh[2 * (d + 1) + 1] - bh[2 * d + 1]; mine[d] = pc[d]; mine[N + d] = cc[d]; }
+                mine[2 * N] = P.n_occ; mine[2 * N + 1] = n;
+            } catch (const prim::Error &e) {
+                local_err = e.what();
+                std::fill(mine.begin(), mine.end(), 0);
+                std::fill(pc.begin(), pc.end(), 0); std::fill(cc.begin(), cc.end(), 0);
+                mine[2 * N + 2] = (u64)(u32)(-e.code);
             }
-            prim::for_each((u64)N + 1, KeyBoundFn{okey, P.D, soff.p, bound.p}, "dist.owner_bounds");
-            std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
-            std::vector<u64> mine(2 * (u64)N + 2);
-            for (int d = 0; d < N; d++) { pc[d] = bh[2 * (d + 1)] - bh[2 * d]; cc[d] = bh[2 * (d + 1) + 1] - bh[2 * d + 1]; mine[d] = pc[d]; mine[N + d] = cc[d]; }
-            mine[2 * N] = P.n_occ; mine[2 * N + 1] = n;
             const u64 w = mine.size();
             std::vector<u64> mat = C.allgather_u64(mine);
+            for (int g = 0; g < N; g++)
+                if (mat[g * w + 2 * N + 2])
+                    throw prim::Error(-(int)mat[g * w + 2 * N + 2], g == me ? local_err : "rank " + std::to_string(g) + " failed in its parsing round (error " +
+                                                                                              std::to_string(-(long long)mat[g * w + 2 * N + 2]) + ")");
             u64 maxc = 0;
             for (int g = 0; g < N; g++) {
                 rpc[g] = mat[g * w + me]; rcc[g] = mat[g * w + N + me];

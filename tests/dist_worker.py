@@ -64,6 +64,20 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if case == "injected":
+        # one rank fails inside its parsing round (a failure only that shard can have): every rank must raise
+        good = workloads.sampled_reads(400, 50, 3000, seed=3)
+        shard = gdist.shard_records(good, rank, world)
+        try:
+            gdist.grl_bwt_algo_sharded(shard.tobytes(), 1, device, lib, 0)
+            verdict = "returned"
+        except engine.GrlbwtError as e:
+            verdict = "raised %d" % e.code
+        with open(os.path.join(out_dir, "injected.rank%d" % rank), "w") as f:
+            f.write(verdict)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if case == "reads":
         data = workloads.sampled_reads(3001, 100, 20000, seed=11)
     elif case == "uniform":

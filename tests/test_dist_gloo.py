@@ -101,6 +101,14 @@ def test_ill_formed_shard_fails_on_every_rank(sim, tmp_path):
     assert got[1] == "raised -84" and got[0].startswith("raised") and got[2].startswith("raised"), got
 
 
+def test_local_failure_inside_a_round_fails_on_every_rank(sim, tmp_path, monkeypatch):
+    """A failure only one shard can have (e.g. its phrase table overflows) travels with the next exchange: all ranks raise
+    the same error instead of waiting for the failed one."""
+    monkeypatch.setenv("GRLBWT_TEST_FAIL_RANK", "1")
+    _run(3, sim, "injected", tmp_path, 29595)
+    assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -28"] * 3
+
+
 def test_fewer_strings_than_ranks_is_rejected():
     import numpy as np
     from grlbwt_amd import dist as gdist
