@@ -1616,9 +1616,10 @@ struct IotaIdxFn {
 // The reference reads records one by one through kseq; here the file is a table of lines.  Every line is a HEADER (starts a
 // record), a SEQUENCE line (its bytes belong to the record above) or SKIPPED ('+' and quality lines of FASTQ); a record's
 // string is the concatenation of its sequence lines, each without the "\r" kseq drops (kseq.h:141), followed by the
-// separator, and with FX_REVCOMP by its reverse complement and another separator.  Two layouts are taken: no '+' line
-// outside headers (FASTA, any wrapping, blank lines), or strict four-line FASTQ records, verified on the device; anything
-// else is refused (kseq would follow it line by line: multi-line FASTQ, truncated qualities).
+// separator, and with FX_REVCOMP by its reverse complement and another separator.  Two layouts are classified in parallel:
+// no '+' line outside headers (FASTA, any wrapping, blank lines), and strict four-line FASTQ records (verified on the
+// device); anything else (FASTQ over several lines, damaged records) is walked record by record by one lane like kseq does
+// (FxSeqClassFn) -- the byte work stays parallel in every case.
 enum : u8 { FX_SKIP = 0, FX_HDR = 1, FX_SEQ = 2 };
 struct FxNlWordsFn {      // one lane per 64 input bytes: bit b of words[w] = (in[64w + b] == '\n')
     const u8 *in; u64 n; u64 *words;
@@ -1692,6 +1693,64 @@ struct FxClassFn {        // class and provisional kept length of every line
         cls[i] = c;
         raw[i] = c == FX_SEQ ? fx_kept(L) : 0;
     }
+};
+// kseq's record walk (kseq.h:179-220) line by line, ONE lane: for the layouts the parallel rules above do not cover
+// (FASTQ records over several lines, '+' lines in odd places, a quality string that stops early).  Sequential like the
+// reference's parser -- such files are rare and small; the four-line and FASTA layouts never come here.  Outputs the same
+// (class, kept length) per line as the parallel path; res[0] = first line that no longer counts (kseq gives up at a
+// record whose quality string has another length than its sequence: that record and everything behind it is not written).
+struct FxSeqClassFn {
+    const u8 *in; u64 n; const u64 *nlpos; u64 m; bool tail;
+    u8 *cls; u64 *kept; u64 *res;
+    GRL_DEV void operator()(u64) const {
+        int st = 0;                                   // 0 looking for a header, 1 sequence lines, 2 quality lines
+        u64 seq_l = 0, qual_l = 0, cur_hdr = 0, stop = m;
+        u8 qlast = 0, qprev = 0;
+        bool halted = false;
+        for (u64 i = 0; i < m && !halted; i++) {
+            const FxLine L = fx_line(in, nlpos, i);
+            const bool last_line = i == m - 1;
+            u8 c = FX_SKIP;
+            u64 k = 0;
+            if (st == 0) {                            // kseq.h:183-186: characters are skipped up to the first '>' or '@'
+                u64 pos = L.len;
+                for (u64 x = 0; x < L.len && pos == L.len; x++) if (fx_is_hdr(in[L.start + x])) pos = x;
+                if (pos < L.len) {
+                    if (last_line && tail && pos == L.len - 1) { halted = true; stop = i; }      // the header character ends the input: no record
+                    else { c = FX_HDR; st = 1; seq_l = 0; cur_hdr = i; }
+                }
+            } else if (st == 1) {                     // kseq.h:194-199
+                if (L.len == 0) {
+                } else if (fx_is_hdr(L.first)) {
+                    if (last_line && tail && L.len == 1) { halted = true; stop = i; }
+                    else { c = FX_HDR; seq_l = 0; cur_hdr = i; }
+                } else if (L.first == '+') {
+                    if (last_line && tail) { halted = true; stop = cur_hdr; }                     // :211 no quality string: -2
+                    else { st = 2; qual_l = 0; qlast = 0; qprev = 0; }
+                } else {
+                    c = FX_SEQ;
+                    seq_l += L.len; k = L.len;
+                    if (seq_l > 1 && L.last == '\r') { seq_l--; k--; }                            // kseq.h:141
+                }
+            } else {                                  // kseq.h:214: quality lines until the string is as long as the sequence
+                if (L.len >= 2) { qprev = in[L.start + L.len - 2]; qlast = L.last; }
+                else if (L.len == 1) { qprev = qlast; qlast = L.last; }
+                qual_l += L.len;
+                if (qual_l > 1 && qlast == '\r') { qual_l--; qlast = qprev; qprev = 0; }
+                if (qual_l >= seq_l || last_line) {
+                    st = 0;
+                    if (qual_l != seq_l) { halted = true; stop = cur_hdr; }                        // :217 -2: the conversion ends here
+                }
+            }
+            cls[i] = c; kept[i] = k;
+        }
+        if (!halted && st == 2 && seq_l != 0) stop = cur_hdr;                                      // '+' line, then the input ends
+        res[0] = stop;
+    }
+};
+struct FxStopFn {         // lines from `stop` on do not count
+    u64 stop; u8 *cls; u64 *kept;
+    GRL_DEV void operator()(u64 i) const { if (i >= stop) { cls[i] = FX_SKIP; kept[i] = 0; } }
 };
 struct FxIsHdrIn {
     const u8 *cls;
@@ -3351,26 +3410,38 @@ class Engine {
         DBuf<u64> nlpos(m);
         prim::for_each((n + 63) / 64, FxNlPosFn{words.p, base.p, nlpos.p}, "fastx.line_ends");
         if (tail) prim::h2d(nlpos.p + (m - 1), &n, 8);
-        // layout: FASTA (no '+' line) or strict four-line FASTQ
+        // layout: FASTA (no '+' line) or strict four-line FASTQ take the parallel classification; anything else is walked
+        // record by record like kseq does
         const bool fastq = prim::reduce_sum<u64>(m, FxPlusIn{in, nlpos.p}, "fastx.plus_lines") != 0;
         u64 fq_lines = 0;
+        bool regular = true;
         if (fastq) {
             fq_lines = prim::reduce_max<u64>(m, FxLastNonEmptyIn{nlpos.p}, "fastx.last_line");
-            const bool ok = fq_lines % 4 == 0 && prim::reduce_sum<u64>(fq_lines / 4, FxFastqBadIn{in, nlpos.p}, "fastx.fastq_check") == 0;
-            if (!ok) throw prim::Error(kErrNotFastx, "FASTQ records are not in the four-line layout (or lines starting with '+' in a FASTA file): not supported");
+            regular = fq_lines % 4 == 0 && prim::reduce_sum<u64>(fq_lines / 4, FxFastqBadIn{in, nlpos.p}, "fastx.fastq_check") == 0;
         }
         DBuf<u8> cls(m);
-        DBuf<u64> raw(m), hrank(m + 1), praw(m + 1);
-        prim::for_each(m, FxClassFn{in, nlpos.p, fq_lines, fastq, cls.p, raw.p}, "fastx.classify");
-        u64 R = prim::exclusive_scan<u64>(m, FxIsHdrIn{cls.p}, hrank.p, true, "fastx.records");
-        prim::exclusive_scan_nosync<u64>(m, IdxIn<u64>{raw.p}, praw.p, true, "fastx.raw_offsets");
-        DBuf<u64> hline(R + 1), kept(m), pk(m + 1);
-        prim::for_each(m, FxHdrLinesFn{cls.p, hrank.p, m, R, hline.p}, "fastx.header_lines");
-        prim::for_each(m, FxKeptFn{in, nlpos.p, cls.p, hrank.p, hline.p, praw.p, kept.p}, "fastx.kept");
-        const u64 K = prim::exclusive_scan<u64>(m, IdxIn<u64>{kept.p}, pk.p, true, "fastx.offsets");
+        DBuf<u64> raw(m), hrank(m + 1), praw(m + 1), hline, kept(m), pk(m + 1);
+        u64 R, K;
+        if (regular) {
+            prim::for_each(m, FxClassFn{in, nlpos.p, fq_lines, fastq, cls.p, raw.p}, "fastx.classify");
+            R = prim::exclusive_scan<u64>(m, FxIsHdrIn{cls.p}, hrank.p, true, "fastx.records");
+            prim::exclusive_scan_nosync<u64>(m, IdxIn<u64>{raw.p}, praw.p, true, "fastx.raw_offsets");
+            hline.alloc(R + 1);
+            prim::for_each(m, FxHdrLinesFn{cls.p, hrank.p, m, R, hline.p}, "fastx.header_lines");
+            prim::for_each(m, FxKeptFn{in, nlpos.p, cls.p, hrank.p, hline.p, praw.p, kept.p}, "fastx.kept");
+        } else {
+            DBuf<u64> res(1);
+            cls.zero(); kept.zero();
+            prim::for_each(1, FxSeqClassFn{in, n, nlpos.p, m, tail, cls.p, kept.p, res.p}, "fastx.record_walk");
+            prim::for_each(m, FxStopFn{res.get(0), cls.p, kept.p}, "fastx.record_walk");
+            R = prim::exclusive_scan<u64>(m, FxIsHdrIn{cls.p}, hrank.p, true, "fastx.records");
+            hline.alloc(R + 1);
+            prim::for_each(m, FxHdrLinesFn{cls.p, hrank.p, m, R, hline.p}, "fastx.header_lines");
+        }
+        K = prim::exclusive_scan<u64>(m, IdxIn<u64>{kept.p}, pk.p, true, "fastx.offsets");
         raw.release(); praw.release();
         // a header character that ends the input ("...\n>") opens no record (kseq.h:188: nothing to read after it)
-        if (R && tail) {
+        if (regular && R && tail) {
             const u64 hl = hline.get(R - 1);
             if (hl == m - 1 && n - (hl ? nlpos.get(hl - 1) + 1 : 0) == 1) R--;
         }

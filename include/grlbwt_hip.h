@@ -130,8 +130,9 @@ int grlbwt_get_stats(const grlbwt_ctx *ctx, grlbwt_stats *out);
  * main.cpp:118-136 has switched off.  The file (gzip members are inflated on the host) goes to HBM as it is; the records
  * become the one-string-per-line text on the device: every record's sequence lines joined, '\n' behind it, and with
  * GRLBWT_FASTX_REVCOMP its reverse complement + '\n' as a second string (a symbol outside ACGT: GRLBWT_ENOTDNA, with the
- * reference's message naming the symbol).  Supported layouts: FASTA with any line wrapping, blank and CRLF lines;
- * FASTQ with four lines per record.  Multi-line FASTQ and damaged records are refused (GRLBWT_EINVAL), not guessed at. */
+ * reference's message naming the symbol).  FASTA with any line wrapping and four-line FASTQ are classified in parallel;
+ * other layouts (FASTQ over several lines, damaged records) are walked record by record like kseq does, with kseq's
+ * outcome (a record whose quality string has the wrong length ends the conversion). */
 #define GRLBWT_FASTX_REVCOMP 1u
 int grlbwt_fastx_probe(const char *path, int *is_fastx, int *is_gz);
 int grlbwt_text_load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fastx_flags, uint64_t *n_strings);
