@@ -646,7 +646,7 @@ struct GroupAccumSmallFn {
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
-            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = j; }      // a whole phrase: where its metasymbol will be read
+            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = (u32)g; } // a whole phrase: the group its metasymbol will be read from
         }
         gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
         // the group decision (GroupDecideFn) from what is already in registers
@@ -655,23 +655,26 @@ struct GroupAccumSmallFn {
         gflag[g] = (valid ? 1 : 0) | (ranked ? 2 : 0) | (t1 - t0 > 1 ? 4 : 0);
     }
 };
-struct GroupAccumLargeFn {
-    const u32 *perm; const u32 *gid; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
+struct GroupChunksIn {    // chunks of a group above kGroupChunk members (0 for the others)
+    const u32 *gstart;
+    GRL_DEV u32 operator()(u64 g) const { const u32 sz = gstart[g + 1] - gstart[g]; return sz > kGroupChunk ? (sz + kGroupChunk - 1) / kGroupChunk : 0u; }
+};
+struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per slot spent 27 ms at 10 GB finding out it had nothing to do)
+    const u32 *perm; const u32 *coff; u64 G; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u32 *pslot;
-    GRL_DEV void operator()(u64 t) const {
-        u32 g = gid[t];
-        u32 t0 = gstart[g], t1 = gstart[g + 1];
-        if (t1 - t0 <= kGroupChunk || ((u32)t - t0) % kGroupChunk != 0) return;
-        u32 te = (u32)t + kGroupChunk < t1 ? (u32)t + kGroupChunk : t1;
+    GRL_DEV void operator()(u64 c) const {
+        const u32 g = (u32)upper_bound<u32>(coff, G, (u32)c) - 1;     // the group with coff[g] <= c < coff[g + 1]
+        const u32 t1 = gstart[g + 1], t = gstart[g] + ((u32)c - coff[g]) * kGroupChunk;
+        const u32 te = t + kGroupChunk < t1 ? t + kGroupChunk : t1;
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
-        for (u32 j = (u32)t; j < te; j++) {
+        for (u32 j = t; j < te; j++) {
             const u32 q = perm[j];
             SufRec r = rec[q];
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
-            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = j; }
+            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = g; }
         }
         prim::atomic_min(&gmin[g], mn);
         prim::atomic_max(&gmax[g], mx);
@@ -762,32 +765,35 @@ struct MetaPosFn {         // by sorted slot t: gid[] and ginfo[] are read in or
         if (gi & 1u) meta[perm[t]] = (gi >> 1) + sigma3;
     }
 };
-struct GrammarFn {
-    const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
-    const u32 *meta;
+struct GrammarFn {         // (phrase ends from the dictionary's start bit-vector, which stays in the caches: no phrase-table gathers on the way)
+    const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u8 *ph_lastT;
+    const u32 *meta; const u64 *pw; u64 S;
     u32 MD;
     u32 *g0; u32 *g1;
     GRL_DEV void operator()(u64 u) const {
-        u64 q = repq[u];
-        u32 k = dict_phr[q];
-        u64 e = (u64)ph_off[k + 1] - 1;
-        if (q == e) { g0[u] = MD; g1[u] = dict_sym[q]; return; }                    // :38-41
+        const u64 q = repq[u];
+        u32 a = MD, b = 0;
+        bool done = false;
+        if (q + 1 == S || bit_at(pw, q + 1)) { b = dict_sym[q]; done = true; }       // q is the last cell of its phrase (:38-41)
         u64 x = q + 1;
-        for (;;) {
-            u32 m = meta[x];
-            if (m) { g0[u] = dict_sym[x - 1]; g1[u] = m; return; }                   // :49-80
-            if (x == e) { g0[u] = MD; g1[u] = ph_lastT[k] ? dict_sym[e] : dict_sym[e - 1]; return; }   // :81-85
-            x++;
+        while (!done) {
+            const u32 m = meta[x];
+            if (m) { a = dict_sym[x - 1]; b = m; done = true; }                         // :49-80
+            else if (x + 1 == S || bit_at(pw, x + 1)) {                                 // x is the last cell of the phrase (:81-85)
+                b = ph_lastT[dict_phr[x]] ? dict_sym[x] : dict_sym[x - 1];
+                done = true;
+            } else x++;
         }
+        g0[u] = a; g1[u] = b;
     }
 };
 
 // ------------------------------------------- a9 + a10: ranks -> next text
-struct PhraseValFn {      // pslot[k] = sorted slot of phrase k's whole-phrase suffix (recorded by the group accumulation)
-    const u32 *pslot; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *gid; const u32 *grank;
+struct PhraseValFn {      // pslot[k] = equal-suffix group of phrase k's whole-phrase suffix (recorded by the group accumulation)
+    const u32 *pslot; const idx_t *ph_freq; const u8 *ph_lastT; const u32 *grank;
     u32 *phrase_val;
     GRL_DEV void operator()(u64 k) const {
-        u32 r = grank[gid[pslot[k]]];
+        u32 r = grank[pslot[k]];
         phrase_val[k] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
     }
 };
@@ -1535,10 +1541,10 @@ struct OwnPhraseIn {      // 1 if the whole-phrase suffix of phrase k sorted int
     GRL_DEV u32 operator()(u64 k) const { return pslot[k] != 0xFFFFFFFFu ? 1u : 0u; }
 };
 struct OwnPhrasePairFn {  // (phrase << 32 | metasymbol rank) for those
-    const u32 *pslot; const u32 *ex; const u32 *gid; const u32 *grank; u32 m_off; u64 *pairs;
+    const u32 *pslot; const u32 *ex; const u32 *grank; u32 m_off; u64 *pairs;
     GRL_DEV void operator()(u64 k) const {
-        const u32 t = pslot[k];
-        if (t != 0xFFFFFFFFu) pairs[ex[k]] = ((u64)k << 32) | (u64)(m_off + grank[gid[t]]);
+        const u32 g = pslot[k];
+        if (g != 0xFFFFFFFFu) pairs[ex[k]] = ((u64)k << 32) | (u64)(m_off + grank[g]);
     }
 };
 struct PhraseValDistFn {
@@ -2414,7 +2420,7 @@ class Engine {
                 Lres += (u64)K;
                 iters++;
             }
-            pbits.words.release(); pbits.base.release();
+            pbits.base.release();
             G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
             prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
             prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
@@ -2427,7 +2433,7 @@ class Engine {
         DBuf<u32> grank(G + 1), pidx(G + 1), gmin(G), gmax(G);
         DBuf<idx_t> gacc(G);
         DBuf<u8> gfull(G), gflag(G);
-        DBuf<u32> repq, pslot;                   // pslot[k] = my sorted slot of phrase k's whole-phrase suffix (all ones: not mine)
+        DBuf<u32> repq, pslot;                   // pslot[k] = my group holding phrase k's whole-phrase suffix (all ones: not mine)
         u64 M, P0;
         {
             StageTimer st(&tm.dict_groups);
@@ -2439,7 +2445,9 @@ class Engine {
                 prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
                 prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, dict_phr.p, bwt_code,
                                                     gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p}, "group_accum");
-                prim::for_each(Sg, GroupAccumLargeFn{perm.p, gid.p, gstart.p, rec.p, dict_phr.p, bwt_code,
+                DBuf<u32> coff(G + 1);
+                const u64 NC = prim::exclusive_scan<u32>(G, GroupChunksIn{gstart.p}, coff.p, true, "group_accum_large");
+                prim::for_each(NC, GroupAccumLargeFn{perm.p, coff.p, G, gstart.p, rec.p, dict_phr.p, bwt_code,
                                                      gmin.p, gmax.p, gacc.p, gfull.p, pslot.p}, "group_accum_large");
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
@@ -2495,16 +2503,16 @@ class Engine {
                     DBuf<u64> all = C->template allgather_v<u64>(mp.p, nm, bb);
                     prim::for_each(bb[C->size], ApplyPairsFn{all.p, meta.p}, "grammar_marks");
                 }
-                prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_off, ph_lastT, meta.p, MD, L.g0.p, L.g1.p}, "grammar");
+                prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_lastT, meta.p, pbits.words.p, S, MD, L.g0.p, L.g1.p}, "grammar");
             }
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
-            if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, gid.p, grank.p, phrase_val.p}, "phrase_values");
+            if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, grank.p, phrase_val.p}, "phrase_values");
             else {                               // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
                 DBuf<u32> phrase_rank(D), fex(D + 1);
                 const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{pslot.p}, fex.p, false, "dist.full_scan");
                 DBuf<u64> fp(nf);
-                prim::for_each(D, OwnPhrasePairFn{pslot.p, fex.p, gid.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
+                prim::for_each(D, OwnPhrasePairFn{pslot.p, fex.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
                 std::vector<u64> bb;
                 DBuf<u64> allf = C->template allgather_v<u64>(fp.p, nf, bb);
                 if (bb[C->size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
