@@ -10,17 +10,22 @@
 //   a2  lms_parsing::operator()     include/parsing_strategies.h:82-145     -> StartPred (phrase-start bit-vector)
 //   a3  ext_hash_functor + hash_table::increment_value
 //                                   exact_par_phase.hpp:14-42, hash_table.hpp:453-539 -> HashInsertFn
-//   a5  dictionary ctor             exact_par_phase.hpp:106-183             -> compact_table / DictBuildFn
-//   a6  suffix_induction            exact_LMS_induction.h:94-158            -> sort_dict_suffixes (radix + prefix doubling)
-//   a7  produce_pre_bwt             exact_par_phase.cpp:136-242             -> GroupAccumFn/GroupDecideFn/GroupEmitFn
-//   a8  produce_grammar             exact_par_phase.cpp:14-95               -> GrammarFn
-//   a9  rank assignment             exact_par_phase.cpp:427-450             -> SlotValFn
+//   a5  dictionary ctor             exact_par_phase.hpp:106-183             -> CompactTableFn / DictBuildFn
+//   a6  suffix_induction            exact_LMS_induction.h:94-158            -> Engine::dict_stage: Key0Fn + radix sort, then refinement by
+//                                                                               symbol extension (ExtKeyFn, SegSortSmallFn, SegBig*Fn)
+//   a7  produce_pre_bwt             exact_par_phase.cpp:136-242             -> GroupAccum*Fn/GroupDecideFn/GroupEmitFn
+//   a8  produce_grammar             exact_par_phase.cpp:14-95               -> MetaPosFn + GrammarFn
+//   a9  rank assignment             exact_par_phase.cpp:427-450             -> PhraseValFn / ScatterValFn
 //   a10 ext_parse_functor/parse_text exact_par_phase.hpp:44-84, parsing_strategies.h:644-676 -> MapFn
 //   a11 par_phase loop              exact_par_phase.cpp:338-366,496         -> Engine::parse_phase
 //   a12 parse2bwt                   exact_ind_phase.cpp:603-672             -> Engine::first_bwt
-//   a13 compute_hocc_size           exact_ind_phase.cpp:42-109              -> ChainCountFn
-//   a14 infer_lvl_bwt pass B        exact_ind_phase.cpp:143-258             -> ChainExpandFn + stable radix split
-//   a15 infer_lvl_bwt pass C        exact_ind_phase.cpp:287-361             -> Seg*/Atom* (merge-path style assemble)
+//   a13 compute_hocc_size           exact_ind_phase.cpp:42-109              -> Engine::expand_split: ChainGen through prim::expand_count
+//   a14 infer_lvl_bwt pass B        exact_ind_phase.cpp:143-258             -> ... and prim::expand_sort (expansion fused with the first split pass)
+//   a15 infer_lvl_bwt pass C        exact_ind_phase.cpp:287-361             -> Engine::assemble_t: TakeScanEmitFn, PrePlaceFn, CellAtomsFn,
+//                                                                               PreAtomsFn, BigAtomsFn, merge_atoms
+//   8e  collection-level mode       parsing_strategies.h:200-386 (thread ranges) -> Engine::dist_build (dist_round_t, dist_induce_level, dist_finish)
+//   8f2 .rl_bwt consumers           scripts/*.cpp                            -> image_plain / image_rle / image_stats / image_split_runs / invert_image
+//   8f3 FASTA/Q ingestion           external/bioparsers/lib/fastx_handler.cpp, kseq.h -> Engine::fastx_to_text
 //   a16 bwt_buff_writer format      include/bwt_io.h:377-382,448-490        -> PackRunsFn
 //   a17 final header widths         exact_ind_phase.cpp:274-276 @ level 0   -> Engine::finish
 //
