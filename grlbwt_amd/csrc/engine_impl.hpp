@@ -601,13 +601,6 @@ struct DenseGidFn {       // final dense group id of every slot
 };
 
 // -------------------------------------------- a7: groups -> pre-BWT + ranks
-struct GroupStartFn {
-    const u32 *gid; u64 S; u32 *gstart;
-    GRL_DEV void operator()(u64 t) const {
-        if (t == 0 || gid[t] != gid[t - 1]) gstart[gid[t]] = (u32)t;
-        if (t == S - 1) gstart[gid[t] + 1] = (u32)S;
-    }
-};
 // Per dictionary position q (coalesced pass): left symbol (or the BWT marker for a whole phrase)
 // and the frequency of its phrase, so that the pass over the sorted suffixes needs ONE gather.
 // (the 64-bit build's record has four spare bytes: they carry the phrase, which the whole-phrase suffixes need)
@@ -885,10 +878,6 @@ static inline void build_rankbits32(RankBits &rb, const u32 *pos, u64 count, u64
 }
 
 // ------------------------------------------------------------ run utilities
-struct SymHeadIn {
-    const u32 *s;
-    GRL_DEV u32 operator()(u64 t) const { return (t == 0 || s[t] != s[t - 1]) ? 1u : 0u; }
-};
 template <class L>
 struct IdxIn {
     const L *p;
@@ -910,10 +899,6 @@ struct HeadLenIn {
 struct DiffFn {
     const idx_t *start; idx_t *len;
     GRL_DEV void operator()(u64 r) const { len[r] = start[r + 1] - start[r]; }
-};
-struct SymHeadIdxIn {
-    const u32 *s;
-    GRL_DEV idx_t operator()(u64 t) const { return (t == 0 || s[t] != s[t - 1]) ? (idx_t)1 : (idx_t)0; }
 };
 
 struct Runs {
@@ -990,11 +975,6 @@ struct CellSymFn {
     GRL_DEV void operator()(u64 i) const { sym[i] = t[i] >> 2; len[i] = 1; }
 };
 
-template <class F>
-struct StoreByteFn {      // out[i] = f(i) as a byte flag
-    F f; u8 *out;
-    GRL_DEV void operator()(u64 i) const { out[i] = (u8)f(i); }
-};
 template <class F>
 struct StoreFn {          // out[i] = f(i): materialise an expensive scan input once
     F f; idx_t *out;
@@ -1075,25 +1055,9 @@ struct GatherCellFn {
 };
 
 // --------------------------------------------------------- a15: assemble
-struct CondLenIn {      // len[i] if sym[i] == code else 0
-    const u32 *sym; const idx_t *len; u32 code;
-    GRL_DEV idx_t operator()(u64 i) const { return sym[i] == code ? len[i] : (idx_t)0; }
-};
 struct NotCodeIn {
     const u32 *sym; u32 code;
     GRL_DEV idx_t operator()(u64 i) const { return sym[i] != code ? (idx_t)1 : (idx_t)0; }
-};
-struct SegFromPreFn {   // non-HOCC pre-BWT runs -> segments
-    const u32 *psym; const idx_t *plen; const idx_t *PH; const idx_t *nhb; const idx_t *Hpos; u64 E;
-    u32 bwt_code, hocc_code, take_code;
-    u32 *seg_sym; idx_t *seg_len;
-    GRL_DEV void operator()(u64 j) const {
-        u32 s = psym[j];
-        if (s == hocc_code) return;
-        u64 g = (u64)nhb[j] + lower_bound<idx_t>(Hpos, E, PH[j]);
-        seg_sym[g] = (s == bwt_code) ? take_code : s;
-        seg_len[g] = plen[j];
-    }
 };
 // induced cells in bucket-major order, in one of three forms: ONE 64-bit word per cell, sym | len | bucket (the word
 // the split sorted, when the three fields fit); bucket array + packed payload (sym<<32 | len); bucket array + two
@@ -1108,48 +1072,9 @@ struct CellView {
         return fused ? (idx_t)((fused[t] >> kb) & ((1ull << lb) - 1ull)) : packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t];
     }
 };
-struct CellLenIn {
-    CellView c;
-    GRL_DEV idx_t operator()(u64 t) const { return c.len(t); }
-};
 struct CellHeadIn {     // 1 where a cell does not merge with its predecessor (other bucket or other symbol): the reference's n_runs
     CellView c;
     GRL_DEV u64 operator()(u64 t) const { return (t == 0 || c.key(t) != c.key(t - 1) || c.sym(t) != c.sym(t - 1)) ? 1ull : 0ull; }
-};
-struct SegFromCellFn {  // induced cells (H, bucket-major) -> segments
-    CellView c; const u32 *u_to_p; const idx_t *nhb;
-    u32 *seg_sym; idx_t *seg_len;
-    GRL_DEV void operator()(u64 t) const {
-        u64 j = u_to_p[c.key(t)];                // pre-BWT (HOCC) run this bucket belongs to
-        u64 g = (u64)nhb[j] + t;
-        seg_sym[g] = c.sym(t);
-        seg_len[g] = c.len(t);
-    }
-};
-struct AtomCountIn {    // output atoms per segment: 1 + #(BWT_{r+1} run boundaries strictly inside its T interval)
-    const u32 *seg_sym; const idx_t *seg_len; const idx_t *Toff; const u64 *tw; const idx_t *tb; u32 take_code;
-    GRL_DEV idx_t operator()(u64 g) const {
-        if (seg_sym[g] != take_code) return 1;
-        u64 a = Toff[g], b = a + seg_len[g];
-        return (idx_t)(rank1(tw, tb, b) - rank1(tw, tb, a + 1) + 1);
-    }
-};
-struct AtomFn {
-    const u32 *seg_sym; const idx_t *seg_len; const idx_t *Toff; const idx_t *Tpos; const idx_t *abase; const u32 *term;
-    const u64 *tw; const idx_t *tb; const u64 *aw; const idx_t *ab;
-    u32 take_code;
-    u32 *osym; idx_t *olen;
-    GRL_DEV void operator()(u64 x) const {
-        u64 g = rank1(aw, ab, x + 1) - 1;        // segment owning atom x
-        if (seg_sym[g] != take_code) { osym[x] = seg_sym[g]; olen[x] = seg_len[g]; return; }
-        idx_t a = Toff[g], b = a + seg_len[g];
-        u64 kf = rank1(tw, tb, (u64)a + 1) - 1;  // run of BWT_{r+1} containing T position a
-        u64 k = kf + (x - abase[g]);
-        idx_t s = Tpos[k] > a ? Tpos[k] : a;
-        idx_t e = Tpos[k + 1] < b ? Tpos[k + 1] : b;
-        osym[x] = term[k];
-        olen[x] = e - s;
-    }
 };
 // ---- pass C without materialised segments --------------------------------------------------------------------
 // Output order = pre-BWT order with every HOCC run replaced by the cells of its buckets.  A "segment" is a non-HOCC
@@ -1316,10 +1241,6 @@ struct BigAtomsFn {       // one lane per atom of the queued segments
         if (e > sg.b) e = sg.b;
         em.put(sg.abase + x, term[k], e - s);
     }
-};
-struct UnpackCellFn {   // (sym<<32 | len) payload carried through the radix split
-    const u64 *v; u32 *ssym; idx_t *slen;
-    GRL_DEV void operator()(u64 t) const { u64 x = v[t]; ssym[t] = (u32)(x >> 32); slen[t] = (idx_t)(x & 0xFFFFFFFFull); }
 };
 
 // ------------------------------------------------------- a16: .rl_bwt image
@@ -1528,10 +1449,6 @@ struct OwnCompactFn {
         u64 k = key0[q];
         if (k >= lo && (!has_hi || k < hi)) { u32 i = ex[q]; ka[i] = k; va[i] = (u32)q; }
     }
-};
-struct LessIn {
-    const u64 *key0; u64 lo;
-    GRL_DEV u64 operator()(u64 q) const { return key0[q] < lo ? 1ull : 0ull; }
 };
 struct SampleKeysFn {
     const u64 *key0; u64 stride; u64 *out;
