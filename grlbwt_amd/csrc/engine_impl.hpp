@@ -461,16 +461,60 @@ struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: o
 // ------------------------------------------------ a6: dictionary suffix sort
 // Order: lexicographic with the phrase end comparing as +infinity (the sentinel
 // code is all-ones), equal suffixes of different phrases form one group.
-struct Key0Fn {        // first K symbols packed b bits each
+// The suffix made of just the LAST cell of a phrase that does not end a string forms, with its equals, a group that is
+// never valid (exact_par_phase.cpp:162: no pre-BWT entry, no rank) -- unless it is a whole one-cell phrase, whose value
+// is read from its group.  A quarter of all dictionary suffixes are of that kind (one per phrase): they are left out of
+// the sort, and so of the group stage, altogether.
+struct SufKeep {
+    const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
+    GRL_DEV bool operator()(u64 q) const {
+        const u32 k = dict_phr[q];
+        return !(q + 1 == (u64)ph_off[k + 1] && !ph_lastT[k] && q != (u64)ph_off[k]);
+    }
+};
+GRL_DEV u64 suffix_key0(const u32 *dict_sym, u64 q, u64 end, int K, int b) {     // first K symbols packed b bits each
+    const u64 sent = (1ull << b) - 1;
+    u64 key = 0;
+    for (int j = 0; j < K; j++) key = (key << b) | ((q + j < end) ? (u64)dict_sym[q + j] : sent);
+    return key;
+}
+struct Key0Fn {           // keys of ALL positions (sharded sort: the key decides the owner)
     const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off;
     int K, b;
-    u64 *keys; u32 *vals;
+    u64 *keys;
+    GRL_DEV void operator()(u64 q) const { keys[q] = suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b); }
+};
+struct PhraseDropIn {     // 1 for a phrase whose last-cell suffix is left out (one scan over the PHRASES then places every kept suffix)
+    const u32 *ph_off; const u8 *ph_lastT;
+    GRL_DEV u32 operator()(u64 k) const { return (!ph_lastT[k] && ph_off[k + 1] - ph_off[k] > 1) ? 1u : 0u; }
+};
+struct Key0KeepFn {       // (key, position) of the kept suffixes at position - (suffixes left out in front of the phrase)
+    SufKeep keep; const u32 *dropcnt; const u32 *dict_sym; int K, b; u64 *ka; u32 *va;
     GRL_DEV void operator()(u64 q) const {
-        u64 end = ph_off[dict_phr[q] + 1];
-        u64 sent = (1ull << b) - 1, key = 0;
-        for (int j = 0; j < K; j++) key = (key << b) | ((q + j < end) ? (u64)dict_sym[q + j] : sent);
-        keys[q] = key;
-        if (vals) vals[q] = (u32)q;
+        if (keep(q)) {
+            const u32 k = keep.dict_phr[q];
+            const u64 i = q - (u64)dropcnt[k];
+            ka[i] = suffix_key0(dict_sym, q, keep.ph_off[k + 1], K, b);
+            va[i] = (u32)q;
+        }
+    }
+};
+struct SortKeepIn {       // 1 for the suffixes this engine sorts: kept (SufKeep) and, with key ranges, inside mine
+    SufKeep keep; const u64 *key0; u64 lo, hi; bool has_hi;
+    GRL_DEV u32 operator()(u64 q) const {
+        bool mine = true;
+        if (key0) { const u64 k = key0[q]; mine = k >= lo && (!has_hi || k < hi); }
+        return (mine && keep(q)) ? 1u : 0u;
+    }
+};
+struct SortCompactFn {    // (key, position) of those, compacted
+    SortKeepIn in; const u32 *ex; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; int K, b; u64 *ka; u32 *va;
+    GRL_DEV void operator()(u64 q) const {
+        if (in(q)) {
+            const u32 i = ex[q];
+            ka[i] = in.key0 ? in.key0[q] : suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b);
+            va[i] = (u32)q;
+        }
     }
 };
 struct HeadFlagFn {       // hflag[t] = 1 where the sorted key changes
@@ -1439,17 +1483,6 @@ struct ListValFn {        // value of the i-th phrase of the lists I merged: thr
 // equal keys, so a group never spans two ranks and rank order = sorted order).  Positional ranks are
 // global slots (base of the rank + local slot); after every pass the ranks of the (re)sorted suffixes
 // are exchanged as (position, rank) pairs.
-struct OwnFlagIn {
-    const u64 *key0; u64 lo, hi; bool has_hi;
-    GRL_DEV u32 operator()(u64 q) const { u64 k = key0[q]; return (k >= lo && (!has_hi || k < hi)) ? 1u : 0u; }
-};
-struct OwnCompactFn {
-    const u64 *key0; const u32 *ex; u64 lo, hi; bool has_hi; u64 *ka; u32 *va;
-    GRL_DEV void operator()(u64 q) const {
-        u64 k = key0[q];
-        if (k >= lo && (!has_hi || k < hi)) { u32 i = ex[q]; ka[i] = k; va[i] = (u32)q; }
-    }
-};
 struct SampleKeysFn {
     const u64 *key0; u64 stride; u64 *out;
     GRL_DEV void operator()(u64 i) const { out[i] = key0[i * stride]; }
@@ -2265,27 +2298,37 @@ class Engine {
             // (GRLBWT_SEG_CAP: the tests lower the limit so that ordinary inputs take the large-group path too)
             static const u32 cap = getenv("GRLBWT_SEG_CAP") ? (u32)atoi(getenv("GRLBWT_SEG_CAP")) : kSegCap;
             DBuf<u64> ka;
-            if (!C) {
-                ka.alloc(S); perm.alloc(S);
-                prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, ka.p, perm.p}, "suffix_keys0");
-            } else {
-                DBuf<u64> key0(S);
-                prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, key0.p, nullptr}, "suffix_keys0");
-                // splitters: quantiles of a strided sample of the keys (identical on every rank: replicated data)
+            {
+                const SufKeep keep{dict_phr.p, ph_off, ph_lastT};
+                DBuf<u64> key0;
                 u64 lo = 0, hi = 0;
                 bool has_hi = false;
-                const u64 ns = S < 8192 ? S : 8192, stride = S / ns;
-                DBuf<u64> samp(ns);
-                prim::for_each(ns, SampleKeysFn{key0.p, stride, samp.p}, "dist.sample_keys");
-                std::vector<u64> hs = samp.to_host(ns);
-                std::sort(hs.begin(), hs.end());
-                if (C->rank > 0) lo = hs[(u64)C->rank * ns / C->size];
-                if (C->rank + 1 < C->size) { hi = hs[(u64)(C->rank + 1) * ns / C->size]; has_hi = true; }
-                if (has_hi && hi < lo) hi = lo;
-                DBuf<u32> oex(S + 1);
-                Sg = prim::exclusive_scan<u32>(S, OwnFlagIn{key0.p, lo, hi, has_hi}, oex.p, false, "dist.own_scan");
-                ka.alloc(Sg); perm.alloc(Sg);
-                prim::for_each(S, OwnCompactFn{key0.p, oex.p, lo, hi, has_hi, ka.p, perm.p}, "dist.own_compact");
+                if (C) {
+                    key0.alloc(S);
+                    prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, key0.p}, "suffix_keys0");
+                    // splitters: quantiles of a strided sample of the keys (identical on every rank: replicated data)
+                    const u64 ns = S < 8192 ? S : 8192, stride = S / ns;
+                    DBuf<u64> samp(ns);
+                    prim::for_each(ns, SampleKeysFn{key0.p, stride, samp.p}, "dist.sample_keys");
+                    std::vector<u64> hs = samp.to_host(ns);
+                    std::sort(hs.begin(), hs.end());
+                    if (C->rank > 0) lo = hs[(u64)C->rank * ns / C->size];
+                    if (C->rank + 1 < C->size) { hi = hs[(u64)(C->rank + 1) * ns / C->size]; has_hi = true; }
+                    if (has_hi && hi < lo) hi = lo;
+                }
+                if (!C) {
+                    DBuf<u32> dropcnt(D + 1);
+                    const u64 dropped = prim::exclusive_scan<u32>(D, PhraseDropIn{ph_off, ph_lastT}, dropcnt.p, true, "suffix_keep");
+                    Sg = S - dropped;
+                    ka.alloc(Sg); perm.alloc(Sg);
+                    prim::for_each(S, Key0KeepFn{keep, dropcnt.p, dict_sym.p, K, b, ka.p, perm.p}, "suffix_keys0");
+                } else {
+                    const SortKeepIn in{keep, key0.p, lo, hi, has_hi};
+                    DBuf<u32> oex(S + 1);
+                    Sg = prim::exclusive_scan<u32>(S, in, oex.p, false, "suffix_keep");
+                    ka.alloc(Sg); perm.alloc(Sg);
+                    prim::for_each(S, SortCompactFn{in, oex.p, dict_sym.p, dict_phr.p, ph_off, K, b, ka.p, perm.p}, "suffix_keys0");
+                }
             }
             gid.alloc(Sg); gstart.alloc(Sg + 1);
             DBuf<u8> hflag(Sg), uflag(Sg);
