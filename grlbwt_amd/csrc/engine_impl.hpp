@@ -420,8 +420,8 @@ struct LenIn {
     GRL_DEV u32 operator()(u64 i) const { return l[i]; }
 };
 GRL_HD u64 rank1(const u64 *words, const idx_t *base, u64 x);      // (defined with the rank bit-vectors below)
-template <class cell_t, bool FIRST>
-struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: one phrase lookup, then a forward walk
+template <class cell_t, bool FIRST, int PER = 4>
+struct DictBuildFn {      // one lane per PER consecutive dictionary positions: one phrase lookup, then a forward walk
     const cell_t *t;
     CellOps<cell_t, FIRST> ops;
     const u32 *ph_off; u64 D; u64 S; const u64 *ph_pos;
@@ -429,14 +429,14 @@ struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: o
     const u64 *pw; const idx_t *pb;      // rank bit-vector of the phrase starts over the dictionary positions (nullptr: binary search)
     struct alignas(16) Quad { u32 v[4]; };
     GRL_DEV void operator()(u64 c) const {
-        u64 q0 = c * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
+        u64 q0 = c * PER, q1 = q0 + PER < S ? q0 + PER : S;
         // the phrase holding position q0: two loads through the bit-vector (a binary search over the phrase offsets was
         // 27 dependent probes per lane)
         u64 k = pw ? rank1(pw, pb, q0 + 1) - 1 : upper_bound<u32>(ph_off, D, (u32)q0) - 1;
         u64 nxt = ph_off[k + 1];
-        u32 phr[16], sym[16];
+        u32 phr[PER], sym[PER];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < PER; j++) {
             u64 q = q0 + j;
             if (q < q1) {
                 while (q >= nxt) { k++; nxt = ph_off[k + 1]; }
@@ -444,15 +444,15 @@ struct DictBuildFn {      // one lane per 16 consecutive dictionary positions: o
                 sym[j] = ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
             }
         }
-        if (q1 - q0 == 16) {      // 16-byte stores: a quarter of the store requests of 16 scalar stores per array
+        if (q1 - q0 == PER) {     // 16-byte stores: a quarter of the store requests of scalar stores per array
 #pragma unroll
-            for (int j = 0; j < 16; j += 4) {
+            for (int j = 0; j < PER; j += 4) {
                 *reinterpret_cast<Quad *>(dict_phr + q0 + j) = Quad{{phr[j], phr[j + 1], phr[j + 2], phr[j + 3]}};
                 *reinterpret_cast<Quad *>(dict_sym + q0 + j) = Quad{{sym[j], sym[j + 1], sym[j + 2], sym[j + 3]}};
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; j++)
+            for (int j = 0; j < PER; j++)
                 if (q0 + j < q1) { dict_phr[q0 + j] = phr[j]; dict_sym[q0 + j] = sym[j]; }
         }
     }
@@ -681,6 +681,8 @@ struct GroupAccumSmallFn {
         u32 t0 = gstart[g], t1 = gstart[g + 1];
         if (t1 - t0 > kGroupChunk) return;
         u32 mn = 0xFFFFFFFFu, mx = 0, first = 0; idx_t acc = 0; u8 fl = 0;
+        // (four members per iteration with their gathers issued together was measured slower: 59 vs 56 ms at 10 GB -- the
+        // average group has 2.2 members, the padding gathers cost more than the overlap gives)
         for (u32 j = t0; j < t1; j++) {
             const u32 q = perm[j];
             SufRec r = rec[q];
@@ -2279,7 +2281,8 @@ class Engine {
         {
             StageTimer st(&tm.dict_sort);
             build_rankbits32(pbits, ph_off, D, S + 1, "dict_build");
-            prim::for_each((S + 15) / 16, DictBuildFn<cell_t, FIRST>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p}, "dict_build");
+            // (4 positions per lane: 16 per lane, four phrases walked one after the other, was latency-bound -- 42 ms at 10 GB)
+            prim::for_each((S + 3) / 4, DictBuildFn<cell_t, FIRST, 4>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p}, "dict_build");
         }
         // ---- a6: sort all phrase suffixes (radix on the first K symbols + refinement by symbol extension) ----------
         u64 Sg = S;                              // my slots of the sorted order (all of them without a communicator)
