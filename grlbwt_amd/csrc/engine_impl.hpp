@@ -678,12 +678,14 @@ struct GroupAccumSmallFn {
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag; u32 *pslot;
     GRL_DEV void operator()(u64 g) const {
-        u32 t0 = gstart[g], t1 = gstart[g + 1];
-        if (t1 - t0 > kGroupChunk) return;
+        const u32 t0 = gstart[g], t1 = gstart[g + 1];
+        const bool large = t1 - t0 > kGroupChunk;   // folded by GroupAccumLargeFn with atomics: start from the identities
         u32 mn = 0xFFFFFFFFu, mx = 0, first = 0; idx_t acc = 0; u8 fl = 0;
-        // (four members per iteration with their gathers issued together was measured slower: 59 vs 56 ms at 10 GB -- the
-        // average group has 2.2 members, the padding gathers cost more than the overlap gives)
-        for (u32 j = t0; j < t1; j++) {
+        // (one exit, no early return: see the note in find_or_insert.  Four members per iteration with their gathers issued
+        // together was measured slower: 59 vs 56 ms at 10 GB -- the average group has 2.2 members, the padding gathers cost
+        // more than the overlap gives)
+        const u32 te = large ? t0 : t1;
+        for (u32 j = t0; j < te; j++) {
             const u32 q = perm[j];
             SufRec r = rec[q];
             if (j == t0) first = r.left;
@@ -693,10 +695,12 @@ struct GroupAccumSmallFn {
             if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = (u32)g; } // a whole phrase: the group its metasymbol will be read from
         }
         gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
-        // the group decision (GroupDecideFn) from what is already in registers
-        bool valid = !(first & kRecFinal) || (first & kRecLastT);     // exact_par_phase.cpp:162
-        bool ranked = valid && (mn != mx || fl);                       // :187
-        gflag[g] = (valid ? 1 : 0) | (ranked ? 2 : 0) | (t1 - t0 > 1 ? 4 : 0);
+        if (!large) {
+            // the group decision (GroupDecideFn) from what is already in registers
+            bool valid = !(first & kRecFinal) || (first & kRecLastT);     // exact_par_phase.cpp:162
+            bool ranked = valid && (mn != mx || fl);                       // :187
+            gflag[g] = (valid ? 1 : 0) | (ranked ? 2 : 0) | (t1 - t0 > 1 ? 4 : 0);
+        }
     }
 };
 struct GroupChunksIn {    // chunks of a group above kGroupChunk members (0 for the others)
@@ -2405,9 +2409,8 @@ class Engine {
         u64 M, P0;
         {
             StageTimer st(&tm.dict_groups);
-            gmin.fill_ff(); gmax.zero(); gacc.zero(); gfull.zero();
             pslot.alloc(D);
-            pslot.fill_ff();
+            if (C) pslot.fill_ff();              // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
             {
                 DBuf<SufRec> rec(S);
                 prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
