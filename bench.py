@@ -427,6 +427,23 @@ def main():
             nsteps = args.warmup + args.steps + 1
             out["collectives_per_step"] = {"allgather": comm.n_allgather // nsteps, "alltoallv": comm.n_alltoall // nsteps,
                                            "bytes": comm.bytes_moved // nsteps, "ms_in_callbacks": round(comm.seconds / nsteps * 1e3, 3)}
+            # the sharded result against a single-GPU build of the WHOLE collection on this rank (outside the timed region;
+            # the other ranks wait at the final barrier): the .rl_bwt images must be the same bytes
+            if os.environ.get("GRLBWT_BENCH_VERIFY", "1") != "0":
+                try:
+                    nb, _ = ctx.result_size()
+                    mine = gdist._view(ctx.result_device_ptr(), nb, dev)
+                    full = make_text(args.workload, args.reads, args.read_len, 0, args.reads)
+                    torch.cuda.synchronize()          # (torch's stream wrote the text; the engine has its own)
+                    with engine.Context(local_rank, flags, lib) as c2:
+                        c2.attach_device(full.data_ptr(), full.numel(), 1, keepalive=full)
+                        c2.build()
+                        nb2, _ = c2.result_size()
+                        ref = gdist._view(c2.result_device_ptr(), nb2, dev)
+                        out["sharded_image_equals_single_gpu"] = bool(nb == nb2 and torch.equal(mine, ref))
+                    del full
+                except Exception as e:        # (memory on a smaller device, ...): reported, never fatal for the measurement
+                    out["sharded_image_equals_single_gpu"] = "not checked: %r" % (e,)
     try:
         ctx.close()
     except Exception:

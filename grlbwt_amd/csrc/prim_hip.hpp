@@ -336,12 +336,19 @@ inline void pool_reserve(size_t bytes) {
     if (pool_disabled()) return;
     Pool &P = pool();
     if (arena_create(P)) return;                     // the arena grows with the build: nothing to reserve
-    for (auto &sl : P.slabs) if (sl.base && sl.size >= bytes) return;
+    size_t largest = 0;
+    for (auto &sl : P.slabs) if (sl.base && sl.size > largest) largest = sl.size;
+    if (largest >= bytes) return;
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
-    size_t cap = fr > ((size_t)4 << 30) ? fr - ((size_t)2 << 30) : fr / 2;
+    // (24 GB stay with the host framework -- its own tensors, a second context; a cap at 60 % of the free memory was
+    // measured to cost 3.4x on the 10 GB build: it then outgrew the slab and paid for further hipMallocs in every step)
+    size_t cap = fr > ((size_t)64 << 30) ? fr - ((size_t)24 << 30) : (fr > ((size_t)4 << 30) ? fr - ((size_t)2 << 30) : fr / 2);
     if (bytes > cap) bytes = cap;
-    if (bytes < ((size_t)1 << 30)) return;          // the doubling schedule covers small builds
+    if (bytes > ((size_t)128 << 30)) bytes = (size_t)128 << 30;     // hipMalloc is instant up to 128 GB and takes seconds to minutes above (tools/alloc_probe.hip)
+    if (bytes < ((size_t)1 << 30) || bytes <= largest) return;      // the doubling schedule covers small builds; a second, smaller
+                                                                    // reservation next to the first helps nobody (and cost a hipFree +
+                                                                    // hipMalloc of tens of GB in EVERY build when it was tried)
     pool_trim();                                     // give idle slabs back first
     void *base = nullptr;
     if (hipMalloc(&base, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
