@@ -422,6 +422,9 @@ def main():
             "kernel_ms_total": round(total_kernel_ms, 3),
             "device_memory": {"peak_live_bytes": mem["peak_live_bytes"], "reserved_bytes": mem["reserved_bytes"]},
             "idx_bytes": cnt["idx_bytes"], "extra_configs1_101MB": extra,
+            # per-GPU view of the same run (the collection is fixed, so this is NOT a weak-scaling measurement: a rank's work
+            # includes the replicated parts of the dictionary stage, which do not shrink with N)
+            "per_gpu": {"shard_bytes_rank0": n_bytes, "value_per_gpu": round(value / world, 3)},
         }
         if comm is not None:     # totals over warmup + timed + profile steps on rank 0
             nsteps = args.warmup + args.steps + 1
