@@ -2193,12 +2193,28 @@ class Engine {
             if (!stream_ordered) prim::sync();
             if (ag(user, send, recv, bytes) != 0) throw prim::Error(-5, "allgather callback failed");
         }
+        // A failure that only this rank can have (its phrase table overflows, its device runs out of memory, an internal
+        // check fails) must not leave the others waiting in the next exchange: the local code records it here (fail()) and
+        // carries on to the next counter exchange with harmless values; every counter exchange carries the flag, and every
+        // rank raises there.
+        mutable int pending = 0;
+        mutable std::string pending_msg;
+        void fail(const prim::Error &e) const { if (!pending) { pending = e.code ? e.code : -71; pending_msg = e.what(); } }
         std::vector<u64> allgather_u64(const std::vector<u64> &mine) const {
-            u64 c = mine.size();
-            DBuf<u64> s(c), r(c * size);
-            prim::h2d(s.p, mine.data(), c * 8);
-            allgather(s.p, r.p, c * 8);
-            return r.to_host(c * size);
+            const u64 c = mine.size(), w = c + 1;
+            std::vector<u64> m2(mine);
+            m2.push_back((u64)(u32)(-pending));
+            DBuf<u64> s(w), r(w * size);
+            prim::h2d(s.p, m2.data(), w * 8);
+            allgather(s.p, r.p, w * 8);
+            std::vector<u64> all = r.to_host(w * size), out(c * size);
+            for (int g = 0; g < size; g++) {
+                if (all[g * w + c])
+                    throw prim::Error(-(int)all[g * w + c], g == rank ? pending_msg : "rank " + std::to_string(g) + " failed (error " +
+                                                                                       std::to_string(-(long long)all[g * w + c]) + ")");
+                for (u64 i = 0; i < c; i++) out[g * c + i] = all[g * w + i];
+            }
+            return out;
         }
         // counts in elements of `elem` bytes; send blocks packed in destination order, receive blocks in source order.
         // `max_block` = the largest block of the whole exchange in elements (all ranks pass the same value: they hold the
@@ -2895,10 +2911,9 @@ class Engine {
             StageTimer st(&tm.hash);
             DBuf<u32> slen, scells;
             DBuf<u64> sfreq;
-            std::vector<u64> mine(2 * (u64)N + 3, 0);
-            // A failure that only this shard can have (phrase table overflow, a parse beyond the supported range) must not leave
-            // the other ranks waiting in the exchange below: the verdict travels with the counts and every rank raises.
-            std::string local_err;
+            std::vector<u64> mine(2 * (u64)N + 2, 0);
+            // (a failure only this shard can have -- phrase table overflow, a parse beyond the supported range -- travels with the
+            // counts: Comm::fail)
             try {
                 // (GRLBWT_TEST_FAIL_RANK=<rank>: the tests make one rank fail here)
                 if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK")) if (atoi(fr) == me) throw prim::Error(-28, "phrase hash table overflow (injected by the test)");
@@ -2927,17 +2942,12 @@ class Engine {
                 for (int d = 0; d < N; d++) { pc[d] = bh[2 * (d + 1)] - bh[2 * d]; cc[d] = bh[2 * (d + 1) + 1] - bh[2 * d + 1]; mine[d] = pc[d]; mine[N + d] = cc[d]; }
                 mine[2 * N] = P.n_occ; mine[2 * N + 1] = n;
             } catch (const prim::Error &e) {
-                local_err = e.what();
+                C.fail(e);
                 std::fill(mine.begin(), mine.end(), 0);
                 std::fill(pc.begin(), pc.end(), 0); std::fill(cc.begin(), cc.end(), 0);
-                mine[2 * N + 2] = (u64)(u32)(-e.code);
             }
             const u64 w = mine.size();
             std::vector<u64> mat = C.allgather_u64(mine);
-            for (int g = 0; g < N; g++)
-                if (mat[g * w + 2 * N + 2])
-                    throw prim::Error(-(int)mat[g * w + 2 * N + 2], g == me ? local_err : "rank " + std::to_string(g) + " failed in its parsing round (error " +
-                                                                                              std::to_string(-(long long)mat[g * w + 2 * N + 2]) + ")");
             u64 maxc = 0;
             for (int g = 0; g < N; g++) {
                 rpc[g] = mat[g * w + me]; rcc[g] = mat[g * w + N + me];
@@ -3069,14 +3079,17 @@ class Engine {
         LevelInfo &I = linfo[r];
         I.R_next = R; I.P = P;
         // (1) one cell layout for all shards, then passes A+B over my slice (the single-GPU kernels)
+        // (local failures -- out of memory, an internal check -- are recorded with C.fail and travel with the next counter
+        // exchange, where every rank raises: nobody is left waiting for a rank that gave up)
         DBuf<idx_t> Tpos(R + 1);
-        u64 Tlocal, maxrun = 0, Toff = 0, Ttotal = 0;
+        u64 Tlocal = 0, maxrun = 0, Toff = 0, Ttotal = 0;
         {
-            StageTimer st(&tm.ind_expand);
-            Tlocal = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "dist.Tpos");
-        }
-        {
-            const u64 mr = level_maxrun();
+            u64 mr = 0;
+            try {
+                StageTimer st(&tm.ind_expand);
+                Tlocal = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "dist.Tpos");
+                mr = level_maxrun();
+            } catch (const prim::Error &e) { C.fail(e); Tlocal = 0; mr = 0; }
             std::vector<u64> g1 = C.allgather_u64({mr, Tlocal});
             for (int g = 0; g < N; g++) {
                 if (g1[2 * g] > maxrun) maxrun = g1[2 * g];
@@ -3085,16 +3098,19 @@ class Engine {
             }
         }
         DBuf<u32> term(R);
-        int kb, lb;
-        u64 E = expand_split(L, term, maxrun, kb, lb);
-        I.E = E;
+        int kb = 1, lb = 1;
+        u64 E = 0;
         u32 p0, p1, u0, u1;
-        u64 n_out, n_r;
-        {
+        u64 n_out, n_r = 0;
+        std::vector<u64> sp, cbh, v(2 * (u64)N, 0);
+        DBuf<u64> split(4 * ((u64)N + 1));
+        try {
+            // (GRLBWT_TEST_FAIL_RANK_INDUCE=<rank>: the tests make one rank fail here)
+            if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_INDUCE")) if (atoi(fr) == me) throw prim::Error(-12, "out of device memory (injected by the test)");
+            E = expand_split(L, term, maxrun, kb, lb);
+            I.E = E;
             StageTimer st(&tm.ind_assemble);
             // (2) owners of the output: pre-BWT run ranges of about n_r / size symbols, and the buckets inside them
-            std::vector<u64> sp;
-            DBuf<u64> split(4 * ((u64)N + 1));
             {
                 DBuf<idx_t> Ppos(P + 1);
                 DBuf<HoccBwt> PHB(P + 1);
@@ -3105,7 +3121,6 @@ class Engine {
                 sp = split.to_host(4 * ((u64)N + 1));
             }
             // my cells and my TAKE symbols per owner
-            std::vector<u64> cbh, v(2 * (u64)N, 0);
             {
                 const CellView mine = cell_view(kb, lb);
                 DBuf<u64> cb((u64)N + 1);
@@ -3117,6 +3132,9 @@ class Engine {
                     v[N + d] = cnt ? prim::reduce_sum<u64>(cnt, CellTakeOffIn{mine, take_code, cbh[d]}, "dist.take_sums") : 0;
                 }
             }
+        } catch (const prim::Error &e) { C.fail(e); std::fill(v.begin(), v.end(), 0); }
+        {
+            StageTimer st(&tm.ind_assemble);
             std::vector<u64> mat = C.allgather_u64(v);           // mat[s*2N + d] cells, mat[s*2N + N + d] TAKE symbols of rank s for owner d
             // symbols of the rewritten BWT_{r+1} consumed in front of every owner's piece (output order = consumption order)
             std::vector<u64> Tc((u64)N + 1);
@@ -3140,17 +3158,23 @@ class Engine {
                     ab[2 * d + 1] = hi < Tlocal ? hi : Tlocal;
                 }
                 DBuf<u64> abd(2 * (u64)N), kc(2 * (u64)N), sod((u64)N + 1);
-                prim::h2d(abd.p, ab.data(), 2 * (u64)N * 8);
-                prim::for_each((u64)N, WindowRunsFn{Tpos.p, R, abd.p, kc.p}, "dist.window_runs");
-                std::vector<u64> kch = kc.to_host(2 * (u64)N);
-                for (int d = 0; d < N; d++) { scnt[d] = kch[2 * d + 1]; soff[d + 1] = soff[d] + scnt[d]; }
+                try {
+                    prim::h2d(abd.p, ab.data(), 2 * (u64)N * 8);
+                    prim::for_each((u64)N, WindowRunsFn{Tpos.p, R, abd.p, kc.p}, "dist.window_runs");
+                    std::vector<u64> kch = kc.to_host(2 * (u64)N);
+                    for (int d = 0; d < N; d++) { scnt[d] = kch[2 * d + 1]; soff[d + 1] = soff[d] + scnt[d]; }
+                } catch (const prim::Error &e) { C.fail(e); std::fill(scnt.begin(), scnt.end(), 0); std::fill(soff.begin(), soff.end(), 0); }
                 std::vector<u64> rc = C.allgather_u64(scnt);     // rc[s*N + d]
                 for (int g = 0; g < N; g++) { rcnt[g] = rc[(u64)g * N + me]; Rw += rcnt[g]; }
                 const u64 maxw = *std::max_element(rc.begin(), rc.end());
-                DBuf<u32> ssym(soff[N]); DBuf<idx_t> slen(soff[N]);
-                prim::h2d(sod.p, soff.data(), ((u64)N + 1) * 8);
-                prim::for_each(soff[N], WindowSendFn{Tpos.p, term.p, abd.p, kc.p, sod.p, N, ssym.p, slen.p}, "dist.window_send");
-                wsym.alloc(Rw); wlen.alloc(Rw);
+                DBuf<u32> ssym; DBuf<idx_t> slen;
+                try {
+                    ssym.alloc(soff[N]); slen.alloc(soff[N]);
+                    prim::h2d(sod.p, soff.data(), ((u64)N + 1) * 8);
+                    prim::for_each(soff[N], WindowSendFn{Tpos.p, term.p, abd.p, kc.p, sod.p, N, ssym.p, slen.p}, "dist.window_send");
+                    wsym.alloc(Rw); wlen.alloc(Rw);
+                } catch (const prim::Error &e) { C.fail(e); }
+                C.allgather_u64({});                             // (nothing but the failure flag: the bulk exchanges below have no way back)
                 C.alltoall(ssym.p, scnt, wsym.p, rcnt, sizeof(u32), maxw);
                 C.alltoall(slen.p, scnt, wlen.p, rcnt, sizeof(idx_t), maxw);
             }
@@ -3210,18 +3234,25 @@ class Engine {
             term = std::move(wsym);
         }
         // (5) pass C on my piece (the single-GPU kernels)
-        if (n_out == 0) {
-            if (E || bwt.R) throw prim::Error(-71, "dist induction: cells or BWT_{r+1} symbols for an empty piece (level " + std::to_string(r) + ")");
+        try {
+            if (n_out == 0) {
+                if (E || bwt.R) throw prim::Error(-71, "dist induction: cells or BWT_{r+1} symbols for an empty piece (level " + std::to_string(r) + ")");
+                release_cells();
+                bwt = Runs();
+                bwt.sym.alloc(0); bwt.len.alloc(0);
+            } else {
+                const u64 Pm = p1 - p0, Mm = u1 - u0;
+                DBuf<u32> u2p(Mm), p2u(Pm);
+                prim::for_each(Mm, RebaseFn{L.u_to_p.p + u0, p0, u2p.p}, "dist.piece_maps");
+                if (L.p_to_u.p) prim::for_each(Pm, RebaseFn{L.p_to_u.p + p0, u0, p2u.p}, "dist.piece_maps");
+                else prim::for_each(Pm, PieceMetaFn{L.u_to_p.p, M, p0, u0, p2u.p}, "dist.piece_maps");
+                assemble(AsmIn{L.prebwt.sym.p + p0, L.prebwt.len.p + p0, Pm, u2p.p, p2u.p, Mm, L.sigma, n_out}, I, cell_view(kb, lb, u0), E, term, r);
+            }
+        } catch (const prim::Error &e) {          // the next counter exchange (next level, or the image assembly) raises on every rank
+            C.fail(e);
             release_cells();
             bwt = Runs();
             bwt.sym.alloc(0); bwt.len.alloc(0);
-        } else {
-            const u64 Pm = p1 - p0, Mm = u1 - u0;
-            DBuf<u32> u2p(Mm), p2u(Pm);
-            prim::for_each(Mm, RebaseFn{L.u_to_p.p + u0, p0, u2p.p}, "dist.piece_maps");
-            if (L.p_to_u.p) prim::for_each(Pm, RebaseFn{L.p_to_u.p + p0, u0, p2u.p}, "dist.piece_maps");
-            else prim::for_each(Pm, PieceMetaFn{L.u_to_p.p, M, p0, u0, p2u.p}, "dist.piece_maps");
-            assemble(AsmIn{L.prebwt.sym.p + p0, L.prebwt.len.p + p0, Pm, u2p.p, p2u.p, Mm, L.sigma, n_out}, I, cell_view(kb, lb, u0), E, term, r);
         }
         bwt_level = r;
         I.R = bwt.R; I.n = n_r;

@@ -107,6 +107,11 @@ def test_local_failure_inside_a_round_fails_on_every_rank(sim, tmp_path, monkeyp
     monkeypatch.setenv("GRLBWT_TEST_FAIL_RANK", "1")
     _run(3, sim, "injected", tmp_path, 29595)
     assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -28"] * 3
+    # ... and inside an induction level (rank 2 "runs out of memory" in its passes A+B)
+    monkeypatch.delenv("GRLBWT_TEST_FAIL_RANK")
+    monkeypatch.setenv("GRLBWT_TEST_FAIL_RANK_INDUCE", "2")
+    _run(3, sim, "injected", tmp_path, 29596)
+    assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -12"] * 3
 
 
 def test_fewer_strings_than_ranks_is_rejected():
