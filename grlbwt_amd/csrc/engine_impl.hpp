@@ -2464,7 +2464,6 @@ class Engine {
                 plen0 = C->template allgather_v<idx_t>(plen0.p, P0l, bbP, true);
                 pu0 = C->template allgather_v<u32>(pu0.p, P0l, bbP, true);
                 L.has_hocc = C->template allgather_v<u8>(L.has_hocc.p, Ml, bbM, true);
-                repq = C->template allgather_v<u32>(repq.p, Ml, bbM, true);
                 u_to_p0 = C->template allgather_v<u32>(u_to_p0.p, Ml, bbM, true);
             }
             DBuf<u32> merged(P0);
@@ -2490,7 +2489,13 @@ class Engine {
                     DBuf<u64> all = C->template allgather_v<u64>(mp.p, nm, bb);
                     prim::for_each(bb[C->size], ApplyPairsFn{all.p, meta.p}, "grammar_marks");
                 }
-                prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_lastT, meta.p, pbits.words.p, S, MD, L.g0.p, L.g1.p}, "grammar");
+                if (!C) prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_lastT, meta.p, pbits.words.p, S, MD, L.g0.p, L.g1.p}, "grammar");
+                else {                           // every rank walks for its own metasymbols; the cells are all-gathered
+                    DBuf<u32> g0l(Ml), g1l(Ml);
+                    prim::for_each(Ml, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_lastT, meta.p, pbits.words.p, S, MD, g0l.p, g1l.p}, "grammar");
+                    C->template allgather_v<u32>(g0l.p, Ml, bbM, true, L.g0.p);
+                    C->template allgather_v<u32>(g1l.p, Ml, bbM, true, L.g1.p);
+                }
             }
             // ---- a9: metasymbol of every phrase --------------------------------
             phrase_val.alloc(D);
