@@ -64,6 +64,15 @@ def test_stagewise_tokens_u16(hip, oracle_mod):
     parity.check_stagewise(hip, workloads.zipf_tokens(400000, doc_len=500, vocab=20000).tobytes(), 2)
 
 
+@pytest.mark.parametrize("layout", ["packed", "separate"])
+def test_wider_cell_layouts(hip, oracle_mod, monkeypatch, layout):
+    """The induced-cell layouts for levels whose bucket + run length + symbol exceed 64 bits (bucket array + packed payload,
+    or three arrays), forced on ordinary inputs: the HIP kernels of those branches against the oracle, stage by stage."""
+    monkeypatch.setenv("GRLBWT_CELL_LAYOUT", layout)
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+
+
 def test_stagewise_idx64(hip, oracle_mod):
     parity.check_stagewise(hip, workloads.sampled_reads(5000, 80, 30000, seed=2).tobytes(), 1, engine.FLAG_FORCE_IDX64)
 
