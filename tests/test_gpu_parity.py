@@ -73,6 +73,14 @@ def test_wider_cell_layouts(hip, oracle_mod, monkeypatch, layout):
     parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
+def test_unfused_expansion_branch(hip, oracle_mod, monkeypatch):
+    """The count + scan + expand + split fallback of passes A+B (taken when a run drops more cells than the fused kernel
+    stages): the limit is lowered so that ordinary inputs take it on the device."""
+    monkeypatch.setenv("GRLBWT_XS_MAXC", "1")
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1, engine.FLAG_FORCE_IDX64)
+
+
 def test_stagewise_idx64(hip, oracle_mod):
     parity.check_stagewise(hip, workloads.sampled_reads(5000, 80, 30000, seed=2).tobytes(), 1, engine.FLAG_FORCE_IDX64)
 
