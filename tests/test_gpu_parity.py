@@ -110,14 +110,14 @@ def test_long_equal_runs_and_long_phrases(hip, oracle_mod):
     parity.check_final(hip, data, 1)
 
 
-@pytest.mark.parametrize("w", [1, 2, 4])
+@pytest.mark.parametrize("w", [1, 2, 4, 8])
 def test_equal_runs_across_word_and_tile_boundaries(hip, oracle_mod, w):
     # run-length structured strings: runs of 1..200 equal symbols end on every offset modulo 64 (the word of the
     # start-bit kernel) and modulo its LDS tile, with descents into and ascents out of the runs, plus runs that
     # reach the end of a string
     rng = np.random.default_rng(77 + w)
-    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[w]
-    sep, hi = 1, {1: 6, 2: 300, 4: 70000}[w]
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[w]
+    sep, hi = 1, {1: 6, 2: 300, 4: 70000, 8: 90000}[w]
     pieces = []
     for _ in range(40):
         syms = rng.integers(2, hi, size=400)
