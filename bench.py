@@ -73,6 +73,19 @@ def induction_bytes(rounds, levels, r, run_len_bytes=1):
     return ab, c
 
 
+def dict_bytes(rounds, levels):
+    """dictionary stage (outside SURVEY 8(d)'s pricing): per round every dictionary suffix as a
+    (key, position) record read and written ONCE -- S_r * (8 + 4) * 2 -- + the grammar written, 2 * c_r * M_r, + the
+    pre-BWT written, P_r * (sbP + fbP), in the reference's cell widths."""
+    tot = 0
+    for r, rd in enumerate(rounds):
+        sigma3 = rd["sigma"] + 3
+        c_r = cdiv8(bitlen(sigma3 + rd["n_metasyms"] + 1))
+        sbP, fbP = cdiv8(bitlen(sigma3)), cdiv8(bitlen(rd["n_in"]))
+        tot += rd["dict_syms"] * 12 * 2 + 2 * c_r * rd["n_metasyms"] + levels[r]["prebwt_runs"] * (sbP + fbP)
+    return tot
+
+
 def parse_bytes(rounds, cell_bytes):
     """classify+hash pass: n_r*w_r read; lookup-emit pass: n_r*w_r read + n_{r+1}*w_{r+1} written (w = 4 above level 0)."""
     hash_b = emit_b = 0
@@ -84,11 +97,18 @@ def parse_bytes(rounds, cell_bytes):
 
 
 # launch sites (prim::prof names, "#<phase><level>" stripped) of each accounting group
+def _is_hash_emit(s):
+    return s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases", "slot_values", "emit_parse",
+                 "hash_prepare", "hash_lookup")
+
+
 GROUP_SITES = {
     "induce_AB": lambda s, ph: ph == "i" and (s == "induce" or s.startswith("induce_") or s.startswith("induce.")),
     "induce_C": lambda s, ph: ph == "i" and (s.startswith("asm.") or s.startswith("merge_runs")),
-    "hash_emit": lambda s, ph: ph == "p" and s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases",
-                                                    "slot_values", "emit_parse", "hash_prepare", "hash_lookup"),
+    "hash_emit": lambda s, ph: ph == "p" and _is_hash_emit(s),
+    # everything else of a parsing round: dictionary compaction and build, suffix sort + refinement, groups -> pre-BWT and
+    # ranks, grammar (reference: dictionary ctor, suffix_induction, produce_pre_bwt, produce_grammar -- rows a5-a9)
+    "dict_stage": lambda s, ph: ph == "p" and not _is_hash_emit(s),
 }
 # rocprofv3 kernel-name fragments of the kernels a group launches (PMC traffic lookup)
 GROUP_KERNELS = {
@@ -96,6 +116,9 @@ GROUP_KERNELS = {
     "induce_C": ["TakeScanEmitFn", "CellTakeIn", "PrePlaceFn", "BucketEdgesFn", "BucketSizeIn", "CellAtomsFn", "PreAtomsFn", "BigAtomsFn",
                  "BigCountIn", "AtomHeadLenIn", "PreScanIn", "NotCodeIn"],
     "hash_emit": ["HashInsertFn", "k_start_bits", "MapFn", "ScatterValFn"],
+    "dict_stage": ["ClaimCompactFn", "DictBuildFn", "Key0KeepFn", "unsigned int, 0>", "k_rs_hist<unsigned long, 0>", "HeadFlagFn", "FirstUnresolvedFn",
+                   "ExtKeyFn", "SegStartFn", "SegSortSmallFn", "SegBig", "GroupStartsFn", "DenseGidFn", "SuffixRecFn", "GroupAccum", "GroupDecideFn",
+                   "GroupEmitFn", "PackGroupInfoFn", "MetaPosFn", "GrammarFn", "PhraseValFn", "ComposeMapFn", "PreToMetaFn", "BuildBits32Fn"],
 }
 
 
@@ -158,6 +181,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=400000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 101 MB configs[1] side measurement")
+    ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end leg through the grlbwt executable (file in -> .rl_bwt file closed)")
     args = ap.parse_args()
     if args.reads is None:
         args.reads = 66225166 if args.workload == "illumina" else 1000000
@@ -261,6 +285,14 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total_bytes * args.steps / dt / 1e6
 
+    # the image the timed steps produced (outside the timed region): size, runs, md5 -- so that a driver run and a lease run
+    # can be compared, and tests/test_gpu_parity.py::test_headline_10GB_round_trip decodes exactly this image
+    image = None
+    if rank == 0 and os.environ.get("GRLBWT_BENCH_MD5", "1") != "0":
+        from grlbwt_amd import dist as _gd
+        nb_img, nr_img = ctx.result_size()
+        image = {"bytes": nb_img, "runs": nr_img, "md5": workloads.md5_device(_gd._view(ctx.result_device_ptr(), nb_img, dev))}
+
     # ---- roofline leg: one more step with HIP-event timing of every kernel on the engine's stream.
     # Every rank takes the step (for N > 1 it contains collectives); only rank 0 records and reports.
     if rank == 0:
@@ -309,7 +341,7 @@ def main():
                 c_bytes += cb
                 per_level.append({"level": r, "AB_bytes": ab, "C_bytes": cb})
         hash_b, emit_b = parse_bytes(rounds, 1)
-        gbytes = {"induce_AB": ab_bytes, "induce_C": c_bytes, "hash_emit": hash_b + emit_b}
+        gbytes = {"induce_AB": ab_bytes, "induce_C": c_bytes, "hash_emit": hash_b + emit_b, "dict_stage": dict_bytes(rounds, levels)}
         total_kernel_ms = sum(ms for _, ms, _ in prof_detail.values())
 
         def group_obj(gname):
@@ -370,8 +402,15 @@ def main():
             step1()
         torch.cuda.synchronize()
         d1 = (time.perf_counter() - t0) / 10
+        c1.profile_enable(True)                  # one more build with per-launch events: kernel time vs wall, launches, host waits
+        step1()
+        p1 = c1.profile()
+        syncs1 = p1.pop("@host_sync", (0, 0.0, 0))[0]
+        c1.profile_enable(False)
         extra = {"workload": "1000000 x 100 bp uniform ACGT reads (101000000 bytes), BASELINE configs[1]",
-                 "ms_per_step": round(d1 * 1e3, 3), "value_MBps": round(101.0 / d1, 1), "steps": 10}
+                 "ms_per_step": round(d1 * 1e3, 3), "value_MBps": round(101.0 / d1, 1), "steps": 10,
+                 "kernel_ms_total": round(sum(ms for _, ms, _ in p1.values()), 3), "kernel_launches": sum(c for c, _, _ in p1.values()),
+                 "host_syncs": syncs1}
         c1.close()
         del t1
 
@@ -393,6 +432,60 @@ def main():
                          "reference binary needs SDSL-lite and cannot be built in this image), %.1f s" % (m, sample.size, tcpu),
                "host_cpus": os.cpu_count()}
 
+    # ---- SURVEY 8(d)'s metric as worded: wall time of the whole CLI run, file read -> .rl_bwt closed (main.cpp:98-154,
+    # grl_bwt.hpp:77), through grlbwt_amd/bin/grlbwt on the SAME bytes (file in the page cache), twice; outside the timed region
+    cli_e2e = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_cli:
+        import hashlib
+        import re
+        import shutil
+        try:
+            ctx.close()
+        except Exception:
+            pass
+        tmpdir = os.environ.get("GRLBWT_E2E_TMP") or tempfile.gettempdir()
+        need = n_bytes + (image["bytes"] if image else n_bytes) + (1 << 30)
+        if shutil.disk_usage(tmpdir).free < need:
+            cli_e2e = {"skipped": "less than %d bytes free under %s" % (need, tmpdir)}
+        else:
+            cli = g.build_cli()
+            fin, fout = os.path.join(tmpdir, "grlbwt_bench_in.txt"), os.path.join(tmpdir, "grlbwt_bench_out.rl_bwt")
+            try:
+                stage = torch.empty(min(1 << 28, n_bytes), dtype=torch.uint8, pin_memory=True)
+                with open(fin, "wb") as f:
+                    for a in range(0, n_bytes, 1 << 28):
+                        m = min(1 << 28, n_bytes - a)
+                        stage[:m].copy_(text[a:a + m])
+                        torch.cuda.synchronize()
+                        f.write(memoryview(stage[:m].numpy()))
+                runs = []
+                for rep in range(2):
+                    tc = time.perf_counter()
+                    p = subprocess.run([cli, fin, "-o", fout], capture_output=True, text=True)
+                    wall = time.perf_counter() - tc
+                    mt = re.search(r"grlbwt-timing: read\+upload ([\d.]+) s, build ([\d.]+) s, write ([\d.]+) s, total ([\d.]+) s", p.stdout)
+                    if p.returncode != 0 or not mt:
+                        runs.append({"failed": p.returncode, "stderr": p.stderr[-300:]})
+                        break
+                    runs.append({"wall_s": round(wall, 3), "read_upload_s": float(mt.group(1)), "build_s": float(mt.group(2)),
+                                 "write_s": float(mt.group(3)), "MBps_wall": round(n_bytes / 1e6 / wall, 1)})
+                hh = hashlib.md5()
+                if os.path.exists(fout):
+                    with open(fout, "rb") as f:
+                        for blk in iter(lambda: f.read(1 << 26), b""):
+                            hh.update(blk)
+                best = min((r for r in runs if "wall_s" in r), key=lambda r: r["wall_s"], default=None)
+                cli_e2e = {"command": "grlbwt_amd/bin/grlbwt FILE -o OUT (file in the page cache, output to %s)" % tmpdir, "runs": runs,
+                           "md5_equals_hbm_image": bool(image and hh.hexdigest() == image["md5"])}
+                if best:
+                    cli_e2e.update(best)
+            finally:
+                for pth in (fin, fout):
+                    try:
+                        os.remove(pth)
+                    except OSError:
+                        pass
+
     if rank == 0:
         if args.workload == "illumina":
             wl = ("%d x 150 bp Illumina-style reads (%d bytes) from a %d bp genome, 0.5%% substitutions; BASELINE configs[3]%s"
@@ -410,7 +503,7 @@ def main():
                                        "the ONE collection sharded by record over %d GPUs (%d reads each): local LMS parsing/hashing/emission, "
                                        "hash-partitioned dictionary merge (all-to-all) + key-range-sharded dictionary stage per round, induction "
                                        "sharded by output piece (cells and BWT_{r+1} windows cross the fabric once per level), RCCL" % (world, hi - lo))},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "image": image, "cli_end_to_end": cli_e2e,
             "roofline_groups": groups, "pass_efficiency": pass_eff[:12],
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
             "top_sites": top, "rounds": nr,

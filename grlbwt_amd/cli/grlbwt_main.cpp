@@ -7,6 +7,7 @@
 // -t/-f/-b/-T are accepted and validated as in the reference; they are tuning knobs of
 // the reference's CPU tables/tmp files and never change the output.
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -35,6 +36,7 @@ struct arguments {
     int alph_bytes = 1;
     int device = 0;
     bool rev_comp = false;                  // -R (main.cpp:17,75): also the DNA reverse complements, FASTA/Q inputs
+    bool fastx = false;                     // --fastx: TEXT holds FASTA/Q records (the reference's own conversion, main.cpp:117-136, is switched off upstream)
     int gpus = 1;                           // --gpus N: one process per GPU, record shards, RCCL (collection-level mode)
     std::string version = "v1.0.1 alpha";   // main.cpp:20 (reference version string)
 };
@@ -53,7 +55,9 @@ static void usage(const char *prog) {
               << "  -b,--run-len-bytes     Max. number of bytes to encode the run lengths in the recursive BWTs (def. 1)\n"
               << "  -T,--tmp               Temporary folder (def. /tmp/grl.bwt.xxxx)\n"
               << "  -v,--version           Print the software version and exit\n"
-              << "  -R,--rev-comp          Also consider the DNA reverse complements of the strings in TEXT (FASTA/Q input)\n"
+              << "  --fastx                TEXT is a FASTA/Q file (optionally gzip): its records become the strings.  Without this\n"
+              << "                         flag TEXT is always taken as one-string-per-line cells, as the reference does\n"
+              << "  -R,--rev-comp          Also consider the DNA reverse complements of the strings in TEXT (implies --fastx)\n"
               << "  -g,--gpu               HIP device ordinal (def. 0; with --gpus: the first of N consecutive devices)\n"
               << "  --gpus                 Number of GPUs: the collection is sharded by record, one process per GPU,\n"
               << "                         exchanges over RCCL; the output does not depend on it (def. 1)\n";
@@ -88,6 +92,7 @@ struct SharedPage {
     std::atomic<int> id_ready;
     char id[GRLBWT_RCCL_ID_BYTES];
     std::atomic<int> loaded[64];            // 0 = not yet, 1 = shard loaded, < 0 = the error code of the load
+    std::atomic<int> aborted;               // set by the parent when a rank died: the others stop waiting on this page
 };
 static bool read_cell(int fd, uint64_t idx, int w, uint64_t *out) {
     unsigned char b[8] = {0};
@@ -114,20 +119,21 @@ static uint64_t next_record_start(int fd, uint64_t from, uint64_t n, int w, uint
     }
     return n;
 }
-static int rank_main(const arguments &args, int rank, int size, uint64_t off_bytes, uint64_t n_bytes, SharedPage *sh) {
+static int rank_main(const arguments &args, int rank, int size, uint64_t off_bytes, uint64_t n_bytes, bool idx64, SharedPage *sh) {
     const bool root = rank == 0;
     const auto t_start = std::chrono::steady_clock::now();
     grlbwt_ctx *ctx = nullptr;
     // (GRLBWT_CLI_SAME_DEVICE=1: every rank on --gpu's device, for boxes with fewer GPUs than ranks -- if the RCCL build allows it)
     const int dev = std::getenv("GRLBWT_CLI_SAME_DEVICE") ? args.device : args.device + rank;
-    int rc = grlbwt_ctx_create(dev, GRLBWT_FLAG_CLASSIC_POOL, &ctx);                      // buffers are handed to RCCL
+    // the index width follows the COLLECTION, not the shard: every rank takes the same one (the ranks exchange idx_t arrays)
+    int rc = grlbwt_ctx_create(dev, GRLBWT_FLAG_CLASSIC_POOL | (idx64 ? GRLBWT_FLAG_FORCE_IDX64 : 0u), &ctx);   // (classic pool: buffers are handed to RCCL)
     if (rc == GRLBWT_OK) rc = grlbwt_text_load_file_range(ctx, args.input_file.c_str(), off_bytes, n_bytes, args.alph_bytes);
     // every rank learns whether every shard loaded before the first collective (nobody may be left waiting in one)
     sh->loaded[rank].store(rc == GRLBWT_OK ? 1 : (rc < 0 ? rc : -1));
     int worst = 1;
     for (int g = 0; g < size; g++) {
         int v;
-        while ((v = sh->loaded[g].load()) == 0) usleep(200);
+        while ((v = sh->loaded[g].load()) == 0) { if (sh->aborted.load()) return 2; usleep(200); }
         if (v < 0 && worst == 1) worst = v;
     }
     if (worst < 0) {
@@ -148,7 +154,7 @@ static int rank_main(const arguments &args, int rank, int size, uint64_t off_byt
         sh->id_ready.store(rc == GRLBWT_OK ? 1 : -1);
     }
     int ready;
-    while ((ready = sh->id_ready.load()) == 0) usleep(200);
+    while ((ready = sh->id_ready.load()) == 0) { if (sh->aborted.load()) return 2; usleep(200); }
     if (ready < 0) { if (root) std::cerr << "grlbwt: RCCL is not available" << std::endl; return 3; }
     grlbwt_comm comm;
     std::memset(&comm, 0, sizeof comm);
@@ -224,25 +230,42 @@ static int run_multi_gpu(const arguments &args) {
     if (sh == MAP_FAILED) fail(2, "grlbwt: cannot map the rendezvous page");
     new (sh) SharedPage();
     sh->id_ready.store(0);
+    sh->aborted.store(0);
     for (int g = 0; g < 64; g++) sh->loaded[g].store(0);
+    const bool idx64 = n >= 0xFFFFFF00ull;       // (include/grlbwt_hip.h: 64-bit positions from 2^32 - 256 cells on)
     std::cout << std::flush;
     std::vector<pid_t> kids;
     for (int g = 0; g < N; g++) {
         pid_t pid = fork();                  // (this process has not touched the GPU: the children initialise HIP themselves)
         if (pid < 0) fail(2, "grlbwt: fork failed");
         if (pid == 0) {
-            int rc = rank_main(args, g, N, cut[g] * (uint64_t)w, (cut[g + 1] - cut[g]) * (uint64_t)w, sh);
+            int rc = rank_main(args, g, N, cut[g] * (uint64_t)w, (cut[g + 1] - cut[g]) * (uint64_t)w, idx64, sh);
             std::cout << std::flush;
             _exit(rc);
         }
         kids.push_back(pid);
     }
+    // Reap in completion order.  A rank that ends abnormally (non-zero exit, a signal) may leave its peers inside a
+    // collective that will never complete: the page tells the ones still at the rendezvous, the others are killed.
     int worst = 0;
-    for (pid_t pid : kids) {
+    size_t left = kids.size();
+    bool killed = false;
+    while (left > 0) {
         int status = 0;
-        waitpid(pid, &status, 0);
+        const pid_t pid = waitpid(-1, &status, 0);
+        if (pid < 0) break;
+        bool mine = false;
+        for (pid_t &k : kids) if (k == pid) { k = -1; mine = true; }
+        if (!mine) continue;
+        left--;
         const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 2;
         if (code > worst) worst = code;
+        if (code != 0 && !killed) {
+            sh->aborted.store(1);
+            usleep(300000);                      // ranks that fail together (an agreed error) print their message and leave by themselves
+            for (pid_t k : kids) if (k > 0) kill(k, SIGKILL);
+            killed = true;
+        }
     }
     return worst;
 }
@@ -275,7 +298,9 @@ int main(int argc, char **argv) {
             args.tmp_dir = need("--tmp");
             if (!is_dir(args.tmp_dir)) fail(105, "--tmp: Directory does not exist: " + args.tmp_dir);
         } else if (a == "-g" || a == "--gpu") args.device = std::atoi(need("--gpu").c_str());
-        else if (a == "-R" || a == "--rev-comp") args.rev_comp = true;
+        else if (a == "-R" || a == "--rev-comp") { args.rev_comp = true; args.fastx = true; }
+        else if (a == "--fastx") args.fastx = true;
+        else if (a == "--plain") args.fastx = false;                              // (the default: kept so that scripts can say it)
         else if (a == "--gpus") {
             args.gpus = std::atoi(need("--gpus").c_str());
             if (args.gpus < 1 || args.gpus > 64) fail(105, "--gpus: Value not in range 1 to 64");
@@ -294,14 +319,22 @@ int main(int argc, char **argv) {
     std::cout << (args.alph_bytes > 1 ? "Alphabet type:    integer" : "Alphabet type:    byte") << std::endl;
     std::cout << "Temporary folder: (none: all levels stay resident in HBM)" << std::endl;
     std::cout << "BWT type:         BCR exact" << std::endl;
+    // FASTA/Q conversion is OPT-IN (--fastx / -R).  The reference has its is_fastx branch commented out (main.cpp:117-136) and
+    // runs collection_stats on the raw file whatever it starts with, so a one-string-per-line collection whose first byte
+    // happens to be '>' or '@' (quoted mail, handles) must give the BWT of exactly those bytes here too.
     // is_fastx (external/cdt/lib/utils.cpp:13-30): first (decompressed) byte '>' or '@'
     int fastx = 0, is_gz = 0;
-    if (grlbwt_fastx_probe(args.input_file.c_str(), &fastx, &is_gz) != GRLBWT_OK) fastx = 0;
-    if (fastx) {
+    int looks_fastx = 0;
+    if (grlbwt_fastx_probe(args.input_file.c_str(), &looks_fastx, &is_gz) != GRLBWT_OK) looks_fastx = 0;
+    if (args.fastx) {
+        if (!looks_fastx) fail(105, "--fastx: TEXT is not in FASTA/Q format (its first byte is neither '>' nor '@')");
+        fastx = 1;
         if (args.alph_bytes != 1) fail(105, "--alphabet: a FASTA/Q input has a byte alphabet");
         if (args.gpus > 1) fail(105, "--gpus: FASTA/Q inputs are converted on one GPU; convert first or use one GPU");
         std::cout << "The input is in FASTA/Q format" << (is_gz ? " (gzip)" : "") << std::endl;          // main.cpp:120
-    } else if (args.rev_comp) fail(105, "--rev-comp: TEXT is not in FASTA/Q format (the reference has no reverse complements for plain inputs either, main.cpp:126-134)");
+    } else if (looks_fastx && args.alph_bytes == 1)
+        std::cerr << "grlbwt: note: TEXT starts like a FASTA/Q file but is read as one-string-per-line cells (the reference does the same); "
+                     "pass --fastx to convert its records" << std::endl;
     // GRLBWT_CLI_FORCE_RCCL=1: the collection-level path also with one GPU (that is all a single-GPU box can test)
     if (args.gpus > 1 || std::getenv("GRLBWT_CLI_FORCE_RCCL")) return run_multi_gpu(args);
 

@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -323,9 +324,20 @@ void read_fastx_raw(const char *path, RawText &R) {
                     zs.next_in = cin.data(); zs.avail_in = (uInt)len;
                 }
                 const int r = inflate(&zs, Z_NO_FLUSH);
-                if (r == Z_STREAM_END) {                             // next member of a multi-member file, if any
-                    if (zs.avail_in == 0 && in_off >= bytes) done = true;
-                    else if (inflateReset(&zs) != Z_OK) throw prim::Error(GRLBWT_EINTERNAL, "zlib: inflateReset failed");
+                if (r == Z_STREAM_END) {
+                    // another member follows only if the bytes behind this one start with the gzip magic; anything else
+                    // (zero padding of blocked / tape files, stray bytes) is ignored, as gzread does
+                    if (zs.avail_in < 2 && in_off < bytes) {          // the two bytes may straddle a read: pull more behind the leftover
+                        const size_t keep = zs.avail_in;
+                        if (keep) memmove(cin.data(), zs.next_in, keep);
+                        const uint64_t len = bytes - in_off < cin.size() - keep ? bytes - in_off : cin.size() - keep;
+                        if (!par_io(fd, (char *)cin.data() + keep, in_off, len, false, 1)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+                        in_off += len;
+                        zs.next_in = cin.data(); zs.avail_in = (uInt)(keep + len);
+                    }
+                    if (zs.avail_in >= 2 && zs.next_in[0] == 0x1F && zs.next_in[1] == 0x8B) {
+                        if (inflateReset(&zs) != Z_OK) throw prim::Error(GRLBWT_EINTERNAL, "zlib: inflateReset failed");
+                    } else done = true;
                 } else if (r != Z_OK && r != Z_BUF_ERROR) {
                     throw prim::Error(GRLBWT_EINVAL, std::string("the gzip stream is damaged (zlib: ") + (zs.msg ? zs.msg : "error") + ")");
                 } else if (r == Z_BUF_ERROR && zs.avail_in == 0 && in_off >= bytes) done = true;       // truncated file: take what there is (gzread does)
@@ -382,12 +394,12 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
     if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
     char *bufs[2] = {nullptr, nullptr};
     prim::Fence fences[2];
-    bool ok = true;
+    std::atomic<bool> ok(true);               // written by the writer thread, read by the loop
+    std::thread writer;                       // outside the try block: a failing copy must not unwind past a joinable thread
     try {
         const uint64_t chunk = nb < kIoChunk ? nb : kIoChunk;
         for (int k = 0; k < 2; k++) bufs[k] = (char *)prim::pinned_alloc(chunk ? chunk : 16);
         if (ftruncate(fd, (off_t)nb) != 0) ok = false;
-        std::thread writer;
         uint64_t poff = 0, plen = 0;
         int k = 0, pk = 0;
         for (uint64_t off = 0; off < nb && ok; off += chunk, k ^= 1) {
@@ -401,6 +413,7 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
         }
         if (writer.joinable()) writer.join();
     } catch (...) {
+        if (writer.joinable()) writer.join();
         try { prim::sync(); } catch (...) {}
         for (int k = 0; k < 2; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
         close(fd);
@@ -795,8 +808,8 @@ int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_b
         const uint64_t total = grl64::Engine::image_total_symbols(dev_image, image_bytes);
         if (total > capacity_cells) throw prim::Error(GRLBWT_EINVAL, "inversion: output buffer too small");
         bool big = total >= 0xFFFFFF00ull || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
-        uint64_t n = big ? grl64::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells)
-                         : grl32::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells);
+        uint64_t n = big ? grl64::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells, total)
+                         : grl32::Engine::invert_image(dev_image, image_bytes, cell_bytes, dev_text_out, capacity_cells, total);
         if (n_cells_out) *n_cells_out = n;
     });
 }

@@ -176,6 +176,11 @@ struct HashInsertFn {
     u32 *scal;        // [1] error flag, [2..3] debug
     u64 n, n_occ;
     u64 *rep_pos = nullptr;   // [capacity] exact keys: position of the occurrence that claimed the slot (the dictionary reads the phrase there)
+    // claim protocol of prim::for_each_agg: with claim_bits set, the slot id returned for the occurrence whose CAS created the
+    // table entry carries prim::kClaimBit, and the kernel sets bit (position of that occurrence) -- one bit per distinct
+    // phrase, from which the dictionary is compacted without a scan over the (sparse) table
+    u64 *claim_bits = nullptr;
+    static constexpr bool kClaims = true;
     // Byte cells: 4 phrases per lane at once through the exact-key path (process_batch).  A phrase of <= 7 cells is cut
     // out of ONE unaligned 8-byte load with the start bits and a zero-byte test for the terminator -- no loop -- its
     // bytes are the table key, so a probe that matches needs no look at a representative occurrence, and the text,
@@ -257,7 +262,7 @@ struct HashInsertFn {
                 const u64 mine = kExactKey | (len << 60) | content;
                 found = insert_exact(mine, p, exact_hash(mine) & mask, 0, false);
             } else found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
-            if (found != prim::kNoBucket) out_slot[ord] = found;
+            if (found != prim::kNoBucket) out_slot[ord] = found & ~prim::kClaimBit;
         }
         return found;
     }
@@ -311,7 +316,7 @@ struct HashInsertFn {
             if (ex && found != prim::kNoBucket) {
                 const u64 ord = (u64)wb[j] + (u64)__builtin_popcountll(wp[j] & ((1ull << (p & 63)) - 1ull));
                 if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; found = prim::kNoBucket; }
-                else out_slot[ord] = found;
+                else out_slot[ord] = found & ~prim::kClaimBit;
             }
             if (valid[j] && !fast[j]) found = prim::kDeferBucket;      // the long cases go through process() later, 64 at a time
             slot[j] = found;
@@ -326,6 +331,7 @@ struct HashInsertFn {
     GRL_DEV u32 insert_exact(u64 mine, u64 p, u64 sl, u64 c, bool have_first) const {
         u32 found = prim::kNoBucket;
         bool stop = false;                      // the table overflowed elsewhere: give up (the host re-runs the pass)
+        bool claimed = false;
         for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket && !stop; probes++) {
             if (probes || !have_first) {
                 if (probes == 16 && prim::load_relaxed(&scal[1])) stop = true;
@@ -333,11 +339,12 @@ struct HashInsertFn {
             }
             if (c == 0) {
                 u64 old = prim::atomic_cas(&keys[sl << ks], 0ull, mine);
-                if (old == 0) { c = mine; rep_pos[sl] = p; } else c = old;
+                if (old == 0) { c = mine; rep_pos[sl] = p; claimed = true; } else c = old;
             }
             if (c == mine) found = (u32)sl; else sl = (sl + 1) & mask;
         }
         if (found == prim::kNoBucket) scal[1] = 1;
+        else if (claimed && claim_bits) found |= prim::kClaimBit;
         return found;
     }
     // claim or find the table slot of the phrase t[p .. p+len) whose (finalised) hash is h
@@ -351,6 +358,7 @@ struct HashInsertFn {
         // partial exec mask, so lanes that matched an existing key returned a stale value.
         u32 found = prim::kNoBucket;
         bool stop = false;
+        bool claimed = false;
         for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket && !stop; probes++) {
             // once probing gets long, look at the overflow flag (L1-bypassing load; done rarely: a coherent load of one
             // address by every lane was measured to serialise and cost 20 ms per 10 M phrases)
@@ -358,7 +366,7 @@ struct HashInsertFn {
             u64 cur = prim::load_relaxed(&keys[slot << ks]);   // L1-bypassing: a stale 0 from L1 would turn every later occurrence of a hot phrase into a CAS on one address
             if (cur == 0) {
                 u64 old = prim::atomic_cas(&keys[slot << ks], 0ull, mine);
-                if (old == 0) cur = mine;
+                if (old == 0) { cur = mine; claimed = true; }
                 else cur = old;
             }
             bool hit = (cur == mine);
@@ -367,6 +375,7 @@ struct HashInsertFn {
             else slot = (slot + 1) & mask;
         }
         if (found == prim::kNoBucket) scal[1] = 1;   // table full / out of probes
+        else if (claimed && claim_bits) found |= prim::kClaimBit;
         return found;
     }
 };
@@ -379,6 +388,24 @@ struct OccIn {
     const u64 *keys; int ks;
     GRL_DEV u32 operator()(u64 i) const { return keys[i << ks] != 0 ? 1u : 0u; }
 };
+// The same functor over a SAMPLE of the positions: virtual index v -> block v / blk of the text (blocks `stride` apart),
+// offset v % blk (prim::for_each_agg protocol)
+template <class F>
+struct SampledFn {
+    F f; u64 blk, stride;
+    static constexpr int kBatch = F::kBatch;
+    static constexpr bool kClaims = false;        // (the sampled functor runs with claim_bits == nullptr: untagged slot ids)
+    GRL_DEV u64 map(u64 v) const { return (v / blk) * stride + (v % blk); }
+    GRL_DEV bool is_start(u64 v) const { return f.is_start(map(v)); }
+    GRL_DEV u32 process(u64 v) const { return f.process(map(v)); }
+    GRL_DEV u32 operator()(u64 v) const { return f(map(v)); }
+    GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const {
+        u64 m[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) m[j] = map(item[j]);
+        f.process_batch(m, valid, slot);
+    }
+};
 
 // ------------------------------------------------------ a5: dictionary view
 template <class cell_t, bool FIRST>
@@ -386,13 +413,11 @@ struct CompactTableFn {
     const cell_t *t;
     CellOps<cell_t, FIRST> ops;
     const u64 *startbits;
-    const u64 *keys; const idx_t *counts; const u32 *slot_ph;
+    const u64 *keys; const idx_t *counts;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
     int ks; u64 cs; const u64 *rep_pos;
-    GRL_DEV void operator()(u64 s) const {
+    GRL_DEV void emit(u64 s, u64 k) const {        // table slot s is phrase k of the dictionary
         u64 k64 = keys[s << ks];
-        if (!k64) return;
-        u32 k = slot_ph[s];
         // (one exit: an early return from the first branch cost the ends-a-string flag of a few phrases in the 64-bit build
         // -- the flag store of the second branch ran for lanes of the first; see the note in find_or_insert)
         u64 pos, len;
@@ -414,6 +439,32 @@ struct CompactTableFn {
         ph_pos[k] = pos; ph_freq[k] = counts[s * cs]; ph_len[k] = (u32)len; ph_slot[k] = (u32)s;
         ph_lastT[k] = lastT ? 1 : 0;
     }
+};
+// The distinct phrases from the claim bits of the hashing pass (bit p: the occurrence at text position p created its table
+// entry): one lane per word of 64 positions; phrase numbers = rank of the claim, i.e. phrases in order of first claim.
+// (Rounds 1-2 scanned the table -- three passes over 2^31 16-byte slots at level 1 of the 10 GB build, 22 ms, to find 101 M
+// entries; the bit-vector has n / 8 bytes whatever the table size.)
+struct ClaimSlotsFn {       // step 1, one lane per word: the table slot of every claim, in claim order (out_slot is read nearly in sequence)
+    const u64 *claim_bits; const idx_t *cbase; const u64 *startbits; const idx_t *wordbase; const u32 *out_slot; u32 *ph_slot;
+    GRL_DEV void operator()(u64 w) const {
+        u64 m = claim_bits[w];
+        if (m) {
+            const u64 sb = startbits[w];
+            const u64 ob = (u64)wordbase[w];
+            u64 k = (u64)cbase[w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                ph_slot[k++] = out_slot[ob + (u64)__builtin_popcountll(sb & ((1ull << b) - 1ull))];
+            }
+        }
+    }
+};
+template <class cell_t, bool FIRST>
+struct ClaimCompactFn {     // step 2, one lane per phrase: its table entry (a random gather per phrase, all of them in flight together --
+                            // one lane walking the claims of a word took them one after the other: 13 ms for 159 M phrases, 2.2x the table scan it replaced)
+    CompactTableFn<cell_t, FIRST> c;
+    GRL_DEV void operator()(u64 k) const { c.emit((u64)c.ph_slot[k], k); }
 };
 struct LenIn {
     const u32 *l;
@@ -962,6 +1013,7 @@ struct Runs {
 // One fused scan gives every input run its output run index and its symbol offset; the scan hands both straight to
 // the run heads (no prefix array of n pairs in between).
 struct MergeEmitFn {
+    static constexpr bool kWaveEmit = false;
     const u32 *sym; u64 n;
     u32 *osym; idx_t *ostart; u32 *map;
     GRL_DEV void operator()(u64 t, HeadLen ex, HeadLen v) const {
@@ -996,6 +1048,7 @@ struct AtomHeadLenIn {
     }
 };
 struct AtomMergeEmitFn {
+    static constexpr bool kWaveEmit = false;
     const u64 *a; int lbits; u64 n;
     u32 *osym; idx_t *ostart;
     GRL_DEV void operator()(u64 t, HeadLen ex, HeadLen v) const {
@@ -1187,6 +1240,28 @@ struct TakeScanEmitFn {
         if (t == E - 1) Tc[E] = ex + v;
         if (c.sym(t) == take_code) mark_coincidence(tw, cw, (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b);
     }
+#ifdef GRLBWT_PRIM_HIP
+    // Wave-cooperative form (prim::k_scan_tiles calls it with all lanes): the marks of 64 consecutive cells fall into a
+    // handful of words of cw -- TAKE segments start where runs of BWT_{r+1} start far more often than not, 738 M marks at
+    // level 0 of the 10 GB build -- so the wave ORs them together and issues one atomic per word (device atomics run at
+    // ~20-27 G/s whatever the footprint: tools/membench.hip; this scan took 37 ms there with one atomic per mark).
+    static constexpr bool kWaveEmit = true;
+    GRL_DEV void wave(u64 t, TC ex, TC v, bool valid) const {
+        u64 x = 0;
+        bool mk = false;
+        if (valid) {
+            Tc[t] = ex;
+            if (t == E - 1) Tc[E] = ex + v;
+            if (c.sym(t) == take_code) {
+                x = (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b;
+                mk = x && ((tw[x >> 6] >> (x & 63)) & 1ull);
+            }
+        }
+        prim::wave_or_words(cw, mk, x >> 6, 1ull << (x & 63));
+    }
+#else
+    static constexpr bool kWaveEmit = false;
+#endif
 };
 // first_cell[m] = first cell whose bucket is >= m (m in [0, M]) = exclusive prefix of the bucket sizes.  The bucket heads
 // record where their bucket starts (+1: 0 = empty) and where the bucket in front of them ends; sizes -> one scan.
@@ -1893,6 +1968,7 @@ struct SplitRunsFn {      // one lane per L-piece
 };
 struct RunSymFn {         // for_each_agg protocol: every run is a work item, its bucket is its symbol
     static constexpr int kBatch = 1;
+    static constexpr bool kClaims = false;
     const u32 *rsym;
     GRL_DEV bool is_start(u64) const { return true; }
     GRL_DEV u32 process(u64 i) const { return rsym[i]; }
@@ -1937,6 +2013,65 @@ struct InvertWriteFn {
         u64 end = off[i + 1] - 1, row = i;
         text[end] = (cell_t)sep;
         for (u32 c = bwt[row]; c != sep; c = bwt[row]) { text[--end] = (cell_t)c; row = lf[row]; }
+    }
+};
+
+// ---- the same inversion indexed by RUNS (scripts/fm_index.h:79-83 computes LF from the symbol's rank; over the run-length
+// BWT the rank of a run's first symbol is a prefix sum over the RUNS of that symbol).  A stable sort of the runs by symbol and
+// a scan of their lengths in that order give LF of every run start; LF inside a run is linear, so one record per run --
+// (LF(start) - start, symbol) -- and the run-start bit-vector replace the per-position arrays: 28-36 bytes per RUN instead
+// of 20-36 per symbol, which is what lets the 10 GB headline image (1.66 G runs, 10^10 symbols) round-trip on one device.
+template <int IB> struct RunRecT;
+template <> struct alignas(8) RunRecT<4> { u32 delta; u32 sym; };
+template <> struct alignas(16) RunRecT<8> { u64 delta; u32 sym; u32 pad; };
+typedef RunRecT<sizeof(idx_t)> RunRec;
+struct alignas(16) RankCell { u64 w; u64 b; };        // a word of the run-start bit-vector and the number of run starts in front of it: ONE gather per rank
+struct RankCellFn {
+    const u64 *words; const idx_t *base; RankCell *rc;
+    GRL_DEV void operator()(u64 i) const { rc[i] = RankCell{words[i], (u64)base[i]}; }
+};
+struct IotaFn {
+    idx_t *v;
+    GRL_DEV void operator()(u64 i) const { v[i] = (idx_t)i; }
+};
+struct RunOrderLenIn {    // length of the j-th run in (symbol, position) order
+    const idx_t *rlen; const idx_t *order;
+    GRL_DEV idx_t operator()(u64 j) const { return rlen[order[j]]; }
+};
+struct RunLfEmitFn {      // emit side of that scan: ex = LF of the run's first position
+    static constexpr bool kWaveEmit = false;
+    const idx_t *order; const idx_t *rpos; const u32 *rsym; RunRec *rec;
+    GRL_DEV void operator()(u64 j, idx_t ex, idx_t) const {
+        const u64 k = order[j];
+        RunRec r;
+        r.delta = (decltype(r.delta))(ex - rpos[k]);      // (wraps below zero: row + delta is taken modulo 2^bits)
+        r.sym = rsym[k];
+        rec[k] = r;
+    }
+};
+GRL_DEV u64 run_of_row(const RankCell *rc, u64 row) {      // index of the run holding BWT position row
+    const RankCell c = rc[(row + 1) >> 6];
+    return c.b + (u64)__builtin_popcountll(c.w & ((1ull << ((row + 1) & 63)) - 1ull)) - 1;
+}
+struct RunInvertLenFn {
+    const RankCell *rc; const RunRec *rec; u32 sep; idx_t *slen;
+    GRL_DEV void operator()(u64 i) const {
+        idx_t row = (idx_t)i;
+        u64 l = 1;
+        RunRec r = rec[run_of_row(rc, (u64)row)];
+        while (r.sym != sep) { l++; row = (idx_t)(row + (idx_t)r.delta); r = rec[run_of_row(rc, (u64)row)]; }
+        slen[i] = (idx_t)l;
+    }
+};
+template <class cell_t>
+struct RunInvertWriteFn {
+    const RankCell *rc; const RunRec *rec; const idx_t *off; u32 sep; cell_t *text;
+    GRL_DEV void operator()(u64 i) const {
+        u64 end = off[i + 1] - 1;
+        idx_t row = (idx_t)i;
+        text[end] = (cell_t)sep;
+        RunRec r = rec[run_of_row(rc, (u64)row)];
+        while (r.sym != sep) { text[--end] = (cell_t)r.sym; row = (idx_t)(row + (idx_t)r.delta); r = rec[run_of_row(rc, (u64)row)]; }
     }
 };
 
@@ -2099,37 +2234,56 @@ class Engine {
         // size the table for load <= ~0.6, and grow x4 (re-running the pass) if a lane runs out of
         // probes because the prefix was not representative; cap_max = 2*n_occ always fits.
         u64 cap_max = 1024;
-        while (cap_max < 2 * n_occ) cap_max <<= 1;
+        while (cap_max < 2 * n_occ && cap_max < (1ull << 31)) cap_max <<= 1;      // slot ids are u32 with bit 31 spare (prim::kClaimBit)
         P.next_text.alloc(n_occ);
         DBuf<u32> scal(4);
         u64 cap = cap_max;
         double frac = 1.0;
         {
-            // estimate the distinct fraction on a prefix of the text (first <= 2^20 cells)
+            // Table capacity from a sample of 2^20 cells (256 blocks spread evenly over the text) hashed into a table of its
+            // own: its distinct fraction `frac`, extrapolated to the whole text.  That over-sizes the table whenever repetition
+            // is global rather than local (level 1 of the 10 GB build: 964 M occurrences of 101 M phrases, 90 % distinct within
+            // any 2^20 cells -> 2^31 slots), and measured that is the better side to err on: the pass runs FASTER on the sparse
+            // table (75 ms at 2^31 slots, 83 ms at 2^28: fewer probes), zeroing it costs what that gains, and the compaction
+            // afterwards does not scan the table (claim bits, below).  Estimating the number of distinct phrases from the
+            // sample's abundance classes (Chao1) was tried and is 10-20x too low on this data (heterogeneous abundances):
+            // two overflow re-runs per level.  An exact count (one more hashing pass over a 1/64 slice of the hash space)
+            // costs about what a right-sized table saves.
             StageTimer st(&tm.hash);
             const u64 n_s = n < (1ull << 20) ? n : (1ull << 20);
             if (n_s < n) {
-                u64 occ_s = (u64)wordbase.get(n_s >> 6);
-                if (occ_s < 64) occ_s = 64;
+                const u64 blk = 4096, nblk = n_s / blk, stride = n / nblk;
                 u64 cap_s = 1024;
-                while (cap_s < 2 * occ_s) cap_s <<= 1;
+                while (cap_s < 2 * n_s) cap_s <<= 1;
                 DBuf<u64> tk(cap_s), trep;
                 DBuf<idx_t> tc(cap_s);
                 if (HashInsertFn<cell_t, FIRST>::kExact) trep.alloc(cap_s);
                 tk.zero(); tc.zero(); scal.zero();
-                prim::for_each_agg(n_s, HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0,
-                                                                    P.next_text.p, scal.p, n, n_occ, trep.p},
+                typedef HashInsertFn<cell_t, FIRST> HF;
+                prim::for_each_agg(n_s, SampledFn<HF>{HF{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0,
+                                                         P.next_text.p, scal.p, n, n_occ, trep.p}, blk, stride},
                                    SlotCountAdd{tc.p, 1}, true, "hash_sample");
-                u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
+                const u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
+                const u64 occ_s = std::max<u64>(prim::reduce_sum<u64>(cap_s, IdxIn<idx_t>{tc.p}, "hash_sample_count"), 1);
                 frac = (double)d_s / (double)occ_s;
                 if (frac > 1.0) frac = 1.0;
-                u64 want = (u64)(1.7 * frac * (double)n_occ) + 4096;      // target load <= ~0.6 if the prefix is representative
+                const u64 want = (u64)(1.7 * frac * (double)n_occ) + 4096;      // target load <= ~0.6 if the sample is representative
                 cap = 4096;
                 while (cap < want) cap <<= 1;
                 if (cap > cap_max) cap = cap_max;
+                if (const char *ov = getenv("GRLBWT_TABLE_LOG2")) {      // experiments: "l0,l1,..." log2 of the slots per level (0 = keep)
+                    int lvl = prim::rt().tag, k = 0;
+                    const char *q = ov;
+                    while (k < lvl && *q) { if (*q == ',') k++; q++; }
+                    const int lg = (k == lvl) ? atoi(q) : 0;
+                    if (lg >= 10 && lg <= 40) cap = std::min<u64>((u64)1 << lg, cap_max);
+                }
+                if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: sample %llu occurrences, %llu distinct -> table %llu slots for %llu occurrences\n",
+                                                          prim::rt().tag, (unsigned long long)occ_s, (unsigned long long)d_s, (unsigned long long)cap, (unsigned long long)n_occ);
             }
         }
         DBuf<u64> keys, rep_pos;
+        DBuf<u64> claim(nwords + 1);             // bit p: the phrase occurrence starting at p created its table entry
         DBuf<idx_t> counts;
         // LDS pre-aggregation of the counts pays when few distinct phrases take most occurrences (level 0 of
         // DNA: 20 k phrases, 30 M occurrences); with mostly-distinct phrases the cache only thrashes.
@@ -2156,9 +2310,10 @@ class Engine {
                 counts_p = cnt;
                 if (HashInsertFn<cell_t, FIRST>::kExact) rep_pos.alloc(cap);          // (written by the lanes that claim a slot)
                 scal.zero();
+                claim.zero();
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
                 launch_hash<cell_t, FIRST>(HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit, ks,
-                                                                     P.next_text.p, scal.p, n, n_occ, rep_pos.p}, cnt, cs, n, aggregate);
+                                                                     P.next_text.p, scal.p, n, n_occ, rep_pos.p, claim.p}, cnt, cs, n, aggregate);
                 std::vector<u32> sc = scal.to_host(4);
                 if (sc[1] == 1) {
                     if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");
@@ -2171,18 +2326,20 @@ class Engine {
                 break;
             }
         }
-        wordbase.release();
         P.cap = cap;
 
-        // ---- a5: distinct phrases of this text --------------------------------
+        // ---- a5: distinct phrases of this text (from the claim bits: the table itself is not scanned) -------------------
         {
             StageTimer st(&tm.dict_sort);
-            DBuf<u32> slot_ph(cap);
-            u64 D = prim::exclusive_scan<u32>(cap, OccIn{keys.p, ks}, slot_ph.p, false, "table_compact");
+            DBuf<idx_t> cbase(nwords + 1);
+            const u64 D = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{claim.p}, cbase.p, false, "table_compact");
+            if (D >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 phrases)");
             P.D = D;
             P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
-            prim::for_each(cap, CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, slot_ph.p, P.ph_pos.p,
-                                                              P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p, ks, cs, rep_pos.p}, "table_compact");
+            prim::for_each(nwords, ClaimSlotsFn{claim.p, cbase.p, startbits.p, wordbase.p, P.next_text.p, P.ph_slot.p}, "table_compact");
+            prim::for_each(D, ClaimCompactFn<cell_t, FIRST>{CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, P.ph_pos.p,
+                                                            P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p, ks, cs, rep_pos.p}}, "table_compact");
+            wordbase.release(); claim.release();
             u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{P.ph_freq.p}, "dict_freq_check");
             if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
                                                            std::to_string(n_occ) + ")");
@@ -2318,9 +2475,14 @@ class Engine {
         // ---- a6: sort all phrase suffixes (radix on the first K symbols + refinement by symbol extension) ----------
         u64 Sg = S;                              // my slots of the sorted order (all of them without a communicator)
         DBuf<u32> perm, gid, gstart;
-        u64 G;
-        {
+        u64 G = 0;
+        // (with a communicator the sort and the group stage below work on THIS rank's key range -- sizes, memory and
+        // termination differ from rank to rank: a failure is recorded (Comm::fail) and raised by every rank at the counter
+        // exchange behind the group stage)
+        auto sort_local = [&] {
             StageTimer st(&tm.dict_sort);
+            // (GRLBWT_TEST_FAIL_RANK_SORT=<rank>: the tests make one rank fail here)
+            if (C) if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_SORT")) if (atoi(fr) == C->rank) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
             // as many symbols as fit 64 key bits per pass (up to 8 radix passes over all suffixes in the first one)
@@ -2425,17 +2587,22 @@ class Engine {
             prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
             prim::sync();
             L.info.sort_iters = iters;
-        }
+        };
+        if (!C) sort_local();
+        else { try { sort_local(); } catch (const prim::Error &e) { C->fail(e); } }
 
         // ---- a7: equal-suffix groups -> pre-BWT, ranks -----------------------
         const u32 bwt_code = sigma + 1, hocc_code = sigma + 2, sigma3 = sigma + 3;
-        DBuf<u32> grank(G + 1), pidx(G + 1), gmin(G), gmax(G);
-        DBuf<idx_t> gacc(G);
-        DBuf<u8> gfull(G), gflag(G);
+        DBuf<u32> grank, pidx, gmin, gmax;
+        DBuf<idx_t> gacc;
+        DBuf<u8> gfull, gflag;
         DBuf<u32> repq, pslot;                   // pslot[k] = my group holding phrase k's whole-phrase suffix (all ones: not mine)
         u64 M, P0;
         {
             StageTimer st(&tm.dict_groups);
+            u64 Ml = 0, P0l = 0;
+            auto groups_local = [&] {
+            grank.alloc(G + 1); pidx.alloc(G + 1); gmin.alloc(G); gmax.alloc(G); gacc.alloc(G); gfull.alloc(G); gflag.alloc(G);
             pslot.alloc(D);
             if (C) pslot.fill_ff();              // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
             {
@@ -2450,8 +2617,11 @@ class Engine {
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
-            const u64 Ml = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
-            const u64 P0l = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
+            Ml = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
+            P0l = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
+            };
+            if (!C) groups_local();
+            else if (!C->pending) { try { groups_local(); } catch (const prim::Error &e) { C->fail(e); Ml = 0; P0l = 0; } }
             u64 Moff = 0, P0off = 0;
             M = Ml; P0 = P0l;
             std::vector<u64> bbM, bbP;
@@ -2879,6 +3049,7 @@ class Engine {
     void dist_stats(const Comm &C) {
         std::vector<u64> mine(8 + 256, 0);
         mine[0] = stats.n_syms; mine[1] = stats.n_strings; mine[2] = stats.min_sym; mine[3] = stats.max_sym;
+        mine[4] = sizeof(idx_t);                // the ranks exchange idx_t arrays: one width for the whole collection
         if (cell_bytes == 1) {
             u64 h[256];
             prim::byte_histogram((const u8 *)text0, n0, h);
@@ -2894,13 +3065,19 @@ class Engine {
             if (all[g * w + 3] > mx) mx = all[g * w + 3];
             for (int i = 0; i < 256; i++) hist[i] += all[g * w + 8 + i];
         }
+        // (a context picks its index width from its OWN shard unless GRLBWT_FLAG_FORCE_IDX64 is set: shards on either side of
+        // 2^32 - 256 cells, or shards below it of a collection above it, must be refused by every rank alike)
+        for (int g = 0; g < C.size; g++)
+            if (all[g * w + 4] != sizeof(idx_t))
+                throw prim::Error(-22, "the ranks disagree on the index width: create every context with GRLBWT_FLAG_FORCE_IDX64 when the collection has >= 2^32 - 256 cells");
         // every shard ends with the separator == its own minimum; it must be the global minimum too
         // (decided from the gathered values so that every rank takes the same branch)
         for (int g = 0; g < C.size; g++)
             if (all[g * w + 2] != mn) throw prim::Error(-84, "Error: the file is ill formed");
         u64 F = n;
         if (cell_bytes == 1) { F = 0; for (int i = 0; i < 256; i++) if (hist[i] > F) F = hist[i]; }
-        if (sizeof(idx_t) == 4 && n >= 0xFFFFFF00ull) throw prim::Error(-75, "collection too large for the 32-bit index build");
+        if (sizeof(idx_t) == 4 && n >= 0xFFFFFF00ull)
+            throw prim::Error(-75, "collection too large for the 32-bit index build: create every context with GRLBWT_FLAG_FORCE_IDX64");
         g_n_strings = ns; g_n_syms = n;
         stats.max_sym = mx; stats.max_sym_freq = F;
         stats.sb = (bitlen64(mx + 4) + 7) / 8;
@@ -2980,7 +3157,8 @@ class Engine {
         L.info.n_in = n_total;
         L.info.parse_size = occ_total;
         // ---- merge what I own: one table over the received lists --------------------------------------------------
-        DBuf<u32> list_slot(Dr), slot_min, rep_ex(Dr + 1);
+        DBuf<u32> list_slot, slot_min, rep_ex;
+        try { list_slot.alloc(Dr); rep_ex.alloc(Dr + 1); } catch (const prim::Error &e) { C.fail(e); }
         DBuf<u32> gcells, ph_len, ph_off;
         DBuf<idx_t> ph_freq;
         DBuf<u8> ph_lastT;
@@ -2990,27 +3168,35 @@ class Engine {
         u32 maxlen;
         {
             StageTimer st(&tm.hash);
-            DBuf<u64> goff(Dr + 1);
-            const u64 chk = prim::exclusive_scan<u64>(Dr, LenIn{rlen.p}, goff.p, true, "dist.list_offsets");
-            if (chk != Sr) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
-            u64 cap = 1024;
-            while (cap < 2 * Dr) cap <<= 1;
-            DBuf<u64> keys(cap);
-            DBuf<idx_t> counts(cap);
-            DBuf<u32> scal(4);
-            keys.zero(); counts.zero(); scal.zero();
-            prim::for_each(Dr, ListInsertFn{rcells.p, goff.p, rlen.p, rfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p}, "dist.merge_phrases");
-            if (scal.to_host(2)[1]) throw prim::Error(-28, "merged phrase table overflow");
-            keys.release();
-            // deterministic layout: representatives = smallest list index per slot, phrases in representative order
-            slot_min.alloc(cap);
-            slot_min.fill_ff();
-            prim::for_each(Dr, SlotMinFn{list_slot.p, slot_min.p}, "dist.slot_min");
-            const u64 Do = prim::exclusive_scan<u32>(Dr, IsRepIn{list_slot.p, slot_min.p}, rep_ex.p, false, "dist.merge_compact");
-            DBuf<u64> o_pos(Do); DBuf<idx_t> o_freq(Do); DBuf<u32> o_len(Do), o_off(Do + 1); DBuf<u8> o_lastT(Do);
-            prim::for_each(Dr, ListPhraseFn{rcells.p, goff.p, rlen.p, list_slot.p, slot_min.p, rep_ex.p, counts.p, o_pos.p, o_freq.p,
-                                            o_len.p, o_lastT.p}, "dist.merge_compact");
-            const u64 So64 = prim::reduce_sum<u64>(Do, LenIn{o_len.p}, "dist.dict_syms");
+            // (rank-local, sized by what THIS rank received: a failure here -- memory, table overflow -- is recorded and
+            // travels with the counter exchange below, where every rank raises)
+            u64 Do = 0, So64 = 0;
+            DBuf<u64> goff, o_pos; DBuf<idx_t> o_freq; DBuf<u32> o_len, o_off; DBuf<u8> o_lastT;
+            try {
+                // (GRLBWT_TEST_FAIL_RANK_MERGE=<rank>: the tests make one rank fail here)
+                if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_MERGE")) if (atoi(fr) == me) throw prim::Error(-28, "merged phrase table overflow (injected by the test)");
+                goff.alloc(Dr + 1);
+                const u64 chk = prim::exclusive_scan<u64>(Dr, LenIn{rlen.p}, goff.p, true, "dist.list_offsets");
+                if (chk != Sr) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
+                u64 cap = 1024;
+                while (cap < 2 * Dr) cap <<= 1;
+                DBuf<u64> keys(cap);
+                DBuf<idx_t> counts(cap);
+                DBuf<u32> scal(4);
+                keys.zero(); counts.zero(); scal.zero();
+                prim::for_each(Dr, ListInsertFn{rcells.p, goff.p, rlen.p, rfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p}, "dist.merge_phrases");
+                if (scal.to_host(2)[1]) throw prim::Error(-28, "merged phrase table overflow");
+                keys.release();
+                // deterministic layout: representatives = smallest list index per slot, phrases in representative order
+                slot_min.alloc(cap);
+                slot_min.fill_ff();
+                prim::for_each(Dr, SlotMinFn{list_slot.p, slot_min.p}, "dist.slot_min");
+                Do = prim::exclusive_scan<u32>(Dr, IsRepIn{list_slot.p, slot_min.p}, rep_ex.p, false, "dist.merge_compact");
+                o_pos.alloc(Do); o_freq.alloc(Do); o_len.alloc(Do); o_off.alloc(Do + 1); o_lastT.alloc(Do);
+                prim::for_each(Dr, ListPhraseFn{rcells.p, goff.p, rlen.p, list_slot.p, slot_min.p, rep_ex.p, counts.p, o_pos.p, o_freq.p,
+                                                o_len.p, o_lastT.p}, "dist.merge_compact");
+                So64 = prim::reduce_sum<u64>(Do, LenIn{o_len.p}, "dist.dict_syms");
+            } catch (const prim::Error &e) { C.fail(e); Do = 0; So64 = 0; }
             // ---- the merged dictionary, replicated: owner parts in rank order -----------------------------------
             std::vector<u64> cnt = C.allgather_u64({Do, So64});
             for (int g = 0; g < N; g++) { dbase[g + 1] = dbase[g] + cnt[2 * g]; sbase[g + 1] = sbase[g] + cnt[2 * g + 1]; }
@@ -3080,8 +3266,15 @@ class Engine {
     // go to the owners of their buckets (8 bytes per cell in the usual layout) and are merged by one stable split on the
     // bucket bits (rank order inside a bucket = slice order); (5) every rank runs the single-GPU pass C on its piece and
     // ends up holding its slice of BWT_r.  Nothing is replicated and no symbol crosses the fabric more than once per level.
-    void dist_first_bwt() {
-        first_bwt();     // local: my strings' final symbols, in collection order
+    void dist_first_bwt(const Comm &C) {
+        try { first_bwt(); }     // local: my strings' final symbols, in collection order
+        catch (const prim::Error &e) {            // (raised by every rank at the first counter exchange of the level below)
+            C.fail(e);
+            bwt = Runs();
+            bwt.sym.alloc(0); bwt.len.alloc(0);
+            bwt_level = (int)levels.size();
+            linfo.assign(levels.size() + 1, LevelInfo());
+        }
     }
 
     void dist_induce_level(const Comm &C) {
@@ -3098,12 +3291,13 @@ class Engine {
         // (1) one cell layout for all shards, then passes A+B over my slice (the single-GPU kernels)
         // (local failures -- out of memory, an internal check -- are recorded with C.fail and travel with the next counter
         // exchange, where every rank raises: nobody is left waiting for a rank that gave up)
-        DBuf<idx_t> Tpos(R + 1);
+        DBuf<idx_t> Tpos;
         u64 Tlocal = 0, maxrun = 0, Toff = 0, Ttotal = 0;
         {
             u64 mr = 0;
             try {
                 StageTimer st(&tm.ind_expand);
+                Tpos.alloc(R + 1);
                 Tlocal = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "dist.Tpos");
                 mr = level_maxrun();
             } catch (const prim::Error &e) { C.fail(e); Tlocal = 0; mr = 0; }
@@ -3114,14 +3308,16 @@ class Engine {
                 Ttotal += g1[2 * g + 1];
             }
         }
-        DBuf<u32> term(R);
+        DBuf<u32> term;
         int kb = 1, lb = 1;
         u64 E = 0;
         u32 p0, p1, u0, u1;
         u64 n_out, n_r = 0;
-        std::vector<u64> sp, cbh, v(2 * (u64)N, 0);
-        DBuf<u64> split(4 * ((u64)N + 1));
+        std::vector<u64> sp(4 * ((u64)N + 1), 0), cbh, v(2 * (u64)N, 0);
+        DBuf<u64> split;
         try {
+            term.alloc(R);
+            split.alloc(4 * ((u64)N + 1));
             // (GRLBWT_TEST_FAIL_RANK_INDUCE=<rank>: the tests make one rank fail here)
             if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_INDUCE")) if (atoi(fr) == me) throw prim::Error(-12, "out of device memory (injected by the test)");
             E = expand_split(L, term, maxrun, kb, lb);
@@ -3325,7 +3521,7 @@ class Engine {
     }
 
     void dist_induce(const Comm &C) {
-        dist_first_bwt();
+        dist_first_bwt(C);
         while (bwt_level > 0) dist_induce_level(C);
         dist_finish(C);
     }
@@ -3388,8 +3584,51 @@ class Engine {
     }
     template <class T>
     static void d2d_copy(T *dst, const T *src, u64 n) { prim::d2d(dst, src, n * sizeof(T)); }
+    // the run-indexed form (functor block "the same inversion indexed by RUNS")
+    template <class cell_t>
+    static u64 invert_runs_t(const u8 *img, u64 R, u32 sb, u32 fb, cell_t *text_out, u64 capacity) {
+        DBuf<u32> rsym(R);
+        DBuf<idx_t> rlen(R), rpos(R + 1);
+        prim::for_each(R, UnpackRunsFn{img, sb, fb, rsym.p, rlen.p}, "inv.unpack");
+        const u64 n = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{rlen.p}, rpos.p, true, "inv.positions");
+        if (n > capacity) throw prim::Error(-22, "inversion: output buffer too small");
+        const u32 sep = prim::reduce_min<u32>(R, PtrU32In{rsym.p}, "inv.sep");
+        const u32 mx = prim::reduce_max<u32>(R, PtrU32In{rsym.p}, "inv.max");
+        const u64 k = prim::reduce_sum<u64>(R, SepLenIn{rsym.p, rlen.p, sep}, "inv.nstrings");      // strings = separators
+        // run-start bit-vector with the rank of every word beside it
+        DBuf<RankCell> rc;
+        {
+            RankBits rb;
+            build_rankbits(rb, rpos.p, R, n + 1, "inv.runbits");
+            const u64 nw = (n + 1) / 64 + 2;
+            rc.alloc(nw);
+            prim::for_each(nw, RankCellFn{rb.words.p, rb.base.p, rc.p}, "inv.rankcells");
+        }
+        // LF of every run start: runs in (symbol, position) order, scan of their lengths
+        DBuf<RunRec> rec(R);
+        {
+            DBuf<u32> k2(R), k3(R);
+            DBuf<idx_t> ia(R), ib(R);
+            d2d_copy(k2.p, rsym.p, R);
+            prim::for_each(R, IotaFn{ia.p}, "inv.iota");
+            int bits = (int)bitlen64(mx);
+            if (bits < 1) bits = 1;
+            const int res = prim::sort_pairs<u32, idx_t>(k2.p, ia.p, k3.p, ib.p, R, 0, bits, "inv.lf_sort");
+            const idx_t *order = res ? ib.p : ia.p;
+            const u64 tot = (u64)prim::exclusive_scan_emit<idx_t>(R, RunOrderLenIn{rlen.p, order}, RunLfEmitFn{order, rpos.p, rsym.p, rec.p}, "inv.lf");
+            if (tot != n) throw prim::Error(-71, "inversion: run lengths do not add up");
+        }
+        rsym.release(); rlen.release(); rpos.release();
+        DBuf<idx_t> slen(k + 1);
+        prim::for_each(k, RunInvertLenFn{rc.p, rec.p, sep, slen.p}, "inv.lengths");
+        const u64 tot = (u64)prim::exclusive_scan<idx_t>(k, IdxIn<idx_t>{slen.p}, slen.p, true, "inv.offsets");
+        if (tot != n) throw prim::Error(-71, "inversion: string lengths do not add up to the BWT length");
+        prim::for_each(k, RunInvertWriteFn<cell_t>{rc.p, rec.p, slen.p, sep, text_out}, "inv.write");
+        prim::sync();
+        return n;
+    }
 
-    static u64 invert_image(const void *dev_image, u64 image_bytes, int cell_bytes, void *dev_text_out, u64 capacity_cells) {
+    static u64 invert_image(const void *dev_image, u64 image_bytes, int cell_bytes, void *dev_text_out, u64 capacity_cells, u64 n_total_hint = 0) {
         if (image_bytes < 16) throw prim::Error(-22, "not an .rl_bwt image");
         u64 hdr[2];
         prim::d2h(hdr, dev_image, 16);
@@ -3397,6 +3636,21 @@ class Engine {
         if (sb == 0 || sb > 8 || fb == 0 || fb > 8 || (image_bytes - 16) % (sb + fb)) throw prim::Error(-22, "bad .rl_bwt header");
         u64 R = (image_bytes - 16) / (sb + fb);
         const u8 *img = (const u8 *)dev_image;
+        // Two index forms.  Per POSITION (LF array: one gather per symbol of a string, (12 + 3 * sizeof(idx_t)) bytes per symbol
+        // while it is built) when that fits the device comfortably; per RUN (two dependent gathers per symbol, 30-50 bytes per
+        // run) otherwise -- the 10 GB headline image needs 360 GB in the first form and ~100 GB in the second.
+        // GRLBWT_INVERT=runs|positions forces one (the tests take both on small inputs).
+        bool by_runs = (n_total_hint ? n_total_hint : capacity_cells) * (12 + 3 * (u64)sizeof(idx_t)) > prim::mem_available() / 2;
+        if (const char *f = getenv("GRLBWT_INVERT")) by_runs = f[0] == 'r';
+        if (by_runs) {
+            switch (cell_bytes) {
+                case 1: return invert_runs_t<u8>(img, R, (u32)sb, (u32)fb, (u8 *)dev_text_out, capacity_cells);
+                case 2: return invert_runs_t<u16>(img, R, (u32)sb, (u32)fb, (u16 *)dev_text_out, capacity_cells);
+                case 4: return invert_runs_t<u32>(img, R, (u32)sb, (u32)fb, (u32 *)dev_text_out, capacity_cells);
+                case 8: return invert_runs_t<u64>(img, R, (u32)sb, (u32)fb, (u64 *)dev_text_out, capacity_cells);
+                default: throw prim::Error(-22, "bad cell width");
+            }
+        }
         switch (cell_bytes) {
             case 1: return invert_t<u8>(img, R, (u32)sb, (u32)fb, (u8 *)dev_text_out, capacity_cells);
             case 2: return invert_t<u16>(img, R, (u32)sb, (u32)fb, (u16 *)dev_text_out, capacity_cells);

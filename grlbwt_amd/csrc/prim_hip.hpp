@@ -243,6 +243,13 @@ inline void pool_stage_end(u64 old_peak, const void *stage_id) {
 inline void pool_classic() { pool().classic = true; }    // hipMalloc slabs only (takes effect when no arena is live)
 inline u64 pool_peak_bytes() { return pool().peak_bytes; }
 inline u64 pool_reserved_bytes() { return pool().slab_bytes; }
+// device memory a caller could still get from dev_alloc: what the runtime reports free + what the slabs hold unused
+inline u64 mem_available() {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
+    const Pool &P = pool();
+    return (u64)fr + (u64)(P.slab_bytes > P.live_bytes ? P.slab_bytes - P.live_bytes : 0);
+}
 inline bool pool_disabled() {
     static int d = getenv("GRLBWT_NOPOOL") ? 1 : 0;
     return d != 0;
@@ -683,6 +690,23 @@ inline void start_bitvector(u64 n, const cell_t *t, OPS ops, F /*pred*/, u64 *wo
     after_launch(name);
 }
 
+// OR of (word, mask) contributions of the lanes of a wave into words[]: ONE atomic per distinct word instead of one per lane
+// (the lanes of a wave hold consecutive elements, whose marks fall into a handful of words)
+GRL_DEV void wave_or_words(u64 *words, bool has, u64 w, u64 m) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(has);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const u64 wl = (u64)__shfl((unsigned long long)w, leader);
+        const bool same = has && w == wl;
+        unsigned long long mm = same ? (unsigned long long)m : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mm |= __shfl_xor(mm, off);
+        if (lane == leader) atomicOr(reinterpret_cast<unsigned long long *>(&words[wl]), mm);
+        pending &= ~__ballot(same);
+    }
+}
+
 // ------------------------------------------ for_each with LDS count aggregation
 // f(i) returns a bucket id (u32) or kNoBucket; every returned id must be counted once
 // in a global table through add(id, count).  Same-address global atomics serialise at
@@ -698,6 +722,22 @@ static constexpr u32 kNoBucket = 0xFFFFFFFFu;
 // counters read 69-88 % of the wave cycles waiting on memory at 6-7 waves per SIMD: the rest is gather latency.)
 static constexpr int kAggChunk = 2048;
 static constexpr u32 kDeferBucket = 0xFFFFFFFEu;   // process_batch: "take this item through process() later"
+// CLAIMS (functors with F::kClaims and a non-null f.claim_bits): a bucket id with bit 31 set tells that THIS work item created
+// its bucket (the lane's CAS claimed the table slot).  The kernel strips the bit and sets bit (item) of f.claim_bits --
+// the lanes of a wave hold neighbouring items, so the wave ORs its marks together and issues one atomic per word.  The set bits
+// are the distinct buckets, each once: the caller compacts from them instead of scanning a sparse table.  (Bucket ids < 2^31.)
+static constexpr u32 kClaimBit = 0x80000000u;
+template <class F>
+GRL_DEV u32 agg_take_claim(const F &f, u32 s, u64 item, bool valid) {
+    if constexpr (F::kClaims) {
+        if (f.claim_bits) {                                      // (uniform)
+            const bool real = valid && s != kNoBucket && s != kDeferBucket;
+            wave_or_words(f.claim_bits, real && (s & kClaimBit), item >> 6, 1ull << (item & 63));
+            if (real) s &= ~kClaimBit;
+        }
+    }
+    return s;
+}
 template <int SLOTS, bool AGG, class F, class A>
 __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F f, A add) {
     __shared__ u32 c_key[AGG ? SLOTS : 1];
@@ -744,7 +784,9 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 const u32 k = dh + (u32)lane;
                 const bool v = k < dt;                  // (u32 counters never wrap: a block has < 2^32 positions)
                 u32 s = kNoBucket;
-                if (v) s = f.process(start + defer[k & (DCAP - 1)]);
+                const u64 it = start + (v ? defer[k & (DCAP - 1)] : 0u);
+                if (v) s = f.process(it);
+                s = agg_take_claim(f, s, it, v);
                 if (v) count(s);
                 dh = dt - dh >= 64u ? dh + 64u : dt;
             }
@@ -763,6 +805,7 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 f.process_batch(item, valid, slot);
 #pragma unroll
                 for (int j = 0; j < F::kBatch; j++) {
+                    slot[j] = agg_take_claim(f, slot[j], item[j], valid[j]);
                     const bool df = valid[j] && slot[j] == kDeferBucket;
                     const unsigned long long m = __ballot(df);
                     if (df) defer[(dt + (u32)__popcll(m & ((1ull << lane) - 1ull))) & (DCAP - 1)] = (u32)(item[j] - start);
@@ -799,7 +842,15 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 if (st) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)(i - base);
                 qn += (u32)__popcll(m);
             }
-            for (u32 q = lane; q < qn; q += 64) count(f.process(base + queue[q]));
+            for (u32 q0 = 0; q0 < qn; q0 += 64) {         // (uniform trip count: the claim marks are wave-cooperative)
+                const u32 q = q0 + (u32)lane;
+                const bool v = q < qn;
+                const u64 it = base + (v ? queue[q] : 0u);
+                u32 s = kNoBucket;
+                if (v) s = f.process(it);
+                s = agg_take_claim(f, s, it, v);
+                if (v) count(s);
+            }
         }
     }
     if (AGG) {
@@ -813,7 +864,18 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
 template <class F, class A>
 struct NoAggFn {
     F f; A add;
-    GRL_DEV void operator()(u64 i) const { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
+    GRL_DEV void operator()(u64 i) const {
+        u32 s = f(i);
+        if (s != kNoBucket) {
+            if constexpr (F::kClaims) {
+                if (f.claim_bits) {
+                    if (s & kClaimBit) atomicOr(reinterpret_cast<unsigned long long *>(&f.claim_bits[i >> 6]), 1ull << (i & 63));
+                    s &= ~kClaimBit;
+                }
+            }
+            add(s, 1u);
+        }
+    }
 };
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool aggregate, const char *name = "for_each_agg") {
@@ -959,7 +1021,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_tile_sums(u64 n, F in, T *tile_
 }
 // tile_offsets == nullptr: single tile, offset 0.  The thread holding element n-1 stores the grand
 // total to total_a / total_b when they are non-null (no separate copy kernels for scalars).
-struct NoEmit {};
+struct NoEmit { static constexpr bool kWaveEmit = false; };
 template <class T, class F, class E = NoEmit>
 __global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *tile_offsets, T *out, T *total_a, T *total_b, E emit = E()) {
     __shared__ T s_w[4];
@@ -1008,7 +1070,17 @@ __global__ void __launch_bounds__(kBlock) k_scan_tiles(u64 n, F in, const T *til
         for (int j = 0; j < kScanItems; j++) {
             u32 k = (u32)j * kBlock + threadIdx.x;
             u64 i = tile_base + k;
-            if (i < n) {
+            if constexpr (E::kWaveEmit) {
+                // wave-cooperative consumer: called by ALL lanes of the wave (valid tells whether i is an element), so that
+                // it may use ballots / shuffles over the 64 consecutive elements the wave holds
+                const T e = s_x[k + (k >> 5)];
+                if (i == n - 1) {
+                    T nx = e + vs[j];
+                    if (total_a) *total_a = nx;
+                    if (total_b) *total_b = nx;
+                }
+                emit.wave(i, e, vs[j], i < n);
+            } else if (i < n) {
                 T e = s_x[k + (k >> 5)];
                 if (i == n - 1) {
                     T nx = e + vs[j];

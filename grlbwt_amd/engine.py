@@ -84,7 +84,7 @@ FASTX_REVCOMP = 1
 
 def fastx_probe(path, lib=None):
     """(is_fastx, is_gz) as the reference's is_fastx / check_gzip decide them (host only: no device is touched)."""
-    L = load_library(lib, allow_test_standin=os.environ.get("GRLBWT_ALLOW_TEST_STANDIN") == "1")
+    L = load_library(lib)
     a, b = C.c_int(0), C.c_int(0)
     rc = L.grlbwt_fastx_probe(os.fsencode(path), C.byref(a), C.byref(b))
     if rc != 0:
@@ -97,12 +97,20 @@ class IllFormedInput(GrlbwtError):
 
 
 _libs = {}
+_standin_paths = set()
+
+
+def _test_allow_standin(path):
+    """TESTS ONLY: accept the serial stand-in library at exactly this path (tests/hostsim).  There is deliberately no
+    environment switch: nothing outside a test's own code can point the product at a CPU path."""
+    _standin_paths.add(os.path.abspath(path))
 
 
 def load_library(path=None, allow_test_standin=False):
     """dlopen the C-ABI library; fails loudly when it has not been built.  Only the HIP build is accepted:
     the serial stand-in of tests/hostsim identifies itself and is refused unless a test explicitly allows it."""
     path = path or os.environ.get("GRLBWT_HIP_LIB", DEFAULT_LIB)
+    allow_test_standin = allow_test_standin or os.path.abspath(path) in _standin_paths
     if path in _libs:
         L = _libs[path]
         if L.grlbwt_backend_name() != b"hip-gfx950" and not allow_test_standin:
@@ -173,7 +181,7 @@ class Context:
     """One engine context per GPU (grlbwt_ctx)."""
 
     def __init__(self, device=0, flags=0, lib=None, _test_standin=False):
-        self.L = load_library(lib, allow_test_standin=_test_standin or os.environ.get("GRLBWT_ALLOW_TEST_STANDIN") == "1")
+        self.L = load_library(lib, allow_test_standin=_test_standin)
         h = C.c_void_p()
         rc = self.L.grlbwt_ctx_create(device, flags, C.byref(h))
         if rc != OK:

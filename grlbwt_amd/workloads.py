@@ -213,3 +213,19 @@ def zipf_tokens_torch(n_cells, doc_len=1000, vocab=65000, s=1.1, seed=20260005, 
         view[d0:d1, :doc_len] = tok.view(d1 - d0, doc_len).to(torch.int16)     # wraps to the uint16 bit pattern
         del z, u, tok
     return out
+
+
+def md5_device(t, chunk=1 << 28):
+    """md5 of a uint8 device tensor, downloaded through one pinned staging buffer (bench.py prints it for the image it
+    times; tests/test_gpu_parity.py compares the 10 GB headline image with the committed value)."""
+    import hashlib
+    import torch
+    h = hashlib.md5()
+    n = t.numel()
+    stage = torch.empty(min(chunk, max(n, 1)), dtype=torch.uint8, pin_memory=True)
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        stage[:m].copy_(t[o:o + m])
+        torch.cuda.synchronize()
+        h.update(stage[:m].numpy().tobytes() if m < 1 << 20 else memoryview(stage[:m].numpy()))
+    return h.hexdigest()

@@ -25,7 +25,7 @@ def build(force=False):
 
 
 REF_DIR = os.path.join(_HERE, "_ref")
-REF_PROGS = ("bwt_stats", "grl2plain", "grlbwt2rle", "split_runs", "fastx2plain")
+REF_PROGS = ("bwt_stats", "grl2plain", "grlbwt2rle", "split_runs", "fastx2plain", "ref_stats")
 REFERENCE_ROOT = "/root/reference"
 
 

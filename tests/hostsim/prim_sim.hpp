@@ -103,6 +103,17 @@ template <class cell_t, class OPS, class F>
 inline void start_bitvector(u64 n, const cell_t *, OPS, F pred, u64 *words, const char * = "") { bitvector_from_pred(n, pred, words); }
 static constexpr u32 kNoBucket = 0xFFFFFFFFu;
 static constexpr u32 kDeferBucket = 0xFFFFFFFEu;
+static constexpr u32 kClaimBit = 0x80000000u;
+template <class F>
+inline u32 agg_take_claim(const F &f, u32 s, u64 item) {       // the claim protocol of prim_hip.hpp, serially
+    if constexpr (F::kClaims) {
+        if (f.claim_bits && s != kNoBucket && s != kDeferBucket) {
+            if (s & kClaimBit) f.claim_bits[item >> 6] |= 1ull << (item & 63);
+            s &= ~kClaimBit;
+        }
+    }
+    return s;
+}
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     if constexpr (F::kBatch > 1) {       // the functor's batched form (what the HIP kernel calls), kBatch work items at a time
@@ -114,7 +125,8 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             for (int j = k; j < F::kBatch; j++) { item[j] = 0; valid[j] = false; }
             f.process_batch(item, valid, slot);
             for (int j = 0; j < k; j++) {
-                if (slot[j] == kDeferBucket) slot[j] = f.process(item[j]);       // (the HIP kernel queues these up)
+                slot[j] = agg_take_claim(f, slot[j], item[j]);
+                if (slot[j] == kDeferBucket) slot[j] = agg_take_claim(f, f.process(item[j]), item[j]);       // (the HIP kernel queues these up)
                 if (slot[j] != kNoBucket) add(slot[j], 1u);
             }
             k = 0;
@@ -123,7 +135,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             if (f.is_start(i)) { item[k] = i; valid[k] = true; if (++k == F::kBatch) flush(); }
         if (k) flush();
     } else {
-        for (u64 i = 0; i < n; i++) { u32 s = f(i); if (s != kNoBucket) add(s, 1u); }
+        for (u64 i = 0; i < n; i++) { u32 s = agg_take_claim(f, f(i), i); if (s != kNoBucket) add(s, 1u); }
     }
 }
 // stage clocks: host wall time here (the HIP runtime uses event pairs on its stream)
@@ -151,6 +163,7 @@ inline u64 pool_stage_begin() { return 0; }
 inline void pool_stage_end(u64, const void *) {}
 inline u64 pool_peak_bytes() { return 0; }
 inline u64 pool_reserved_bytes() { return 0; }
+inline u64 mem_available() { return ~0ull >> 1; }
 template <class T, class F>
 inline T reduce_sum(u64 n, F f, const char * = "") { T r = 0; for (u64 i = 0; i < n; i++) r += (T)f(i); return r; }
 template <class T, class F>

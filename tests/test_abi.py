@@ -72,10 +72,12 @@ def test_test_standin_is_refused_by_the_product(monkeypatch):
     d = os.path.join(ROOT, "tests", "hostsim")
     subprocess.check_call(["make", "-s", "-C", d], stdout=subprocess.DEVNULL)
     sim = os.path.join(d, "_build", "libgrlbwt_sim.so")
-    monkeypatch.delenv("GRLBWT_ALLOW_TEST_STANDIN", raising=False)
     from grlbwt_amd import engine
+    monkeypatch.setattr(engine, "_standin_paths", set())
+    monkeypatch.setenv("GRLBWT_ALLOW_TEST_STANDIN", "1")       # the environment is not a way in
     with pytest.raises(RuntimeError, match="not the HIP library"):
         engine.Context(0, 0, sim)
+    assert "GRLBWT_ALLOW_TEST_STANDIN" not in open(engine.__file__).read()
     lib = ctypes.CDLL(sim)
     lib.grlbwt_backend_name.restype = ctypes.c_char_p
     assert lib.grlbwt_backend_name() == b"serial-test-standin"

@@ -37,7 +37,9 @@ def test_cli_argument_contract(cli, tmp_path):
     rc, out, _ = run(cli, "--help")
     assert rc == 0 and "--gpus" in out and "--rev-comp" in out
     assert run(cli, f, "-a", "2", "-R")[0] == 105                 # reverse complements need a FASTA/Q input
-    assert run(cli, os.path.join(GOLD, "fastx", "fq_regular.fq"), "-a", "2")[0] == 105
+    assert run(cli, os.path.join(GOLD, "fastx", "fq_regular.fq"), "--fastx", "-a", "2")[0] == 105
+    assert run(cli, f, "--fastx")[0] == 105                       # --fastx on a file that is not FASTA/Q
+    assert "--fastx" in out
 
 
 @pytest.mark.gpu
@@ -99,13 +101,27 @@ def test_cli_collection_level_mode_over_rccl(cli, tmp_path):
 def test_cli_fasta_fastq_inputs(cli, tmp_path, oracle_mod):
     """FASTA/FASTQ (gzip) inputs from the command line, with and without -R: the .rl_bwt of the converted collection."""
     import zlib
-    for name, flags in (("fa_wrapped60.fa", []), ("fq_gz.fq.gz", ["-R"]), ("fa_gz.fa.gz", ["--rev-comp"])):
+    for name, flags in (("fa_wrapped60.fa", ["--fastx"]), ("fq_gz.fq.gz", ["-R"]), ("fa_gz.fa.gz", ["--rev-comp"])):
         raw = open(os.path.join(GOLD, "fastx", name), "rb").read()
         if raw[:2] == b"\x1f\x8b":
             raw = zlib.decompress(raw, 31)
-        text, _ = oracle_mod.fastx2plain(raw, bool(flags))
+        text, _ = oracle_mod.fastx2plain(raw, flags != ["--fastx"])
         p = subprocess.run([cli, os.path.join(GOLD, "fastx", name), "-o", str(tmp_path / "fx")] + flags, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "The input is in FASTA/Q format" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
         assert open(tmp_path / "fx.rl_bwt", "rb").read() == oracle_mod.rl_bwt(text, 1)
     p = subprocess.run([cli, os.path.join(GOLD, "fastx", "fq_with_N.fq"), "-R", "-o", str(tmp_path / "n")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 1 and "The input seems not to be DNA (invalid symbol:N)" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_plain_input_that_starts_like_fasta(cli, tmp_path, oracle_mod):
+    """The reference has its FASTA/Q branch switched off (main.cpp:117-136) and takes ANY file as one-string-per-line cells.
+    A plain collection whose first byte is '>' or '@' must therefore give the BWT of exactly its bytes; conversion is opt-in."""
+    for first in (b">", b"@"):
+        data = first + b" quoted line\n>> deeper\n@handle says ACGT\nplain\n"
+        p = tmp_path / "mail.txt"
+        p.write_bytes(data)
+        r = subprocess.run([cli, str(p), "-o", str(tmp_path / "mail")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "The input is in FASTA/Q format" not in r.stdout and "pass --fastx" in r.stderr
+        assert open(tmp_path / "mail.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)

@@ -16,10 +16,8 @@ ROOT = os.path.dirname(HERE)
 
 @pytest.fixture(scope="module")
 def sim():
-    d = os.path.join(HERE, "hostsim")
-    subprocess.check_call(["make", "-s", "-C", d], stdout=subprocess.DEVNULL)
-    os.environ["GRLBWT_ALLOW_TEST_STANDIN"] = "1"      # the host mirror refuses the stand-in otherwise
-    return os.path.join(d, "_build", "libgrlbwt_sim.so")
+    from tests import simlib
+    return simlib.sim_library()
 
 
 def _run(world, lib, case, out_dir, port):
@@ -112,6 +110,15 @@ def test_local_failure_inside_a_round_fails_on_every_rank(sim, tmp_path, monkeyp
     monkeypatch.setenv("GRLBWT_TEST_FAIL_RANK_INDUCE", "2")
     _run(3, sim, "injected", tmp_path, 29596)
     assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -12"] * 3
+    # ... in the merge of the phrases a rank owns, and in a rank's own key range of the sharded suffix sort
+    monkeypatch.delenv("GRLBWT_TEST_FAIL_RANK_INDUCE")
+    monkeypatch.setenv("GRLBWT_TEST_FAIL_RANK_MERGE", "0")
+    _run(3, sim, "injected", tmp_path, 29597)
+    assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -28"] * 3
+    monkeypatch.delenv("GRLBWT_TEST_FAIL_RANK_MERGE")
+    monkeypatch.setenv("GRLBWT_TEST_FAIL_RANK_SORT", "2")
+    _run(3, sim, "injected", tmp_path, 29598)
+    assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -71"] * 3
 
 
 def test_fewer_strings_than_ranks_is_rejected():

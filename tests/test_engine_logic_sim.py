@@ -18,10 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def sim():
-    d = os.path.join(HERE, "hostsim")
-    subprocess.check_call(["make", "-s", "-C", d], stdout=subprocess.DEVNULL)
-    os.environ["GRLBWT_ALLOW_TEST_STANDIN"] = "1"      # the host mirror refuses the stand-in otherwise
-    return os.path.join(d, "_build", "libgrlbwt_sim.so")
+    from tests import simlib
+    return simlib.sim_library()
 
 
 def test_primitives_selftest(sim):
@@ -108,13 +106,18 @@ def test_table_growth_when_prefix_is_unrepresentative(sim, oracle_mod):
     assert got == oracle_mod.rl_bwt(data, 1)
 
 
-@pytest.mark.parametrize("kind,w", [("reads", 1), ("tokens", 2), ("dups", 1)])
-def test_invert_image_round_trip(sim, kind, w):
-    """reverse_bwt / grl2plain on the (stand-in) device: the image decodes back to the collection."""
+@pytest.mark.parametrize("form", ["positions", "runs"])
+@pytest.mark.parametrize("kind,w", [("reads", 1), ("tokens", 2), ("dups", 1), ("repetitive", 1)])
+def test_invert_image_round_trip(sim, kind, w, form, monkeypatch):
+    """reverse_bwt / grl2plain on the (stand-in) device: the image decodes back to the collection -- through the LF array
+    over the positions and through the per-run records (the form the 10 GB headline image takes)."""
+    monkeypatch.setenv("GRLBWT_INVERT", form)
     if kind == "reads":
         data = workloads.sampled_reads(3000, 100, 20000, seed=4)
     elif kind == "tokens":
         data = workloads.zipf_tokens(20000, doc_len=100, vocab=2000)
+    elif kind == "repetitive":
+        data = workloads.repetitive_copies(12, 6000, seed=5)
     else:
         data = np.frombuffer(b"A\n\nA\nGATTACA\nGATTACA\nT\n\n", dtype=np.uint8)
     for flags in (0, engine.FLAG_FORCE_IDX64):
@@ -182,3 +185,16 @@ def test_large_group_refinement_branch(sim, oracle_mod, monkeypatch, cap):
     parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
     parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=3).tobytes(), 1, engine.FLAG_FORCE_IDX64)
     parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2)
+
+
+def test_table_sizing_from_a_sample(sim, oracle_mod, capfd, monkeypatch):
+    """Texts above 2^20 cells size their phrase tables from a strided sample (distinct phrases estimated from the sample's
+    abundance classes): the sampled hashing functor, the estimate and the build behind it against the oracle -- reads from
+    a small genome (few distinct phrases, many occurrences) and a text whose second half looks nothing like its first."""
+    monkeypatch.setenv("GRLBWT_TABLE_TRACE", "1")
+    data = workloads.sampled_reads(12000, 100, 30000, seed=13).tobytes()
+    assert len(data) > (1 << 20)
+    parity.check_final(sim, data, 1)
+    assert "table" in capfd.readouterr().err
+    rep = (b"ACGTTGCA" * 16 + b"\n") * 6000
+    parity.check_final(sim, rep + workloads.uniform_reads(6000, 100, seed=77).tobytes(), 1)

@@ -197,6 +197,49 @@ def test_device_side_generator_matches_host(hip):
     assert np.array_equal(a, b)
 
 
+def _expected_header_torch(text, w):
+    """(sb, fb) of SURVEY A.8 from the input itself, on the device (no engine code): sb from max_sym + 4, fb from the largest
+    byte frequency (-a 1) or the number of cells (-a 2/4/8)."""
+    import torch
+    n = text.numel()
+    if w == 1:
+        hist = torch.zeros(256, dtype=torch.int64, device=text.device)
+        step = 1 << 28
+        for o in range(0, n, step):
+            hist += torch.bincount(text[o:o + step].to(torch.int64), minlength=256)
+        mx = int(torch.nonzero(hist).max().item())
+        F = int(hist.max().item())
+    else:
+        v = text.view(torch.int16).to(torch.int32) & 0xFFFF if w == 2 else text
+        mx, F = int(v.max().item()), n
+    return ((mx + 4).bit_length() + 7) // 8, (F.bit_length() + 7) // 8
+
+
+def _assert_image_properties(ctx, text, w):
+    """Header widths == the A.8 rule on the input, size == 16 + runs * (sb + fb), every run differs from its predecessor
+    (maximal runs) and the run lengths add up to the input -- checked with torch on the image bytes, not by the engine."""
+    import torch
+    from grlbwt_amd import dist as gdist
+    nb, nr = ctx.result_size()
+    img = gdist._view(ctx.result_device_ptr(), nb, text.device)
+    sb, fb = (int.from_bytes(bytes(img[o:o + 8].cpu().numpy()), "little") for o in (0, 8))
+    assert (sb, fb) == _expected_header_torch(text, w), (sb, fb)
+    assert nb == 16 + nr * (sb + fb)
+    rec = img[16:].view(nr, sb + fb)
+    step = 1 << 27
+    total = 0
+    for o in range(0, nr, step):
+        blk = rec[o:o + step + 1]
+        assert bool((blk[1:, :sb] != blk[:-1, :sb]).any(dim=1).all()), "a run repeats the symbol of the run before it"
+        ln = torch.zeros(min(step, nr - o), dtype=torch.int64, device=text.device)
+        for b in range(fb):
+            ln += rec[o:o + step, sb + b].to(torch.int64) << (8 * b)
+        assert int(ln.min().item()) > 0
+        total += int(ln.sum().item())
+    assert total == text.numel()
+    return nb, nr
+
+
 def test_full_size_encode_decode_round_trip(hip):
     """BASELINE config[1] at full size (101 MB): build the BWT, invert the image on the device
     (grl2plain + reverse_bwt kernels), compare with the input byte for byte."""
@@ -207,10 +250,31 @@ def test_full_size_encode_decode_round_trip(hip):
     with engine.Context(0, 0, hip) as ctx:
         ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
         ctx.build()
-        nb, _ = ctx.result_size()
+        nb, _ = _assert_image_properties(ctx, text, 1)
         n = ctx.invert_image(ctx.result_device_ptr(), nb, 1, out.data_ptr(), out.numel())
     torch.cuda.synchronize()
     assert n == text.numel() and torch.equal(out, text)
+
+
+@pytest.mark.parametrize("form", ["positions", "runs"])
+def test_both_inverter_forms(hip, monkeypatch, form):
+    """grlbwt_invert_image has two index forms (LF array over the positions; one record per run, which is what the 10 GB
+    headline image takes): both forced on the same inputs, 32- and 64-bit positions, byte and uint16 cells."""
+    import torch
+    monkeypatch.setenv("GRLBWT_INVERT", form)
+    for data, w, flags in ((workloads.sampled_reads(200000, 100, 2000000, seed=21), 1, 0),
+                           (workloads.sampled_reads(50000, 100, 500000, seed=22), 1, engine.FLAG_FORCE_IDX64),
+                           (workloads.zipf_tokens(500000, doc_len=300, vocab=20000), 2, 0),
+                           (workloads.repetitive_copies(20, 100000, seed=9), 1, engine.FLAG_FORCE_IDX64)):
+        t = torch.from_numpy(data.view(np.int16) if w == 2 else data).to("cuda:0")
+        out = torch.zeros_like(t)
+        with engine.Context(0, flags, hip) as ctx:
+            ctx.attach_device(t.data_ptr(), data.size, w, keepalive=t)
+            ctx.build()
+            nb, _ = ctx.result_size()
+            n = ctx.invert_image(ctx.result_device_ptr(), nb, w, out.data_ptr(), data.size)
+        torch.cuda.synchronize()
+        assert n == data.size and torch.equal(out, t)
 
 
 def test_round_trip_u16_and_long_strings(hip):
@@ -264,7 +328,7 @@ def test_baseline_configs_at_stated_size_round_trip(hip, config):
         ctx.build()
         st = ctx.stats()
         assert st["n_syms"] == text.numel() and st["n_strings"] == (100 if w == 1 else 499500)
-        nb, nr = ctx.result_size()
+        nb, nr = _assert_image_properties(ctx, text, w)
         assert nb == 16 + nr * (st["sb"] + st["fb"])
         n = ctx.invert_image(ctx.result_device_ptr(), nb, w, back.data_ptr(), back.numel())
     torch.cuda.synchronize()
@@ -303,7 +367,7 @@ def test_idx64_build_round_trip_4_3GB(hip):
         assert ctx.counters()["idx_bytes"] == 8
         st = ctx.stats()
         assert (st["n_strings"], st["n_syms"]) == (reads, text.numel())
-        nb, nr = ctx.result_size()
+        nb, nr = _assert_image_properties(ctx, text, 1)
         img = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
         from grlbwt_amd import dist as gdist
         img.copy_(gdist._view(ctx.result_device_ptr(), nb, torch.device("cuda:0")))
@@ -311,6 +375,38 @@ def test_idx64_build_round_trip_4_3GB(hip):
     # a fresh context: the build's buffers are gone, the inversion has the device to itself (36 B per symbol)
     out = torch.zeros_like(text)
     with engine.Context(0, 0, hip) as ctx:
+        n = ctx.invert_image(img.data_ptr(), nb, 1, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    assert n == text.numel()
+    assert torch.equal(out, text)
+
+
+def test_headline_10GB_round_trip(hip):
+    """BASELINE.json configs[3] / the metric's own configuration at its stated size on ONE GPU: 66,225,166 x 150 bp
+    Illumina-style reads (10,000,000,066 bytes) -- what bench.py times.  The image must (a) carry the header of SURVEY A.8
+    and maximal runs, (b) be the image bench.py hashes (tests/golden/headline_10GB.json), and (c) decode back to the input
+    byte for byte: grlbwt_invert_image through the per-run LF records (scripts/reverse_bwt.cpp:36-52 + fm_index.h:79-83
+    over the run-length BWT; the per-position LF array would need 360 GB here)."""
+    import torch
+    reads = 66225166
+    text = workloads.sampled_reads_torch(reads, 150, 330000000, seed=20260003, device="cuda:0")
+    assert text.numel() == 10000000066
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+        st = ctx.stats()
+        assert (st["n_strings"], st["n_syms"]) == (reads, text.numel())
+        nb, nr = _assert_image_properties(ctx, text, 1)
+        from grlbwt_amd import dist as gdist
+        img = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+        img.copy_(gdist._view(ctx.result_device_ptr(), nb, torch.device("cuda:0")))
+        torch.cuda.synchronize()
+    gold = json.load(open(os.path.join(parity.GOLD, "headline_10GB.json")))
+    assert (nb, nr) == (gold["image_bytes"], gold["runs"])
+    assert workloads.md5_device(img) == gold["md5"]
+    out = torch.zeros_like(text)
+    with engine.Context(0, 0, hip) as ctx:       # a fresh context: the build's buffers are gone
         n = ctx.invert_image(img.data_ptr(), nb, 1, out.data_ptr(), out.numel())
     torch.cuda.synchronize()
     assert n == text.numel()
