@@ -569,6 +569,12 @@ int selftest(uint64_t n, uint64_t seed) {
     { int r = test_sort<uint64_t, uint32_t>(n, seed + 4, 3); if (r) return -50 - r; }   // heavy duplicates
     { int r = test_sort<uint64_t, uint64_t>(n, seed + 5, 33); if (r) return -60 - r; }
     { int r = test_sort_keys(n, seed + 6, 21); if (r) return -90 - r; }
+    // digit plans with 9- and 10-bit digits (GRLBWT_SORT_DIGIT): 54 = 6 x 9, 51 = 9,9,9,8,8,8, 18 = 9,9, 27 = 9,9,9, 20 = 10,10
+    { int r = test_sort<uint64_t, uint32_t>(n, seed + 7, 54); if (r) return -100 - r; }
+    { int r = test_sort<uint64_t, uint32_t>(n, seed + 8, 51); if (r) return -110 - r; }
+    { int r = test_sort_keys(n, seed + 9, 18); if (r) return -120 - r; }
+    { int r = test_sort<uint32_t, uint64_t>(n, seed + 10, 27); if (r) return -130 - r; }
+    { int r = test_sort<uint32_t, uint32_t>(n, seed + 11, 20); if (r) return -140 - r; }
     // 7: fused pair scans (8- and 16-byte elements: the 16-byte result stores and the LDS staging of the scan)
     { int r = test_pair_scan<uint32_t, uint32_t>(n, h, d.p); if (r) return -70 - r; }
     { int r = test_pair_scan<uint64_t, uint64_t>(n, h, d.p); if (r) return -80 - r; }

@@ -181,6 +181,16 @@ struct HashInsertFn {
     // phrase, from which the dictionary is compacted without a scan over the (sparse) table
     u64 *claim_bits = nullptr;
     static constexpr bool kClaims = true;
+    GRL_DEV u64 claim_pos(u64 item) const { return item; }
+    // HOT TABLE (level 0 of DNA-like texts: a few thousand phrases take 97 % of the occurrences).  hot_keys[0 .. hot_mask] is a
+    // small dense table holding the phrases of a sample of the text, built before this pass and READ-ONLY during it: a
+    // probe is a plain cached load into a few hundred KB that stay in every XCD's L2 (random loads: 255 G/s from a 4 MiB
+    // window, 80 G/s from 16 MiB, 51 G/s from HBM -- tools/membench.hip; the one big sparse table kept every hot key on a
+    // line of its own, 5 MB of them).  A phrase that is not there goes on to the big table (keys / mask), whose slot ids
+    // follow the hot ones (slot_base).
+    const u64 *hot_keys = nullptr;
+    u64 hot_mask = 0;
+    u32 slot_base = 0;
     // Byte cells: 4 phrases per lane at once through the exact-key path (process_batch).  A phrase of <= 7 cells is cut
     // out of ONE unaligned 8-byte load with the start bits and a zero-byte test for the terminator -- no loop -- its
     // bytes are the table key, so a probe that matches needs no look at a representative occurrence, and the text,
@@ -260,7 +270,7 @@ struct HashInsertFn {
                 u64 content = 0;
                 for (u64 j = 0; j < len; j++) content |= (u64)t[p + j] << (8 * j);
                 const u64 mine = kExactKey | (len << 60) | content;
-                found = insert_exact(mine, p, exact_hash(mine) & mask, 0, false);
+                found = insert_exact(mine, p, exact_hash(mine) & (hot_keys ? hot_mask : mask), 0, false);
             } else found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
             if (found != prim::kNoBucket) out_slot[ord] = found & ~prim::kClaimBit;
         }
@@ -302,10 +312,10 @@ struct HashInsertFn {
             fast[j] = fast[j] && len <= 7;
             const u64 content = chunk[j] & ((1ull << (8 * len)) - 1ull);
             mine[j] = kExactKey | ((u64)len << 60) | content;
-            idx[j] = exact_hash(mine[j]) & mask;
+            idx[j] = exact_hash(mine[j]) & (hot_keys ? hot_mask : mask);
         }
 #pragma unroll
-        for (int j = 0; j < B; j++) cur[j] = prim::load_relaxed(&keys[(fast[j] ? idx[j] : 0) << ks]);
+        for (int j = 0; j < B; j++) cur[j] = hot_keys ? hot_keys[fast[j] ? idx[j] : 0] : prim::load_relaxed(&keys[(fast[j] ? idx[j] : 0) << ks]);
 #pragma unroll
         for (int j = 0; j < B; j++) {
             // (no continue/break/return inside divergent code here: see the note in find_or_insert)
@@ -330,8 +340,22 @@ struct HashInsertFn {
     // find or claim the slot of an exact key; (sl, c) = first slot and, if `have_first`, the key already loaded from it
     GRL_DEV u32 insert_exact(u64 mine, u64 p, u64 sl, u64 c, bool have_first) const {
         u32 found = prim::kNoBucket;
+        if (hot_keys) {                         // (sl, c) refer to the hot table: look the key up there first (read-only: plain loads)
+            bool miss = false;
+            bool first = have_first;
+            while (found == prim::kNoBucket && !miss) {
+                if (!first) c = hot_keys[sl];
+                first = false;
+                if (c == mine) found = (u32)sl;
+                else if (c == 0) miss = true;
+                else sl = (sl + 1) & hot_mask;
+            }
+            sl = exact_hash(mine) & mask;
+            have_first = false;
+        }
         bool stop = false;                      // the table overflowed elsewhere: give up (the host re-runs the pass)
         bool claimed = false;
+        const bool was_hot = found != prim::kNoBucket;
         for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket && !stop; probes++) {
             if (probes || !have_first) {
                 if (probes == 16 && prim::load_relaxed(&scal[1])) stop = true;
@@ -341,10 +365,10 @@ struct HashInsertFn {
                 u64 old = prim::atomic_cas(&keys[sl << ks], 0ull, mine);
                 if (old == 0) { c = mine; rep_pos[sl] = p; claimed = true; } else c = old;
             }
-            if (c == mine) found = (u32)sl; else sl = (sl + 1) & mask;
+            if (c == mine) found = (u32)sl + slot_base; else sl = (sl + 1) & mask;
         }
         if (found == prim::kNoBucket) scal[1] = 1;
-        else if (claimed && claim_bits) found |= prim::kClaimBit;
+        else if (!was_hot && claimed && claim_bits) found |= prim::kClaimBit;
         return found;
     }
     // claim or find the table slot of the phrase t[p .. p+len) whose (finalised) hash is h
@@ -353,10 +377,21 @@ struct HashInsertFn {
         u64 hi = ((h >> 54) << 13) | ((u64)lastT << 12) | lsat;          // tag:10 | ends-a-string:1 | len:12 (bit 63 of the key stays clear)
         u64 mine = (hi << kPosBits) | (p + 1);
         u64 slot = h & mask;
+        u32 hot_found = prim::kNoBucket;
+        if (hot_keys) {                         // hot table first (read-only)
+            u64 hs = h & hot_mask;
+            bool miss = false;
+            while (hot_found == prim::kNoBucket && !miss) {
+                const u64 cur = hot_keys[hs];
+                if (cur == 0) miss = true;
+                else if ((cur >> kPosBits) == hi && same_phrase(key_pos(cur), p, len, lsat == kLenSat)) hot_found = (u32)hs;
+                else hs = (hs + 1) & hot_mask;
+            }
+        }
         // NOTE: the result is carried in `found` and returned after the loop.  Returning from inside
         // the probe loop made hipcc 7.2 (gfx950) reuse the return register as a scratch under a
         // partial exec mask, so lanes that matched an existing key returned a stale value.
-        u32 found = prim::kNoBucket;
+        u32 found = hot_found;
         bool stop = false;
         bool claimed = false;
         for (u64 probes = 0; probes < probe_limit && found == prim::kNoBucket && !stop; probes++) {
@@ -371,7 +406,7 @@ struct HashInsertFn {
             }
             bool hit = (cur == mine);
             if (!hit && (cur >> kPosBits) == hi) hit = same_phrase(key_pos(cur), p, len, lsat == kLenSat);
-            if (hit) found = (u32)slot;
+            if (hit) found = (u32)slot + slot_base;
             else slot = (slot + 1) & mask;
         }
         if (found == prim::kNoBucket) scal[1] = 1;   // table full / out of probes
@@ -382,6 +417,9 @@ struct HashInsertFn {
 struct SlotCountAdd {
     idx_t *counts; u64 cs;     // count of slot s at counts[s * cs]
     GRL_DEV void operator()(u32 slot, u32 c) const { prim::atomic_add(&counts[(u64)slot * cs], (idx_t)c); }
+};
+struct NoCountAdd {            // (experiments: the hashing pass without its count atomics)
+    GRL_DEV void operator()(u32, u32) const {}
 };
 
 struct OccIn {
@@ -394,8 +432,10 @@ template <class F>
 struct SampledFn {
     F f; u64 blk, stride;
     static constexpr int kBatch = F::kBatch;
-    static constexpr bool kClaims = false;        // (the sampled functor runs with claim_bits == nullptr: untagged slot ids)
+    static constexpr bool kClaims = F::kClaims;   // (claims are marked at the REAL position: claim_pos)
+    u64 *claim_bits = nullptr;                    // = f.claim_bits
     GRL_DEV u64 map(u64 v) const { return (v / blk) * stride + (v % blk); }
+    GRL_DEV u64 claim_pos(u64 v) const { return map(v); }
     GRL_DEV bool is_start(u64 v) const { return f.is_start(map(v)); }
     GRL_DEV u32 process(u64 v) const { return f.process(map(v)); }
     GRL_DEV u32 operator()(u64 v) const { return f(map(v)); }
@@ -728,6 +768,7 @@ struct GroupAccumSmallFn {
     const u32 *perm; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag; u32 *pslot;
+    u32 *gphr;            // non-null: the whole phrase of a group is recorded BY GROUP (sequential store) instead of pslot[phrase] = group
     GRL_DEV void operator()(u64 g) const {
         const u32 t0 = gstart[g], t1 = gstart[g + 1];
         const bool large = t1 - t0 > kGroupChunk;   // folded by GroupAccumLargeFn with atomics: start from the identities
@@ -743,7 +784,11 @@ struct GroupAccumSmallFn {
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
-            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = (u32)g; } // a whole phrase: the group its metasymbol will be read from
+            if (left == bwt_code) {                 // a whole phrase: the group its metasymbol will be read from
+                fl = 1;
+                const u32 k = r.phr(dict_phr, q);
+                if (gphr) gphr[g] = k; else pslot[k] = (u32)g;
+            }
         }
         gmin[g] = mn; gmax[g] = mx; gacc[g] = acc; gfull[g] = fl;
         if (!large) {
@@ -761,7 +806,7 @@ struct GroupChunksIn {    // chunks of a group above kGroupChunk members (0 for 
 struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per slot spent 27 ms at 10 GB finding out it had nothing to do)
     const u32 *perm; const u32 *coff; u64 G; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
     u32 bwt_code;
-    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u32 *pslot;
+    u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u32 *pslot; u32 *gphr;
     GRL_DEV void operator()(u64 c) const {
         const u32 g = (u32)upper_bound<u32>(coff, G, (u32)c) - 1;     // the group with coff[g] <= c < coff[g + 1]
         const u32 t1 = gstart[g + 1], t = gstart[g] + ((u32)c - coff[g]) * kGroupChunk;
@@ -773,7 +818,11 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
-            if (left == bwt_code) { fl = 1; pslot[r.phr(dict_phr, q)] = g; }
+            if (left == bwt_code) {
+                fl = 1;
+                const u32 k = r.phr(dict_phr, q);
+                if (gphr) gphr[g] = k; else pslot[k] = g;
+            }
         }
         prim::atomic_min(&gmin[g], mn);
         prim::atomic_max(&gmax[g], mx);
@@ -857,31 +906,48 @@ struct MetaPairFn {        // (position << 32 | metasymbol) of the marked slots,
         if (gi & 1u) pairs[ex[t]] = ((u64)perm[t] << 32) | (u64)((gi >> 1) + sigma3);
     }
 };
-struct MetaPosFn {         // by sorted slot t: gid[] and ginfo[] are read in order, only the marked suffixes scatter (meta[] zeroed before)
-    const u32 *perm; const u32 *gid; const u32 *ginfo; u32 sigma3; u32 *meta;
-    GRL_DEV void operator()(u64 t) const {
-        u32 gi = ginfo[gid[t]];
-        if (gi & 1u) meta[perm[t]] = (gi >> 1) + sigma3;
+// The grammar walk reads ONE array: dm[q] = meta << 32 | last-cell-of-its-phrase << 31 | that-phrase-ends-a-string << 30 | symbol
+// (symbols and metasymbols are < 2^30).  A walk then touches one or two neighbouring 64-byte lines per metasymbol.  (Rounds 1-2 kept
+// meta[], dict_sym[], the phrase-start bit-vector, dict_phr[] and ph_lastT[] apart: five random lines for 8 bytes of
+// output, 161 GB fetched to write 4 GB at 10 GB -- 46 ms.)
+static constexpr u32 kDmEnd = 0x80000000u, kDmLastT = 0x40000000u, kDmSym = 0x3FFFFFFFu;
+struct DictMetaInitFn {    // streaming: low half of dm[] from the dictionary, meta = 0
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT; u64 *dm;
+    GRL_DEV void operator()(u64 q) const {
+        const u32 k = dict_phr[q];
+        const bool end = q + 1 == (u64)ph_off[k + 1];
+        dm[q] = (u64)(dict_sym[q] | (end ? kDmEnd : 0u) | ((end && ph_lastT[k]) ? kDmLastT : 0u));
     }
 };
-struct GrammarFn {         // (phrase ends from the dictionary's start bit-vector, which stays in the caches: no phrase-table gathers on the way)
-    const u32 *repq; const u32 *dict_sym; const u32 *dict_phr; const u8 *ph_lastT;
-    const u32 *meta; const u64 *pw; u64 S;
+struct MetaPosFn {         // by sorted slot t: gid[] and ginfo[] are read in order, only the marked suffixes scatter (the high halves of dm[])
+    const u32 *perm; const u32 *gid; const u32 *ginfo; u32 sigma3; u64 *dm;
+    GRL_DEV void operator()(u64 t) const {
+        u32 gi = ginfo[gid[t]];
+        if (gi & 1u) reinterpret_cast<u32 *>(dm)[2 * (u64)perm[t] + 1] = (gi >> 1) + sigma3;
+    }
+};
+struct ApplyMetaPairsFn {  // the same from (position << 32 | metasymbol) pairs (sharded dictionary stage)
+    const u64 *pairs; u64 *dm;
+    GRL_DEV void operator()(u64 i) const { const u64 p = pairs[i]; reinterpret_cast<u32 *>(dm)[2 * (p >> 32) + 1] = (u32)p; }
+};
+struct GrammarFn {
+    const u32 *repq; const u64 *dm;
     u32 MD;
     u32 *g0; u32 *g1;
     GRL_DEV void operator()(u64 u) const {
-        const u64 q = repq[u];
+        u64 x = repq[u];
+        u64 prev = dm[x];
         u32 a = MD, b = 0;
         bool done = false;
-        if (q + 1 == S || bit_at(pw, q + 1)) { b = dict_sym[q]; done = true; }       // q is the last cell of its phrase (:38-41)
-        u64 x = q + 1;
+        if ((u32)prev & kDmEnd) { b = (u32)prev & kDmSym; done = true; }               // the representative is the last cell of its phrase (:38-41)
         while (!done) {
-            const u32 m = meta[x];
-            if (m) { a = dict_sym[x - 1]; b = m; done = true; }                         // :49-80
-            else if (x + 1 == S || bit_at(pw, x + 1)) {                                 // x is the last cell of the phrase (:81-85)
-                b = ph_lastT[dict_phr[x]] ? dict_sym[x] : dict_sym[x - 1];
+            const u64 e = dm[++x];
+            const u32 m = (u32)(e >> 32);
+            if (m) { a = (u32)prev & kDmSym; b = m; done = true; }                      // :49-80
+            else if ((u32)e & kDmEnd) {                                                 // x is the last cell of the phrase (:81-85)
+                b = ((u32)e & kDmLastT) ? ((u32)e & kDmSym) : ((u32)prev & kDmSym);
                 done = true;
-            } else x++;
+            } else prev = e;
         }
         g0[u] = a; g1[u] = b;
     }
@@ -894,6 +960,23 @@ struct PhraseValFn {      // pslot[k] = equal-suffix group of phrase k's whole-p
     GRL_DEV void operator()(u64 k) const {
         u32 r = grank[pslot[k]];
         phrase_val[k] = (r << 2) | ((ph_freq[k] > 1) ? 2u : 0u) | (ph_lastT[k] ? 1u : 0u);
+    }
+};
+// Single-GPU rounds: the value of a phrase goes from the GROUP of its whole-phrase suffix straight to the table slot the parse
+// reads it from -- one gather (the phrase's slot and flags, packed) and one scatter per phrase.  (Rounds 1-2: pslot[phrase] =
+// group scattered from the sorted side, the rank gathered back per phrase, the value scattered to the slot: two random
+// scatters of D stores each, ~23 G/s in arrays of this size -- tools/membench.hip.)
+struct PackPhraseInfoFn {  // pinfo[k] = slot | (freq > 1) << 32 | ends-a-string << 33
+    const u32 *ph_slot; const idx_t *ph_freq; const u8 *ph_lastT; u64 *pinfo;
+    GRL_DEV void operator()(u64 k) const { pinfo[k] = (u64)ph_slot[k] | ((ph_freq[k] > 1) ? (1ull << 32) : 0ull) | (ph_lastT[k] ? (1ull << 33) : 0ull); }
+};
+struct GroupPhraseValFn {
+    const u8 *gfull; const u32 *gphr; const u32 *grank; const u64 *pinfo; u32 *slot_val;
+    GRL_DEV void operator()(u64 g) const {
+        if (gfull[g]) {
+            const u64 pi = pinfo[gphr[g]];
+            slot_val[(u32)pi] = (grank[g] << 2) | ((pi >> 32) & 1ull ? 2u : 0u) | ((pi >> 33) & 1ull ? 1u : 0u);
+        }
     }
 };
 struct ScatterValFn {
@@ -915,6 +998,7 @@ struct RankBits {
 };
 struct BuildBitsFn {      // one lane per 16 consecutive (sorted, distinct) positions: OR them into their words
     const idx_t *pos; u64 count; u64 *words;
+    u64 ws = 1;           // word i of the bit-vector sits at words[i * ws] (interleaved layouts: TCell)
     struct alignas(16) Chunk { idx_t v[16 / sizeof(idx_t)]; };     // 16 bytes of positions per load
     GRL_DEV void operator()(u64 j) const {
         u64 i0 = j * 16, i1 = i0 + 16 < count ? i0 + 16 : count;
@@ -936,11 +1020,11 @@ struct BuildBitsFn {      // one lane per 16 consecutive (sorted, distinct) posi
         for (int k = 0; k < 16; k++) {
             if (i0 + k < i1) {
                 u64 x = x16[k], w = x >> 6;
-                if (w != cur) { prim::atomic_or(&words[cur], m); m = 0; cur = w; }
+                if (w != cur) { prim::atomic_or(&words[cur * ws], m); m = 0; cur = w; }
                 m |= 1ull << (x & 63);
             }
         }
-        prim::atomic_or(&words[cur], m);
+        prim::atomic_or(&words[cur * ws], m);
     }
 };
 // # boundaries in [0, x)
@@ -1005,6 +1089,7 @@ struct DiffFn {
 struct Runs {
     DBuf<u32> sym;
     DBuf<idx_t> len;
+    DBuf<idx_t> pos;      // optional: first symbol position of every run + total (R + 1 entries), kept from the merge that made the runs
     u64 R = 0;
     u64 n = 0;            // symbols described (set by merge_runs)
 };
@@ -1033,8 +1118,11 @@ static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merg
     out.n = (u64)tot.b;
     out.len.alloc(R);
     prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
-    if (R == n) out.sym = std::move(hsym);
+    // the heads' scratch (sized for the worst case) becomes the symbol array as it is, unless it is much larger than what it
+    // holds (a copy of 4 R bytes -- 6.6 GB at level 0 of the 10 GB build -- for nothing but a tighter allocation otherwise)
+    if (R * 2 >= n) out.sym = std::move(hsym);
     else { out.sym.alloc(R); prim::d2d(out.sym.p, hsym.p, R * sizeof(u32)); }
+    out.pos = std::move(ostart);      // (pass C of the next level wants exactly this prefix: no scan of the lengths there)
     out.R = R;
     return out;
 }
@@ -1066,8 +1154,11 @@ static inline Runs merge_atoms(const u64 *atoms, u64 n, int lbits) {
     out.n = (u64)tot.b;
     out.len.alloc(R);
     prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
-    if (R == n) out.sym = std::move(hsym);
+    // the heads' scratch (sized for the worst case) becomes the symbol array as it is, unless it is much larger than what it
+    // holds (a copy of 4 R bytes -- 6.6 GB at level 0 of the 10 GB build -- for nothing but a tighter allocation otherwise)
+    if (R * 2 >= n) out.sym = std::move(hsym);
     else { out.sym.alloc(R); prim::d2d(out.sym.p, hsym.p, R * sizeof(u32)); }
+    out.pos = std::move(ostart);      // (pass C of the next level wants exactly this prefix: no scan of the lengths there)
     out.R = R;
     return out;
 }
@@ -1208,15 +1299,33 @@ GRL_DEV u64 cell_lower_bound(const CellView &c, u64 E, u32 u) {
     while (lo < hi) { u64 mid = (lo + hi) >> 1; if (c.key(mid) < u) lo = mid + 1; else hi = mid; }
     return lo;
 }
-GRL_DEV void mark_coincidence(const u64 *tw, u64 *cw, u64 x) {
-    if (x && ((tw[x >> 6] >> (x & 63)) & 1ull)) prim::atomic_or(&cw[x >> 6], 1ull << (x & 63));
+// The two bit-vectors over the T axis and their ranks, interleaved: word i of both and the counts in front of it share one
+// 32-byte cell, so that "first atom of a segment" -- a rank in each vector at the same position -- is ONE gather instead of
+// four (the cell and atom kernels were bound by the number of gather instructions: 35 per pair of cells in round 2).
+struct alignas(32) TCell { u64 tw, tb, cw, cb; };        // run starts of BWT_{r+1} / their count in front; coincidences / their count
+struct alignas(16) TCellT { u64 tw, tb; };               // (the first half alone: 16-byte loads)
+GRL_DEV u64 trank(const TCell *tc, u64 x) {              // run starts in [0, x)
+    const TCellT c = *reinterpret_cast<const TCellT *>(&tc[x >> 6]);
+    return c.tb + (u64)__builtin_popcountll(c.tw & ((1ull << (x & 63)) - 1ull));
+}
+struct TCellPopcIn {      // popcount of one of the two vectors (which: 0 = tw, 2 = cw)
+    const TCell *tc; int which;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)__builtin_popcountll(reinterpret_cast<const u64 *>(&tc[i])[which]); }
+};
+struct TCellBaseEmitFn {  // ... and its exclusive prefix into the neighbouring field
+    static constexpr bool kWaveEmit = false;
+    TCell *tc; int which;
+    GRL_DEV void operator()(u64 i, u64 ex, u64) const { reinterpret_cast<u64 *>(&tc[i])[which + 1] = ex; }
+};
+GRL_DEV void mark_coincidence(TCell *tc, u64 x) {
+    if (x && ((tc[x >> 6].tw >> (x & 63)) & 1ull)) prim::atomic_or(&tc[x >> 6].cw, 1ull << (x & 63));
 }
 template <class TC>
 struct PrePlaceFn {       // non-HOCC pre-BWT runs: segment index, T prefix; BWT-marker runs mark their T start
     const u32 *psym; const HoccBwt *PHB; const idx_t *nhb; const u32 *u_to_p; u64 M; CellView c; u64 E; const TC *Tc;
     const u32 *p_to_u; const idx_t *first_cell;      // optional O(1) forms of the two searches (nullptr: search)
     u32 hocc_code, bwt_code;
-    idx_t *pre_g; idx_t *pre_x; const u64 *tw; u64 *cw;
+    idx_t *pre_g; idx_t *pre_x; TCell *tc;
     GRL_DEV void operator()(u64 j) const {
         u32 s = psym[j];
         if (s != hocc_code) {
@@ -1225,7 +1334,7 @@ struct PrePlaceFn {       // non-HOCC pre-BWT runs: segment index, T prefix; BWT
             u64 x = (u64)PHB[j].b + (u64)Tc[cs];
             pre_g[j] = (idx_t)((u64)nhb[j] + cs);
             pre_x[j] = (idx_t)x;
-            if (s == bwt_code) mark_coincidence(tw, cw, x);
+            if (s == bwt_code) mark_coincidence(tc, x);
         }
     }
 };
@@ -1234,11 +1343,11 @@ struct PrePlaceFn {       // non-HOCC pre-BWT runs: segment index, T prefix; BWT
 // two bit-vectors afterwards cost 54 ms at level 0 of the 10 GB build, this costs one bit test per TAKE cell)
 template <class TC>
 struct TakeScanEmitFn {
-    CellView c; const u32 *u_to_p; const HoccBwt *PHB; u32 take_code; u64 E; const u64 *tw; TC *Tc; u64 *cw;
+    CellView c; const u32 *u_to_p; const HoccBwt *PHB; u32 take_code; u64 E; TCell *tc; TC *Tc;
     GRL_DEV void operator()(u64 t, TC ex, TC v) const {
         Tc[t] = ex;
         if (t == E - 1) Tc[E] = ex + v;
-        if (c.sym(t) == take_code) mark_coincidence(tw, cw, (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b);
+        if (c.sym(t) == take_code) mark_coincidence(tc, (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b);
     }
 #ifdef GRLBWT_PRIM_HIP
     // Wave-cooperative form (prim::k_scan_tiles calls it with all lanes): the marks of 64 consecutive cells fall into a
@@ -1254,10 +1363,10 @@ struct TakeScanEmitFn {
             if (t == E - 1) Tc[E] = ex + v;
             if (c.sym(t) == take_code) {
                 x = (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b;
-                mk = x && ((tw[x >> 6] >> (x & 63)) & 1ull);
+                mk = x && ((tc[x >> 6].tw >> (x & 63)) & 1ull);
             }
         }
-        prim::wave_or_words(cw, mk, x >> 6, 1ull << (x & 63));
+        prim::wave_or_words(reinterpret_cast<u64 *>(tc), mk, (x >> 6) * 4 + 2, 1ull << (x & 63));      // (word index of TCell::cw)
     }
 #else
     static constexpr bool kWaveEmit = false;
@@ -1283,11 +1392,17 @@ struct BucketSizeIn {
 static constexpr u32 kInlineAtoms = 16;
 struct BigSeg { u64 abase, a, b, k0; };
 struct AtomEmitter {
-    const u64 *tw; const idx_t *tb; const u64 *cw; const idx_t *cb; const idx_t *Tpos; const u32 *term;
+    const TCell *tc; const idx_t *Tpos; const u32 *term;
     u32 *osym; idx_t *olen; u64 *oatom; int lbits;      // oatom != nullptr: packed atoms sym << lbits | len
     BigSeg *big; u32 *big_n; u32 big_cap;
     GRL_DEV u64 abase_of(u64 g, u64 x) const {
-        return x ? g + (rank1(tw, tb, x) - 1) - rank1(cw, cb, x) : g;
+        u64 o = g;
+        if (x) {
+            const TCell c = tc[x >> 6];
+            const u64 below = (1ull << (x & 63)) - 1ull;
+            o = g + (c.tb + (u64)__builtin_popcountll(c.tw & below) - 1) - (c.cb + (u64)__builtin_popcountll(c.cw & below));
+        }
+        return o;
     }
     GRL_DEV void put(u64 o, u32 sym, u64 len) const {
         if (oatom) oatom[o] = ((u64)sym << lbits) | len;
@@ -1295,8 +1410,8 @@ struct AtomEmitter {
     }
     GRL_DEV void literal(u64 g, u64 x, u32 sym, idx_t len) const { put(abase_of(g, x), sym, (u64)len); }
     GRL_DEV void take(u64 g, u64 a, u64 len) const {
-        const u64 k0 = rank1(tw, tb, a + 1) - 1;                     // run of BWT_{r+1} holding T position a
-        take_at(abase_of(g, a), a, len, k0, rank1(tw, tb, a + len) - k0);
+        const u64 k0 = trank(tc, a + 1) - 1;                         // run of BWT_{r+1} holding T position a
+        take_at(abase_of(g, a), a, len, k0, trank(tc, a + len) - k0);
     }
     // TAKE segment [a, a+len) whose first atom is o, first run k0, number of runs touched cnt
     GRL_DEV void take_at(u64 o, u64 a, u64 len, u64 k0, u64 cnt) const {
@@ -1341,10 +1456,9 @@ struct CellAtomsFn {
         // ranks of all cells: the loads of the chains are independent
 #pragma unroll
         for (int e = 0; e < NC; e++) {
-            const u64 r = x[e] ? rank1(em.tw, em.tb, x[e]) : 0, q = x[e] ? rank1(em.cw, em.cb, x[e]) : 0;
-            o[e] = x[e] ? g[e] + (r - 1) - q : g[e];
-            f[e] = tk[e] ? rank1(em.tw, em.tb, x[e] + 1) - 1 : 0;                   // run holding the TAKE start
-            n[e] = tk[e] ? rank1(em.tw, em.tb, x[e] + l[e]) - f[e] : 0;
+            o[e] = em.abase_of(g[e], x[e]);                                         // (one 32-byte gather)
+            f[e] = tk[e] ? trank(em.tc, x[e] + 1) - 1 : 0;                          // run holding the TAKE start
+            n[e] = tk[e] ? trank(em.tc, x[e] + l[e]) - f[e] : 0;
         }
 #pragma unroll
         for (int e = 0; e < NC; e++) {
@@ -1363,8 +1477,8 @@ struct PreAtomsFn {
     }
 };
 struct BigCountIn {
-    const BigSeg *big; const u64 *tw; const idx_t *tb;
-    GRL_DEV u64 operator()(u64 i) const { return rank1(tw, tb, big[i].b) - big[i].k0; }
+    const BigSeg *big; const TCell *tc;
+    GRL_DEV u64 operator()(u64 i) const { return trank(tc, big[i].b) - big[i].k0; }
 };
 struct BigAtomsFn {       // one lane per atom of the queued segments
     const BigSeg *big; const u64 *bbase; u64 nbig; const idx_t *Tpos; const u32 *term; AtomEmitter em;
@@ -1969,6 +2083,7 @@ struct SplitRunsFn {      // one lane per L-piece
 struct RunSymFn {         // for_each_agg protocol: every run is a work item, its bucket is its symbol
     static constexpr int kBatch = 1;
     static constexpr bool kClaims = false;
+    GRL_DEV u64 claim_pos(u64 i) const { return i; }
     const u32 *rsym;
     GRL_DEV bool is_start(u64) const { return true; }
     GRL_DEV u32 process(u64 i) const { return rsym[i]; }
@@ -2239,6 +2354,7 @@ class Engine {
         DBuf<u32> scal(4);
         u64 cap = cap_max;
         double frac = 1.0;
+        u64 s_blk = 0, s_stride = 0, s_n = 0, s_distinct = 0;      // the sample (blocks of s_blk cells, s_stride apart) and its distinct phrases
         {
             // Table capacity from a sample of 2^20 cells (256 blocks spread evenly over the text) hashed into a table of its
             // own: its distinct fraction `frac`, extrapolated to the whole text.  That over-sizes the table whenever repetition
@@ -2250,9 +2366,12 @@ class Engine {
             // two overflow re-runs per level.  An exact count (one more hashing pass over a 1/64 slice of the hash space)
             // costs about what a right-sized table saves.
             StageTimer st(&tm.hash);
-            const u64 n_s = n < (1ull << 20) ? n : (1ull << 20);
+            // (first level of a large text: 2^22 cells, so that the sample's phrases -- the hot table below -- cover the occurrences well)
+            const u64 want_s = (FIRST && n >= (1ull << 26)) ? (1ull << 22) : (1ull << 20);
+            const u64 n_s = n < want_s ? n : want_s;
             if (n_s < n) {
                 const u64 blk = 4096, nblk = n_s / blk, stride = n / nblk;
+                s_blk = blk; s_stride = stride; s_n = n_s;
                 u64 cap_s = 1024;
                 while (cap_s < 2 * n_s) cap_s <<= 1;
                 DBuf<u64> tk(cap_s), trep;
@@ -2267,6 +2386,7 @@ class Engine {
                 const u64 occ_s = std::max<u64>(prim::reduce_sum<u64>(cap_s, IdxIn<idx_t>{tc.p}, "hash_sample_count"), 1);
                 frac = (double)d_s / (double)occ_s;
                 if (frac > 1.0) frac = 1.0;
+                s_distinct = d_s;
                 const u64 want = (u64)(1.7 * frac * (double)n_occ) + 4096;      // target load <= ~0.6 if the sample is representative
                 cap = 4096;
                 while (cap < want) cap <<= 1;
@@ -2295,25 +2415,53 @@ class Engine {
         const int ks = interleaved ? 1 : 0;
         const u64 cs = interleaved ? 16 / sizeof(idx_t) : 1;
         const idx_t *counts_p = nullptr;
+        // Hot table (HashInsertFn::hot_keys): when few phrases dominate, the phrases of the sample get a small dense table of
+        // their own in front of the big one -- slots [0, cap_hot) -- filled by hashing the sample once more (claims on: they
+        // are dictionary phrases like the others) and read-only in the pass over the text.  GRLBWT_NO_HOT_TABLE=1 switches it off.
+        u64 cap_hot = 0;
+        if (aggregate && s_n && !getenv("GRLBWT_NO_HOT_TABLE")) {
+            cap_hot = 1024;
+            while (cap_hot < 4 * s_distinct) cap_hot <<= 1;               // load <= 0.25: short probe chains
+            if (cap_max > (1ull << 30)) cap_max = 1ull << 30;             // slot ids of both tables stay below 2^31
+            if (cap > cap_max) cap = cap_max;
+            if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: hot table of %llu slots for the %llu phrases of the sample\n", prim::rt().tag,
+                                                      (unsigned long long)cap_hot, (unsigned long long)s_distinct);
+        }
         {
             StageTimer st(&tm.hash);
+            typedef HashInsertFn<cell_t, FIRST> HF;
             for (;;) {
                 idx_t *cnt;
                 if (interleaved) {
                     keys.alloc(2 * cap); keys.zero();
                     cnt = (idx_t *)(keys.p + 1);          // the count lives in the second half of the slot
                 } else {
-                    keys.alloc(cap); counts.alloc(cap);
+                    keys.alloc(cap_hot + cap); counts.alloc(cap_hot + cap);
                     keys.zero(); counts.zero();
                     cnt = counts.p;
                 }
                 counts_p = cnt;
-                if (HashInsertFn<cell_t, FIRST>::kExact) rep_pos.alloc(cap);          // (written by the lanes that claim a slot)
+                if (HF::kExact) rep_pos.alloc(cap_hot + cap);                          // (written by the lanes that claim a slot)
                 scal.zero();
                 claim.zero();
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
-                launch_hash<cell_t, FIRST>(HashInsertFn<cell_t, FIRST>{t, ops, startbits.p, wordbase.p, keys.p, cap - 1, probe_limit, ks,
-                                                                     P.next_text.p, scal.p, n, n_occ, rep_pos.p, claim.p}, cnt, cs, n, aggregate);
+                HF f{t, ops, startbits.p, wordbase.p, keys.p + cap_hot, cap - 1, probe_limit, ks,
+                     P.next_text.p, scal.p, n, n_occ, rep_pos.p ? rep_pos.p + cap_hot : nullptr, claim.p};
+                if (cap_hot) {
+                    HF fh{t, ops, startbits.p, wordbase.p, keys.p, cap_hot - 1, cap_hot, 0, P.next_text.p, scal.p, n, n_occ, rep_pos.p, claim.p};
+                    prim::for_each_agg(s_n, SampledFn<HF>{fh, s_blk, s_stride, claim.p}, NoCountAdd{}, false, "hash_hot");
+                    f.hot_keys = keys.p; f.hot_mask = cap_hot - 1; f.slot_base = (u32)cap_hot;
+                }
+                if (getenv("GRLBWT_EXP_NOCOUNT")) {      // experiment: the same pass without counting, timed as "hash_nocount", then thrown away
+                    DBuf<u64> claim2(nwords + 1);
+                    HF f2 = f;
+                    f2.claim_bits = claim2.p;
+                    claim2.zero();
+                    prim::for_each_agg(n, f2, NoCountAdd{}, false, "hash_nocount");
+                    prim::dev_memset(keys.p + (cap_hot << ks), 0, (cap << ks) * sizeof(u64));
+                    scal.zero();
+                }
+                launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
                 std::vector<u32> sc = scal.to_host(4);
                 if (sc[1] == 1) {
                     if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");
@@ -2326,7 +2474,7 @@ class Engine {
                 break;
             }
         }
-        P.cap = cap;
+        P.cap = cap_hot + cap;
 
         // ---- a5: distinct phrases of this text (from the claim bits: the table itself is not scanned) -------------------
         {
@@ -2462,7 +2610,8 @@ class Engine {
     // streaming passes (dictionary, grammar walk) stay replicated.  Same kernels in both modes.
     template <class cell_t, bool FIRST>
     void dict_stage(const Comm *C, const cell_t *t, CellOps<cell_t, FIRST> ops, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
-                    const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val) {
+                    const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val,
+                    const u32 *fused_ph_slot = nullptr, u32 *fused_slot_val = nullptr) {      // (both set: the values go straight to the slots)
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
         DBuf<u32> dict_sym(S), dict_phr(S);
         RankBits pbits;                          // phrase starts over the dictionary positions (dictionary build, suffix refinement)
@@ -2597,23 +2746,25 @@ class Engine {
         DBuf<idx_t> gacc;
         DBuf<u8> gfull, gflag;
         DBuf<u32> repq, pslot;                   // pslot[k] = my group holding phrase k's whole-phrase suffix (all ones: not mine)
+        DBuf<u32> gphr;                          // ... or, single-GPU rounds, gphr[g] = the whole phrase of group g (see GroupPhraseValFn)
+        const bool fused_vals = !C && fused_ph_slot && fused_slot_val;
         u64 M, P0;
         {
             StageTimer st(&tm.dict_groups);
             u64 Ml = 0, P0l = 0;
             auto groups_local = [&] {
             grank.alloc(G + 1); pidx.alloc(G + 1); gmin.alloc(G); gmax.alloc(G); gacc.alloc(G); gfull.alloc(G); gflag.alloc(G);
-            pslot.alloc(D);
+            if (fused_vals) gphr.alloc(G); else pslot.alloc(D);
             if (C) pslot.fill_ff();              // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
             {
                 DBuf<SufRec> rec(S);
                 prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
                 prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, dict_phr.p, bwt_code,
-                                                    gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p}, "group_accum");
+                                                    gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
                 DBuf<u32> coff(G + 1);
                 const u64 NC = prim::exclusive_scan<u32>(G, GroupChunksIn{gstart.p}, coff.p, true, "group_accum_large");
                 prim::for_each(NC, GroupAccumLargeFn{perm.p, coff.p, G, gstart.p, rec.p, dict_phr.p, bwt_code,
-                                                     gmin.p, gmax.p, gacc.p, gfull.p, pslot.p}, "group_accum_large");
+                                                     gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
@@ -2649,6 +2800,7 @@ class Engine {
             }
             DBuf<u32> merged(P0);
             L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
+            L.prebwt.pos.release();
             L.u_to_p.alloc(M);
             prim::for_each(M, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
             L.p_to_u.alloc(L.prebwt.R);
@@ -2657,10 +2809,11 @@ class Engine {
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
             {
-                DBuf<u32> ginfo(G), meta(S);
+                DBuf<u32> ginfo(G);
+                DBuf<u64> dm(S);
                 prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, (u32)Moff, ginfo.p}, "grammar_ginfo");
-                meta.zero();
-                if (!C) prim::for_each(Sg, MetaPosFn{perm.p, gid.p, ginfo.p, sigma3, meta.p}, "grammar_marks");
+                prim::for_each(S, DictMetaInitFn{dict_sym.p, dict_phr.p, ph_off, ph_lastT, dm.p}, "grammar_init");
+                if (!C) prim::for_each(Sg, MetaPosFn{perm.p, gid.p, ginfo.p, sigma3, dm.p}, "grammar_marks");
                 else {                           // the marked positions of every rank's groups, as (position, metasymbol) pairs
                     DBuf<u32> mex(Sg + 1);
                     const u64 nm = prim::exclusive_scan<u32>(Sg, MarkedIn{gid.p, ginfo.p}, mex.p, false, "dist.mark_scan");
@@ -2668,19 +2821,24 @@ class Engine {
                     prim::for_each(Sg, MetaPairFn{perm.p, gid.p, ginfo.p, mex.p, sigma3, mp.p}, "dist.mark_pairs");
                     std::vector<u64> bb;
                     DBuf<u64> all = C->template allgather_v<u64>(mp.p, nm, bb);
-                    prim::for_each(bb[C->size], ApplyPairsFn{all.p, meta.p}, "grammar_marks");
+                    prim::for_each(bb[C->size], ApplyMetaPairsFn{all.p, dm.p}, "grammar_marks");
                 }
-                if (!C) prim::for_each(M, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_lastT, meta.p, pbits.words.p, S, MD, L.g0.p, L.g1.p}, "grammar");
+                if (!C) prim::for_each(M, GrammarFn{repq.p, dm.p, MD, L.g0.p, L.g1.p}, "grammar");
                 else {                           // every rank walks for its own metasymbols; the cells are all-gathered
                     DBuf<u32> g0l(Ml), g1l(Ml);
-                    prim::for_each(Ml, GrammarFn{repq.p, dict_sym.p, dict_phr.p, ph_lastT, meta.p, pbits.words.p, S, MD, g0l.p, g1l.p}, "grammar");
+                    prim::for_each(Ml, GrammarFn{repq.p, dm.p, MD, g0l.p, g1l.p}, "grammar");
                     C->template allgather_v<u32>(g0l.p, Ml, bbM, true, L.g0.p);
                     C->template allgather_v<u32>(g1l.p, Ml, bbM, true, L.g1.p);
                 }
             }
             // ---- a9: metasymbol of every phrase --------------------------------
-            phrase_val.alloc(D);
-            if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, grank.p, phrase_val.p}, "phrase_values");
+            if (fused_vals) {
+                DBuf<u64> pinfo(D);
+                prim::for_each(D, PackPhraseInfoFn{fused_ph_slot, ph_freq, ph_lastT, pinfo.p}, "phrase_values");
+                prim::for_each(G, GroupPhraseValFn{gfull.p, gphr.p, grank.p, pinfo.p, fused_slot_val}, "slot_values");
+            } else phrase_val.alloc(D);
+            if (fused_vals) {}
+            else if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, grank.p, phrase_val.p}, "phrase_values");
             else {                               // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
                 DBuf<u32> phrase_rank(D), fex(D + 1);
                 const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{pslot.p}, fex.p, false, "dist.full_scan");
@@ -2697,11 +2855,15 @@ class Engine {
     }
 
     // a10: the local parse: slot id of every occurrence -> (rank<<2 | rep<<1 | T) of its phrase
-    void emit_local(LocalParse &P, const u32 *val_of_local_phrase) {
+    // (slot_val given: the dictionary stage has already put every phrase's value at its slot)
+    void emit_local(LocalParse &P, const u32 *val_of_local_phrase, DBuf<u32> *slot_val_filled = nullptr) {
         StageTimer st(&tm.emit);
-        DBuf<u32> slot_val(P.cap);
-        prim::for_each(P.D, ScatterValFn{P.ph_slot.p, val_of_local_phrase, slot_val.p}, "slot_values");
-        prim::for_each(P.n_occ, MapFn{slot_val.p, P.next_text.p}, "emit_parse");
+        DBuf<u32> own;
+        if (!slot_val_filled) {
+            own.alloc(P.cap);
+            prim::for_each(P.D, ScatterValFn{P.ph_slot.p, val_of_local_phrase, own.p}, "slot_values");
+        }
+        prim::for_each(P.n_occ, MapFn{slot_val_filled ? slot_val_filled->p : own.p, P.next_text.p}, "emit_parse");
         prim::sync();
     }
 
@@ -2730,9 +2892,10 @@ class Engine {
         L.info.sigma = sigma;
         LocalParse P;
         hash_local<cell_t, FIRST>(t, n, ops, P, L);
-        DBuf<u32> phrase_val;
-        dict_stage<cell_t, FIRST>(nullptr, t, ops, P.D, P.S, P.maxlen, P.ph_pos.p, P.ph_freq.p, P.ph_off.p, P.ph_lastT.p, sigma, L, phrase_val);
-        emit_local(P, phrase_val.p);
+        DBuf<u32> phrase_val, slot_val(P.cap);
+        dict_stage<cell_t, FIRST>(nullptr, t, ops, P.D, P.S, P.maxlen, P.ph_pos.p, P.ph_freq.p, P.ph_off.p, P.ph_lastT.p, sigma, L, phrase_val,
+                                  P.ph_slot.p, slot_val.p);
+        emit_local(P, nullptr, &slot_val);
         finish_round(P, L, stats.n_strings, P.n_occ);
     }
 
@@ -2900,8 +3063,13 @@ class Engine {
     struct AsmIn { const u32 *psym; const idx_t *plen; u64 P; const u32 *u_to_p; const u32 *p_to_u; u64 M; u32 sigma; u64 n_out; };
     void assemble(const AsmIn &in, LevelInfo &I, const CellView &cells, u64 E, DBuf<u32> &term, int r) {
         StageTimer st(&tm.ind_assemble);
-        DBuf<idx_t> Tpos(bwt.R + 1);
-        const u64 Tsum = (u64)prim::exclusive_scan<idx_t>(bwt.R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
+        DBuf<idx_t> Tpos;
+        u64 Tsum;
+        if (bwt.pos.p) { Tpos = std::move(bwt.pos); Tsum = bwt.n; }       // the run merge that produced BWT_{r+1} left its prefix behind
+        else {
+            Tpos.alloc(bwt.R + 1);
+            Tsum = (u64)prim::exclusive_scan<idx_t>(bwt.R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
+        }
         if (Tsum < 0xFFFFFFFFull) assemble_t<u32>(in, I, cells, E, Tpos, Tsum, term, r);      // the cells' TAKE prefix fits 32 bits
         else assemble_t<u64>(in, I, cells, E, Tpos, Tsum, term, r);
     }
@@ -2929,6 +3097,7 @@ class Engine {
         }
         assemble(AsmIn{L.prebwt.sym.p, L.prebwt.len.p, L.prebwt.R, L.u_to_p.p, L.p_to_u.p, L.M, L.sigma, L.info.n_in}, I, cells, E, term, r);
         bwt_level = r;
+        if (r == 0) bwt.pos.release();           // (no level below wants the prefix)
         I.R = bwt.R;
         I.n = L.info.n_in;
         if (keep_texts) keep_bwt(r);
@@ -2946,17 +3115,16 @@ class Engine {
         const u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.psym, hocc_code}, nhb.p, true, "asm.nhb");
         const u64 PBsum = (u64)PHB.get(P).b;
         // bit-vectors over the T axis (n_{r+1} bits): run starts of BWT_{r+1}; TAKE segment starts that are run starts too
-        RankBits tbits, cbits;
-        build_rankbits(tbits, Tpos.p, R, Tsum + 1, "asm.tbits");
         const u64 nw = Tsum / 64 + 2;
-        cbits.words.alloc(nw);
-        cbits.base.alloc(nw + 1);
-        cbits.words.zero();
+        DBuf<TCell> tcell(nw);
+        tcell.zero();
+        prim::for_each((R + 15) / 16, BuildBitsFn{Tpos.p, R, reinterpret_cast<u64 *>(tcell.p), 4}, "asm.tbits");
+        prim::exclusive_scan_emit<u64>(nw, TCellPopcIn{tcell.p, 0}, TCellBaseEmitFn{tcell.p, 0}, "asm.tbits");
         // the cells' TAKE prefix (scan fused with the coincidence marks)
         DBuf<TC> Tc(E + 1);
         u64 TCsum = 0;
         if (E) TCsum = (u64)prim::exclusive_scan_emit<TC>(E, CellTakeIn<TC>{cells, take_code},
-                                                           TakeScanEmitFn<TC>{cells, L.u_to_p, PHB.p, take_code, E, tbits.words.p, Tc.p, cbits.words.p},
+                                                           TakeScanEmitFn<TC>{cells, L.u_to_p, PHB.p, take_code, E, tcell.p, Tc.p},
                                                            "asm.take_scan");
         else Tc.zero();
         if (PBsum + TCsum != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
@@ -2976,9 +3144,9 @@ class Engine {
                 prim::exclusive_scan_nosync<idx_t>(M, BucketSizeIn{bstart1.p, bend.p}, first_cell.p, true, "asm.first_cell");
             }
             prim::for_each(P, PrePlaceFn<TC>{L.psym, PHB.p, nhb.p, L.u_to_p, M, cells, E, Tc.p, L.p_to_u, first_cell.p,
-                                             hocc_code, bwt_code, pre_g.p, pre_x.p, tbits.words.p, cbits.words.p}, "asm.pre_place");
+                                             hocc_code, bwt_code, pre_g.p, pre_x.p, tcell.p}, "asm.pre_place");
         }
-        const u64 Ctot = (u64)prim::exclusive_scan<idx_t>(nw, PopcIn{cbits.words.p}, cbits.base.p, true, "asm.coinc_rank");
+        const u64 Ctot = prim::exclusive_scan_emit<u64>(nw, TCellPopcIn{tcell.p, 2}, TCellBaseEmitFn{tcell.p, 2}, "asm.coinc_rank");
         const u64 A = G + (R ? R - 1 : 0) - Ctot;           // every run start in (0, Tsum) that is no TAKE segment start cuts one atom
         I.A = A;
         // atoms: one packed word  sym << lbits | len  whenever a symbol and a length of this level fit 64 bits together
@@ -2992,7 +3160,7 @@ class Engine {
         DBuf<BigSeg> big(big_cap);
         DBuf<u32> big_n(1);
         big_n.zero();
-        const AtomEmitter em{tbits.words.p, tbits.base.p, cbits.words.p, cbits.base.p, Tpos.p, term.p, osym.p, olen.p,
+        const AtomEmitter em{tcell.p, Tpos.p, term.p, osym.p, olen.p,
                              packed_atoms ? oatom.p : nullptr, lbits, big.p, big_n.p, big_cap};
         // (four cells per lane: 46.3 vs 43.2 ms at level 0 of the 10 GB build -- two it stays)
         prim::for_each((E + 1) / 2, CellAtomsFn<TC, 2>{cells, L.u_to_p, PHB.p, nhb.p, Tc.p, take_code, em, E}, "asm.cell_atoms");
@@ -3001,12 +3169,12 @@ class Engine {
         if (nbig > big_cap) throw prim::Error(-71, "induction: wide-segment queue overflow (level " + std::to_string(r) + ")");
         if (nbig) {                                          // TAKE segments spanning many runs: one lane per atom
             DBuf<u64> bbase(nbig + 1);
-            const u64 nb_atoms = prim::exclusive_scan<u64>(nbig, BigCountIn{big.p, tbits.words.p, tbits.base.p}, bbase.p, true, "asm.big_scan");
+            const u64 nb_atoms = prim::exclusive_scan<u64>(nbig, BigCountIn{big.p, tcell.p}, bbase.p, true, "asm.big_scan");
             prim::for_each(nb_atoms, BigAtomsFn{big.p, bbase.p, nbig, Tpos.p, term.p, em}, "asm.big_atoms");
         }
         // everything but the atoms can go before the merge allocates its scan arrays (peak memory)
         Tc.release(); pre_g.release(); pre_x.release(); PHB.release(); nhb.release(); big.release();
-        tbits.words.release(); tbits.base.release(); cbits.words.release(); cbits.base.release();
+        tcell.release();
         Tpos.release(); term.release();
         release_cells();
         bwt.sym.release(); bwt.len.release();
@@ -3392,7 +3560,7 @@ class Engine {
                 C.alltoall(slen.p, scnt, wlen.p, rcnt, sizeof(idx_t), maxw);
             }
             Tpos.release(); term.release();
-            bwt.sym.release(); bwt.len.release();
+            bwt.sym.release(); bwt.len.release(); bwt.pos.release();
             // (4) the cells of my buckets, from every rank; rank order inside a bucket = order of the slices
             {
                 std::vector<u64> scnt(N), rcnt(N);

@@ -732,7 +732,8 @@ GRL_DEV u32 agg_take_claim(const F &f, u32 s, u64 item, bool valid) {
     if constexpr (F::kClaims) {
         if (f.claim_bits) {                                      // (uniform)
             const bool real = valid && s != kNoBucket && s != kDeferBucket;
-            wave_or_words(f.claim_bits, real && (s & kClaimBit), item >> 6, 1ull << (item & 63));
+            const u64 cp = f.claim_pos(item);                  // (a functor over a sample of the positions maps its virtual index)
+            wave_or_words(f.claim_bits, real && (s & kClaimBit), cp >> 6, 1ull << (cp & 63));
             if (real) s &= ~kClaimBit;
         }
     }
@@ -869,7 +870,8 @@ struct NoAggFn {
         if (s != kNoBucket) {
             if constexpr (F::kClaims) {
                 if (f.claim_bits) {
-                    if (s & kClaimBit) atomicOr(reinterpret_cast<unsigned long long *>(&f.claim_bits[i >> 6]), 1ull << (i & 63));
+                    const u64 cp = f.claim_pos(i);
+                    if (s & kClaimBit) atomicOr(reinterpret_cast<unsigned long long *>(&f.claim_bits[cp >> 6]), 1ull << (cp & 63));
                     s &= ~kClaimBit;
                 }
             }
@@ -1334,6 +1336,42 @@ __global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int sh
     counts[(u64)blockIdx.x * 256 + threadIdx.x] = tot;      // tile-major: one coalesced row per tile
 }
 
+// Digits wider than 8 bits (9 or 10: one pass fewer over 51-56-bit suffix keys and 18-19-bit bucket residues): per-wave LDS tables,
+// one LDS atomic per key (measured equal to the ballot form at 8 bits).
+template <class K, int SITE, int DB>
+__global__ void __launch_bounds__(kBlock) k_rs_hist_wide(const K *keys, u64 n, int shift, u32 dmask, u32 *counts, u32 tiles) {
+    constexpr int NB = 1 << DB;
+    __shared__ u32 s_h[kBlock / 64][NB];
+    for (int i = threadIdx.x; i < (kBlock / 64) * NB; i += kBlock) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    u32 *h = s_h[threadIdx.x >> 6];
+    const u64 base = (u64)blockIdx.x * kRsTile;
+    const bool full = base + kRsTile <= n;
+    constexpr int per = 16 / (int)sizeof(K);
+    struct alignas(16) Vec { K v[per]; };
+    if (full && ((uintptr_t)keys & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < kRsItems / per; j++) {
+            Vec x = *reinterpret_cast<const Vec *>(keys + base + ((u64)j * kBlock + threadIdx.x) * per);
+#pragma unroll
+            for (int e = 0; e < per; e++) atomicAdd(&h[(u32)(x.v[e] >> shift) & dmask], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kRsItems; r++) {
+            u64 i = base + (u64)r * kBlock + threadIdx.x;
+            if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & dmask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < NB; d += kBlock) {
+        u32 tot = 0;
+#pragma unroll
+        for (int q = 0; q < kBlock / 64; q++) tot += s_h[q][d];
+        counts[(u64)blockIdx.x * NB + d] = tot;
+    }
+}
+
 // Global write positions from the tile-major counts.  The order of a stable pass is digit-major (all tiles of digit
 // 0, then digit 1, ...); storing counts/offsets in that order makes every tile's row 256 accesses `tiles` words apart
 // (measured: the histogram kernel ran at the rate of its scattered 4-byte stores, 10 G/s, not of its key reads).
@@ -1385,19 +1423,19 @@ inline void rs_offsets(const u32 *counts, u32 tiles, u32 *chunk_sums, u64 *chunk
 // once the keys' registers are free; those loads overlap the key write-out.
 static constexpr int kRsKeys = kRsTile / kBlock;
 struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays are read or written
-template <class K, class V, int SITE = 0>
+// (DB = digit bits, 8-10: thread t owns the BPT = 2^DB / 256 neighbouring bins [t * BPT, (t + 1) * BPT) in the offset phase)
+template <class K, class V, int SITE = 0, int DB = 8>
 __global__ void __launch_bounds__(kBlock)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
-                        const u64 *offsets /*[tiles][256] exclusive*/, u32 tiles) {
+                        const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles) {
+    constexpr int NB = 1 << DB, BPT = NB / kBlock;
     constexpr int EB = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[kRsTile * EB];
-    __shared__ u32 s_cnt[4][256];     // per wave: running count, then exclusive base, of each digit
-    __shared__ u32 s_start[256];      // tile-local first index of each digit
-    __shared__ u64 s_gbase[256];      // global position of tile-local index 0 of the digit's run (may wrap; mod 2^64)
+    __shared__ u32 s_cnt[4][NB];      // per wave: running count, then exclusive base, of each digit
+    __shared__ u64 s_gbase[NB];       // global position of tile-local index 0 of the digit's run (may wrap; mod 2^64)
     __shared__ u32 s_wsum[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 4; k++) s_cnt[k][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 4 * NB; i += kBlock) (&s_cnt[0][0])[i] = 0;
     const u64 base = (u64)blockIdx.x * kRsTile;
     const u64 left = n - base;
     const u32 tile_n = left < (u64)kRsTile ? (u32)left : (u32)kRsTile;
@@ -1420,7 +1458,7 @@ __global__ void __launch_bounds__(kBlock)
         u32 d = (u32)(key[q] >> shift) & dmask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < DB; b++) {
             unsigned long long m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -1435,10 +1473,17 @@ __global__ void __launch_bounds__(kBlock)
         idx[q] = old + below;            // rank among this wave's keys of digit d
     }
     __syncthreads();
-    {   // thread d: wave bases, tile-local digit starts, global base
-        u32 c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x], c3 = s_cnt[3][threadIdx.x];
-        u32 total = c0 + c1 + c2 + c3;
-        u32 incl = total;
+    {   // thread t, bins [t*BPT, (t+1)*BPT): wave bases, tile-local digit starts, global bases
+        u32 cw[BPT][4], tt[BPT], sum = 0;
+#pragma unroll
+        for (int e = 0; e < BPT; e++) {
+            const int d = threadIdx.x * BPT + e;
+            tt[e] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { cw[e][k] = s_cnt[k][d]; tt[e] += cw[e][k]; }
+            sum += tt[e];
+        }
+        u32 incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             u32 o = (u32)__shfl_up((int)incl, off);
@@ -1446,15 +1491,18 @@ __global__ void __launch_bounds__(kBlock)
         }
         if (lane == 63) s_wsum[w] = incl;
         __syncthreads();
-        u32 wprev = 0;
-        for (int k = 0; k < w; k++) wprev += s_wsum[k];
-        u32 start = wprev + incl - total;
-        s_start[threadIdx.x] = start;
-        s_cnt[0][threadIdx.x] = start;
-        s_cnt[1][threadIdx.x] = start + c0;
-        s_cnt[2][threadIdx.x] = start + c0 + c1;
-        s_cnt[3][threadIdx.x] = start + c0 + c1 + c2;
-        s_gbase[threadIdx.x] = offsets[(u64)blockIdx.x * 256 + threadIdx.x] - (u64)start;
+        u32 start = incl - sum;
+        for (int k = 0; k < w; k++) start += s_wsum[k];
+#pragma unroll
+        for (int e = 0; e < BPT; e++) {
+            const int d = threadIdx.x * BPT + e;
+            s_cnt[0][d] = start;
+            s_cnt[1][d] = start + cw[e][0];
+            s_cnt[2][d] = start + cw[e][0] + cw[e][1];
+            s_cnt[3][d] = start + cw[e][0] + cw[e][1] + cw[e][2];
+            s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
+            start += tt[e];
+        }
     }
     __syncthreads();
     K *kb = (K *)s_buf;
@@ -1475,16 +1523,16 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
     __syncthreads();
-    u32 dpack[(kRsKeys + 3) / 4];
+    u32 dpack[(kRsKeys + 1) / 2];            // the digit of every key this thread writes out (16 bits each): the values follow them
 #pragma unroll
-    for (int j = 0; j < (kRsKeys + 3) / 4; j++) dpack[j] = 0;
+    for (int j = 0; j < (kRsKeys + 1) / 2; j++) dpack[j] = 0;
 #pragma unroll
     for (int j = 0; j < kRsKeys; j++) {
         u32 t = (u32)j * kBlock + threadIdx.x;
         if (t < tile_n) {
             K k = kb[t];
             u32 d = (u32)(k >> shift) & dmask;
-            dpack[j >> 2] |= d << (8 * (j & 3));
+            dpack[j >> 1] |= d << (16 * (j & 1));
             keys_out[s_gbase[d] + t] = k;
         }
     }
@@ -1501,13 +1549,31 @@ __global__ void __launch_bounds__(kBlock)
         for (int j = 0; j < kRsKeys; j++) {
             u32 t = (u32)j * kBlock + threadIdx.x;
             if (t < tile_n) {
-                u32 d = (dpack[j >> 2] >> (8 * (j & 3))) & 255u;
+                u32 d = (dpack[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
                 vals_out[s_gbase[d] + t] = vb[t];
             }
         }
     }
 }
 
+// Digit plan of an LSD sort over `bits` key bits: the fewest passes with digits of at most rs_max_digit() bits, widths as equal
+// as possible (at 9: 51 bits = 9,9,9,8,8,8; 54 = 6 x 9; 18 = 9,9).  GRLBWT_SORT_DIGIT=8|9|10 sets the widest digit; the default
+// stays 8: measured on the 10 GB build (profiles/r03), 9- and 10-bit digits save a pass over the 51-56-bit suffix keys and the
+// 18-19-bit bucket residues but every pass gets slower by more than that -- a 4096-key tile then leaves 8 or 4 keys per bin,
+// i.e. 32-64-byte runs of keys and 16-32-byte runs of values at the write front: suffix_sort0 at level 2, 7 passes x 5.5 ms
+// vs 6 x 7.2 ms; whole build 1005 / 1010 / 1011 ms at 8 / 9 / 10 bits.
+inline int rs_max_digit() {
+    static const int d = [] { const char *e = getenv("GRLBWT_SORT_DIGIT"); int v = e ? atoi(e) : 8; return v < 8 ? 8 : (v > 10 ? 10 : v); }();
+    return d;
+}
+inline int rs_plan(int bits, int *widths /*[>= bits/8 + 1]*/) {
+    const int maxd = rs_max_digit();
+    const int passes = (bits + maxd - 1) / maxd;
+    if (bits <= 8) { widths[0] = bits; return 1; }
+    const int lo = bits / passes, extra = bits % passes;
+    for (int p = 0; p < passes; p++) widths[p] = lo + (p < extra ? 1 : 0);
+    return passes;
+}
 inline int sort_keys_fwd(u64 *a, u64 *b, u64 n, int begin_bit, int end_bit, const char *name);
 // ------------------------------------------------------- expand + multi-split
 // Stable multi-split of GENERATED keys.  Item i (0 <= i < n) walks a chain through a table of packed node records and
@@ -1595,8 +1661,10 @@ __global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, 
     }
     if (threadIdx.x == 0 && s_max) atomicMax(&scal[0], s_max);
 }
-template <class GEN, int DB>
-__global__ void __launch_bounds__(kBlock, 3) k_xs_scatter(u64 n, GEN gen, u32 dmask, const u8 *cnt8, const u64 *offsets /*[tiles][NB]*/, u64 *out,
+// (MINB = workgroups per CU the register budget is cut for: at 3 the kernel spills ~100 bytes per lane to scratch (168 VGPRs);
+// at 2 it keeps everything in registers at 8 instead of 12 waves per CU -- GRLBWT_XS_OCC=2|3 picks, see expand_sort)
+template <class GEN, int DB, int MINB = 3>
+__global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32 dmask, const u8 *cnt8, const u64 *offsets /*[tiles][NB]*/, u64 *out,
                                                        int xcd_aware) {
     constexpr int NB = 1 << DB, BPT = NB / kBlock > 0 ? NB / kBlock : 1;     // bins per thread (contiguous)
     constexpr int ROWS = kXsWin / kBlock;                                   // 16 rows of 64 keys per wave and round
@@ -1772,7 +1840,10 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char *name
     plan.n = n; plan.bits = bits;
     if (n == 0) { plan.ok = true; return 0; }
     // 9-bit first digit when that saves a pass over all keys (the later passes take 8 bits each)
-    plan.db = (bits > 8 && (bits - 9 + 7) / 8 < (bits - 8 + 7) / 8) ? 9 : 8;
+    {
+        const int md = rs_max_digit();
+        plan.db = (bits > 8 && (bits - 9 + md - 1) / md < (bits - 8 + md - 1) / md) ? 9 : 8;
+    }
     const int NB = 1 << plan.db;
     const u32 dmask = bits >= plan.db ? (u32)NB - 1u : (1u << bits) - 1u;
     plan.tiles = (u32)((n + kXsTileItems - 1) / kXsTileItems);
@@ -1812,45 +1883,65 @@ inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char
     // 16.9 vs 14.8 at level 1): the round-robin deal already lets the 8 L2s share every digit's write front; opt-in only
     static const int xcd_aware = getenv("GRLBWT_XCD_MAP") ? 1 : 0;
     prof_begin(std::string(name) + ".xscatter", plan.E * 8);
-    if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
-    else hipLaunchKernelGGL((k_xs_scatter<GEN, 8>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+    static const int occ = getenv("GRLBWT_XS_OCC") ? atoi(getenv("GRLBWT_XS_OCC")) : 3;
+    if (occ == 2) {
+        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9, 2>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8, 2>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+    } else {
+        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+    }
     prof_end();
     after_launch(name);
     if (plan.bits <= plan.db || plan.E == 0) return 0;
     return sort_keys_fwd(buf_a, buf_b, plan.E, plan.db, plan.bits, name);
 }
 
+template <class K, class V, int SITE, int DB>
+inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shift, u32 dmask, u32 tiles, u32 *counts, u64 *offsets,
+                    u32 *chunk_sums, u64 *chunk_off, const char *name) {
+    prof_begin(std::string(name) + ".hist", n * sizeof(K));
+    if constexpr (DB == 8) hipLaunchKernelGGL((k_rs_hist<K, SITE>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
+    else hipLaunchKernelGGL((k_rs_hist_wide<K, SITE, DB>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
+    prof_end();
+    after_launch(name);
+    rs_offsets<(1 << DB)>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
+    prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
+    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles);
+    prof_end();
+    after_launch(name);
+}
 // Sorts n pairs by key bits [begin_bit, end_bit).  Buffers a/b ping-pong; returns
 // 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b).
 template <class K, class V, int SITE = 0>
 inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit,
                       const char *name = "radix_sort") {
     if (n == 0 || end_bit <= begin_bit) return 0;
+    int widths[16];
+    const int passes = rs_plan(end_bit - begin_bit, widths);
+    int maxw = 8;
+    for (int p = 0; p < passes; p++) if (widths[p] > maxw) maxw = widths[p];
+    const u64 NBmax = (u64)1 << maxw;
     u32 tiles = (u32)((n + kRsTile - 1) / kRsTile);
-    u32 *counts = (u32 *)dev_alloc((u64)256 * tiles * sizeof(u32));
-    u64 *offsets = (u64 *)dev_alloc((u64)256 * tiles * sizeof(u64));
+    u32 *counts = (u32 *)dev_alloc(NBmax * tiles * sizeof(u32));
+    u64 *offsets = (u64 *)dev_alloc(NBmax * tiles * sizeof(u64));
     u32 chunks = (tiles + kRsChunk - 1) / kRsChunk;
-    u32 *chunk_sums = (u32 *)dev_alloc((u64)256 * chunks * sizeof(u32));
-    u64 *chunk_off = (u64 *)dev_alloc((u64)256 * chunks * sizeof(u64));
-    int cur = 0;
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
-        // the last digit may be narrower than 8 bits: key bits at and above end_bit (a payload riding in the key)
-        // must not take part in the order
-        const u32 dmask = end_bit - shift >= 8 ? 255u : (1u << (end_bit - shift)) - 1u;
+    u32 *chunk_sums = (u32 *)dev_alloc(NBmax * chunks * sizeof(u32));
+    u64 *chunk_off = (u64 *)dev_alloc(NBmax * chunks * sizeof(u64));
+    int cur = 0, shift = begin_bit;
+    for (int p = 0; p < passes; p++) {
+        // a digit narrower than its kernel's table: key bits at and above end_bit (a payload riding in the key) must not
+        // take part in the order
+        const int wd = widths[p];
+        const u32 dmask = (1u << wd) - 1u;
         K *kin = cur ? keys_b : keys_a;
         V *vin = cur ? vals_b : vals_a;
         K *kout = cur ? keys_a : keys_b;
         V *vout = cur ? vals_a : vals_b;
-        prof_begin(std::string(name) + ".hist", n * sizeof(K));
-        hipLaunchKernelGGL((k_rs_hist<K, SITE>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
-        prof_end();
-        after_launch(name);
-        rs_offsets<256>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
-        prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
-        hipLaunchKernelGGL((k_rs_scatter<K, V, SITE>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n,
-                           shift, dmask, offsets, tiles);
-        prof_end();
-        after_launch(name);
+        if (wd <= 8) rs_pass<K, V, SITE, 8>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+        else if (wd == 9) rs_pass<K, V, SITE, 9>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+        else rs_pass<K, V, SITE, 10>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+        shift += wd;
         cur ^= 1;
     }
     dev_free(counts);      // stream-ordered reuse: no host synchronisation needed

@@ -108,7 +108,8 @@ template <class F>
 inline u32 agg_take_claim(const F &f, u32 s, u64 item) {       // the claim protocol of prim_hip.hpp, serially
     if constexpr (F::kClaims) {
         if (f.claim_bits && s != kNoBucket && s != kDeferBucket) {
-            if (s & kClaimBit) f.claim_bits[item >> 6] |= 1ull << (item & 63);
+            const u64 cp = f.claim_pos(item);
+            if (s & kClaimBit) f.claim_bits[cp >> 6] |= 1ull << (cp & 63);
             s &= ~kClaimBit;
         }
     }

@@ -195,6 +195,22 @@ def test_table_sizing_from_a_sample(sim, oracle_mod, capfd, monkeypatch):
     data = workloads.sampled_reads(12000, 100, 30000, seed=13).tobytes()
     assert len(data) > (1 << 20)
     parity.check_final(sim, data, 1)
-    assert "table" in capfd.readouterr().err
+    err = capfd.readouterr().err
+    assert "table" in err and "hot table of" in err              # few phrases dominate: they get the small dense table in front
+    monkeypatch.setenv("GRLBWT_NO_HOT_TABLE", "1")
+    parity.check_final(sim, data, 1)
+    monkeypatch.delenv("GRLBWT_NO_HOT_TABLE")
     rep = (b"ACGTTGCA" * 16 + b"\n") * 6000
     parity.check_final(sim, rep + workloads.uniform_reads(6000, 100, seed=77).tobytes(), 1)
+
+
+def test_hot_table_with_generic_keys(sim, oracle_mod, capfd, monkeypatch):
+    """uint16 cells (no exact keys): a text above 2^20 cells made of few distinct documents -- the generic (hash tag + compare)
+    keys through the hot table, and the mixed case where half of the text never shows up in the sample."""
+    monkeypatch.setenv("GRLBWT_TABLE_TRACE", "1")
+    rng = np.random.default_rng(3)
+    docs = [np.concatenate([rng.integers(1, 50, size=int(rng.integers(20, 60))), [0]]).astype(np.uint16) for _ in range(40)]
+    cells = np.concatenate([docs[int(i)] for i in rng.integers(0, 40, size=30000)])
+    assert cells.size > (1 << 20)
+    parity.check_final(sim, cells.tobytes(), 2)
+    assert "hot table of" in capfd.readouterr().err

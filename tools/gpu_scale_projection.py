@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""What can be known about N = 2/4/8 on a ONE-GPU box: the N-rank collection-level flow with the ranks
+TIME-SHARING cuda:0 -- gloo transport, and a cross-process lock that lets only one rank have kernels in flight at a time
+(taken when a rank leaves a collective, released when it enters the next), so that the HIP-event time of every launch is
+that rank's own kernel time (waiting excluded, no other rank's kernels in between).
+
+Per N it records, per rank: kernel ms by stage, peak device memory; per exchange: bytes.  From these:
+  critical path  = sum over stages of the slowest rank's kernel ms      (the ranks run a stage concurrently on N GPUs)
+  transfer       = bytes a rank sends / receives, priced at the xGMI point-to-point rate (7 links x ~50 GB/s usable per direction
+                   when all peers exchange at once: an all-to-all block crosses ONE link; 153 GB/s per link is the raw figure)
+  projected step = critical path + transfer + collectives x latency
+and the implied speed-up against the single-GPU build of the same collection, i.e. the Amdahl ceiling of the replicated work.
+
+  python tools/gpu_scale_projection.py [--reads R --genome G] [--ranks 2,4,8]      (parent: spawns torchrun per N)
+Results -> gpurun_out/scale_projection.json
+"""
+import argparse
+import fcntl
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+STAGES = [
+    ("parse.local (LMS breaks, hashing, table compaction)", lambda s: s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases", "hash_nocount", "table_compact", "dict_freq_check", "dict_maxlen", "dict_syms", "dict_offsets")),
+    ("parse.dictionary exchange + merge", lambda s: s.startswith("dist.") and not any(k in s for k in ("Tpos", "Ppos", "pre_scan", "owners", "cell_bounds", "take_sums", "window", "merge_cells", "piece_maps", "sample_keys", "mark_", "full_", "apply_phrase"))),
+    ("parse.dictionary stage (sort, groups, grammar)", lambda s: s.startswith(("dict_build", "suffix_", "group_", "prebwt_", "grammar", "phrase_values", "merge_runs")) or s in ("dist.sample_keys", "dist.mark_scan", "dist.mark_pairs", "dist.full_scan", "dist.full_pairs", "dist.apply_phrase_ranks")),
+    ("parse.emit", lambda s: s in ("slot_values", "emit_parse", "dist.list_values", "dist.local_values")),
+    ("induce (A+B, exchange prep, C)", lambda s: s.startswith(("induce", "asm.", "parse2bwt", "stat.")) or any(k in s for k in ("dist.Tpos", "dist.Ppos", "dist.pre_scan", "dist.owners", "dist.cell_bounds", "dist.take_sums", "dist.window", "dist.merge_cells", "dist.piece_maps"))),
+    ("image", lambda s: s in ("pack_rl_bwt", "byte_hist")),
+]
+
+
+def stage_of(site, phase):
+    for name, pred in STAGES:
+        if pred(site):
+            if name.startswith("parse.dictionary stage") and phase == "i":
+                return "induce (A+B, exchange prep, C)"          # merge_runs of pass C
+            return name
+    return "other"
+
+
+def worker(args):
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    from grlbwt_amd import dist as gdist
+    from grlbwt_amd import engine, workloads
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda", 0)
+    lib = g.build_hip()
+    lo, hi = args.reads * rank // world, args.reads * (rank + 1) // world
+    lockf = open(args.lock, "r+")
+
+    class SerialComm(gdist.Communicator):          # one rank computes at a time; everybody may sit in a collective
+        held = False
+
+        def take(self):
+            fcntl.flock(lockf, fcntl.LOCK_EX)
+            self.held = True
+
+        def give(self):
+            torch.cuda.synchronize()
+            if self.held:
+                fcntl.flock(lockf, fcntl.LOCK_UN)
+            self.held = False
+
+        def _allgather(self, *a):
+            self.give()
+            rc = super()._allgather(*a)
+            self.take()
+            return rc
+
+        def _alltoallv(self, *a):
+            self.give()
+            rc = super()._alltoallv(*a)
+            self.take()
+            return rc
+
+    comm = SerialComm(dev)
+    comm._ag = gdist._AG(comm._allgather)
+    comm._a2a = gdist._A2A(comm._alltoallv)
+    comm.struct = gdist.CommStruct(comm.rank, comm.size, None, comm._ag, comm._a2a, 0)
+    comm.log = []
+    comm.take()
+    text = workloads.sampled_reads_torch(args.reads, 150, args.genome, seed=20260003, device=dev, read_lo=lo, read_hi=hi)
+    torch.cuda.synchronize()
+    flags = engine.FLAG_FORCE_IDX64 if args.reads * 151 >= 0xFFFFFF00 else 0
+    out = {"rank": rank, "shard_bytes": int(text.numel())}
+    with engine.Context(0, flags, lib) as ctx:
+        ctx.profile_enable(True)
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        t0 = time.time()
+        if world == 1 and not args.force_dist:
+            ctx.build()
+        else:
+            gdist.dist_build(ctx, comm)
+        torch.cuda.synchronize()
+        out["wall_s_serialised"] = round(time.time() - t0, 3)
+        prof = ctx.profile()
+        prof.pop("@host_sync", None)
+        st = {}
+        for k, (c, ms, nb) in prof.items():
+            site, _, tag = k.partition("#")
+            name = stage_of(site, tag[:1])
+            st[name] = st.get(name, 0.0) + ms
+        out["kernel_ms_by_stage"] = {k: round(v, 2) for k, v in st.items()}
+        out["kernel_ms_total"] = round(sum(st.values()), 2)
+        out["top_sites"] = [[k, round(v[1], 2)] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]]
+        out["peak_bytes"] = ctx.memory_usage()["peak_live_bytes"]
+        nb, nr = ctx.result_size()
+        import hashlib
+        out["image_md5"] = workloads.md5_device(gdist._view(ctx.result_device_ptr(), nb, dev)) if rank == 0 and nb < (2 << 30) else None
+        out["image_bytes"] = nb
+    comm.give()
+    ag = [b for k, b, _ in comm.log if k == "allgather"]
+    aa = [b for k, b, _ in comm.log if k == "alltoallv"]
+    out["collectives"] = {"allgather_calls": len(ag), "allgather_bytes_received": sum(ag), "alltoallv_calls": len(aa), "alltoallv_bytes_sent": sum(aa),
+                          "largest_alltoallv_bytes": max(aa) if aa else 0}
+    with open(os.path.join(args.out, "rank%d.json" % rank), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=6622517)
+    ap.add_argument("--genome", type=int, default=33000000)
+    ap.add_argument("--ranks", default="1,2,4,8")
+    ap.add_argument("--worker", action="store_true")
+    ap.add_argument("--force-dist", action="store_true")
+    ap.add_argument("--lock", default="")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    if args.worker:
+        return worker(args)
+    import tempfile
+    res = {"collection": {"reads": args.reads, "genome": args.genome, "bytes": args.reads * 151},
+           "method": "ranks time-share one MI355X, gloo transport, one rank computes at a time (flock): HIP-event kernel ms per rank and stage", "runs": []}
+    # xGMI: 7 links per GPU, ~153 GB/s raw per link; an all-to-all block to one peer crosses one link.  Usable ~ 0.7x.
+    link = 0.7 * 153e9
+    base_ms = None
+    for n in [int(x) for x in args.ranks.split(",")]:
+        with tempfile.TemporaryDirectory() as td:
+            lock = os.path.join(td, "lock")
+            open(lock, "w").close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                   "--master-port", str(29700 + n), os.path.abspath(__file__), "--worker", "--reads", str(args.reads), "--genome", str(args.genome),
+                   "--lock", lock, "--out", td]
+            t0 = time.time()
+            p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+            if p.returncode != 0:
+                res["runs"].append({"ranks": n, "failed": p.returncode, "stderr": p.stderr[-1500:]})
+                print(json.dumps(res["runs"][-1]), flush=True)
+                continue
+            ranks = [json.load(open(os.path.join(td, "rank%d.json" % r))) for r in range(n)]
+        stages = sorted({k for r in ranks for k in r["kernel_ms_by_stage"]})
+        by_stage = {s: {"max_rank_ms": round(max(r["kernel_ms_by_stage"].get(s, 0.0) for r in ranks), 2),
+                        "min_rank_ms": round(min(r["kernel_ms_by_stage"].get(s, 0.0) for r in ranks), 2)} for s in stages}
+        crit = sum(v["max_rank_ms"] for v in by_stage.values())
+        sent = max(r["collectives"]["alltoallv_bytes_sent"] for r in ranks)
+        recv_ag = max(r["collectives"]["allgather_bytes_received"] for r in ranks)
+        ncoll = max(r["collectives"]["allgather_calls"] + r["collectives"]["alltoallv_calls"] for r in ranks)
+        # all-to-all: a rank's bytes leave over its 7 links in parallel when the peers are distinct (N-1 of them); all-gather of B
+        # bytes in total: every rank receives B*(N-1)/N over its links
+        links = max(1, min(7, n - 1))
+        xfer_ms = 0.0 if n == 1 else (sent * (n - 1) / n / (links * link) + recv_ag * (n - 1) / n / (links * link)) * 1e3
+        lat_ms = 0.0 if n == 1 else ncoll * 0.03
+        run = {"ranks": n, "wall_s": round(time.time() - t0, 1), "kernel_ms_by_stage": by_stage, "critical_path_kernel_ms": round(crit, 2),
+               "max_rank_total_kernel_ms": max(r["kernel_ms_total"] for r in ranks), "peak_bytes_max_rank": max(r["peak_bytes"] for r in ranks),
+               "bytes_sent_alltoallv_max_rank": sent, "bytes_received_allgather_max_rank": recv_ag, "collective_calls": ncoll,
+               "projected_transfer_ms": round(xfer_ms, 2), "projected_latency_ms": round(lat_ms, 2),
+               "projected_step_ms": round(crit + xfer_ms + lat_ms, 2), "image_md5": ranks[0].get("image_md5"), "image_bytes": ranks[0]["image_bytes"],
+               "top_sites_rank0": ranks[0]["top_sites"]}
+        if n == 1:
+            base_ms = run["projected_step_ms"]
+        if base_ms:
+            run["projected_speedup_vs_1"] = round(base_ms / run["projected_step_ms"], 2)
+        res["runs"].append(run)
+        print(json.dumps({k: run[k] for k in ("ranks", "critical_path_kernel_ms", "projected_transfer_ms", "projected_step_ms", "peak_bytes_max_rank", "image_md5")} |
+                         ({"speedup": run.get("projected_speedup_vs_1")})), flush=True)
+    md5s = {r.get("image_md5") for r in res["runs"] if r.get("image_md5")}
+    res["same_image_for_every_N"] = len(md5s) <= 1
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "scale_projection%s.json" % args.tag), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
