@@ -569,11 +569,9 @@ GRL_DEV u64 suffix_key0(const u32 *dict_sym, u64 q, u64 end, int K, int b) {    
     for (int j = 0; j < K; j++) key = (key << b) | ((q + j < end) ? (u64)dict_sym[q + j] : sent);
     return key;
 }
-struct Key0Fn {           // keys of ALL positions (sharded sort: the key decides the owner)
-    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off;
-    int K, b;
-    u64 *keys;
-    GRL_DEV void operator()(u64 q) const { keys[q] = suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b); }
+struct SampleKey0Fn {     // keys at strided positions: the splitter sample of the sharded sort
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; int K, b; u64 stride; u64 *out;
+    GRL_DEV void operator()(u64 i) const { const u64 q = i * stride; out[i] = suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b); }
 };
 struct PhraseDropIn {     // 1 for a phrase whose last-cell suffix is left out (one scan over the PHRASES then places every kept suffix)
     const u32 *ph_off; const u8 *ph_lastT;
@@ -590,23 +588,27 @@ struct Key0KeepFn {       // (key, position) of the kept suffixes at position - 
         }
     }
 };
-struct SortKeepIn {       // 1 for the suffixes this engine sorts: kept (SufKeep) and, with key ranges, inside mine
-    SufKeep keep; const u64 *key0; u64 lo, hi; bool has_hi;
-    GRL_DEV u32 operator()(u64 q) const {
-        bool mine = true;
-        if (key0) { const u64 k = key0[q]; mine = k >= lo && (!has_hi || k < hi); }
-        return (mine && keep(q)) ? 1u : 0u;
-    }
+struct KeepRangeIn {      // 1 for the kept suffixes (SufKeep) among the positions q0 + i of my share of the dictionary
+    SufKeep keep; u64 q0;
+    GRL_DEV u32 operator()(u64 i) const { return keep(q0 + i) ? 1u : 0u; }
 };
-struct SortCompactFn {    // (key, position) of those, compacted
-    SortKeepIn in; const u32 *ex; const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; int K, b; u64 *ka; u32 *va;
-    GRL_DEV void operator()(u64 q) const {
-        if (in(q)) {
-            const u32 i = ex[q];
-            ka[i] = in.key0 ? in.key0[q] : suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b);
-            va[i] = (u32)q;
+struct KeyRangeFn {       // (key, position, owner of the key's range) of those, compacted
+    SufKeep keep; const u32 *ex; u64 q0; const u32 *dict_sym; int K, b; const u64 *spl; int N;
+    u64 *lk; u32 *lp; u32 *own; u32 *idx;
+    GRL_DEV void operator()(u64 i) const {
+        const u64 q = q0 + i;
+        if (keep(q)) {
+            const u32 o = ex[i];
+            const u64 key = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b);
+            u32 d = 0;
+            for (int r = 1; r < N; r++) if (key >= spl[r]) d = (u32)r;      // the LAST rank whose range starts at or below the key
+            lk[o] = key; lp[o] = (u32)q; own[o] = d; idx[o] = o;
         }
     }
+};
+struct GatherKeyPosFn {   // records in owner order
+    const u32 *order; const u64 *lk; const u32 *lp; u64 *sk; u32 *sp;
+    GRL_DEV void operator()(u64 j) const { const u32 i = order[j]; sk[j] = lk[i]; sp[j] = lp[i]; }
 };
 struct HeadFlagFn {       // hflag[t] = 1 where the sorted key changes
     const u64 *k; u8 *hflag;
@@ -1689,10 +1691,6 @@ struct ListValFn {        // value of the i-th phrase of the lists I merged: thr
 // equal keys, so a group never spans two ranks and rank order = sorted order).  Positional ranks are
 // global slots (base of the rank + local slot); after every pass the ranks of the (re)sorted suffixes
 // are exchanged as (position, rank) pairs.
-struct SampleKeysFn {
-    const u64 *key0; u64 stride; u64 *out;
-    GRL_DEV void operator()(u64 i) const { out[i] = key0[i * stride]; }
-};
 struct ApplyPairsFn {     // value[pair >> 32] = low 32 bits
     const u64 *pairs; u32 *value;
     GRL_DEV void operator()(u64 i) const { u64 p = pairs[i]; value[p >> 32] = (u32)p; }
@@ -2630,8 +2628,6 @@ class Engine {
         // exchange behind the group stage)
         auto sort_local = [&] {
             StageTimer st(&tm.dict_sort);
-            // (GRLBWT_TEST_FAIL_RANK_SORT=<rank>: the tests make one rank fail here)
-            if (C) if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_SORT")) if (atoi(fr) == C->rank) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
             // as many symbols as fit 64 key bits per pass (up to 8 radix passes over all suffixes in the first one)
@@ -2645,22 +2641,6 @@ class Engine {
             DBuf<u64> ka;
             {
                 const SufKeep keep{dict_phr.p, ph_off, ph_lastT};
-                DBuf<u64> key0;
-                u64 lo = 0, hi = 0;
-                bool has_hi = false;
-                if (C) {
-                    key0.alloc(S);
-                    prim::for_each(S, Key0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, key0.p}, "suffix_keys0");
-                    // splitters: quantiles of a strided sample of the keys (identical on every rank: replicated data)
-                    const u64 ns = S < 8192 ? S : 8192, stride = S / ns;
-                    DBuf<u64> samp(ns);
-                    prim::for_each(ns, SampleKeysFn{key0.p, stride, samp.p}, "dist.sample_keys");
-                    std::vector<u64> hs = samp.to_host(ns);
-                    std::sort(hs.begin(), hs.end());
-                    if (C->rank > 0) lo = hs[(u64)C->rank * ns / C->size];
-                    if (C->rank + 1 < C->size) { hi = hs[(u64)(C->rank + 1) * ns / C->size]; has_hi = true; }
-                    if (has_hi && hi < lo) hi = lo;
-                }
                 if (!C) {
                     DBuf<u32> dropcnt(D + 1);
                     const u64 dropped = prim::exclusive_scan<u32>(D, PhraseDropIn{ph_off, ph_lastT}, dropcnt.p, true, "suffix_keep");
@@ -2668,11 +2648,53 @@ class Engine {
                     ka.alloc(Sg); perm.alloc(Sg);
                     prim::for_each(S, Key0KeepFn{keep, dropcnt.p, dict_sym.p, K, b, ka.p, perm.p}, "suffix_keys0");
                 } else {
-                    const SortKeepIn in{keep, key0.p, lo, hi, has_hi};
-                    DBuf<u32> oex(S + 1);
-                    Sg = prim::exclusive_scan<u32>(S, in, oex.p, false, "suffix_keep");
-                    ka.alloc(Sg); perm.alloc(Sg);
-                    prim::for_each(S, SortCompactFn{in, oex.p, dict_sym.p, dict_phr.p, ph_off, K, b, ka.p, perm.p}, "suffix_keys0");
+                    // Sample-sort exchange.  Every rank makes the (key, position) records of ITS 1/N of the dictionary positions,
+                    // groups them by the rank that owns their key range (splitters from a strided sample: replicated data, same
+                    // on every rank) and sends them there: a rank computes S/N keys and receives the records of its own range,
+                    // positions ascending (rank order = position order, the owner grouping is stable).  (Round 2: every rank
+                    // computed the keys of ALL S positions and scanned them all to find its own -- two replicated O(S) passes,
+                    // 36 ms per rank at any N on the 10 GB collection: profiles/r03/scale_projection_10GB.json.)
+                    const int N = C->size, me = C->rank;
+                    std::vector<u64> scnt(N, 0), rcnt(N, 0);
+                    DBuf<u64> sk;
+                    DBuf<u32> sp;
+                    try {
+                        // (GRLBWT_TEST_FAIL_RANK_SORT=<rank>: the tests make one rank fail here)
+                        if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_SORT")) if (atoi(fr) == me) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
+                        const u64 ns = S < 8192 ? S : 8192, stride = S / ns;
+                        DBuf<u64> samp(ns), dspl(N);
+                        prim::for_each(ns, SampleKey0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, stride, samp.p}, "dist.sample_keys");
+                        std::vector<u64> hs = samp.to_host(ns), spl(N, 0);
+                        std::sort(hs.begin(), hs.end());
+                        for (int d = 1; d < N; d++) spl[d] = hs[(u64)d * ns / N];          // rank d owns keys in [spl[d], spl[d + 1])
+                        prim::h2d(dspl.p, spl.data(), (u64)N * 8);
+                        const u64 q0 = S * (u64)me / (u64)N, q1 = S * (u64)(me + 1) / (u64)N, nq = q1 - q0;
+                        DBuf<u32> kex(nq + 1);
+                        const u64 nk = prim::exclusive_scan<u32>(nq, KeepRangeIn{keep, q0}, kex.p, false, "suffix_keep");
+                        DBuf<u64> lk(nk), bound(2 * ((u64)N + 1));
+                        DBuf<u32> lp(nk), own(nk), own2(nk), idx(nk), idx2(nk);
+                        prim::for_each(nq, KeyRangeFn{keep, kex.p, q0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p}, "suffix_keys0");
+                        int obits = (int)bitlen64((u64)N - 1);
+                        if (obits < 1) obits = 1;
+                        const int res = prim::sort_pairs<u32, u32>(own.p, idx.p, own2.p, idx2.p, nk, 0, obits, "dist.key_owner_sort");
+                        sk.alloc(nk); sp.alloc(nk);
+                        prim::for_each(nk, GatherKeyPosFn{res ? idx2.p : idx.p, lk.p, lp.p, sk.p, sp.p}, "dist.key_owner_sort");
+                        prim::for_each((u64)N + 1, KeyBoundFn{res ? own2.p : own.p, nk, nullptr, bound.p}, "dist.owner_bounds");
+                        std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
+                        for (int d = 0; d < N; d++) scnt[d] = bh[2 * (d + 1)] - bh[2 * d];
+                    } catch (const prim::Error &e) { C->fail(e); std::fill(scnt.begin(), scnt.end(), 0); }
+                    std::vector<u64> mat = C->allgather_u64(scnt);           // (raises on every rank if one of them failed above)
+                    u64 maxb = 0;
+                    Sg = 0;
+                    for (int g = 0; g < N; g++) {
+                        rcnt[g] = mat[(u64)g * N + me];
+                        Sg += rcnt[g];
+                        for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]);
+                    }
+                    try { ka.alloc(Sg); perm.alloc(Sg); } catch (const prim::Error &e) { C->fail(e); }
+                    C->allgather_u64({});                                    // (the bulk exchanges below have no way back)
+                    C->alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
+                    C->alltoall(sp.p, scnt, perm.p, rcnt, 4, maxb);
                 }
             }
             gid.alloc(Sg); gstart.alloc(Sg + 1);
