@@ -160,6 +160,29 @@ struct PhraseHash {
     }
 };
 
+// ---- phrase records of the partitioned naming (levels above 0, single-GPU rounds; prim::PartSort / prim::part_dedupe) ----
+// A phrase of at most cmax = min(7, 124 / b) cells (b = bits per symbol) IS a 128-bit record: symbol j at bits [j b, (j+1) b) of
+// (lo, hi), hi bit 60 = the phrase ends a string, hi bits 61..63 = its length (0 = no record: the phrase is longer and goes
+// through the hash table as before).  Equal records <=> equal phrases: no hashing, no look at the text to tell them apart.
+static constexpr u64 kPhrLastT = 1ull << 60;
+GRL_HD void rec_put(u64 &lo, u64 &hi, u32 sym, u32 j, int b) {
+    const u32 o = j * (u32)b;
+    if (o < 64) { lo |= (u64)sym << o; if (o + (u32)b > 64) hi |= (u64)sym >> (64 - o); }
+    else hi |= (u64)sym << (o - 64);
+}
+GRL_HD u32 rec_sym(const prim::U128 &r, u32 j, int b) {
+    const u32 o = j * (u32)b;
+    u64 v;
+    if (o < 64) { v = r.lo >> o; if (o + (u32)b > 64) v |= r.hi << (64 - o); }
+    else v = r.hi >> (o - 64);
+    return (u32)(v & ((1ull << b) - 1ull));
+}
+GRL_HD u32 rec_len(const prim::U128 &r) { return (u32)(r.hi >> 61); }
+struct RecValid {
+    GRL_DEV bool operator()(const prim::U128 &r) const { return (r.hi >> 61) != 0; }
+};
+static constexpr u32 kLongMark = 0x80000000u;      // in the per-occurrence slot array: the occurrence went through the hash table (slot in the low bits)
+
 // One lane per text position; lanes on a phrase start hash the phrase, find/claim its
 // slot and return the slot id (the caller counts it: prim::for_each_agg).
 template <class cell_t, bool FIRST>
@@ -191,6 +214,10 @@ struct HashInsertFn {
     const u64 *hot_keys = nullptr;
     u64 hot_mask = 0;
     u32 slot_base = 0;
+    // partitioned naming (see "phrase records"): with rec_h set, a phrase of <= rec_cmax cells leaves a record at its ordinal and
+    // does NOT touch the table; longer ones take the table as before and mark their slot entry with kLongMark
+    u32 *rec_h = nullptr; prim::U128 *rec_v = nullptr; int rec_b = 0; u32 rec_cmax = 0;
+    u32 *long_count = nullptr;     // (sample pass: how many phrases are longer than rec_cmax)
     // Byte cells: 4 phrases per lane at once through the exact-key path (process_batch).  A phrase of <= 7 cells is cut
     // out of ONE unaligned 8-byte load with the start bits and a zero-byte test for the terminator -- no loop -- its
     // bytes are the table key, so a probe that matches needs no look at a representative occurrence, and the text,
@@ -230,11 +257,52 @@ struct HashInsertFn {
     GRL_DEV u32 process(u64 p) const {
         u64 w = startbits[p >> 6];
         u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+        const bool pack = !kExact && rec_cmax != 0;      // (uniform) partitioned naming: short phrases become records
+        bool fast = false;
+        if (pack && p + (u64)rec_cmax + 1 <= n) {
+            // Straight-line cut of a short phrase: the cells p .. p+cmax-1 and ONE window of start bits decide where it ends (at
+            // the first terminator cell, or at the first phrase start behind p: that cell is shared with the next phrase) --
+            // no loop of dependent loads, no hashing.  (The general walk below took 32 ms for the 964 M phrases of level 1.)
+            const u64 b0 = p + 1;
+            u64 bits = startbits[b0 >> 6] >> (b0 & 63);
+            if ((b0 & 63) + (u64)rec_cmax > 64) bits |= startbits[(b0 >> 6) + 1] << (64 - (b0 & 63));
+            cell_t cs[7];
+#pragma unroll
+            for (u32 j = 0; j < 7; j++) cs[j] = j < rec_cmax ? t[p + j] : cell_t(0);
+            u32 m = ((u32)(bits << 1)) & ((1u << rec_cmax) - 1u) & ~1u;      // bit j: position p + j starts a phrase (j >= 1)
+            u32 tm = 0;
+#pragma unroll
+            for (u32 j = 0; j < 7; j++) if (j < rec_cmax && ops.isT(cs[j])) tm |= 1u << j;
+            m |= tm;
+            if (m) {
+                const u32 eo = (u32)__builtin_ctz(m);                          // offset of the phrase's last cell
+                u64 klo = 0, khi = 0;
+#pragma unroll
+                for (u32 j = 0; j < 7; j++) if (j <= eo) rec_put(klo, khi, ops.sym(cs[j]), j, rec_b);
+                const u64 len = (u64)eo + 1;
+                if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; }
+                else if (rec_h) {
+                    rec_h[ord] = (u32)((((klo ^ (khi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) ^ (len * 0x85EBCA6Bull)) >> 32);
+                    rec_v[ord] = prim::U128(klo, khi | (((tm >> eo) & 1u) ? kPhrLastT : 0ull) | (len << 61));
+                    out_slot[ord] = 0;
+                }
+                fast = true;
+            }
+        }
+        // (single exit, no return from the divergent branch above: see the compiler note in find_or_insert)
+        u32 res = prim::kNoBucket;
+        if (!fast) res = process_walk(p, ord, pack);
+        return res;
+    }
+    // the general form: walk the phrase cell by cell (any length), hash it, find/claim its slot -- or leave its record
+    GRL_DEV u32 process_walk(u64 p, u64 ord, bool pack) const {
         PhraseHash ph = PhraseHash::init();
         u64 e = p;                               // last cell taken so far
         cell_t c = t[p];
         ph.add(ops.sym(c));
         bool done = ops.isT(c);
+        u64 klo = 0, khi = 0;
+        if (pack) rec_put(klo, khi, ops.sym(c), 0, rec_b);
         // cells are taken 8 bytes at a time while that stays inside the text (one load covers a whole DNA phrase;
         // phrases of millions of cells -- e.g. N-runs -- would otherwise pay one memory latency per cell)
         while (!done && e + 1 + kCh <= n) {
@@ -248,6 +316,7 @@ struct HashInsertFn {
                     cell_t cj = (cell_t)(sizeof(cell_t) == 8 ? chunk : (chunk >> (8 * sizeof(cell_t) * j)));
                     ph.add(ops.sym(cj));
                     e = b0 + j;
+                    if (pack && e - p < (u64)rec_cmax) rec_put(klo, khi, ops.sym(cj), (u32)(e - p), rec_b);
                     done = ((bits >> j) & 1ull) || ops.isT(cj);
                 }
             }
@@ -259,11 +328,26 @@ struct HashInsertFn {
             else {
                 c = t[e];
                 ph.add(ops.sym(c));
+                if (pack && e - p < (u64)rec_cmax) rec_put(klo, khi, ops.sym(c), (u32)(e - p), rec_b);
                 done = bit_at(startbits, e) || ops.isT(c);
             }
         }
         if (ok && ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; ok = false; }
         u32 found = prim::kNoBucket;
+        if (ok && pack) {
+            const u64 len = e - p + 1;
+            if (len <= (u64)rec_cmax) {
+                if (rec_h) {                       // the phrase is its record: nothing to look up
+                    rec_h[ord] = (u32)((((klo ^ (khi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) ^ (len * 0x85EBCA6Bull)) >> 32);
+                    rec_v[ord] = prim::U128(klo, khi | (ops.isT(t[e]) ? kPhrLastT : 0ull) | (len << 61));
+                    out_slot[ord] = 0;
+                }
+                ok = false;                        // (not an error: no table work for this phrase)
+            } else {
+                if (long_count) prim::atomic_add(long_count, 1u);
+                if (rec_h) { rec_h[ord] = (u32)ord * 2654435761u; rec_v[ord] = prim::U128(ord, 0ull); }
+            }
+        }
         if (ok) {
             u64 len = e - p + 1;
             if (kExact && len <= 7) {              // same key form as process_batch: a phrase has ONE entry whichever path saw it
@@ -272,7 +356,7 @@ struct HashInsertFn {
                 const u64 mine = kExactKey | (len << 60) | content;
                 found = insert_exact(mine, p, exact_hash(mine) & (hot_keys ? hot_mask : mask), 0, false);
             } else found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
-            if (found != prim::kNoBucket) out_slot[ord] = found & ~prim::kClaimBit;
+            if (found != prim::kNoBucket) out_slot[ord] = (found & ~prim::kClaimBit) | (pack ? kLongMark : 0u);
         }
         return found;
     }
@@ -495,7 +579,7 @@ struct ClaimSlotsFn {       // step 1, one lane per word: the table slot of ever
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
-                ph_slot[k++] = out_slot[ob + (u64)__builtin_popcountll(sb & ((1ull << b) - 1ull))];
+                ph_slot[k++] = out_slot[ob + (u64)__builtin_popcountll(sb & ((1ull << b) - 1ull))] & ~kLongMark;
             }
         }
     }
@@ -505,6 +589,32 @@ struct ClaimCompactFn {     // step 2, one lane per phrase: its table entry (a r
                             // one lane walking the claims of a word took them one after the other: 13 ms for 159 M phrases, 2.2x the table scan it replaced)
     CompactTableFn<cell_t, FIRST> c;
     GRL_DEV void operator()(u64 k) const { c.emit((u64)c.ph_slot[k], k); }
+};
+struct PartBoundsFn {      // lane p in [0, 2^P]: first record of partition p in the sorted key array
+    const u32 *skeys; u64 n; int shift; u64 nparts; u64 *pstart;
+    GRL_DEV void operator()(u64 p) const { pstart[p] = p == nparts ? n : lower_bound<u32>(skeys, n, (u32)(p << shift)); }
+};
+struct PartPhraseFn {      // distinct phrase k of the partitioned naming: from the staging area of its partition
+    const u32 *pbase; u64 nparts; const u64 *pstart; const prim::U128 *dval; const u32 *dcnt; u32 slot0;
+    prim::U128 *ph_key; u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
+    GRL_DEV void operator()(u64 k) const {
+        const u64 p = upper_bound<u32>(pbase, nparts, (u32)k) - 1;
+        const u64 src = pstart[p] + (k - (u64)pbase[p]);
+        const prim::U128 r = dval[src];
+        ph_key[k] = r; ph_pos[k] = 0; ph_freq[k] = (idx_t)dcnt[src]; ph_len[k] = rec_len(r); ph_slot[k] = slot0 + (u32)k;
+        ph_lastT[k] = (r.hi & kPhrLastT) ? 1 : 0;
+    }
+};
+struct PartValFn {         // record at sorted position i -> the value of its phrase (read where GroupPhraseValFn put it)
+    const u32 *skeys; int shift; const u32 *pbase; const u32 *lid; const u32 *slot_val; u32 slot0; u32 *out;
+    GRL_DEV void operator()(u64 i) const {
+        const u32 l = lid[i];
+        out[i] = l == prim::kNoId ? 0u : slot_val[(u64)slot0 + (u64)pbase[skeys[i] >> shift] + (u64)l];
+    }
+};
+struct PartCombineFn {     // the parse: occurrences that went through the table read their slot's value, the others take the value that came back
+    const u32 *slot_val; const u32 *vals; u32 *text;
+    GRL_DEV void operator()(u64 i) const { const u32 m = text[i]; text[i] = (m & kLongMark) ? slot_val[m & ~kLongMark] : vals[i]; }
 };
 struct LenIn {
     const u32 *l;
@@ -518,6 +628,7 @@ struct DictBuildFn {      // one lane per PER consecutive dictionary positions: 
     const u32 *ph_off; u64 D; u64 S; const u64 *ph_pos;
     u32 *dict_sym; u32 *dict_phr;
     const u64 *pw; const idx_t *pb;      // rank bit-vector of the phrase starts over the dictionary positions (nullptr: binary search)
+    const prim::U128 *pkeys = nullptr; u64 pDs = 0; int pkb = 0;      // phrases [0, pDs) are given by their records (partitioned naming): no look at the text
     struct alignas(16) Quad { u32 v[4]; };
     GRL_DEV void operator()(u64 c) const {
         u64 q0 = c * PER, q1 = q0 + PER < S ? q0 + PER : S;
@@ -532,7 +643,7 @@ struct DictBuildFn {      // one lane per PER consecutive dictionary positions: 
             if (q < q1) {
                 while (q >= nxt) { k++; nxt = ph_off[k + 1]; }
                 phr[j] = (u32)k;
-                sym[j] = ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
+                sym[j] = (pkeys && k < pDs) ? rec_sym(pkeys[k], (u32)(q - ph_off[k]), pkb) : ops.sym(t[ph_pos[k] + (q - ph_off[k])]);
             }
         }
         if (q1 - q0 == PER) {     // 16-byte stores: a quarter of the store requests of scalar stores per array
@@ -2316,6 +2427,17 @@ class Engine {
         u32 maxlen = 0;
         DBuf<u32> next_text;       // slot id of every phrase occurrence, then the parse itself
         DBuf<u64> ph_pos; DBuf<idx_t> ph_freq; DBuf<u32> ph_len, ph_slot, ph_off; DBuf<u8> ph_lastT;
+        // partitioned naming (levels above 0): phrases [0, Ds) are given by their records; what the emission needs to send the
+        // phrases' values back to text order
+        u64 Ds = 0; int part_bits = 0, rec_b = 0; u32 slot0 = 0;
+        DBuf<prim::U128> ph_key;
+        DBuf<u32> rec_h, lid, pbase;
+        prim::PartSort<u32, prim::U128> psort;
+        void clear() {
+            n_occ = D = S = cap = Ds = 0; maxlen = 0; part_bits = rec_b = 0; slot0 = 0;
+            next_text.release(); ph_pos.release(); ph_freq.release(); ph_len.release(); ph_slot.release(); ph_off.release(); ph_lastT.release();
+            ph_key.release(); rec_h.release(); lid.release(); pbase.release(); psort.release();
+        }
     };
 
     // phrase hashing launch: one lane per text position, counts pre-aggregated in LDS when few phrases dominate
@@ -2327,7 +2449,7 @@ class Engine {
     }
 
     template <class cell_t, bool FIRST>
-    void hash_local(const cell_t *t, u64 n, CellOps<cell_t, FIRST> ops, LocalParse &P, LevelData &L) {
+    void hash_local(const cell_t *t, u64 n, CellOps<cell_t, FIRST> ops, LocalParse &P, LevelData &L, bool allow_part = false) {
         const u64 nwords = (n + 63) / 64;
         DBuf<u64> startbits(nwords + 1);
         DBuf<idx_t> wordbase(nwords + 1);
@@ -2341,6 +2463,29 @@ class Engine {
         L.info.parse_size = n_occ;
         if (n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "parse too large for u32 phrase ordinals");
 
+        // ---- partitioned naming (levels above 0, single-GPU rounds): a phrase of <= cmax cells is a 128-bit record; the records
+        // are grouped by a hash prefix into partitions that fit an LDS table (prim::PartSort), de-duplicated and counted there
+        // (prim::part_dedupe), and the phrases' values travel back through the sort's passes in reverse (emit_local).  Only the
+        // longer phrases (1 % at level 1, ~12 % at levels 2-3 of the 10 GB build) still go through the hash table below.
+        // Round 2's table took 3 random HBM accesses per occurrence (probe, verification, count atomic: 51 / 51 / 18 G/s) and the
+        // emission a fourth; this path streams.  GRLBWT_NO_PART=1 switches it off; GRLBWT_PART_MIN_OCC sets the smallest level.
+        int rec_b = 0;
+        u32 rec_cmax = 0;
+        bool part = false;
+        if (allow_part && !FIRST && sizeof(cell_t) == 4 && !getenv("GRLBWT_NO_PART")) {
+            rec_b = (int)bitlen64(L.sigma > 1 ? (u64)L.sigma - 1 : 1);
+            rec_cmax = (u32)std::min<int>(7, 124 / rec_b);
+            const u64 min_occ = getenv("GRLBWT_PART_MIN_OCC") ? (u64)atoll(getenv("GRLBWT_PART_MIN_OCC")) : ((u64)1 << 20);
+            part = rec_cmax >= 2 && n_occ >= min_occ;
+            if (!part) rec_cmax = 0;
+        }
+        int part_bits = 0;
+        if (part) {
+            // partitions of at most ~5000 records: even a level whose phrases are ALL distinct fits the LDS tables (8192 entries)
+            part_bits = 4;
+            while (part_bits < 20 && (n_occ >> part_bits) > 5000) part_bits++;
+        }
+
         // ---- a3: hash every phrase occurrence ------------------------------
         // table capacity: the number of distinct phrases is unknown and usually << the number of
         // occurrences (20 k vs 30 M at level 0 of DNA reads): estimate the distinct fraction on a prefix,
@@ -2353,6 +2498,7 @@ class Engine {
         u64 cap = cap_max;
         double frac = 1.0;
         u64 s_blk = 0, s_stride = 0, s_n = 0, s_distinct = 0;      // the sample (blocks of s_blk cells, s_stride apart) and its distinct phrases
+        u64 s_long = 0;                                             // partitioned naming: phrase occurrences of the sample that are too long for a record
         {
             // Table capacity from a sample of 2^20 cells (256 blocks spread evenly over the text) hashed into a table of its
             // own: its distinct fraction `frac`, extrapolated to the whole text.  That over-sizes the table whenever repetition
@@ -2377,15 +2523,17 @@ class Engine {
                 if (HashInsertFn<cell_t, FIRST>::kExact) trep.alloc(cap_s);
                 tk.zero(); tc.zero(); scal.zero();
                 typedef HashInsertFn<cell_t, FIRST> HF;
-                prim::for_each_agg(n_s, SampledFn<HF>{HF{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0,
-                                                         P.next_text.p, scal.p, n, n_occ, trep.p}, blk, stride},
-                                   SlotCountAdd{tc.p, 1}, true, "hash_sample");
+                HF fs{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0, P.next_text.p, scal.p, n, n_occ, trep.p};
+                fs.rec_b = rec_b; fs.rec_cmax = rec_cmax;       // (partitioned naming: only the long phrases reach the sample's table)
+                prim::for_each_agg(n_s, SampledFn<HF>{fs, blk, stride}, SlotCountAdd{tc.p, 1}, true, "hash_sample");
                 const u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
                 const u64 occ_s = std::max<u64>(prim::reduce_sum<u64>(cap_s, IdxIn<idx_t>{tc.p}, "hash_sample_count"), 1);
+                if (part) s_long = occ_s;
                 frac = (double)d_s / (double)occ_s;
                 if (frac > 1.0) frac = 1.0;
                 s_distinct = d_s;
-                const u64 want = (u64)(1.7 * frac * (double)n_occ) + 4096;      // target load <= ~0.6 if the sample is representative
+                u64 want = (u64)(1.7 * frac * (double)n_occ) + 4096;            // target load <= ~0.6 if the sample is representative
+                if (part) want = (u64)(3.0 * (double)s_long * ((double)n / (double)n_s)) + 4096;   // the table only sees the long phrases: room for all of them being distinct
                 cap = 4096;
                 while (cap < want) cap <<= 1;
                 if (cap > cap_max) cap = cap_max;
@@ -2417,7 +2565,9 @@ class Engine {
         // their own in front of the big one -- slots [0, cap_hot) -- filled by hashing the sample once more (claims on: they
         // are dictionary phrases like the others) and read-only in the pass over the text.  GRLBWT_NO_HOT_TABLE=1 switches it off.
         u64 cap_hot = 0;
-        if (aggregate && s_n && !getenv("GRLBWT_NO_HOT_TABLE")) {
+        DBuf<prim::U128> rec_v, rec_v2;
+        if (part) { P.rec_h.alloc(n_occ); rec_v.alloc(n_occ); }
+        if (aggregate && s_n && !part && !getenv("GRLBWT_NO_HOT_TABLE")) {
             cap_hot = 1024;
             while (cap_hot < 4 * s_distinct) cap_hot <<= 1;               // load <= 0.25: short probe chains
             if (cap_max > (1ull << 30)) cap_max = 1ull << 30;             // slot ids of both tables stay below 2^31
@@ -2445,19 +2595,11 @@ class Engine {
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
                 HF f{t, ops, startbits.p, wordbase.p, keys.p + cap_hot, cap - 1, probe_limit, ks,
                      P.next_text.p, scal.p, n, n_occ, rep_pos.p ? rep_pos.p + cap_hot : nullptr, claim.p};
+                if (part) { f.rec_h = P.rec_h.p; f.rec_v = rec_v.p; f.rec_b = rec_b; f.rec_cmax = rec_cmax; }
                 if (cap_hot) {
                     HF fh{t, ops, startbits.p, wordbase.p, keys.p, cap_hot - 1, cap_hot, 0, P.next_text.p, scal.p, n, n_occ, rep_pos.p, claim.p};
                     prim::for_each_agg(s_n, SampledFn<HF>{fh, s_blk, s_stride, claim.p}, NoCountAdd{}, false, "hash_hot");
                     f.hot_keys = keys.p; f.hot_mask = cap_hot - 1; f.slot_base = (u32)cap_hot;
-                }
-                if (getenv("GRLBWT_EXP_NOCOUNT")) {      // experiment: the same pass without counting, timed as "hash_nocount", then thrown away
-                    DBuf<u64> claim2(nwords + 1);
-                    HF f2 = f;
-                    f2.claim_bits = claim2.p;
-                    claim2.zero();
-                    prim::for_each_agg(n, f2, NoCountAdd{}, false, "hash_nocount");
-                    prim::dev_memset(keys.p + (cap_hot << ks), 0, (cap << ks) * sizeof(u64));
-                    scal.zero();
                 }
                 launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
                 std::vector<u32> sc = scal.to_host(4);
@@ -2474,17 +2616,62 @@ class Engine {
         }
         P.cap = cap_hot + cap;
 
+        // ---- partitioned naming: group the records, de-duplicate and count per partition -------------------------------
+        u64 Ds = 0;
+        DBuf<u64> pstart;
+        DBuf<u32> dcnt;
+        const prim::U128 *dval = nullptr;
+        if (part) {
+            StageTimer st(&tm.hash);
+            rec_v2.alloc(n_occ);
+            const int res = P.psort.forward(P.rec_h.p, rec_v.p, rec_v2.p, n_occ, 32 - part_bits, 32, "phrase_part");
+            const prim::U128 *svals = res ? rec_v2.p : rec_v.p;
+            prim::U128 *stage = res ? rec_v.p : rec_v2.p;
+            const u64 nparts = (u64)1 << part_bits;
+            pstart.alloc(nparts + 1);
+            prim::for_each(nparts + 1, PartBoundsFn{P.psort.sorted_keys(), n_occ, 32 - part_bits, nparts, pstart.p}, "phrase_part.bounds");
+            P.lid.alloc(n_occ); P.pbase.alloc(nparts + 1); dcnt.alloc(n_occ);
+            DBuf<u32> pcount(nparts), ovf(1);
+            ovf.zero();
+            prim::part_dedupe(nparts, pstart.p, svals, RecValid{}, P.lid.p, pcount.p, stage, dcnt.p, ovf.p, "phrase_dedupe");
+            if (ovf.get(0)) {
+                // a partition with more distinct phrases than its LDS table takes (or an injected limit in the tests): this level
+                // goes through the hash table after all
+                if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: a phrase partition overflowed, falling back to the hash table\n", prim::rt().tag);
+                L.info.table_retries++;
+                rec_v.release(); rec_v2.release(); keys.release(); counts.release(); rep_pos.release(); claim.release();
+                startbits.release(); wordbase.release(); pstart.release(); dcnt.release();
+                P.clear();
+                hash_local<cell_t, FIRST>(t, n, ops, P, L, false);
+                return;
+            }
+            Ds = (u64)prim::exclusive_scan<u32>(nparts, PtrU32In{pcount.p}, P.pbase.p, true, "phrase_dedupe.scan");
+            dval = stage;
+            (res ? rec_v2 : rec_v).release();            // the sorted records are no longer needed (the staging buffer is)
+            P.Ds = Ds; P.part_bits = part_bits; P.rec_b = rec_b; P.slot0 = (u32)P.cap;
+            if (P.cap + Ds >= (1ull << 32)) throw prim::Error(-75, "phrase tables beyond 2^32 entries");
+            P.cap += Ds;                                  // values of the record phrases live behind the table's slots
+        }
+
         // ---- a5: distinct phrases of this text (from the claim bits: the table itself is not scanned) -------------------
         {
             StageTimer st(&tm.dict_sort);
             DBuf<idx_t> cbase(nwords + 1);
-            const u64 D = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{claim.p}, cbase.p, false, "table_compact");
+            const u64 Dl = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{claim.p}, cbase.p, false, "table_compact");
+            const u64 D = Ds + Dl;
             if (D >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 phrases)");
             P.D = D;
             P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
-            prim::for_each(nwords, ClaimSlotsFn{claim.p, cbase.p, startbits.p, wordbase.p, P.next_text.p, P.ph_slot.p}, "table_compact");
-            prim::for_each(D, ClaimCompactFn<cell_t, FIRST>{CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, P.ph_pos.p,
-                                                            P.ph_freq.p, P.ph_len.p, P.ph_slot.p, P.ph_lastT.p, ks, cs, rep_pos.p}}, "table_compact");
+            if (part) {                                   // phrases [0, Ds): from the partitions' staging areas
+                P.ph_key.alloc(Ds);
+                prim::for_each(Ds, PartPhraseFn{P.pbase.p, (u64)1 << part_bits, pstart.p, dval, dcnt.p, P.slot0, P.ph_key.p, P.ph_pos.p, P.ph_freq.p,
+                                                P.ph_len.p, P.ph_slot.p, P.ph_lastT.p}, "phrase_dedupe.phrases");
+                rec_v.release(); rec_v2.release(); dcnt.release(); pstart.release();
+            }
+            // ... and the phrases of the table behind them
+            prim::for_each(nwords, ClaimSlotsFn{claim.p, cbase.p, startbits.p, wordbase.p, P.next_text.p, P.ph_slot.p + Ds}, "table_compact");
+            prim::for_each(Dl, ClaimCompactFn<cell_t, FIRST>{CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, P.ph_pos.p + Ds,
+                                                             P.ph_freq.p + Ds, P.ph_len.p + Ds, P.ph_slot.p + Ds, P.ph_lastT.p + Ds, ks, cs, rep_pos.p}}, "table_compact");
             wordbase.release(); claim.release();
             u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{P.ph_freq.p}, "dict_freq_check");
             if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
@@ -2609,7 +2796,8 @@ class Engine {
     template <class cell_t, bool FIRST>
     void dict_stage(const Comm *C, const cell_t *t, CellOps<cell_t, FIRST> ops, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
                     const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val,
-                    const u32 *fused_ph_slot = nullptr, u32 *fused_slot_val = nullptr) {      // (both set: the values go straight to the slots)
+                    const u32 *fused_ph_slot = nullptr, u32 *fused_slot_val = nullptr,        // (both set: the values go straight to the slots)
+                    const prim::U128 *pkeys = nullptr, u64 pDs = 0, int pkb = 0) {            // (phrases [0, pDs) given by their records)
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
         DBuf<u32> dict_sym(S), dict_phr(S);
         RankBits pbits;                          // phrase starts over the dictionary positions (dictionary build, suffix refinement)
@@ -2617,7 +2805,8 @@ class Engine {
             StageTimer st(&tm.dict_sort);
             build_rankbits32(pbits, ph_off, D, S + 1, "dict_build");
             // (4 positions per lane: 16 per lane, four phrases walked one after the other, was latency-bound -- 42 ms at 10 GB)
-            prim::for_each((S + 3) / 4, DictBuildFn<cell_t, FIRST, 4>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p}, "dict_build");
+            prim::for_each((S + 3) / 4, DictBuildFn<cell_t, FIRST, 4>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p,
+                                                                      pkeys, pDs, pkb}, "dict_build");
         }
         // ---- a6: sort all phrase suffixes (radix on the first K symbols + refinement by symbol extension) ----------
         u64 Sg = S;                              // my slots of the sorted order (all of them without a communicator)
@@ -2885,7 +3074,17 @@ class Engine {
             own.alloc(P.cap);
             prim::for_each(P.D, ScatterValFn{P.ph_slot.p, val_of_local_phrase, own.p}, "slot_values");
         }
-        prim::for_each(P.n_occ, MapFn{slot_val_filled ? slot_val_filled->p : own.p, P.next_text.p}, "emit_parse");
+        const u32 *sv = slot_val_filled ? slot_val_filled->p : own.p;
+        if (P.Ds || P.part_bits) {
+            // partitioned naming: the record at sorted position i takes the value of its phrase (its partition's phrases are
+            // neighbours in the value array), the values go back to text order through the sort's passes in reverse, and the
+            // occurrences that went through the table read theirs from their slot
+            DBuf<u32> va(P.n_occ), vb(P.n_occ), vc(P.n_occ);
+            prim::for_each(P.n_occ, PartValFn{P.psort.sorted_keys(), 32 - P.part_bits, P.pbase.p, P.lid.p, sv, P.slot0, va.p}, "emit_part.values");
+            P.psort.backward(va.p, vb.p, vc.p, "emit_part.back");
+            prim::for_each(P.n_occ, PartCombineFn{sv, vc.p, P.next_text.p}, "emit_parse");
+            P.psort.release(); P.lid.release(); P.pbase.release(); P.rec_h.release(); P.ph_key.release();
+        } else prim::for_each(P.n_occ, MapFn{sv, P.next_text.p}, "emit_parse");
         prim::sync();
     }
 
@@ -2913,10 +3112,10 @@ class Engine {
         L.info.n_in = n;
         L.info.sigma = sigma;
         LocalParse P;
-        hash_local<cell_t, FIRST>(t, n, ops, P, L);
+        hash_local<cell_t, FIRST>(t, n, ops, P, L, true);
         DBuf<u32> phrase_val, slot_val(P.cap);
         dict_stage<cell_t, FIRST>(nullptr, t, ops, P.D, P.S, P.maxlen, P.ph_pos.p, P.ph_freq.p, P.ph_off.p, P.ph_lastT.p, sigma, L, phrase_val,
-                                  P.ph_slot.p, slot_val.p);
+                                  P.ph_slot.p, slot_val.p, P.ph_key.p, P.Ds, P.rec_b);
         emit_local(P, nullptr, &slot_val);
         finish_round(P, L, stats.n_strings, P.n_occ);
     }

@@ -1960,4 +1960,283 @@ inline int sort_keys_fwd(u64 *a, u64 *b, u64 n, int begin_bit, int end_bit, cons
     return sort_keys<u64, 1>(a, b, n, begin_bit, end_bit, name);      // SITE 1: the passes behind the fused expand + first pass
 }
 
+
+// ------------------------------------------------------- partition sort that can be undone + per-partition de-duplication
+// (phrase naming of the levels above 0: every phrase occurrence becomes a 128-bit record, the records are grouped by a hash
+// prefix into partitions small enough for an LDS table, de-duplicated and counted there, and the values of the phrases travel
+// back to text order through the same passes in reverse -- no table in HBM, no per-occurrence atomics or random accesses)
+struct alignas(16) U128 {
+    u64 lo, hi;
+    U128() = default;
+    GRL_HD U128(int) : lo(0), hi(0) {}
+    GRL_HD U128(u64 l, u64 h) : lo(l), hi(h) {}
+    GRL_HD bool operator==(const U128 &o) const { return lo == o.lo && hi == o.hi; }
+};
+static constexpr u32 kNoId = 0xFFFFFFFFu;
+
+// One pass of PartSort::backward: src holds one element per record in the OUTPUT order of the forward pass, dst gets them in its
+// INPUT order.  The ranking of k_rs_scatter is recomputed from the pass's input keys; the elements are gathered (runs of
+// equal digits are neighbours in src) and written linearly.
+// (The other form -- the forward pass stores where every element went, the way back is a plain gather -- was measured slower on
+// the 964 M records of level 1 of the 10 GB build: forward 36 + back 22.8 ms against 32.4 + 19.2 ms; the 4 bytes per element per
+// pass of destinations cost more than the ballot ranking they save.)
+template <class K, class W, int DB = 8>
+__global__ void __launch_bounds__(kBlock)
+    k_rs_unscatter(const K *keys_in, const W *src, W *dst, u64 n, int shift, u32 dmask, const u64 *offsets /*[tiles][NB]*/) {
+    constexpr int NB = 1 << DB, BPT = NB / kBlock;
+    __shared__ u32 s_cnt[4][NB];
+    __shared__ u64 s_gbase[NB];
+    __shared__ u32 s_wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * NB; i += kBlock) (&s_cnt[0][0])[i] = 0;
+    const u64 base = (u64)blockIdx.x * kRsTile;
+    const u64 left = n - base;
+    const u32 tile_n = left < (u64)kRsTile ? (u32)left : (u32)kRsTile;
+    const u32 wbase = (u32)w * (64 * kRsKeys);
+    u32 dig[kRsKeys], idx[kRsKeys];
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        dig[q] = t < tile_n ? ((u32)(keys_in[base + t] >> shift) & dmask) : 0u;
+    }
+    __syncthreads();
+    volatile u32 *cnt = &s_cnt[w][0];
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        bool valid = t < tile_n;
+        const u32 d = dig[q];
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < DB; b++) {
+            unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+        u32 old = 0;
+        if (valid && below == 0) {
+            old = cnt[d];
+            cnt[d] = old + (u32)__popcll(peers);
+        }
+        int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+        old = (u32)__shfl((int)old, leader);
+        idx[q] = old + below;
+    }
+    __syncthreads();
+    {
+        u32 cw[BPT][4], tt[BPT], sum = 0;
+#pragma unroll
+        for (int e = 0; e < BPT; e++) {
+            const int d = threadIdx.x * BPT + e;
+            tt[e] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { cw[e][k] = s_cnt[k][d]; tt[e] += cw[e][k]; }
+            sum += tt[e];
+        }
+        u32 incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 o = (u32)__shfl_up((int)incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wsum[w] = incl;
+        __syncthreads();
+        u32 start = incl - sum;
+        for (int k = 0; k < w; k++) start += s_wsum[k];
+#pragma unroll
+        for (int e = 0; e < BPT; e++) {
+            const int d = threadIdx.x * BPT + e;
+            s_cnt[0][d] = start;
+            s_cnt[1][d] = start + cw[e][0];
+            s_cnt[2][d] = start + cw[e][0] + cw[e][1];
+            s_cnt[3][d] = start + cw[e][0] + cw[e][1] + cw[e][2];
+            s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
+            start += tt[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kRsKeys; q++) {
+        u32 t = wbase + q * 64 + lane;
+        if (t < tile_n) dst[base + t] = src[s_gbase[dig[q]] + (u64)(idx[q] + s_cnt[w][dig[q]])];
+    }
+}
+
+// Stable sort of n (key, value) records by key bits [begin_bit, end_bit) that remembers what it takes to send one element per
+// record back from sorted order to the original order (the passes' input keys and tile offsets).  `keys` must stay alive and
+// unchanged until the last backward() call.
+template <class K, class V>
+struct PartSort {
+    u64 n = 0;
+    int passes = 0, shifts[8], widths[8];
+    u32 tiles = 0;
+    K *kbuf[9] = {nullptr};          // kbuf[0] = the caller's keys (kept), kbuf[p + 1] = keys after pass p (owned)
+    u64 *offs[8] = {nullptr};
+    const K *sorted_keys() const { return kbuf[passes]; }
+    // vals_a holds the values; returns 0 if the sorted values end in vals_a, 1 if in vals_b
+    int forward(K *keys, V *vals_a, V *vals_b, u64 n_, int begin_bit, int end_bit, const char *name = "part_sort") {
+        release();
+        n = n_;
+        passes = 0;
+        kbuf[0] = keys;
+        if (n == 0 || end_bit <= begin_bit) return 0;
+        // two passes up to 20 bits (digits of up to 10 bits: a pass fewer matters more here than the shorter runs at the write
+        // front -- the values are 16-byte records), three beyond
+        const int bits = end_bit - begin_bit;
+        passes = bits <= 8 ? 1 : (bits <= 20 ? 2 : (bits + 9) / 10);
+        for (int p = 0, sh = begin_bit; p < passes; p++) {
+            widths[p] = bits / passes + (p < bits % passes ? 1 : 0);
+            shifts[p] = sh;
+            sh += widths[p];
+        }
+        tiles = (u32)((n + kRsTile - 1) / kRsTile);
+        u32 *counts = (u32 *)dev_alloc((u64)1024 * tiles * sizeof(u32));
+        u32 chunks = (tiles + kRsChunk - 1) / kRsChunk;
+        u32 *chunk_sums = (u32 *)dev_alloc((u64)1024 * chunks * sizeof(u32));
+        u64 *chunk_off = (u64 *)dev_alloc((u64)1024 * chunks * sizeof(u64));
+        int cur = 0;
+        for (int p = 0; p < passes; p++) {
+            const int db = widths[p] <= 8 ? 8 : widths[p];
+            kbuf[p + 1] = (K *)dev_alloc(n * sizeof(K));
+            offs[p] = (u64 *)dev_alloc(((u64)1 << db) * tiles * sizeof(u64));
+            const u32 dmask = (1u << widths[p]) - 1u;
+            V *vin = cur ? vals_b : vals_a, *vout = cur ? vals_a : vals_b;
+            if (db == 8) rs_pass<K, V, 2, 8>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+            else if (db == 9) rs_pass<K, V, 2, 9>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+            else rs_pass<K, V, 2, 10>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+            cur ^= 1;
+        }
+        dev_free(counts); dev_free(chunk_sums); dev_free(chunk_off);
+        return cur;
+    }
+    // in[j] belongs to the record at sorted position j; out[i] = the element of the record that was at position i originally.
+    // tmp: scratch of n elements (used with more than one pass); `in` is overwritten when passes > 2.
+    template <class W>
+    void backward(W *in, W *tmp, W *out, const char *name = "part_sort.back") const {
+        if (n == 0) return;
+        if (passes == 0) { d2d(out, in, n * sizeof(W)); return; }
+        W *src = in;
+        for (int p = passes - 1; p >= 0; p--) {
+            W *dst = (p == 0) ? out : ((src == tmp) ? in : tmp);
+            const u32 dmask = (1u << widths[p]) - 1u;
+            prof_begin(name, n * (sizeof(K) + 2 * sizeof(W)));
+            if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            prof_end();
+            after_launch(name);
+            src = dst;
+        }
+    }
+    void release() {
+        for (int p = 0; p < 8; p++) {
+            if (kbuf[p + 1]) dev_free(kbuf[p + 1]);
+            if (offs[p]) dev_free(offs[p]);
+            kbuf[p + 1] = nullptr; offs[p] = nullptr;
+        }
+        kbuf[0] = nullptr;
+        passes = 0; n = 0;
+    }
+    PartSort() {}
+    PartSort(const PartSort &) = delete;
+    PartSort &operator=(const PartSort &) = delete;
+    ~PartSort() { release(); }
+};
+
+// Per-partition de-duplication of 128-bit values in LDS.  Partition p = records [pstart[p], pstart[p + 1]).  One workgroup
+// of 1024 threads per partition: an open-addressing table of kPdSlots entries (hash tag | index of the representative
+// record) and a counter per entry; a match is confirmed against the representative's value (the partition was just read:
+// it sits in L2).  Records with valid(v) == false take no part (lid = kNoId).  Outputs: lid[i] = dense local id of record
+// i's value among the distinct values of its partition; pcount[p]; the j-th distinct value of p and its count at
+// dval[pstart[p] + j], dcnt[pstart[p] + j].  *overflow is set when a partition does not fit (more distinct values than the
+// table takes, or more than 2^26 records): the caller falls back to another method.
+static constexpr int kPdSlots = 8192, kPdThreads = 1024;
+template <class VALID>
+__global__ void __launch_bounds__(kPdThreads) k_part_dedupe(const u64 *pstart, const U128 *vals, VALID valid, u32 *lid, u32 *pcount,
+                                                            U128 *dval, u32 *dcnt, u32 *overflow) {
+    __shared__ unsigned long long s_tab[kPdSlots];
+    __shared__ u32 s_cnt[kPdSlots];
+    __shared__ u32 s_dense[kPdSlots];
+    __shared__ u32 s_w[kPdThreads / 64];
+    __shared__ u32 s_fail;
+    const u64 a = pstart[blockIdx.x], b = pstart[blockIdx.x + 1];
+    for (int i = threadIdx.x; i < kPdSlots; i += kPdThreads) { s_tab[i] = 0ull; s_cnt[i] = 0u; }
+    if (threadIdx.x == 0) s_fail = (b - a >= (1ull << 26)) ? 1u : 0u;
+    __syncthreads();
+    const bool usable = s_fail == 0;
+    for (u64 i = a + threadIdx.x; i < b && usable; i += kPdThreads) {
+        const U128 v = vals[i];
+        u32 res = kNoId;
+        if (valid(v)) {
+            u64 g = (v.lo ^ (v.hi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+            g ^= g >> 32; g *= 0xFF51AFD7ED558CCDull; g ^= g >> 29;
+            const unsigned long long tag = g >> 26;
+            const unsigned long long mine = (tag << 26) | (unsigned long long)(i - a + 1);
+            u32 slot = (u32)g & (kPdSlots - 1);
+            bool done = false;
+            for (int probes = 0; probes < kPdSlots && !done; probes++) {
+                unsigned long long e = s_tab[slot];
+                if (e == 0ull) {
+                    const unsigned long long old = atomicCAS(&s_tab[slot], 0ull, mine);
+                    e = old == 0ull ? mine : old;
+                }
+                if (e == mine) done = true;
+                else if ((e >> 26) == tag) {
+                    const U128 r = vals[a + ((e & ((1ull << 26) - 1ull)) - 1ull)];
+                    if (r.lo == v.lo && r.hi == v.hi) done = true;
+                }
+                if (!done) slot = (slot + 1) & (kPdSlots - 1);
+            }
+            if (done) { atomicAdd(&s_cnt[slot], 1u); res = slot; }
+            else s_fail = 1u;                       // table full
+        }
+        lid[i] = res;
+    }
+    __syncthreads();
+    // dense numbering of the occupied slots (slot order): thread t takes slots [8t, 8t + 8)
+    constexpr int PER = kPdSlots / kPdThreads;
+    u32 occ = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) occ += s_tab[threadIdx.x * PER + k] != 0ull ? 1u : 0u;
+    u32 incl = occ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 o = (u32)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    u32 before = incl - occ, total = 0;
+    for (int k = 0; k < kPdThreads / 64; k++) { if (k < w) before += s_w[k]; total += s_w[k]; }
+    u32 j = before;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int sl = threadIdx.x * PER + k;
+        const unsigned long long e = s_tab[sl];
+        if (e != 0ull) {
+            s_dense[sl] = j;
+            dval[a + j] = vals[a + ((e & ((1ull << 26) - 1ull)) - 1ull)];
+            dcnt[a + j] = s_cnt[sl];
+            j++;
+        }
+    }
+    __syncthreads();
+    if (s_fail) { if (threadIdx.x == 0) { *overflow = 1u; pcount[blockIdx.x] = 0; } return; }
+    for (u64 i = a + threadIdx.x; i < b; i += kPdThreads) {
+        const u32 sl = lid[i];
+        if (sl != kNoId) lid[i] = s_dense[sl];
+    }
+    if (threadIdx.x == 0) pcount[blockIdx.x] = total;
+}
+template <class VALID>
+inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID valid, u32 *lid, u32 *pcount, U128 *dval, u32 *dcnt, u32 *overflow,
+                        const char *name = "part_dedupe") {
+    if (nparts == 0) return;
+    prof_begin(name);
+    hipLaunchKernelGGL((k_part_dedupe<VALID>), dim3((unsigned)nparts), dim3(kPdThreads), 0, rt().stream, pstart, vals, valid, lid, pcount, dval, dcnt, overflow);
+    prof_end();
+    after_launch(name);
+}
+
 }   // namespace prim

@@ -285,4 +285,56 @@ inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char
     return sort_keys<u64>(buf_a, buf_b, plan.E, 0, plan.bits);
 }
 
+
+// partition sort that can be undone + per-partition de-duplication (serial forms of the primitives of prim_hip.hpp)
+struct alignas(16) U128 {
+    u64 lo, hi;
+    U128() = default;
+    U128(int) : lo(0), hi(0) {}
+    U128(u64 l, u64 h) : lo(l), hi(h) {}
+    bool operator==(const U128 &o) const { return lo == o.lo && hi == o.hi; }
+};
+static constexpr u32 kNoId = 0xFFFFFFFFu;
+template <class K, class V>
+struct PartSort {
+    u64 n = 0;
+    std::vector<u64> order;          // order[j] = original position of the record at sorted position j
+    std::vector<K> skeys;
+    const K *sorted_keys() const { return skeys.data(); }
+    int forward(K *keys, V *vals_a, V *vals_b, u64 n_, int begin_bit, int end_bit, const char * = "") {
+        n = n_;
+        order.resize(n); skeys.resize(n);
+        std::iota(order.begin(), order.end(), 0);
+        const int bits = end_bit - begin_bit;
+        const K mask = bits >= (int)(8 * sizeof(K)) ? ~K(0) : (K)((K(1) << bits) - 1);
+        std::stable_sort(order.begin(), order.end(), [&](u64 a, u64 b) { return ((keys[a] >> begin_bit) & mask) < ((keys[b] >> begin_bit) & mask); });
+        for (u64 j = 0; j < n; j++) { skeys[j] = keys[order[j]]; vals_b[j] = vals_a[order[j]]; }
+        return 1;
+    }
+    template <class W>
+    void backward(W *in, W *, W *out, const char * = "") const { for (u64 j = 0; j < n; j++) out[order[j]] = in[j]; }
+    void release() { order.clear(); skeys.clear(); n = 0; }
+};
+template <class VALID>
+inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID valid, u32 *lid, u32 *pcount, U128 *dval, u32 *dcnt, u32 *overflow,
+                        const char * = "") {
+    // (GRLBWT_SIM_PD_LIMIT: the tests make partitions "overflow" so that the caller's fallback runs)
+    const char *lim = getenv("GRLBWT_SIM_PD_LIMIT");
+    const u32 limit = lim ? (u32)atoi(lim) : 6000u;
+    for (u64 p = 0; p < nparts; p++) {
+        const u64 a = pstart[p], b = pstart[p + 1];
+        u32 d = 0;
+        for (u64 i = a; i < b; i++) {
+            if (!valid(vals[i])) { lid[i] = kNoId; continue; }
+            u32 j = 0;
+            while (j < d && !(dval[a + j] == vals[i])) j++;
+            if (j == d) { dval[a + d] = vals[i]; dcnt[a + d] = 0; d++; }
+            dcnt[a + j]++;
+            lid[i] = j;
+        }
+        pcount[p] = d;
+        if (d > limit) *overflow = 1;
+    }
+}
+
 }   // namespace prim

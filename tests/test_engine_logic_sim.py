@@ -214,3 +214,26 @@ def test_hot_table_with_generic_keys(sim, oracle_mod, capfd, monkeypatch):
     assert cells.size > (1 << 20)
     parity.check_final(sim, cells.tobytes(), 2)
     assert "hot table of" in capfd.readouterr().err
+
+
+def test_partitioned_phrase_naming(sim, oracle_mod, monkeypatch, capfd):
+    """Levels above 0 of single-GPU builds name their phrases through 128-bit records, a partition sort that can be undone and
+    per-partition de-duplication (prim::PartSort / prim::part_dedupe; by default from 2^20 occurrences per level on): forced
+    on for small inputs here, stage by stage against the oracle -- reads, long repeats (phrases longer than a record: the
+    mixed case with the hash table), uint16 tokens, 64-bit indices -- and with partitions that "overflow" (the level then
+    falls back to the hash table)."""
+    monkeypatch.setenv("GRLBWT_PART_MIN_OCC", "0")
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.uniform_reads(2000, 100, seed=5).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=3).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+    parity.check_stagewise(sim, open(os.path.join(parity.GOLD, "test_2bytes_alphabet.txt"), "rb").read(), 2)
+    rng = np.random.default_rng(99)
+    for kind in parity.KINDS:
+        for _ in range(12):
+            data, w = parity.rand_collection(rng, kind)
+            parity.check_final(sim, data, w)
+    monkeypatch.setenv("GRLBWT_SIM_PD_LIMIT", "3")
+    monkeypatch.setenv("GRLBWT_TABLE_TRACE", "1")
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=12).tobytes(), 1)
+    assert "falling back to the hash table" in capfd.readouterr().err
