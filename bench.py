@@ -243,59 +243,7 @@ def main():
     total_bytes = args.reads * (args.read_len + 1)
     torch.cuda.synchronize()
 
-    # ---- SURVEY 8(d)'s metric as worded: wall time of the whole CLI run, file read -> .rl_bwt closed (main.cpp:98-154,
-    # grl_bwt.hpp:77), through grlbwt_amd/bin/grlbwt on the SAME bytes (file in the page cache), twice; outside the timed region
-    # and BEFORE this process builds anything itself: the engine's arena stays mapped for the life of a process (~117 GB after
-    # a 10 GB build), and a child that finds the device that full falls back to small slabs (measured: its build 2.6-7 s
-    # instead of 1.2 s)
     cli_e2e = None
-    if rank == 0 and world == 1 and not force_dist and not args.no_cli:
-        import hashlib
-        import re
-        import shutil
-        torch.cuda.empty_cache()                 # (the generator's temporaries: the child process needs the device's memory)
-        tmpdir = os.environ.get("GRLBWT_E2E_TMP") or tempfile.gettempdir()
-        need = 2 * n_bytes + (1 << 30)
-        if shutil.disk_usage(tmpdir).free < need:
-            cli_e2e = {"skipped": "less than %d bytes free under %s" % (need, tmpdir)}
-        else:
-            cli = g.build_cli()
-            fin, fout = os.path.join(tmpdir, "grlbwt_bench_in.txt"), os.path.join(tmpdir, "grlbwt_bench_out.rl_bwt")
-            try:
-                stage = torch.empty(min(1 << 28, n_bytes), dtype=torch.uint8, pin_memory=True)
-                with open(fin, "wb") as f:
-                    for a in range(0, n_bytes, 1 << 28):
-                        m = min(1 << 28, n_bytes - a)
-                        stage[:m].copy_(text[a:a + m])
-                        torch.cuda.synchronize()
-                        f.write(memoryview(stage[:m].numpy()))
-                runs = []
-                for rep in range(2):
-                    tc = time.perf_counter()
-                    p = subprocess.run([cli, fin, "-o", fout], capture_output=True, text=True)
-                    wall = time.perf_counter() - tc
-                    mt = re.search(r"grlbwt-timing: read\+upload ([\d.]+) s, build ([\d.]+) s, write ([\d.]+) s, total ([\d.]+) s", p.stdout)
-                    if p.returncode != 0 or not mt:
-                        runs.append({"failed": p.returncode, "stderr": p.stderr[-300:]})
-                        break
-                    runs.append({"wall_s": round(wall, 3), "read_upload_s": float(mt.group(1)), "build_s": float(mt.group(2)),
-                                 "write_s": float(mt.group(3)), "MBps_wall": round(n_bytes / 1e6 / wall, 1)})
-                hh = hashlib.md5()
-                if os.path.exists(fout):
-                    with open(fout, "rb") as f:
-                        for blk in iter(lambda: f.read(1 << 26), b""):
-                            hh.update(blk)
-                best = min((r for r in runs if "wall_s" in r), key=lambda r: r["wall_s"], default=None)
-                cli_e2e = {"command": "grlbwt_amd/bin/grlbwt FILE -o OUT (file in the page cache, output to %s)" % tmpdir, "runs": runs,
-                           "output_md5": hh.hexdigest(), "md5_equals_hbm_image": None}
-                if best:
-                    cli_e2e.update(best)
-            finally:
-                for pth in (fin, fout):
-                    try:
-                        os.remove(pth)
-                    except OSError:
-                        pass
 
     comm = None
     flags = 0
@@ -346,8 +294,62 @@ def main():
         from grlbwt_amd import dist as _gd
         nb_img, nr_img = ctx.result_size()
         image = {"bytes": nb_img, "runs": nr_img, "md5": workloads.md5_device(_gd._view(ctx.result_device_ptr(), nb_img, dev))}
-        if cli_e2e and cli_e2e.get("output_md5"):
-            cli_e2e["md5_equals_hbm_image"] = cli_e2e["output_md5"] == image["md5"]
+
+    # ---- SURVEY 8(d)'s metric as worded: wall time of the whole CLI run, file read -> .rl_bwt closed (main.cpp:98-154,
+    # grl_bwt.hpp:77), through grlbwt_amd/bin/grlbwt on the SAME bytes (file in the page cache), three times, best reported;
+    # outside the timed region and AFTER this process's own builds: device memory that no process has touched since the box
+    # came up is slow to back (the first 90 GB cost a build 2.7-6 s on a fresh box, tens of milliseconds afterwards), so the
+    # first child run still pays for the pages this process does not hold -- the later ones show the steady state.  This
+    # process keeps its arena (~90 GB) and the text while the child runs; the device has room for both.
+    if rank == 0 and world == 1 and not force_dist and not args.no_cli:
+        import hashlib
+        import re
+        import shutil
+        torch.cuda.empty_cache()                 # (the generator's temporaries: the child process needs the device's memory)
+        tmpdir = os.environ.get("GRLBWT_E2E_TMP") or tempfile.gettempdir()
+        need = 2 * n_bytes + (1 << 30)
+        if shutil.disk_usage(tmpdir).free < need:
+            cli_e2e = {"skipped": "less than %d bytes free under %s" % (need, tmpdir)}
+        else:
+            cli = g.build_cli()
+            fin, fout = os.path.join(tmpdir, "grlbwt_bench_in.txt"), os.path.join(tmpdir, "grlbwt_bench_out.rl_bwt")
+            try:
+                stage = torch.empty(min(1 << 28, n_bytes), dtype=torch.uint8, pin_memory=True)
+                with open(fin, "wb") as f:
+                    for a in range(0, n_bytes, 1 << 28):
+                        m = min(1 << 28, n_bytes - a)
+                        stage[:m].copy_(text[a:a + m])
+                        torch.cuda.synchronize()
+                        f.write(memoryview(stage[:m].numpy()))
+                runs = []
+                for rep in range(3):
+                    tc = time.perf_counter()
+                    p = subprocess.run([cli, fin, "-o", fout], capture_output=True, text=True)
+                    wall = time.perf_counter() - tc
+                    mt = re.search(r"grlbwt-timing: read\+upload ([\d.]+) s, build ([\d.]+) s, write ([\d.]+) s, total ([\d.]+) s", p.stdout)
+                    if p.returncode != 0 or not mt:
+                        runs.append({"failed": p.returncode, "stderr": p.stderr[-300:]})
+                        break
+                    runs.append({"wall_s": round(wall, 3), "read_upload_s": float(mt.group(1)), "build_s": float(mt.group(2)),
+                                 "write_s": float(mt.group(3)), "MBps_wall": round(n_bytes / 1e6 / wall, 1)})
+                hh = hashlib.md5()
+                if os.path.exists(fout):
+                    with open(fout, "rb") as f:
+                        for blk in iter(lambda: f.read(1 << 26), b""):
+                            hh.update(blk)
+                best = min((r for r in runs if "wall_s" in r), key=lambda r: r["wall_s"], default=None)
+                cli_e2e = {"command": "grlbwt_amd/bin/grlbwt FILE -o OUT (file in the page cache, output to %s)" % tmpdir, "runs": runs,
+                           "output_md5": hh.hexdigest(), "md5_equals_hbm_image": None}
+                if best:
+                    cli_e2e.update(best)
+            finally:
+                for pth in (fin, fout):
+                    try:
+                        os.remove(pth)
+                    except OSError:
+                        pass
+    if cli_e2e and image and cli_e2e.get("output_md5"):
+        cli_e2e["md5_equals_hbm_image"] = cli_e2e["output_md5"] == image["md5"]
 
     # ---- roofline leg: one more step with HIP-event timing of every kernel on the engine's stream.
     # Every rank takes the step (for N > 1 it contains collectives); only rank 0 records and reports.

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -201,7 +202,7 @@ inline void after_launch(const char *name) {
 //
 // The preferred slab is an ARENA: one virtual address range as large as the device's memory, reserved once
 // (hipMemAddressReserve costs nothing) and backed with physical memory in 1 GiB steps as the high-water mark rises
-// (hipMemCreate + hipMemMap + hipMemSetAccess: ~0.03 ms per GiB measured).  One contiguous slab never fragments across
+// (hipMemCreate + hipMemMap + hipMemSetAccess per 1 GiB piece: ~0.4 ms on a warm device).  One contiguous slab never fragments across
 // slabs and costs only what a build touches -- a single hipMalloc of > ~130 GB was measured at 6 s on this device
 // (tools/alloc_probe.hip: 128 GB 0.000 s, 200 GB 6.18 s), which is what a whole-device reservation used to cost a
 // one-shot run.  hipMalloc slabs (1 GiB, doubling) remain as the fallback when the virtual-memory calls are not
@@ -291,35 +292,83 @@ inline bool arena_create(Pool &P) {
     return true;
 }
 // back at least `more` further bytes of the arena (slab 0); false when the device has no memory left for it
+struct PoolTrace {                            // GRLBWT_POOL_TRACE=1: what backing the arena cost this process, printed at exit
+    bool on = getenv("GRLBWT_POOL_TRACE") != nullptr;
+    double grow_s = 0, malloc_s = 0;
+    u64 grows = 0, grow_fail = 0, mallocs = 0, malloc_bytes = 0;
+    ~PoolTrace() {
+        if (on) fprintf(stderr, "[grlbwt] pool: %llu arena steps in %.3f s (%llu refused), %llu hipMalloc slabs (%.2f GB) in %.3f s\n",
+                        (unsigned long long)grows, grow_s, (unsigned long long)grow_fail, (unsigned long long)mallocs, malloc_bytes / 1e9, malloc_s);
+    }
+};
+inline PoolTrace &pool_trace() { static PoolTrace t; return t; }
+inline bool arena_grow_impl(Pool &P, size_t more);
 inline bool arena_grow(Pool &P, size_t more) {
+    PoolTrace &T = pool_trace();
+    if (!T.on) return arena_grow_impl(P, more);
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool ok = arena_grow_impl(P, more);
+    T.grow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    T.grows++; if (!ok) T.grow_fail++;
+    return ok;
+}
+inline bool arena_grow_impl(Pool &P, size_t more) {
     Slab &sl = P.slabs[0];
     const size_t gib = (size_t)1 << 30;
     size_t want = (more + gib - 1) / gib * gib;
-    if (sl.size + want > sl.va_size) return false;
+    if (sl.size + want > sl.va_size) {
+        if (pool_trace().on) fprintf(stderr, "[grlbwt] pool: arena of %.2f GB cannot take %.2f GB more (address range %.2f GB)\n", sl.size / 1e9, want / 1e9, sl.va_size / 1e9);
+        return false;
+    }
+    // Pieces of exactly 1 GiB, each with its own handle: hipMemSetAccess refuses ("invalid argument") a piece mapped behind a
+    // piece of another size in most combinations (tools/arena_probe.hip, profiles/r03/arena_probe.txt: 10 GiB then 1 GiB,
+    // 4 then 1, 1-2-4, 4-4-2 all fail; 104 x 1 GiB works) -- with steps of "whatever the request needs" the arena stopped
+    // growing after a first multi-GiB step and every later request became a hipMalloc slab (145-177 GB held for a 10 GB build).
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = rt().device;
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, want, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemMap(sl.base + sl.size, want, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
     hipMemAccessDesc ad = {};
     ad.location = prop.location;
     ad.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(sl.base + sl.size, want, &ad, 1) != hipSuccess) {
-        (void)hipGetLastError(); (void)hipMemUnmap(sl.base + sl.size, want); (void)hipMemRelease(h); return false;
+    size_t added = 0;
+    bool ok = true;
+    while (added < want && ok) {
+        char *at = sl.base + sl.size + added;
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, gib, &prop, 0);
+        const char *what = "hipMemCreate";
+        if (e == hipSuccess) {
+            e = hipMemMap(at, gib, 0, h, 0);
+            what = "hipMemMap";
+            if (e == hipSuccess) {
+                e = hipMemSetAccess(at, gib, &ad, 1);
+                what = "hipMemSetAccess";
+                if (e != hipSuccess) (void)hipMemUnmap(at, gib);
+            }
+            if (e != hipSuccess) (void)hipMemRelease(h);
+        }
+        if (e != hipSuccess) {
+            if (pool_trace().on) fprintf(stderr, "[grlbwt] pool: %s(1 GiB) at arena size %.2f GB: %s\n", what, (sl.size + added) / 1e9, hipGetErrorString(e));
+            (void)hipGetLastError();
+            ok = false;
+        } else {
+            sl.chunks.emplace_back(h, gib);
+            added += gib;
+        }
     }
-    sl.chunks.emplace_back(h, want);
-    // the new range joins the free list (coalescing with a free tail)
-    size_t off = sl.size, len = want;
-    if (!sl.free_list.empty()) {
-        auto last = std::prev(sl.free_list.end());
-        if (last->first + last->second == off) { off = last->first; len += last->second; sl.free_list.erase(last); }
+    if (added) {
+        // the new range joins the free list (coalescing with a free tail)
+        size_t off = sl.size, len = added;
+        if (!sl.free_list.empty()) {
+            auto last = std::prev(sl.free_list.end());
+            if (last->first + last->second == off) { off = last->first; len += last->second; sl.free_list.erase(last); }
+        }
+        sl.free_list.emplace(off, len);
+        sl.size += added;
+        P.slab_bytes += added;
     }
-    sl.free_list.emplace(off, len);
-    sl.size += want;
-    P.slab_bytes += want;
-    return true;
+    return ok;
 }
 inline void *slab_take(Pool &P, int si, size_t need) {
     Slab &sl = P.slabs[si];
@@ -394,7 +443,12 @@ inline void *dev_alloc(size_t bytes) {
     if (want > cap) want = cap;
     if (want < need) want = need;
     void *base = nullptr;
+    const auto t_m0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&base, want);
+    if (pool_trace().on) {
+        pool_trace().malloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_m0).count();
+        pool_trace().mallocs++; pool_trace().malloc_bytes += want;
+    }
     if (e != hipSuccess && want > need) { (void)hipGetLastError(); want = need; e = hipMalloc(&base, want); }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -1745,7 +1799,7 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
             // ---- rank the window's keys by the digit and write them out (the body of k_rs_scatter)
             const u32 hn = tot - win < (u32)kXsWin ? tot - win : (u32)kXsWin;
             if (hn == 0) continue;                                    // uniform (tot == 0)
-            const u32 rpw = ((hn + 63) / 64 + 3) / 4;                // rows per wave: every wave takes a contiguous share
+            const u32 rpw = (u32)__builtin_amdgcn_readfirstlane((int)(((hn + 63) / 64 + 3) / 4));   // rows per wave (uniform, in an SGPR): every wave takes a contiguous share
             for (int d = threadIdx.x; d < (kBlock / 64) * NB; d += kBlock) (&s_cnt[0][0])[d] = 0;
             u64 key[ROWS];
             u32 idx[ROWS];
@@ -1758,24 +1812,28 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
             volatile u32 *cnt = &s_cnt[w][0];
 #pragma unroll
             for (int q = 0; q < ROWS; q++) {
-                const u32 t = ((u32)w * rpw + q) * 64 + lane;
-                const bool valid = (u32)q < rpw && t < hn;
-                const u32 d = (u32)key[q] & dmask;
-                unsigned long long peers = __ballot(valid);
+                // (rows behind rpw hold nothing: skipped by a workgroup-uniform branch -- a sub-batch of 1024 runs drops about
+                // 1600 keys at level 0, 7 of the 16 rows)
+                if ((u32)q < rpw) {
+                    const u32 t = ((u32)w * rpw + q) * 64 + lane;
+                    const bool valid = t < hn;
+                    const u32 d = (u32)key[q] & dmask;
+                    unsigned long long peers = __ballot(valid);
 #pragma unroll
-                for (int bb = 0; bb < DB; bb++) {
-                    unsigned long long mk = __ballot((d >> bb) & 1u);
-                    peers &= ((d >> bb) & 1u) ? mk : ~mk;
+                    for (int bb = 0; bb < DB; bb++) {
+                        unsigned long long mk = __ballot((d >> bb) & 1u);
+                        peers &= ((d >> bb) & 1u) ? mk : ~mk;
+                    }
+                    const u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+                    u32 old = 0;
+                    if (valid && below == 0) {
+                        old = cnt[d];
+                        cnt[d] = old + (u32)__popcll(peers);
+                    }
+                    const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+                    old = (u32)__shfl((int)old, leader);
+                    idx[q] = old + below;
                 }
-                const u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-                u32 old = 0;
-                if (valid && below == 0) {
-                    old = cnt[d];
-                    cnt[d] = old + (u32)__popcll(peers);
-                }
-                const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
-                old = (u32)__shfl((int)old, leader);
-                idx[q] = old + below;
             }
             __syncthreads();
             {   // thread t owns bins [t*BPT, (t+1)*BPT): wave bases, round-local digit starts, global bases
