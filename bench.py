@@ -112,7 +112,7 @@ GROUP_SITES = {
 }
 # rocprofv3 kernel-name fragments of the kernels a group launches (PMC traffic lookup)
 GROUP_KERNELS = {
-    "induce_AB": ["k_xs_count", "k_xs_scatter", "PackGrammarFn", "ChainCountFn", "ChainExpandFn", "NoVal, 1>", "k_rs_hist<unsigned long, 1>"],
+    "induce_AB": ["k_xs_count", "k_xs_scatter", "PackGrammarFn", "ChainCountFn", "ChainExpandFn", "NoVal, 1>", "k_rs_hist<unsigned long, 1>", "k_rs_hist<unsigned int, 1>"],
     "induce_C": ["TakeScanEmitFn", "CellTakeIn", "PrePlaceFn", "BucketEdgesFn", "BucketSizeIn", "CellAtomsFn", "PreAtomsFn", "BigAtomsFn",
                  "BigCountIn", "AtomHeadLenIn", "PreScanIn", "NotCodeIn"],
     "hash_emit": ["HashInsertFn", "k_start_bits", "MapFn", "ScatterValFn"],

@@ -1373,10 +1373,16 @@ struct CellView {
     const u64 *fused; int kb, lb;
     const u32 *skey; const u64 *packed; const u32 *ssym; const idx_t *slen;
     u32 u0;                 // first bucket of the piece being assembled (collection-level mode: buckets are owned by ranges)
-    GRL_DEV u32 key(u64 t) const { return (fused ? (u32)(fused[t] & ((1ull << kb) - 1ull)) : skey[t]) - u0; }
-    GRL_DEV u32 sym(u64 t) const { return fused ? (u32)(fused[t] >> (kb + lb)) : packed ? (u32)(packed[t] >> 32) : ssym[t]; }
+    const u32 *fused32;     // the one-word form in 32 bits (bucket + length + symbol bits <= 32: level 0 of DNA collections)
+    GRL_DEV u32 key(u64 t) const {
+        return (fused32 ? (fused32[t] & ((1u << kb) - 1u)) : fused ? (u32)(fused[t] & ((1ull << kb) - 1ull)) : skey[t]) - u0;
+    }
+    GRL_DEV u32 sym(u64 t) const {
+        return fused32 ? (fused32[t] >> (kb + lb)) : fused ? (u32)(fused[t] >> (kb + lb)) : packed ? (u32)(packed[t] >> 32) : ssym[t];
+    }
     GRL_DEV idx_t len(u64 t) const {
-        return fused ? (idx_t)((fused[t] >> kb) & ((1ull << lb) - 1ull)) : packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t];
+        return fused32 ? (idx_t)((fused32[t] >> kb) & ((1u << lb) - 1u))
+                       : fused ? (idx_t)((fused[t] >> kb) & ((1ull << lb) - 1ull)) : packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t];
     }
 };
 struct CellHeadIn {     // 1 where a cell does not merge with its predecessor (other bucket or other symbol): the reference's n_runs
@@ -3172,7 +3178,7 @@ class Engine {
     // passes A+B (exact_ind_phase.cpp:42-109,143-258) over the runs this engine holds of BWT_{r+1}: chain walks through
     // the level's grammar, cells split by bucket (stable).  The cells stay in c_* (bucket-major), term[i] = rewritten symbol
     // of run i.  `maxrun` = longest run of BWT_{r+1} (of ALL shards in the collection-level mode: it fixes the cell layout).
-    u64 expand_split(LevelData &L, DBuf<u32> &term, u64 maxrun, int &kb, int &lb) {
+    u64 expand_split(LevelData &L, DBuf<u32> &term, u64 maxrun, int &kb, int &lb, bool allow32 = true) {
         const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, take_code = bwt_code;
         const u64 R = bwt.R, M = L.M;
         DBuf<idx_t> eoff;
@@ -3182,6 +3188,7 @@ class Engine {
         DBuf<u32> skey;                         // bucket of every induced cell, bucket-major order
         DBuf<u64> spack;                        // (sym<<32 | len) of every induced cell, same order (packed path)
         DBuf<u64> sfused;                       // sym | len | bucket in one word per cell (fused path)
+        DBuf<u32> sfused32;                     // the same word in 32 bits when the three fields fit (kb + lb + sbits <= 32 < 2^32: kb < 32)
         kb = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
         if (kb < 1) kb = 1;
         lb = (int)bitlen64(maxrun);
@@ -3199,6 +3206,8 @@ class Engine {
             // (GRLBWT_CELL_LAYOUT=packed|separate: the tests take the wider layouts on inputs that would never need them)
             const char *force = getenv("GRLBWT_CELL_LAYOUT");
             const bool fused = kb + lb + sbits <= 64 && !force;
+            if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] induction level %d: %llu runs, longest %llu, cell bits: bucket %d + length %d + symbol %d\n",
+                                                      prim::rt().tag, (unsigned long long)R, (unsigned long long)maxrun, kb, lb, sbits);
             // otherwise the payload (sym, len) rides through the split as one u64 whenever every run length fits 32 bits
             const bool packed = !fused && maxrun < 0xFFFFFFFFull && !(force && force[0] == 's');
             bool done = false;
@@ -3211,7 +3220,16 @@ class Engine {
                     StageTimer st(&tm.ind_expand);
                     E = prim::expand_count(R, gen, bits, plan, "induce");
                 }
-                if (plan.ok) {
+                // 4-byte cells when everything fits (level 0 of the 10 GB DNA build: 17 + 8 + 7 bits): every pass of the split and
+                // pass C move half the bytes.  Not in the collection-level mode (the cells travel between ranks as 8-byte words).
+                const bool cell32 = allow32 && kb + lb + sbits <= 32 && kb < 32 && !getenv("GRLBWT_NO_CELL32");
+                if (plan.ok && cell32) {
+                    DBuf<u32> ef(E), ef2(E);
+                    StageTimer st(&tm.ind_sort);
+                    int res = prim::expand_sort<ChainGen, u32>(gen, plan, ef.p, ef2.p, "induce");
+                    sfused32 = std::move(res ? ef2 : ef);
+                    done = true;
+                } else if (plan.ok) {
                     DBuf<u64> ef(E), ef2(E);
                     StageTimer st(&tm.ind_sort);
                     int res = prim::expand_sort(gen, plan, ef.p, ef2.p, "induce");
@@ -3271,10 +3289,10 @@ class Engine {
         }
         // the cells move to the engine: pass C drops them before its run merge (peak memory)
         c_skey = std::move(skey); c_ssym = std::move(ssym); c_slen = std::move(slen); c_spack = std::move(spack);
-        c_sfused = std::move(sfused); c_gp = std::move(gp);
+        c_sfused = std::move(sfused); c_sfused32 = std::move(sfused32); c_gp = std::move(gp);
         return E;
     }
-    CellView cell_view(int kb, int lb, u32 u0 = 0) const { return CellView{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p, u0}; }
+    CellView cell_view(int kb, int lb, u32 u0 = 0) const { return CellView{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p, u0, c_sfused32.p}; }
     u64 level_maxrun() {
         StageTimer st(&tm.ind_expand);
         return prim::reduce_max<u64>(bwt.R, IdxIn64{bwt.len.p}, "induce_maxrun");
@@ -3404,8 +3422,8 @@ class Engine {
                                                               " symbols, the level has " + std::to_string(L.n_out));
     }
     // the induced cells of the level being assembled (owned here so that pass C can drop them before the run merge)
-    DBuf<u32> c_skey, c_ssym; DBuf<idx_t> c_slen; DBuf<u64> c_spack, c_sfused, c_gp;
-    void release_cells() { c_skey.release(); c_ssym.release(); c_slen.release(); c_spack.release(); c_sfused.release(); c_gp.release(); }
+    DBuf<u32> c_skey, c_ssym, c_sfused32; DBuf<idx_t> c_slen; DBuf<u64> c_spack, c_sfused, c_gp;
+    void release_cells() { c_skey.release(); c_ssym.release(); c_slen.release(); c_spack.release(); c_sfused.release(); c_sfused32.release(); c_gp.release(); }
 
     void induce_phase() {                                        // exact_ind_phase.cpp:674-697
         first_bwt();
@@ -3709,7 +3727,7 @@ class Engine {
             split.alloc(4 * ((u64)N + 1));
             // (GRLBWT_TEST_FAIL_RANK_INDUCE=<rank>: the tests make one rank fail here)
             if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_INDUCE")) if (atoi(fr) == me) throw prim::Error(-12, "out of device memory (injected by the test)");
-            E = expand_split(L, term, maxrun, kb, lb);
+            E = expand_split(L, term, maxrun, kb, lb, false);
             I.E = E;
             StageTimer st(&tm.ind_assemble);
             // (2) owners of the output: pre-BWT run ranges of about n_r / size symbols, and the buckets inside them

@@ -1629,6 +1629,7 @@ inline int rs_plan(int bits, int *widths /*[>= bits/8 + 1]*/) {
     return passes;
 }
 inline int sort_keys_fwd(u64 *a, u64 *b, u64 n, int begin_bit, int end_bit, const char *name);
+inline int sort_keys_fwd(u32 *a, u32 *b, u64 n, int begin_bit, int end_bit, const char *name);
 // ------------------------------------------------------- expand + multi-split
 // Stable multi-split of GENERATED keys.  Item i (0 <= i < n) walks a chain through a table of packed node records and
 // drops one u64 key per step; the result is the sequence of all keys ordered by key bits [0, bits), stable with respect
@@ -1717,12 +1718,13 @@ __global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, 
 }
 // (MINB = workgroups per CU the register budget is cut for: at 3 the kernel spills ~100 bytes per lane to scratch (168 VGPRs);
 // at 2 it keeps everything in registers at 8 instead of 12 waves per CU -- GRLBWT_XS_OCC=2|3 picks, see expand_sort)
-template <class GEN, int DB, int MINB = 3>
-__global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32 dmask, const u8 *cnt8, const u64 *offsets /*[tiles][NB]*/, u64 *out,
+// (K = u64, or u32 when a whole key fits 32 bits: half the bytes in LDS, in the write-out and in every later pass)
+template <class GEN, int DB, int MINB = 3, class K = u64>
+__global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32 dmask, const u8 *cnt8, const u64 *offsets /*[tiles][NB]*/, K *out,
                                                        int xcd_aware) {
     constexpr int NB = 1 << DB, BPT = NB / kBlock > 0 ? NB / kBlock : 1;     // bins per thread (contiguous)
     constexpr int ROWS = kXsWin / kBlock;                                   // 16 rows of 64 keys per wave and round
-    __shared__ __attribute__((aligned(16))) u64 s_cells[kXsWin];
+    __shared__ __attribute__((aligned(16))) K s_cells[kXsWin];
     __shared__ u32 s_cnt[kBlock / 64][NB];
     __shared__ u64 s_goff[NB];       // running global offset of every digit for this tile
     __shared__ u64 s_gbase[NB];      // global position of round-local index 0 of the digit's run (mod 2^64)
@@ -1771,7 +1773,7 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
                 pos[j] = o[j] - win;                                   // may wrap below zero: the window test below is unsigned
                 ib[j] = act[j] ? gen.item_bits(item[j]) : 0;
                 if (act[j] && gen.owns(rec[j])) {
-                    if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = gen.key_own(cur[j], ib[j]);
+                    if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = (K)gen.key_own(cur[j], ib[j]);
                     pos[j]++;
                 }
             }
@@ -1787,7 +1789,7 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
 #pragma unroll
                 for (int j = 0; j < kXsIpt; j++) {
                     if (m[j]) {
-                        if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = gen.key_step(rec[j], nx[j], ib[j]);
+                        if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = (K)gen.key_step(rec[j], nx[j], ib[j]);
                         pos[j]++;
                         rec[j] = nrec[j];
                     }
@@ -1801,12 +1803,12 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
             if (hn == 0) continue;                                    // uniform (tot == 0)
             const u32 rpw = (u32)__builtin_amdgcn_readfirstlane((int)(((hn + 63) / 64 + 3) / 4));   // rows per wave (uniform, in an SGPR): every wave takes a contiguous share
             for (int d = threadIdx.x; d < (kBlock / 64) * NB; d += kBlock) (&s_cnt[0][0])[d] = 0;
-            u64 key[ROWS];
+            K key[ROWS];
             u32 idx[ROWS];
 #pragma unroll
             for (int q = 0; q < ROWS; q++) {
                 const u32 t = ((u32)w * rpw + q) * 64 + lane;
-                key[q] = ((u32)q < rpw && t < hn) ? s_cells[t] : 0ull;
+                key[q] = ((u32)q < rpw && t < hn) ? s_cells[t] : K(0);
             }
             __syncthreads();
             volatile u32 *cnt = &s_cnt[w][0];
@@ -1882,7 +1884,7 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
             for (int j = 0; j < ROWS; j++) {
                 const u32 t = (u32)j * kBlock + threadIdx.x;
                 if (t < hn) {
-                    const u64 k = s_cells[t];
+                    const K k = s_cells[t];
                     out[s_gbase[(u32)k & dmask] + t] = k;
                 }
             }
@@ -1931,8 +1933,8 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char *name
     return plan.E;
 }
 // Phase 2: generate + first pass into buf_a, remaining passes ping-pong; returns 0 if the result is in buf_a, 1 if in buf_b
-template <class GEN>
-inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char *name = "expand") {
+template <class GEN, class K = u64>
+inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *name = "expand") {
     if (!plan.ok) throw Error(-71, "expand_sort: plan not usable");
     if (plan.n == 0) return 0;                 // (with E == 0 the walk still runs: cells() has side effects)
     const int NB = 1 << plan.db;
@@ -1940,14 +1942,14 @@ inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char
     // XCD-contiguous tile ranges were measured 7 % SLOWER for this kernel on the 10 GB build (32.8 vs 30.6 ms at level 0,
     // 16.9 vs 14.8 at level 1): the round-robin deal already lets the 8 L2s share every digit's write front; opt-in only
     static const int xcd_aware = getenv("GRLBWT_XCD_MAP") ? 1 : 0;
-    prof_begin(std::string(name) + ".xscatter", plan.E * 8);
+    prof_begin(std::string(name) + ".xscatter", plan.E * sizeof(K));
     static const int occ = getenv("GRLBWT_XS_OCC") ? atoi(getenv("GRLBWT_XS_OCC")) : 3;
     if (occ == 2) {
-        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9, 2>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
-        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8, 2>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9, 2, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8, 2, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
     } else {
-        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
-        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9, 3, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8, 3, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
     }
     prof_end();
     after_launch(name);
@@ -2016,6 +2018,9 @@ inline int sort_keys(K *keys_a, K *keys_b, u64 n, int begin_bit, int end_bit, co
 }
 inline int sort_keys_fwd(u64 *a, u64 *b, u64 n, int begin_bit, int end_bit, const char *name) {
     return sort_keys<u64, 1>(a, b, n, begin_bit, end_bit, name);      // SITE 1: the passes behind the fused expand + first pass
+}
+inline int sort_keys_fwd(u32 *a, u32 *b, u64 n, int begin_bit, int end_bit, const char *name) {
+    return sort_keys<u32, 1>(a, b, n, begin_bit, end_bit, name);
 }
 
 

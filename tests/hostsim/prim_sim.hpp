@@ -276,13 +276,13 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char * = "
     plan.ok = plan.maxc <= (lim ? (u32)atoi(lim) : 32u);
     return plan.E;
 }
-template <class GEN>
-inline int expand_sort(GEN gen, XsPlan &plan, u64 *buf_a, u64 *buf_b, const char * = "") {
+template <class GEN, class K = u64>
+inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char * = "") {
     if (!plan.ok) throw Error(-71, "expand_sort: plan not usable");
     u64 e = 0;
-    for (u64 i = 0; i < plan.n; i++) xs_walk(gen, i, true, [&](u64 k) { buf_a[e++] = k; });
+    for (u64 i = 0; i < plan.n; i++) xs_walk(gen, i, true, [&](u64 k) { buf_a[e++] = (K)k; });
     if (e != plan.E) throw Error(-71, "expand_sort: generator produced a different number of keys");
-    return sort_keys<u64>(buf_a, buf_b, plan.E, 0, plan.bits);
+    return sort_keys<K>(buf_a, buf_b, plan.E, 0, plan.bits);
 }
 
 
