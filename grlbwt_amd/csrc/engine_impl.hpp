@@ -125,6 +125,10 @@ struct PopcIn {
     const u64 *w;
     GRL_DEV u64 operator()(u64 i) const { return (u64)__builtin_popcountll(w[i]); }
 };
+struct PopcIn32 {
+    const u64 *w;
+    GRL_DEV u32 operator()(u64 i) const { return (u32)__builtin_popcountll(w[i]); }
+};
 
 // ------------------------------------------------- a3: phrase hashing/count
 // phrase table: u64 keys and idx_t counts.  Two key forms (0 = empty):
@@ -529,6 +533,100 @@ struct SampledFn {
         for (int j = 0; j < kBatch; j++) m[j] = map(item[j]);
         f.process_batch(m, valid, slot);
     }
+};
+
+// Partitioned naming, the pass over the text: ONE lane per position, nothing but the straight-line cut of HashInsertFn::process
+// (a window of start bits + rec_cmax cell loads -> the phrase's 128-bit record at its ordinal).  Phrases that do not end within
+// rec_cmax cells (and the few at the very end of the text) are only LISTED here; ListedFn sends them through the general walk and
+// the hash table afterwards.  The record pass through prim::for_each_agg with the whole HashInsertFn inlined took 33 ms for the
+// 964 M phrases of level 1 of the 10 GB build, 25 of them with neither the cell loads nor the record stores.
+// (B = bits per symbol at compile time, hence cmax and every shift: the record is assembled in four 32-bit words by constant
+// shifts, no loop or branch per cell.  The run-time form with 64-bit shifts ran ~250 vector + ~200 scalar instructions per 64
+// positions and was bound by exactly that -- 27.7 ms at level 1; with run-time word indices the compiler kept the four words
+// in scratch memory -- 66 ms.  B = 0: the run-time form, for symbol widths without an instance.)
+template <int B>
+GRL_HD void rec_put32(u32 &W0, u32 &W1, u32 &W2, u32 &W3, u32 s, int j) {      // symbol s at bits [j B, (j + 1) B) of W3:W2:W1:W0
+    const int o = j * B, wi = o >> 5, sh = o & 31;
+    const u32 a = s << sh;
+    const u32 c = (sh + B > 32) ? s >> ((32 - sh) & 31) : 0u;
+    if (wi == 0) { W0 |= a; W1 |= c; }
+    else if (wi == 1) { W1 |= a; W2 |= c; }
+    else if (wi == 2) { W2 |= a; W3 |= c; }
+    else W3 |= a;
+}
+template <class cell_t, int B>
+struct PhraseRecordFn {
+    static constexpr int CMAX = B ? (124 / B < 7 ? 124 / B : 7) : 7;
+    const cell_t *t; CellOps<cell_t, false> ops; const u64 *startbits; const idx_t *wordbase;
+    u64 n, n_occ;
+    u32 *rec_h; prim::U128 *rec_v; int rec_b; u32 rec_cmax;      // (B == 0 reads these two)
+    u64 *long_bits;       // bit p: the phrase starting at p is left to the walk (a counter for a list of them serialised the pass:
+                          // 38 M same-address atomics at level 2 of the 10 GB build, 171 ms)
+    u32 *scal;
+    GRL_DEV void operator()(u64 p) const {
+        const u64 w = startbits[p >> 6];
+        bool listed = false;
+        if ((w >> (p & 63)) & 1ull) {
+            const u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+            const u32 cmax = B ? (u32)CMAX : rec_cmax;
+            listed = true;
+            if (p + (u64)cmax + 1 <= n) {
+                const u64 b0 = p + 1;
+                u64 bits = startbits[b0 >> 6] >> (b0 & 63);
+                if ((b0 & 63) + (u64)cmax > 64) bits |= startbits[(b0 >> 6) + 1] << (64 - (b0 & 63));
+                cell_t cs[CMAX];
+#pragma unroll
+                for (int j = 0; j < CMAX; j++) cs[j] = (u32)j < cmax ? t[p + j] : cell_t(0);
+                u32 m = ((u32)(bits << 1)) & ((1u << cmax) - 1u) & ~1u;      // bit j: position p + j starts a phrase (j >= 1)
+                u32 tm = 0;
+#pragma unroll
+                for (int j = 0; j < CMAX; j++) tm |= ((u32)j < cmax && ops.isT(cs[j]) ? 1u : 0u) << j;
+                m |= tm;
+                if (m) {
+                    const u32 eo = (u32)__builtin_ctz(m);                          // offset of the phrase's last cell
+                    u64 klo = 0, khi = 0;
+                    if constexpr (B != 0) {
+                        u32 W0 = 0, W1 = 0, W2 = 0, W3 = 0;
+#pragma unroll
+                        for (int j = 0; j < CMAX; j++) rec_put32<B>(W0, W1, W2, W3, (u32)j <= eo ? ops.sym(cs[j]) : 0u, j);
+                        klo = (u64)W0 | ((u64)W1 << 32); khi = (u64)W2 | ((u64)W3 << 32);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CMAX; j++) if ((u32)j <= eo) rec_put(klo, khi, ops.sym(cs[j]), (u32)j, rec_b);
+                    }
+                    const u64 len = (u64)eo + 1;
+                    if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; }
+                    else {
+                        rec_h[ord] = (u32)((((klo ^ (khi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) ^ (len * 0x85EBCA6Bull)) >> 32);
+                        rec_v[ord] = prim::U128(klo, khi | (((tm >> eo) & 1u) ? kPhrLastT : 0ull) | (len << 61));
+                    }
+                    listed = false;
+                }
+            }
+        }
+        prim::wave_word_store(long_bits, p, listed);
+    }
+};
+struct BitPositionsFn {      // the positions of the set bits of words[], in order: pos[base[w] ..] for word w
+    const u64 *words; const u32 *base; u64 *pos;
+    GRL_DEV void operator()(u64 w) const {
+        u64 x = words[w];
+        u64 k = base[w];
+        while (x) { pos[k++] = w * 64 + (u64)__builtin_ctzll(x); x &= x - 1; }
+    }
+};
+// HashInsertFn over a LIST of phrase starts (prim::for_each_agg protocol; claims are marked at the real position)
+template <class F>
+struct ListedFn {
+    F f; const u64 *pos;
+    static constexpr int kBatch = 1;
+    static constexpr bool kClaims = F::kClaims;
+    u64 *claim_bits = nullptr;                    // = f.claim_bits
+    GRL_DEV u64 claim_pos(u64 v) const { return pos[v]; }
+    GRL_DEV bool is_start(u64) const { return true; }
+    GRL_DEV u32 process(u64 v) const { return f.process(pos[v]); }
+    GRL_DEV u32 operator()(u64 v) const { return f.process(pos[v]); }
+    GRL_DEV void process_batch(const u64 *, const bool *, u32 *) const {}
 };
 
 // ------------------------------------------------------ a5: dictionary view
@@ -2490,6 +2588,8 @@ class Engine {
             // partitions of at most ~5000 records: even a level whose phrases are ALL distinct fits the LDS tables (8192 entries)
             part_bits = 4;
             while (part_bits < 20 && (n_occ >> part_bits) > 5000) part_bits++;
+            // (GRLBWT_PART_BITS: the tests make partitions too large for their table, to take the fallback on the device)
+            if (const char *pb = getenv("GRLBWT_PART_BITS")) part_bits = std::max(1, std::min(20, atoi(pb)));
         }
 
         // ---- a3: hash every phrase occurrence ------------------------------
@@ -2607,7 +2707,32 @@ class Engine {
                     prim::for_each_agg(s_n, SampledFn<HF>{fh, s_blk, s_stride, claim.p}, NoCountAdd{}, false, "hash_hot");
                     f.hot_keys = keys.p; f.hot_mask = cap_hot - 1; f.slot_base = (u32)cap_hot;
                 }
-                launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
+                if constexpr (!FIRST) {
+                    if (part && !getenv("GRLBWT_PART_ONE_PASS")) {
+                        // the records by a lean streaming pass of their own, the long phrases from a list through the table
+                        prim::dev_memset(P.next_text.p, 0, n_occ * sizeof(u32));
+                        DBuf<u64> lbits(nwords + 1);
+                        lbits.zero();
+                        auto records = [&](auto bw) {
+                            prim::for_each(n, PhraseRecordFn<cell_t, decltype(bw)::value>{t, ops, startbits.p, wordbase.p, n, n_occ, P.rec_h.p, rec_v.p, rec_b,
+                                                                                          rec_cmax, lbits.p, scal.p}, "hash_phrases");
+                        };
+                        switch (rec_b) {
+#define GRL_REC_CASE(BW) case BW: records(std::integral_constant<int, BW>()); break;
+                            GRL_REC_CASE(10) GRL_REC_CASE(11) GRL_REC_CASE(12) GRL_REC_CASE(13) GRL_REC_CASE(14) GRL_REC_CASE(15) GRL_REC_CASE(16)
+                            GRL_REC_CASE(17) GRL_REC_CASE(18) GRL_REC_CASE(19) GRL_REC_CASE(20) GRL_REC_CASE(21) GRL_REC_CASE(22) GRL_REC_CASE(23)
+                            GRL_REC_CASE(24) GRL_REC_CASE(25) GRL_REC_CASE(26) GRL_REC_CASE(27) GRL_REC_CASE(28) GRL_REC_CASE(29) GRL_REC_CASE(30)
+#undef GRL_REC_CASE
+                            default: records(std::integral_constant<int, 0>()); break;      // (narrow symbols: small levels)
+                        }
+                        DBuf<u32> lbase(nwords + 1);
+                        const u64 nl = (u64)prim::exclusive_scan<u32>(nwords, PopcIn32{lbits.p}, lbase.p, false, "hash_long_list");
+                        DBuf<u64> lpos(nl ? nl : 1);
+                        if (nl) prim::for_each(nwords, BitPositionsFn{lbits.p, lbase.p, lpos.p}, "hash_long_list");
+                        lbits.release(); lbase.release();
+                        if (nl) prim::for_each_agg(nl, ListedFn<HF>{f, lpos.p, claim.p}, SlotCountAdd{cnt, cs}, false, "hash_long_phrases");
+                    } else launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
+                } else launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
                 std::vector<u32> sc = scal.to_host(4);
                 if (sc[1] == 1) {
                     if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");

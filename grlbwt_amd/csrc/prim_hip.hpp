@@ -761,6 +761,15 @@ GRL_DEV void wave_or_words(u64 *words, bool has, u64 w, u64 m) {
     }
 }
 
+// words[i / 64] = the wave's `has` flags, for a functor of prim::for_each / for_each_agg-free launches whose lanes hold the 64
+// CONSECUTIVE elements i - (i % 64) .. of one word (k_for_each: element = blockIdx * 256 + threadIdx + k * stride, strides are
+// multiples of 256) -- a plain store by one lane, no atomic, nothing when no lane has a flag (words[] starts zeroed).  Call it
+// from converged code (every lane that holds an element).
+GRL_DEV void wave_word_store(u64 *words, u64 i, bool has) {
+    const unsigned long long b = __ballot(has);
+    if (b && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)b) - 1)) words[i >> 6] = (u64)b;
+}
+
 // ------------------------------------------ for_each with LDS count aggregation
 // f(i) returns a bucket id (u32) or kNoBucket; every returned id must be counted once
 // in a global table through add(id, count).  Same-address global atomics serialise at

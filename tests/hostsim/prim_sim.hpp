@@ -77,6 +77,8 @@ inline void dev_memset(void *d, int v, size_t n) { if (n) std::memset(d, v, n); 
 inline u32 atomic_add(u32 *p, u32 v) { u32 o = *p; *p += v; return o; }
 inline u64 atomic_add(u64 *p, u64 v) { u64 o = *p; *p += v; return o; }
 inline void atomic_or(u64 *p, u64 v) { *p |= v; }
+inline void wave_or_words(u64 *words, bool has, u64 w, u64 m) { if (has) words[w] |= m; }      // (the device form: one atomic per wave and word)
+inline void wave_word_store(u64 *words, u64 i, bool has) { if (has) words[i >> 6] |= 1ull << (i & 63); }   // (the device form: one store per wave)
 inline u32 atomic_min(u32 *p, u32 v) { u32 o = *p; if (v < o) *p = v; return o; }
 inline u32 atomic_max(u32 *p, u32 v) { u32 o = *p; if (v > o) *p = v; return o; }
 inline u64 atomic_min(u64 *p, u64 v) { u64 o = *p; if (v < o) *p = v; return o; }

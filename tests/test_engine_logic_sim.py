@@ -147,6 +147,14 @@ def test_wider_cell_layouts(sim, oracle_mod, monkeypatch, layout):
     parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
+def test_one_word_cells_in_64_bits(sim, oracle_mod, monkeypatch):
+    """Induced cells whose bucket + run length + symbol fit 32 bits travel as 4-byte words (every small input does); with
+    GRLBWT_NO_CELL32 they take the 8-byte one-word form the big levels use."""
+    monkeypatch.setenv("GRLBWT_NO_CELL32", "1")
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+
+
 def test_device_side_generators_match_host():
     """The torch generators of the large test inputs (run on the GPU there) produce the host generators' bytes."""
     a = workloads.repetitive_copies(5, 30011)

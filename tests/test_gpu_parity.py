@@ -81,6 +81,34 @@ def test_unfused_expansion_branch(hip, oracle_mod, monkeypatch):
     parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1, engine.FLAG_FORCE_IDX64)
 
 
+def test_one_word_cells_in_64_bits(hip, oracle_mod, monkeypatch):
+    """The 8-byte one-word cells of the big levels (bucket + run length + symbol > 32 bits), forced on small inputs, whose
+    cells otherwise fit the 4-byte form."""
+    monkeypatch.setenv("GRLBWT_NO_CELL32", "1")
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+
+
+def test_partitioned_phrase_naming(hip, oracle_mod, monkeypatch, capfd):
+    """prim::PartSort (forward passes + the re-ranking passes back) and prim::k_part_dedupe on the device: partitioned phrase
+    naming forced on for small inputs (by default it starts at 2^20 phrase occurrences per level), stage by stage against the
+    oracle; then with partitions that cannot fit their LDS table (one partition for 3 M distinct phrases)."""
+    monkeypatch.setenv("GRLBWT_PART_MIN_OCC", "0")
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+    rng = np.random.default_rng(2026)
+    for kind in parity.KINDS:
+        for _ in range(6):
+            data, w = parity.rand_collection(rng, kind)
+            parity.check_final(hip, data, w)
+    monkeypatch.setenv("GRLBWT_PART_BITS", "1")
+    monkeypatch.setenv("GRLBWT_TABLE_TRACE", "1")
+    capfd.readouterr()
+    parity.check_stagewise(hip, workloads.uniform_reads(20000, 100, seed=5).tobytes(), 1)
+    assert "falling back to the hash table" in capfd.readouterr().err
+
+
 def test_stagewise_idx64(hip, oracle_mod):
     parity.check_stagewise(hip, workloads.sampled_reads(5000, 80, 30000, seed=2).tobytes(), 1, engine.FLAG_FORCE_IDX64)
 
