@@ -438,7 +438,8 @@ def main():
             if comm is not None and comm.log is not None:
                 for kind, nb, sec in comm.log:
                     print("  collective %-10s %12d bytes %8.3f ms" % (kind, nb, sec * 1e3), file=sys.stderr)
-            for k, (c, ms, nb) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:120]:
+            lim = 120 if os.environ.get("GRLBWT_BENCH_DETAIL") == "1" else None        # (any other value: every site)
+            for k, (c, ms, nb) in sorted(prof_detail.items(), key=lambda kv: -kv[1][1])[:lim]:
                 print("  %-32s %4d launches %9.3f ms" % (k, c, ms), file=sys.stderr)
 
     # ---- extra: the 101 MB configs[1] workload on one GPU (round-1's headline), a few steps

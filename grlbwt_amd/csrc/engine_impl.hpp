@@ -1454,6 +1454,10 @@ struct ChainGen {
     GRL_DEV u64 key_step(u64 rec, u32 b, u64 ib) const { return ((u64)((u32)rec & 0x7FFFFFFFu) << (kb + lb)) | ib | (u64)b; }
     GRL_DEV void finish(u64 i, u64 rec) const { term[i] = (u32)(rec >> 32); }
 };
+struct NarrowCellFn {
+    const u64 *in; u32 *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = (u32)in[i]; }
+};
 struct GatherCellFn {
     const idx_t *perm; const u32 *esym; const idx_t *elen; u32 *ssym; idx_t *slen;
     GRL_DEV void operator()(u64 t) const { u64 e = perm[t]; ssym[t] = esym[e]; slen[t] = elen[e]; }
@@ -1744,10 +1748,15 @@ struct CellIn {
 template <class cell_t, bool FIRST>
 struct PhraseOwnerFn {
     const cell_t *t; CellOps<cell_t, FIRST> ops; const u64 *pos; const u32 *len; u32 size; u32 *owner; u32 *idx;
+    const prim::U128 *pkeys; u64 pDs; int pkb;      // partitioned naming: phrases [0, pDs) are records, not text positions
     GRL_DEV void operator()(u64 k) const {
         const u64 o = pos[k], l = len[k];
         PhraseHash ph = PhraseHash::init();
-        for (u64 j = 0; j < l; j++) ph.add((u32)ops.sym(t[o + j]));
+        if (k < pDs) {
+            const prim::U128 r = pkeys[k];
+            for (u64 j = 0; j < l; j++) ph.add(rec_sym(r, (u32)j, pkb));
+        } else
+            for (u64 j = 0; j < l; j++) ph.add((u32)ops.sym(t[o + j]));
         const u64 h = ph.finish(l) * 0x9E3779B97F4A7C15ull;        // remixed: the table below takes its slot and tag from the plain hash
         owner[k] = (u32)(((h >> 32) * (u64)size) >> 32);
         idx[k] = (u32)k;
@@ -1771,19 +1780,29 @@ template <class cell_t, bool FIRST>
 struct SendCellsFn {
     const cell_t *t; CellOps<cell_t, FIRST> ops; const u32 *order; const u64 *pos; const u32 *soff; u64 D, S; u32 *out;
     const u64 *pw; const idx_t *pb;      // rank bit-vector of the phrase starts over the output positions
+    const prim::U128 *pkeys; u64 pDs; int pkb;      // partitioned naming: phrases [0, pDs) are records, not text positions
     struct alignas(16) Quad { u32 v[4]; };
+    // (the cell that travels is symbol << 2 | ends-a-string: the "repeated" bit of a parse cell is a function of its symbol and
+    // is not part of a record, so no sender includes it -- equal phrases must be equal words on every rank)
     GRL_DEV void operator()(u64 j) const {
         const u64 q0 = j * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
         u64 i = rank1(pw, pb, q0 + 1) - 1;
-        u64 nxt = soff[i + 1], src = pos[order[i]] + (q0 - soff[i]);
+        u64 nxt = soff[i + 1], cur = order[i], off = q0 - soff[i];
         u32 v[16];
 #pragma unroll
         for (int x = 0; x < 16; x++) {
             const u64 q = q0 + x;
             if (q < q1) {
-                while (q >= nxt) { i++; nxt = soff[i + 1]; src = pos[order[i]]; }
-                const cell_t c = t[src++];
-                v[x] = ((u32)ops.sym(c) << 2) | (ops.rep(c) ? 2u : 0u) | (ops.isT(c) ? 1u : 0u);
+                while (q >= nxt) { i++; nxt = soff[i + 1]; cur = order[i]; off = 0; }
+                if (cur < pDs) {
+                    const prim::U128 r = pkeys[cur];
+                    const bool last = off + 1 == (u64)rec_len(r);
+                    v[x] = (rec_sym(r, (u32)off, pkb) << 2) | ((last && (r.hi & kPhrLastT)) ? 1u : 0u);
+                } else {
+                    const cell_t c = t[pos[cur] + off];
+                    v[x] = ((u32)ops.sym(c) << 2) | (ops.isT(c) ? 1u : 0u);
+                }
+                off++;
             }
         }
         if (q1 - q0 == 16) {
@@ -3303,7 +3322,7 @@ class Engine {
     // passes A+B (exact_ind_phase.cpp:42-109,143-258) over the runs this engine holds of BWT_{r+1}: chain walks through
     // the level's grammar, cells split by bucket (stable).  The cells stay in c_* (bucket-major), term[i] = rewritten symbol
     // of run i.  `maxrun` = longest run of BWT_{r+1} (of ALL shards in the collection-level mode: it fixes the cell layout).
-    u64 expand_split(LevelData &L, DBuf<u32> &term, u64 maxrun, int &kb, int &lb, bool allow32 = true) {
+    u64 expand_split(LevelData &L, DBuf<u32> &term, u64 maxrun, int &kb, int &lb) {
         const u32 sigma3 = L.sigma + 3, bwt_code = L.sigma + 1, take_code = bwt_code;
         const u64 R = bwt.R, M = L.M;
         DBuf<idx_t> eoff;
@@ -3331,6 +3350,7 @@ class Engine {
             // (GRLBWT_CELL_LAYOUT=packed|separate: the tests take the wider layouts on inputs that would never need them)
             const char *force = getenv("GRLBWT_CELL_LAYOUT");
             const bool fused = kb + lb + sbits <= 64 && !force;
+            const bool cell32 = fused && kb + lb + sbits <= 32 && kb < 32 && !getenv("GRLBWT_NO_CELL32");
             if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] induction level %d: %llu runs, longest %llu, cell bits: bucket %d + length %d + symbol %d\n",
                                                       prim::rt().tag, (unsigned long long)R, (unsigned long long)maxrun, kb, lb, sbits);
             // otherwise the payload (sym, len) rides through the split as one u64 whenever every run length fits 32 bits
@@ -3345,9 +3365,9 @@ class Engine {
                     StageTimer st(&tm.ind_expand);
                     E = prim::expand_count(R, gen, bits, plan, "induce");
                 }
-                // 4-byte cells when everything fits (level 0 of the 10 GB DNA build: 17 + 8 + 7 bits): every pass of the split and
-                // pass C move half the bytes.  Not in the collection-level mode (the cells travel between ranks as 8-byte words).
-                const bool cell32 = allow32 && kb + lb + sbits <= 32 && kb < 32 && !getenv("GRLBWT_NO_CELL32");
+                // 4-byte cells when everything fits (level 0 of the 10 GB DNA build: 17 + 8 + 7 bits): every pass of the split, pass C
+                // and -- in the collection-level mode -- the cell exchange move half the bytes.  (A function of the layout alone:
+                // the ranks of a collection-level build agree on it.)
                 if (plan.ok && cell32) {
                     DBuf<u32> ef(E), ef2(E);
                     StageTimer st(&tm.ind_sort);
@@ -3380,7 +3400,10 @@ class Engine {
                 }
                 StageTimer st(&tm.ind_sort);
                 int res = prim::sort_keys<u64, 1>(ef.p, ef2.p, E, 0, bits, "induce_split");
-                sfused = std::move(res ? ef2 : ef);
+                if (cell32) {                    // (the same form as the fused kernel's: the layout decides, not the path taken)
+                    sfused32.alloc(E);
+                    prim::for_each(E, NarrowCellFn{res ? ef2.p : ef.p, sfused32.p}, "induce_split");
+                } else sfused = std::move(res ? ef2 : ef);
                 prim::sync();
             } else if (packed) {
                 DBuf<u32> ekey(E), ekey2(E);
@@ -3643,10 +3666,12 @@ class Engine {
             try {
                 // (GRLBWT_TEST_FAIL_RANK=<rank>: the tests make one rank fail here)
                 if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK")) if (atoi(fr) == me) throw prim::Error(-28, "phrase hash table overflow (injected by the test)");
-                hash_local<cell_t, FIRST>(t, n, ops, P, L);
+                // (levels above 0: partitioned naming as on one GPU -- short phrases are records in P.ph_key, not text positions)
+                hash_local<cell_t, FIRST>(t, n, ops, P, L, !getenv("GRLBWT_DIST_NO_PART"));
                 DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D), soff(P.D + 1);
                 DBuf<u64> bound(2 * ((u64)N + 1));
-                prim::for_each(P.D, PhraseOwnerFn<cell_t, FIRST>{t, ops, P.ph_pos.p, P.ph_len.p, (u32)N, owner.p, idx.p}, "dist.phrase_owner");
+                prim::for_each(P.D, PhraseOwnerFn<cell_t, FIRST>{t, ops, P.ph_pos.p, P.ph_len.p, (u32)N, owner.p, idx.p, P.ph_key.p, P.Ds, P.rec_b},
+                               "dist.phrase_owner");
                 int obits = (int)bitlen64((u64)N - 1);
                 if (obits < 1) obits = 1;
                 const int res = prim::sort_pairs<u32, u32>(owner.p, idx.p, owner2.p, idx2.p, P.D, 0, obits, "dist.owner_sort");
@@ -3660,7 +3685,8 @@ class Engine {
                 {
                     RankBits sbits;
                     build_rankbits32(sbits, soff.p, P.D, P.S + 1, "dist.send_cells");
-                    prim::for_each((P.S + 15) / 16, SendCellsFn<cell_t, FIRST>{t, ops, order.p, P.ph_pos.p, soff.p, P.D, P.S, scells.p, sbits.words.p, sbits.base.p},
+                    prim::for_each((P.S + 15) / 16, SendCellsFn<cell_t, FIRST>{t, ops, order.p, P.ph_pos.p, soff.p, P.D, P.S, scells.p, sbits.words.p, sbits.base.p,
+                                                                              P.ph_key.p, P.Ds, P.rec_b},
                                    "dist.send_cells");
                 }
                 prim::for_each((u64)N + 1, KeyBoundFn{okey, P.D, soff.p, bound.p}, "dist.owner_bounds");
@@ -3852,7 +3878,7 @@ class Engine {
             split.alloc(4 * ((u64)N + 1));
             // (GRLBWT_TEST_FAIL_RANK_INDUCE=<rank>: the tests make one rank fail here)
             if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_INDUCE")) if (atoi(fr) == me) throw prim::Error(-12, "out of device memory (injected by the test)");
-            E = expand_split(L, term, maxrun, kb, lb, false);
+            E = expand_split(L, term, maxrun, kb, lb);
             I.E = E;
             StageTimer st(&tm.ind_assemble);
             // (2) owners of the output: pre-BWT run ranges of about n_r / size symbols, and the buckets inside them
@@ -3934,7 +3960,15 @@ class Engine {
                 u64 maxc = 0;
                 for (int g = 0; g < N; g++) for (int d = 0; d < N; d++) maxc = std::max(maxc, mat[(u64)g * 2 * N + d]);
                 const int bits = kb;
-                if (c_sfused.p) {
+                if (c_sfused32.p) {
+                    DBuf<u32> rf(Er);
+                    C.alltoall(c_sfused32.p, scnt, rf.p, rcnt, 4, maxc);
+                    c_sfused32 = std::move(rf);
+                    if (N > 1 && Er) {
+                        DBuf<u32> tmp(Er);
+                        if (prim::sort_keys<u32, 1>(c_sfused32.p, tmp.p, Er, 0, bits, "dist.merge_cells")) c_sfused32 = std::move(tmp);
+                    }
+                } else if (c_sfused.p) {
                     DBuf<u64> rf(Er);
                     C.alltoall(c_sfused.p, scnt, rf.p, rcnt, 8, maxc);
                     c_sfused = std::move(rf);

@@ -54,6 +54,24 @@ def test_sharded_wider_cell_layouts(sim, oracle_mod, tmp_path, monkeypatch, layo
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
 
 
+@pytest.mark.parametrize("world,case,port", [(2, "reads", 29581), (3, "repetitive", 29582), (2, "tokens", 29583), (3, "uniform", 29584)])
+def test_sharded_partitioned_phrase_naming(sim, oracle_mod, tmp_path, monkeypatch, world, case, port):
+    """Levels above 0 of a collection-level round name their phrases through records as on one GPU (forced on for small
+    inputs): a rank's short phrases reach their owners from the records (PhraseOwnerFn / SendCellsFn), long ones from the text."""
+    monkeypatch.setenv("GRLBWT_PART_MIN_OCC", "0")
+    _run(world, sim, case, tmp_path, port)
+    data = open(tmp_path / (case + ".input"), "rb").read()
+    assert open(tmp_path / (case + ".rl_bwt"), "rb").read() == oracle_mod.rl_bwt(data, 2 if case == "tokens" else 1)
+
+
+def test_sharded_8_byte_one_word_cells(sim, oracle_mod, tmp_path, monkeypatch):
+    """The cell exchange in the 8-byte one-word form (small inputs otherwise send 4-byte cells)."""
+    monkeypatch.setenv("GRLBWT_NO_CELL32", "1")
+    _run(3, sim, "reads", tmp_path, 29585)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+
+
 def test_large_exchanges_go_in_rounds(sim, oracle_mod, tmp_path, monkeypatch):
     """All-to-all blocks above the engine's limit are sent in several rounds (the limit is lowered to 4 KiB here)."""
     monkeypatch.setenv("GRLBWT_A2A_BLOCK", "4096")

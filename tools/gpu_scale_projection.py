@@ -26,10 +26,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 STAGES = [
-    ("parse.local (LMS breaks, hashing, table compaction)", lambda s: s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases", "hash_nocount", "hash_hot", "byte_hist", "table_compact", "dict_freq_check", "dict_maxlen", "dict_syms", "dict_offsets")),
+    ("parse.local (LMS breaks, hashing, table compaction)", lambda s: s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases", "hash_nocount", "hash_hot", "byte_hist", "table_compact", "dict_freq_check", "dict_maxlen", "dict_syms", "dict_offsets", "hash_long_list", "hash_long_phrases") or s.startswith(("phrase_part", "phrase_dedupe"))),
     ("parse.dictionary exchange + merge", lambda s: s.startswith("dist.") and not any(k in s for k in ("Tpos", "Ppos", "pre_scan", "owners", "cell_bounds", "take_sums", "window", "merge_cells", "piece_maps", "sample_keys", "mark_", "full_", "apply_phrase"))),
     ("parse.dictionary stage (sort, groups, grammar)", lambda s: s.startswith(("dict_build", "suffix_", "group_", "prebwt_", "grammar", "phrase_values", "merge_runs")) or s in ("dist.sample_keys", "dist.mark_scan", "dist.mark_pairs", "dist.full_scan", "dist.full_pairs", "dist.apply_phrase_ranks")),
-    ("parse.emit", lambda s: s in ("slot_values", "emit_parse", "dist.list_values", "dist.local_values")),
+    ("parse.emit", lambda s: s in ("slot_values", "emit_parse", "dist.list_values", "dist.local_values") or s.startswith("emit_part")),
     ("induce (A+B, exchange prep, C)", lambda s: s.startswith(("induce", "asm.", "parse2bwt", "stat.")) or any(k in s for k in ("dist.Tpos", "dist.Ppos", "dist.pre_scan", "dist.owners", "dist.cell_bounds", "dist.take_sums", "dist.window", "dist.merge_cells", "dist.piece_maps"))),
     ("image", lambda s: s in ("pack_rl_bwt",)),
 ]
@@ -116,6 +116,12 @@ def worker(args):
         out["kernel_ms_by_stage"] = {k: round(v, 2) for k, v in st.items()}
         out["kernel_ms_total"] = round(sum(st.values()), 2)
         out["top_sites"] = [[k, round(v[1], 2)] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]]
+        allsites = {}
+        for k, (c, ms, nb) in prof.items():
+            site, _, tag = k.partition("#")
+            allsites[site] = allsites.get(site, 0.0) + ms
+        out["sites"] = [[k, round(v, 2)] for k, v in sorted(allsites.items(), key=lambda kv: -kv[1]) if v >= 0.5]      # (all levels of a site together)
+        out["exchanges"] = [[k, b] for k, b, _ in comm.log if b >= (64 << 20)]
         ds = {}
         for k, (c, ms, nb) in prof.items():
             site, _, tag = k.partition("#")
@@ -188,7 +194,8 @@ def main():
                "bytes_sent_alltoallv_max_rank": sent, "bytes_received_allgather_max_rank": recv_ag, "collective_calls": ncoll,
                "projected_transfer_ms": round(xfer_ms, 2), "projected_latency_ms": round(lat_ms, 2),
                "projected_step_ms": round(crit + xfer_ms + lat_ms, 2), "image_md5": ranks[0].get("image_md5"), "image_bytes": ranks[0]["image_bytes"],
-               "top_sites_rank0": ranks[0]["top_sites"], "dictionary_sites_rank0": ranks[0]["dictionary_sites"]}
+               "top_sites_rank0": ranks[0]["top_sites"], "dictionary_sites_rank0": ranks[0]["dictionary_sites"],
+               "sites_rank0": ranks[0].get("sites"), "large_exchanges_rank0": ranks[0].get("exchanges")}
         if n == 1:
             base_ms = run["projected_step_ms"]
         if base_ms:
