@@ -107,8 +107,12 @@ inline void sync() {
     GRL_HIP_CHECK(hipStreamSynchronize(rt().stream));
     if (!rt().stages.empty()) stages_collect();
     if (rt().profile) {
+        // (the last launch name is read before prof_collect() empties the pending list)
+        static const bool by_site = getenv("GRLBWT_SYNC_SITES") != nullptr;      // which launch sites the host waited behind
+        std::string last = by_site && !rt().pending.empty() ? rt().pending.back().name : std::string();
         prof_collect();
         rt().prof["@host_sync"].launches += 1;    // how often the host waited for the stream (no kernel of that name)
+        if (by_site) rt().prof["@sync_after:" + (last.empty() ? std::string("(nothing launched since the last one)") : last)].launches += 1;
     }
 }
 inline void prof_begin(const std::string &name, u64 algo_bytes = 0) {
@@ -815,7 +819,9 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
     // them can take the generic path together -- without this, almost every wave ran the divergent generic code for a few
     // of its lanes in every batch (level 0 of DNA: 5 % long phrases, 96 % of the waves affected, 485 VALU instructions per
     // phrase measured against ~100 in the batch code proper).
-    constexpr u32 QCAP = BATCH ? 1024u : (u32)kWaveChunk, DCAP = BATCH ? 512u : 1u;
+    // (the ring takes the < 64 * kBatch items a batch run leaves plus the starts of HALF a wave chunk: 255 + 256 < 512.  With
+    // 1024 entries per wave the kernel held 40 KB of LDS and ran 4 workgroups per CU; at 32 KB it runs the 5 its registers allow.)
+    constexpr u32 QCAP = BATCH ? 512u : (u32)kWaveChunk, DCAP = BATCH ? 512u : 1u;
     __shared__ u32 s_queue[kBlock / 64][QCAP];
     __shared__ u32 s_defer[kBlock / 64][DCAP];
     if (AGG) {
@@ -880,17 +886,21 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 run_deferred(false);
             }
         };
+        static_assert(!BATCH || 64 * F::kBatch + kWaveChunk / 2 <= (int)QCAP, "the item ring is too small for this batch width");
         for (u64 cbase = start; cbase < end; cbase += kAggChunk) {
             const u64 base = cbase + (u64)w * kWaveChunk;
+#pragma nounroll
+            for (int half = 0; half < 2; half++) {      // (a loop, not two copies of the batch code: the kernel is large already)
 #pragma unroll
-            for (int k = 0; k < kWaveChunk / 64; k++) {
-                u64 i = base + (u64)k * 64 + lane;
-                bool st = (i < end) && f.is_start(i);
-                unsigned long long m = __ballot(st);
-                if (st) queue[(qt + (u32)__popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (u32)(i - start);
-                qt += (u32)__popcll(m);
+                for (int k = half * (kWaveChunk / 128); k < (half + 1) * (kWaveChunk / 128); k++) {
+                    u64 i = base + (u64)k * 64 + lane;
+                    bool st = (i < end) && f.is_start(i);
+                    unsigned long long m = __ballot(st);
+                    if (st) queue[(qt + (u32)__popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (u32)(i - start);
+                    qt += (u32)__popcll(m);
+                }
+                run_batches(false);   // leaves fewer than 64 * kBatch items: the next half chunk's <= kWaveChunk / 2 starts still fit the ring
             }
-            run_batches(false);       // leaves fewer than 64 * kBatch items: the next chunk's <= kWaveChunk starts still fit the ring
         }
         run_batches(true);
         run_deferred(true);
