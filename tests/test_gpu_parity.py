@@ -3,6 +3,7 @@ fixtures and size-independent properties.  Bit-exact is the bar (integer path)."
 import hashlib
 import json
 import os
+import sys
 import zlib
 
 import numpy as np
@@ -12,6 +13,7 @@ from grlbwt_amd import engine, workloads
 from tests import parity
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -407,6 +409,37 @@ def test_idx64_build_round_trip_4_3GB(hip):
     torch.cuda.synchronize()
     assert n == text.numel()
     assert torch.equal(out, text)
+
+
+def test_arena_takes_a_multi_gib_first_step(hip):
+    """The scratch arena in a FRESH process whose first request is several GiB (a host upload of 2.6 GB): it must keep
+    growing afterwards.  hipMemSetAccess refuses a piece mapped behind a piece of another size (tools/arena_probe.hip); when
+    the arena grew by "whatever the request needs" it stopped after such a first step and the rest of the build lived in
+    hipMalloc slabs (reserved memory 2x the peak, seconds of allocation).  Checked through GRLBWT_POOL_TRACE and
+    grlbwt_memory_usage in a child process."""
+    import subprocess
+    code = (
+        "import os, sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from grlbwt_amd import engine, workloads\n"
+        "t = workloads.sampled_reads_torch(17218543, 150, 86000000, seed=20260003, device='cuda:0').cpu().numpy()\n"
+        "with engine.Context(0, 0, %r) as ctx:\n"
+        "    ctx.upload(t, 1)\n"
+        "    ctx.build()\n"
+        "    m = ctx.memory_usage(); nb, nr = ctx.result_size()\n"
+        "print('RESULT', json.dumps({'n': int(t.size), 'mem': m, 'runs': nr}))\n"
+    ) % (ROOT, hip)
+    env = dict(os.environ, GRLBWT_POOL_TRACE="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert res["n"] > (2 << 30)
+    trace = [l for l in p.stderr.splitlines() if "pool:" in l and "arena steps" in l]
+    assert trace, p.stderr[-2000:]
+    assert "(0 refused), 0 hipMalloc slabs" in trace[-1], trace[-1]
+    mem = res["mem"]
+    assert mem["reserved_bytes"] - mem["peak_live_bytes"] < (4 << 30), mem
 
 
 def test_headline_10GB_round_trip(hip):
