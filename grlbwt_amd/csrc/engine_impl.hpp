@@ -3550,6 +3550,8 @@ class Engine {
         const AtomEmitter em{tcell.p, Tpos.p, term.p, osym.p, olen.p,
                              packed_atoms ? oatom.p : nullptr, lbits, big.p, big_n.p, big_cap};
         // (four cells per lane: 46.3 vs 43.2 ms at level 0 of the 10 GB build -- two it stays)
+        // (2 cells per lane; 1 and 4 were measured again in round 3 on the 10 GB build: 43.0 / 40.7 / 42.9 ms at level 0 for
+        // 1 / 2 / 4 -- the kernel is bound neither by loads in flight per lane nor by vector issue)
         prim::for_each((E + 1) / 2, CellAtomsFn<TC, 2>{cells, L.u_to_p, PHB.p, nhb.p, Tc.p, take_code, em, E}, "asm.cell_atoms");
         prim::for_each(P, PreAtomsFn{L.psym, L.plen, pre_g.p, pre_x.p, hocc_code, bwt_code, em}, "asm.pre_atoms");
         const u64 nbig = (u64)big_n.get(0);
