@@ -815,6 +815,31 @@ struct KeyRangeFn {       // (key, position, owner of the key's range) of those,
         }
     }
 };
+struct ByteIn {
+    const u8 *f;
+    GRL_DEV u32 operator()(u64 i) const { return f[i]; }
+};
+// (the same without an exchange, for few ranks: every rank looks at ALL positions and keeps the records of its own key range)
+struct OwnKeyFlagFn {     // flag[q] = 1 for the kept suffixes whose key lies in the range of rank `me`
+    SufKeep keep; const u32 *dict_sym; int K, b; const u64 *spl; int N, me; u8 *flag;
+    GRL_DEV void operator()(u64 q) const {
+        u8 f = 0;
+        if (keep(q)) {
+            const u64 key = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b);
+            int d = 0;
+            for (int r = 1; r < N; r++) if (key >= spl[r]) d = r;
+            f = d == me ? 1 : 0;
+        }
+        flag[q] = f;
+    }
+};
+struct OwnKeyEmitFn {     // ... and their (key, position) records, compacted (positions ascending)
+    static constexpr bool kWaveEmit = false;
+    SufKeep keep; const u32 *dict_sym; int K, b; u64 *ka; u32 *perm;
+    GRL_DEV void operator()(u64 q, u32 ex, u32 v) const {
+        if (v) { ka[ex] = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b); perm[ex] = (u32)q; }
+    }
+};
 struct GatherKeyPosFn {   // records in owner order
     const u32 *order; const u64 *lk; const u32 *lp; u64 *sk; u32 *sp;
     GRL_DEV void operator()(u64 j) const { const u32 i = order[j]; sk[j] = lk[i]; sp[j] = lp[i]; }
@@ -830,10 +855,6 @@ struct FirstUnresolvedFn { // after the first sort: member of a group of > 1 suf
         bool multi = !hflag[t] || (t + 1 < S && !hflag[t + 1]);
         uflag[t] = (multi && (k[t] & sent) != sent) ? 1 : 0;
     }
-};
-struct ByteIn {
-    const u8 *f;
-    GRL_DEV u32 operator()(u64 i) const { return f[i]; }
 };
 // Refinement by SYMBOL EXTENSION.  After the first pass a group of equal keys whose suffixes have not ended is re-sorted,
 // inside the group, by the next K symbols of its members (read straight from the dictionary: one contiguous gather), and so
@@ -2994,9 +3015,16 @@ class Engine {
                     // computed the keys of ALL S positions and scanned them all to find its own -- two replicated O(S) passes,
                     // 36 ms per rank at any N on the 10 GB collection: profiles/r03/scale_projection_10GB.json.)
                     const int N = C->size, me = C->rank;
+                    // With few ranks the exchange costs more than it saves: at N = 2 every rank would send half of its records --
+                    // 4.6 GB over ONE xGMI link at level 2 of the 10 GB build, 40-75 ms -- to save 10 ms of key computation.  Below
+                    // GRLBWT_SORT_EXCHANGE_MIN ranks (default 4) every rank looks at all S positions and keeps its own key range:
+                    // two replicated streaming passes, nothing on the wire.
+                    static const int xmin = getenv("GRLBWT_SORT_EXCHANGE_MIN") ? atoi(getenv("GRLBWT_SORT_EXCHANGE_MIN")) : 4;
+                    const bool exchange = N >= xmin;
                     std::vector<u64> scnt(N, 0), rcnt(N, 0);
                     DBuf<u64> sk;
                     DBuf<u32> sp;
+                    u64 Sown = 0;
                     try {
                         // (GRLBWT_TEST_FAIL_RANK_SORT=<rank>: the tests make one rank fail here)
                         if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_SORT")) if (atoi(fr) == me) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
@@ -3007,7 +3035,14 @@ class Engine {
                         std::sort(hs.begin(), hs.end());
                         for (int d = 1; d < N; d++) spl[d] = hs[(u64)d * ns / N];          // rank d owns keys in [spl[d], spl[d + 1])
                         prim::h2d(dspl.p, spl.data(), (u64)N * 8);
-                        const u64 q0 = S * (u64)me / (u64)N, q1 = S * (u64)(me + 1) / (u64)N, nq = q1 - q0;
+                        if (!exchange) {
+                            DBuf<u8> mine(S);
+                            prim::for_each(S, OwnKeyFlagFn{keep, dict_sym.p, K, b, dspl.p, N, me, mine.p}, "suffix_keys0");
+                            Sown = prim::reduce_sum<u64>(S, ByteIn{mine.p}, "suffix_keep");
+                            ka.alloc(Sown); perm.alloc(Sown);
+                            prim::exclusive_scan_emit<u32>(S, ByteIn{mine.p}, OwnKeyEmitFn{keep, dict_sym.p, K, b, ka.p, perm.p}, "suffix_keys0");
+                        }
+                        const u64 q0 = exchange ? S * (u64)me / (u64)N : 0, q1 = exchange ? S * (u64)(me + 1) / (u64)N : 0, nq = q1 - q0;
                         DBuf<u32> kex(nq + 1);
                         const u64 nk = prim::exclusive_scan<u32>(nq, KeepRangeIn{keep, q0}, kex.p, false, "suffix_keep");
                         DBuf<u64> lk(nk), bound(2 * ((u64)N + 1));
@@ -3023,17 +3058,19 @@ class Engine {
                         for (int d = 0; d < N; d++) scnt[d] = bh[2 * (d + 1)] - bh[2 * d];
                     } catch (const prim::Error &e) { C->fail(e); std::fill(scnt.begin(), scnt.end(), 0); }
                     std::vector<u64> mat = C->allgather_u64(scnt);           // (raises on every rank if one of them failed above)
-                    u64 maxb = 0;
-                    Sg = 0;
-                    for (int g = 0; g < N; g++) {
-                        rcnt[g] = mat[(u64)g * N + me];
-                        Sg += rcnt[g];
-                        for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]);
-                    }
-                    try { ka.alloc(Sg); perm.alloc(Sg); } catch (const prim::Error &e) { C->fail(e); }
-                    C->allgather_u64({});                                    // (the bulk exchanges below have no way back)
-                    C->alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
-                    C->alltoall(sp.p, scnt, perm.p, rcnt, 4, maxb);
+                    if (exchange) {
+                        u64 maxb = 0;
+                        Sg = 0;
+                        for (int g = 0; g < N; g++) {
+                            rcnt[g] = mat[(u64)g * N + me];
+                            Sg += rcnt[g];
+                            for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]);
+                        }
+                        try { ka.alloc(Sg); perm.alloc(Sg); } catch (const prim::Error &e) { C->fail(e); }
+                        C->allgather_u64({});                                // (the bulk exchanges below have no way back)
+                        C->alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
+                        C->alltoall(sp.p, scnt, perm.p, rcnt, 4, maxb);
+                    } else Sg = Sown;
                 }
             }
             gid.alloc(Sg); gstart.alloc(Sg + 1);

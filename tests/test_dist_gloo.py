@@ -64,6 +64,16 @@ def test_sharded_partitioned_phrase_naming(sim, oracle_mod, tmp_path, monkeypatc
     assert open(tmp_path / (case + ".rl_bwt"), "rb").read() == oracle_mod.rl_bwt(data, 2 if case == "tokens" else 1)
 
 
+@pytest.mark.parametrize("world,xmin,port", [(2, "2", 29586), (4, "9", 29587)])
+def test_sharded_suffix_sort_both_forms(sim, oracle_mod, tmp_path, monkeypatch, world, xmin, port):
+    """The sharded first suffix sort takes its records by a sample-sort exchange from 4 ranks on and by looking at all positions
+    (no exchange) below; GRLBWT_SORT_EXCHANGE_MIN moves the switch: the exchange with 2 ranks, the local form with 4."""
+    monkeypatch.setenv("GRLBWT_SORT_EXCHANGE_MIN", xmin)
+    _run(world, sim, "reads", tmp_path, port)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+
+
 def test_sharded_8_byte_one_word_cells(sim, oracle_mod, tmp_path, monkeypatch):
     """The cell exchange in the 8-byte one-word form (small inputs otherwise send 4-byte cells)."""
     monkeypatch.setenv("GRLBWT_NO_CELL32", "1")

@@ -160,8 +160,11 @@ def main():
     import tempfile
     res = {"collection": {"reads": args.reads, "genome": args.genome, "bytes": args.reads * 151},
            "method": "ranks time-share one MI355X, gloo transport, one rank computes at a time (flock): HIP-event kernel ms per rank and stage", "runs": []}
-    # xGMI: 7 links per GPU, ~153 GB/s raw per link; an all-to-all block to one peer crosses one link.  Usable ~ 0.7x.
+    # xGMI: 7 links per GPU, ~153 GB/s raw per link; an all-to-all block to one peer crosses one link.  Two prices: 0.7 x the raw
+    # figure per direction (if 153 GB/s is what one direction carries), and 0.4 x (if it is both directions together: ~61 GB/s,
+    # about what RCCL point-to-point copies reach on the previous generation's 64 GB/s-per-direction links)
     link = 0.7 * 153e9
+    link_slow = 0.4 * 153e9
     base_ms = None
     for n in [int(x) for x in args.ranks.split(",")]:
         with tempfile.TemporaryDirectory() as td:
@@ -188,20 +191,24 @@ def main():
         # bytes in total: every rank receives B*(N-1)/N over its links
         links = max(1, min(7, n - 1))
         xfer_ms = 0.0 if n == 1 else (sent * (n - 1) / n / (links * link) + recv_ag * (n - 1) / n / (links * link)) * 1e3
+        xfer_slow_ms = xfer_ms * link / link_slow
         lat_ms = 0.0 if n == 1 else ncoll * 0.03
         run = {"ranks": n, "wall_s": round(time.time() - t0, 1), "kernel_ms_by_stage": by_stage, "critical_path_kernel_ms": round(crit, 2),
                "max_rank_total_kernel_ms": max(r["kernel_ms_total"] for r in ranks), "peak_bytes_max_rank": max(r["peak_bytes"] for r in ranks),
                "bytes_sent_alltoallv_max_rank": sent, "bytes_received_allgather_max_rank": recv_ag, "collective_calls": ncoll,
                "projected_transfer_ms": round(xfer_ms, 2), "projected_latency_ms": round(lat_ms, 2),
-               "projected_step_ms": round(crit + xfer_ms + lat_ms, 2), "image_md5": ranks[0].get("image_md5"), "image_bytes": ranks[0]["image_bytes"],
+               "projected_step_ms": round(crit + xfer_ms + lat_ms, 2),
+               "projected_transfer_ms_slow_links": round(xfer_slow_ms, 2), "projected_step_ms_slow_links": round(crit + xfer_slow_ms + lat_ms, 2),
+               "image_md5": ranks[0].get("image_md5"), "image_bytes": ranks[0]["image_bytes"],
                "top_sites_rank0": ranks[0]["top_sites"], "dictionary_sites_rank0": ranks[0]["dictionary_sites"],
                "sites_rank0": ranks[0].get("sites"), "large_exchanges_rank0": ranks[0].get("exchanges")}
         if n == 1:
             base_ms = run["projected_step_ms"]
         if base_ms:
             run["projected_speedup_vs_1"] = round(base_ms / run["projected_step_ms"], 2)
+            run["projected_speedup_vs_1_slow_links"] = round(base_ms / run["projected_step_ms_slow_links"], 2)
         res["runs"].append(run)
-        print(json.dumps({k: run[k] for k in ("ranks", "critical_path_kernel_ms", "projected_transfer_ms", "projected_step_ms", "peak_bytes_max_rank", "image_md5")} |
+        print(json.dumps({k: run[k] for k in ("ranks", "critical_path_kernel_ms", "projected_transfer_ms", "projected_step_ms", "projected_step_ms_slow_links", "peak_bytes_max_rank", "image_md5")} |
                          ({"speedup": run.get("projected_speedup_vs_1")})), flush=True)
     md5s = {r.get("image_md5") for r in res["runs"] if r.get("image_md5")}
     res["same_image_for_every_N"] = len(md5s) <= 1
