@@ -1630,6 +1630,34 @@ struct BucketSizeIn {
     const idx_t *bstart1; const idx_t *bend;
     GRL_DEV idx_t operator()(u64 m) const { return bstart1[m] ? bend[m] - (bstart1[m] - 1) : (idx_t)0; }
 };
+// Stable merge of N bucket-sorted blocks of one-word cells (the cell exchange of the collection-level induction: block g =
+// the cells of my buckets that rank g made, rank order inside a bucket = order of the slices).  Per block the bucket edges
+// (BucketEdgesFn over the block), per bucket the blocks' sizes in rank order -> one scan over the buckets gives every
+// (block, bucket) run its place; a cell then moves ONCE.  (A stable radix sort over the bucket bits did the same with two to
+// four passes over all cells: 31 ms per rank at N = 2 on the 10 GB collection.)
+struct BlockTotalIn {     // cells of bucket k over all blocks
+    const idx_t *bstart1; const idx_t *bend; int N; u64 M;
+    GRL_DEV idx_t operator()(u64 k) const {
+        idx_t c = 0;
+        for (int g = 0; g < N; g++) { const u64 j = (u64)g * M + k; if (bstart1[j]) c += bend[j] - (bstart1[j] - 1); }
+        return c;
+    }
+};
+struct BlockOffsetsFn {   // off[g][k]: what to add to a cell's index inside block g to get its place (wraps: unsigned arithmetic)
+    const idx_t *bstart1; const idx_t *bend; const idx_t *base; int N; u64 M; idx_t *off;
+    GRL_DEV void operator()(u64 k) const {
+        idx_t run = base[k];
+        for (int g = 0; g < N; g++) {
+            const u64 j = (u64)g * M + k;
+            if (bstart1[j]) { off[j] = run - (bstart1[j] - 1); run += bend[j] - (bstart1[j] - 1); }
+        }
+    }
+};
+template <class K>
+struct BlockPlaceFn {
+    const K *in; K kmask; u32 u0; const idx_t *off; K *out;
+    GRL_DEV void operator()(u64 t) const { const K c = in[t]; out[(idx_t)(off[(u32)(c & kmask) - u0] + (idx_t)t)] = c; }
+};
 // atoms of one segment; a TAKE segment touching more than kInlineAtoms runs is queued for the wide kernel
 static constexpr u32 kInlineAtoms = 16;
 struct BigSeg { u64 abase, a, b, k0; };
@@ -1809,16 +1837,31 @@ struct SendCellsFn {
         const u64 q0 = j * 16, q1 = q0 + 16 < S ? q0 + 16 : S;
         u64 i = rank1(pw, pb, q0 + 1) - 1;
         u64 nxt = soff[i + 1], cur = order[i], off = q0 - soff[i];
+        // a record phrase is read ONCE and shifted down by one symbol per cell (rec_sym's general 128-bit extraction per cell
+        // made this kernel instruction-bound: 23 ms per rank at N = 2 on the 10 GB collection)
+        u64 lo = 0, hi = 0, left = 0;          // the record's remaining symbols (next one at bit 0), cells left in it
+        bool lastT = false;
+        const u64 smask = (1ull << pkb) - 1ull;
+        auto open_record = [&](u64 skip) {
+            const prim::U128 r = pkeys[cur];
+            left = (u64)rec_len(r) - skip;
+            lastT = (r.hi & kPhrLastT) != 0;
+            lo = r.lo; hi = r.hi & (kPhrLastT - 1ull);
+            const u32 sh = (u32)skip * (u32)pkb;                       // < 128
+            if (sh >= 64) { lo = hi >> (sh - 64); hi = 0; }
+            else if (sh) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; }
+        };
+        if (cur < pDs) open_record(off);
         u32 v[16];
 #pragma unroll
         for (int x = 0; x < 16; x++) {
             const u64 q = q0 + x;
             if (q < q1) {
-                while (q >= nxt) { i++; nxt = soff[i + 1]; cur = order[i]; off = 0; }
+                while (q >= nxt) { i++; nxt = soff[i + 1]; cur = order[i]; off = 0; if (cur < pDs) open_record(0); }
                 if (cur < pDs) {
-                    const prim::U128 r = pkeys[cur];
-                    const bool last = off + 1 == (u64)rec_len(r);
-                    v[x] = (rec_sym(r, (u32)off, pkb) << 2) | ((last && (r.hi & kPhrLastT)) ? 1u : 0u);
+                    left--;
+                    v[x] = ((u32)(lo & smask) << 2) | ((left == 0 && lastT) ? 1u : 0u);
+                    lo = (lo >> pkb) | (hi << (64 - pkb)); hi >>= pkb;      // (1 <= pkb <= 30)
                 } else {
                     const cell_t c = t[pos[cur] + off];
                     v[x] = ((u32)ops.sym(c) << 2) | (ops.isT(c) ? 1u : 0u);
@@ -1878,6 +1921,7 @@ struct ListInsertFn {
     const u32 *cells; const u64 *off; const u32 *len; const u64 *weight;
     u64 *keys; idx_t *counts; u64 mask;      // key = tag:24 | (list index + 1):40
     u32 *list_slot; u32 *scal;
+    u8 *is_rep;                              // [list entries], zeroed: set for the entry that creates its slot (the phrase's representative)
     GRL_DEV void operator()(u64 i) const {
         const u64 o = off[i], l = len[i];
         PhraseHash ph = PhraseHash::init();
@@ -1892,6 +1936,7 @@ struct ListInsertFn {
             if (cur == 0) {
                 u64 old = prim::atomic_cas(&keys[slot], 0ull, mine);
                 cur = (old == 0) ? mine : old;
+                if (old == 0) is_rep[i] = 1;
             }
             bool hit = (cur == mine);
             if (!hit && (cur >> kPosBits) == tag) {
@@ -1912,24 +1957,23 @@ struct ListInsertFn {
         }
     }
 };
-// The merged dictionary must have the SAME layout on every rank (the sharded dictionary stage exchanges
-// dictionary positions): which duplicate wins a table slot is a race, so the representative of a phrase is
-// defined as its smallest list index and an owner numbers its phrases in the order of their representatives.
-struct SlotMinFn {        // slot_min[slot] = smallest list index mapped to the slot
-    const u32 *list_slot; u32 *slot_min;
-    GRL_DEV void operator()(u64 i) const { prim::atomic_min(&slot_min[list_slot[i]], (u32)i); }
+// The representative of a merged phrase is the list entry whose CAS created the table slot (its index sits in the key); an
+// owner numbers its phrases in the order of their representatives.  Which duplicate wins is a race, so the numbering can
+// differ between runs -- it is the owner's alone (every rank receives the owner's part as it is) and nothing downstream
+// depends on the order of a dictionary.  (Until round 3 the representative was the SMALLEST list index per slot, found by
+// one atomicMin per list entry: 13 ms per rank at N = 2 on the 10 GB collection for a determinism nobody needs.)
+struct SlotWinnerFn {     // slot_min[slot] = list index of the entry that created the slot (all-ones for an empty slot)
+    const u64 *keys; u32 *slot_min;
+    GRL_DEV void operator()(u64 s) const { const u64 k = keys[s]; slot_min[s] = k ? (u32)((k & kPosMask) - 1) : 0xFFFFFFFFu; }
 };
-struct IsRepIn {
-    const u32 *list_slot; const u32 *slot_min;
-    GRL_DEV u32 operator()(u64 i) const { return slot_min[list_slot[i]] == (u32)i ? 1u : 0u; }
-};
+
 struct ListPhraseFn {     // phrase k = rank of its representative among the representatives (list order)
-    const u32 *cells; const u64 *off; const u32 *len; const u32 *list_slot; const u32 *slot_min; const u32 *rep_ex;
+    const u32 *cells; const u64 *off; const u32 *len; const u32 *list_slot; const u8 *is_rep; const u32 *rep_ex;
     const idx_t *counts;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u8 *ph_lastT;
     GRL_DEV void operator()(u64 i) const {
-        const u32 s = list_slot[i];
-        if (slot_min[s] == (u32)i) {
+        if (is_rep[i]) {
+            const u32 s = list_slot[i];
             const u32 k = rep_ex[i];
             ph_pos[k] = off[i]; ph_freq[k] = counts[s]; ph_len[k] = len[i];
             ph_lastT[k] = (u8)(cells[off[i] + len[i] - 1] & 1u);
@@ -3477,6 +3521,32 @@ class Engine {
         c_sfused = std::move(sfused); c_sfused32 = std::move(sfused32); c_gp = std::move(gp);
         return E;
     }
+    // the received blocks (rcnt[g] cells from rank g, back to back in `in`) merged by bucket; buckets [u0, u0 + M)
+    template <class K>
+    void merge_cell_blocks(DBuf<K> &in, const std::vector<u64> &rcnt, int kb, int lb, u32 u0, u64 M, u64 Er) {
+        const int N = (int)rcnt.size();
+        DBuf<idx_t> bstart1((u64)N * M), bend((u64)N * M), base(M + 1), off((u64)N * M);
+        bstart1.zero(); bend.zero();
+        u64 ro = 0;
+        for (int g = 0; g < N; g++) {
+            if (rcnt[g]) {
+                const K *blk = in.p + ro;
+                CellView cv{sizeof(K) == 8 ? (const u64 *)blk : nullptr, kb, lb, nullptr, nullptr, nullptr, nullptr, u0, sizeof(K) == 4 ? (const u32 *)blk : nullptr};
+                prim::for_each(rcnt[g], BucketEdgesFn{cv, rcnt[g], bstart1.p + (u64)g * M, bend.p + (u64)g * M}, "dist.merge_cells");
+            }
+            ro += rcnt[g];
+        }
+        prim::exclusive_scan_nosync<idx_t>(M, BlockTotalIn{bstart1.p, bend.p, N, M}, base.p, true, "dist.merge_cells");
+        prim::for_each(M, BlockOffsetsFn{bstart1.p, bend.p, base.p, N, M, off.p}, "dist.merge_cells");
+        DBuf<K> out(Er);
+        const K kmask = (K)((kb >= (int)(8 * sizeof(K))) ? ~K(0) : ((K(1) << kb) - 1));
+        ro = 0;
+        for (int g = 0; g < N; g++) {
+            if (rcnt[g]) prim::for_each(rcnt[g], BlockPlaceFn<K>{in.p + ro, kmask, u0, off.p + (u64)g * M, out.p}, "dist.merge_cells.scatter");
+            ro += rcnt[g];
+        }
+        in = std::move(out);
+    }
     CellView cell_view(int kb, int lb, u32 u0 = 0) const { return CellView{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p, u0, c_sfused32.p}; }
     u64 level_maxrun() {
         StageTimer st(&tm.ind_expand);
@@ -3781,16 +3851,17 @@ class Engine {
                 DBuf<idx_t> counts(cap);
                 DBuf<u32> scal(4);
                 keys.zero(); counts.zero(); scal.zero();
-                prim::for_each(Dr, ListInsertFn{rcells.p, goff.p, rlen.p, rfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p}, "dist.merge_phrases");
+                DBuf<u8> is_rep(Dr);
+                is_rep.zero();
+                prim::for_each(Dr, ListInsertFn{rcells.p, goff.p, rlen.p, rfreq.p, keys.p, counts.p, cap - 1, list_slot.p, scal.p, is_rep.p}, "dist.merge_phrases");
                 if (scal.to_host(2)[1]) throw prim::Error(-28, "merged phrase table overflow");
-                keys.release();
-                // deterministic layout: representatives = smallest list index per slot, phrases in representative order
+                // representatives = the entries that created their slots, phrases in representative (list) order
                 slot_min.alloc(cap);
-                slot_min.fill_ff();
-                prim::for_each(Dr, SlotMinFn{list_slot.p, slot_min.p}, "dist.slot_min");
-                Do = prim::exclusive_scan<u32>(Dr, IsRepIn{list_slot.p, slot_min.p}, rep_ex.p, false, "dist.merge_compact");
+                prim::for_each(cap, SlotWinnerFn{keys.p, slot_min.p}, "dist.slot_min");
+                keys.release();
+                Do = prim::exclusive_scan<u32>(Dr, ByteIn{is_rep.p}, rep_ex.p, false, "dist.merge_compact");
                 o_pos.alloc(Do); o_freq.alloc(Do); o_len.alloc(Do); o_off.alloc(Do + 1); o_lastT.alloc(Do);
-                prim::for_each(Dr, ListPhraseFn{rcells.p, goff.p, rlen.p, list_slot.p, slot_min.p, rep_ex.p, counts.p, o_pos.p, o_freq.p,
+                prim::for_each(Dr, ListPhraseFn{rcells.p, goff.p, rlen.p, list_slot.p, is_rep.p, rep_ex.p, counts.p, o_pos.p, o_freq.p,
                                                 o_len.p, o_lastT.p}, "dist.merge_compact");
                 So64 = prim::reduce_sum<u64>(Do, LenIn{o_len.p}, "dist.dict_syms");
             } catch (const prim::Error &e) { C.fail(e); Do = 0; So64 = 0; }
@@ -3999,21 +4070,30 @@ class Engine {
                 u64 maxc = 0;
                 for (int g = 0; g < N; g++) for (int d = 0; d < N; d++) maxc = std::max(maxc, mat[(u64)g * 2 * N + d]);
                 const int bits = kb;
+                // (the received blocks are bucket-sorted: merged by block offsets; GRLBWT_MERGE_CELLS=sort keeps the stable radix sort)
+                static const bool merge_by_blocks = !(getenv("GRLBWT_MERGE_CELLS") && getenv("GRLBWT_MERGE_CELLS")[0] == 's');
+                const u32 mu0 = (u32)sp[4 * me + 1], mu1 = (u32)sp[4 * (me + 1) + 1];
                 if (c_sfused32.p) {
                     DBuf<u32> rf(Er);
                     C.alltoall(c_sfused32.p, scnt, rf.p, rcnt, 4, maxc);
                     c_sfused32 = std::move(rf);
                     if (N > 1 && Er) {
-                        DBuf<u32> tmp(Er);
-                        if (prim::sort_keys<u32, 1>(c_sfused32.p, tmp.p, Er, 0, bits, "dist.merge_cells")) c_sfused32 = std::move(tmp);
+                        if (merge_by_blocks) merge_cell_blocks<u32>(c_sfused32, rcnt, kb, lb, mu0, (u64)(mu1 - mu0), Er);
+                        else {
+                            DBuf<u32> tmp(Er);
+                            if (prim::sort_keys<u32, 1>(c_sfused32.p, tmp.p, Er, 0, bits, "dist.merge_cells")) c_sfused32 = std::move(tmp);
+                        }
                     }
                 } else if (c_sfused.p) {
                     DBuf<u64> rf(Er);
                     C.alltoall(c_sfused.p, scnt, rf.p, rcnt, 8, maxc);
                     c_sfused = std::move(rf);
                     if (N > 1 && Er) {
-                        DBuf<u64> tmp(Er);
-                        if (prim::sort_keys<u64, 1>(c_sfused.p, tmp.p, Er, 0, bits, "dist.merge_cells")) c_sfused = std::move(tmp);
+                        if (merge_by_blocks) merge_cell_blocks<u64>(c_sfused, rcnt, kb, lb, mu0, (u64)(mu1 - mu0), Er);
+                        else {
+                            DBuf<u64> tmp(Er);
+                            if (prim::sort_keys<u64, 1>(c_sfused.p, tmp.p, Er, 0, bits, "dist.merge_cells")) c_sfused = std::move(tmp);
+                        }
                     }
                 } else if (c_spack.p) {
                     DBuf<u32> rk(Er); DBuf<u64> rp(Er);

@@ -74,6 +74,14 @@ def test_sharded_suffix_sort_both_forms(sim, oracle_mod, tmp_path, monkeypatch, 
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
 
 
+def test_sharded_cell_merge_by_radix_sort(sim, oracle_mod, tmp_path, monkeypatch):
+    """The received cell blocks are merged by block offsets; GRLBWT_MERGE_CELLS=sort keeps the stable radix sort they replaced."""
+    monkeypatch.setenv("GRLBWT_MERGE_CELLS", "sort")
+    _run(3, sim, "reads", tmp_path, 29588)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+
+
 def test_sharded_8_byte_one_word_cells(sim, oracle_mod, tmp_path, monkeypatch):
     """The cell exchange in the 8-byte one-word form (small inputs otherwise send 4-byte cells)."""
     monkeypatch.setenv("GRLBWT_NO_CELL32", "1")
