@@ -1820,8 +1820,8 @@ struct KeyBoundFn {       // first element of every key value in a sorted key ar
     }
 };
 struct SendPhraseFn {     // my phrases in owner order: length and frequency
-    const u32 *order; const u32 *len; const idx_t *freq; u32 *slen; u64 *sfreq;
-    GRL_DEV void operator()(u64 i) const { const u32 k = order[i]; slen[i] = len[k]; sfreq[i] = (u64)freq[k]; }
+    const u32 *order; const u32 *len; const idx_t *freq; u32 *slen; u32 *sfreq;      // (a shard's parse has < 2^32 phrases: its frequencies fit u32)
+    GRL_DEV void operator()(u64 i) const { const u32 k = order[i]; slen[i] = len[k]; sfreq[i] = (u32)freq[k]; }
 };
 // ... and their cells in the exchange format (u32  sym<<2 | rep<<1 | is_terminator on every level), straight from the text.
 // One lane per 16 consecutive output cells: one search for the phrase of the first cell, then a forward walk.
@@ -1918,7 +1918,7 @@ struct ScatterU32Fn {     // out[order[i]] = v[i]
 };
 // phrases given as a list (offset, length, weight) over a cell buffer
 struct ListInsertFn {
-    const u32 *cells; const u64 *off; const u32 *len; const u64 *weight;
+    const u32 *cells; const u64 *off; const u32 *len; const u32 *weight;
     u64 *keys; idx_t *counts; u64 mask;      // key = tag:24 | (list index + 1):40
     u32 *list_slot; u32 *scal;
     u8 *is_rep;                              // [list entries], zeroed: set for the entry that creates its slot (the phrase's representative)
@@ -2050,9 +2050,10 @@ struct WindowRunsFn {     // lane d: my runs of BWT_{r+1} that overlap [a, b) (l
         out[2 * d] = k0; out[2 * d + 1] = cnt;
     }
 };
+template <class LT>       // LT: the type the lengths travel in (u32 whenever the longest run of the level fits: 8 instead of 12 bytes per run)
 struct WindowSendFn {     // the runs of every owner's window, clipped to the window, in owner order
     const idx_t *Tpos; const u32 *term; const u64 *ab; const u64 *k0cnt; const u64 *soff /*[size+1]*/; int size;
-    u32 *ssym; idx_t *slen;
+    u32 *ssym; LT *slen;
     GRL_DEV void operator()(u64 y) const {
         int d = 0;
         while (d + 1 < size && y >= soff[d + 1]) d++;
@@ -2060,8 +2061,16 @@ struct WindowSendFn {     // the runs of every owner's window, clipped to the wi
         const u64 a = ab[2 * d], b = ab[2 * d + 1];
         const u64 s = (u64)Tpos[k] > a ? (u64)Tpos[k] : a, e = (u64)Tpos[k + 1] < b ? (u64)Tpos[k + 1] : b;
         ssym[y] = term[k];
-        slen[y] = (idx_t)(e - s);
+        slen[y] = (LT)(e - s);
     }
+};
+struct NarrowIdxFn {
+    const idx_t *in; u32 *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = (u32)in[i]; }
+};
+struct WidenLenFn {
+    const u32 *in; idx_t *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = (idx_t)in[i]; }
 };
 struct RebaseFn {         // out[i] = in[i] - sub
     const u32 *in; u32 sub; u32 *out;
@@ -3763,12 +3772,12 @@ class Engine {
         DBuf<u32> order;                         // my phrases in owner order
         std::vector<u64> pc(N), cc(N), rpc(N), rcc(N);      // phrases / cells I send to every owner, and receive from every shard
         DBuf<u32> rlen, rcells;
-        DBuf<u64> rfreq;
+        DBuf<u32> rfreq;
         u64 Dr = 0, Sr = 0, occ_total = 0, n_total = 0, maxp = 0;     // maxp: largest phrase block of the exchange (all ranks agree)
         {
             StageTimer st(&tm.hash);
             DBuf<u32> slen, scells;
-            DBuf<u64> sfreq;
+            DBuf<u32> sfreq;
             std::vector<u64> mine(2 * (u64)N + 2, 0);
             // (a failure only this shard can have -- phrase table overflow, a parse beyond the supported range -- travels with the
             // counts: Comm::fail)
@@ -3818,7 +3827,7 @@ class Engine {
             }
             rlen.alloc(Dr); rfreq.alloc(Dr); rcells.alloc(Sr);
             C.alltoall(slen.p, pc, rlen.p, rpc, 4, maxp);
-            C.alltoall(sfreq.p, pc, rfreq.p, rpc, 8, maxp);
+            C.alltoall(sfreq.p, pc, rfreq.p, rpc, 4, maxp);
             C.alltoall(scells.p, cc, rcells.p, rcc, 4, maxc);
         }
         L.info.n_in = n_total;
@@ -3880,7 +3889,13 @@ class Engine {
             rcells.release(); rlen.release(); rfreq.release();
             gcells = C.allgather_v<u32>(ocells.p, So64, sbase, true);
             ph_len = C.allgather_v<u32>(o_len.p, Do, dbase, true);
-            ph_freq = C.allgather_v<idx_t>(o_freq.p, Do, dbase, true);
+            if (sizeof(idx_t) == 8 && occ_total < 0xFFFFFFFFull) {      // (every merged frequency fits u32: 4 instead of 8 bytes per phrase on the wire)
+                DBuf<u32> of32(Do);
+                prim::for_each(Do, NarrowIdxFn{o_freq.p, of32.p}, "dist.dict_offsets");
+                DBuf<u32> all32 = C.allgather_v<u32>(of32.p, Do, dbase, true);
+                ph_freq.alloc(D);
+                prim::for_each(D, WidenLenFn{all32.p, ph_freq.p}, "dist.dict_offsets");
+            } else ph_freq = C.allgather_v<idx_t>(o_freq.p, Do, dbase, true);
             ph_lastT = C.allgather_v<u8>(o_lastT.p, Do, dbase, true);
             const u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dist.freq_check");
             if (fsum != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
@@ -4048,16 +4063,27 @@ class Engine {
                 std::vector<u64> rc = C.allgather_u64(scnt);     // rc[s*N + d]
                 for (int g = 0; g < N; g++) { rcnt[g] = rc[(u64)g * N + me]; Rw += rcnt[g]; }
                 const u64 maxw = *std::max_element(rc.begin(), rc.end());
-                DBuf<u32> ssym; DBuf<idx_t> slen;
+                // (the lengths travel as u32 whenever the level's longest run fits -- the ranks agreed on `maxrun` for the cell layout)
+                const bool narrow = sizeof(idx_t) == 8 && maxrun < 0xFFFFFFFFull;
+                DBuf<u32> ssym, slen32, wlen32; DBuf<idx_t> slen;
                 try {
-                    ssym.alloc(soff[N]); slen.alloc(soff[N]);
+                    ssym.alloc(soff[N]);
                     prim::h2d(sod.p, soff.data(), ((u64)N + 1) * 8);
-                    prim::for_each(soff[N], WindowSendFn{Tpos.p, term.p, abd.p, kc.p, sod.p, N, ssym.p, slen.p}, "dist.window_send");
+                    if (narrow) {
+                        slen32.alloc(soff[N]); wlen32.alloc(Rw);
+                        prim::for_each(soff[N], WindowSendFn<u32>{Tpos.p, term.p, abd.p, kc.p, sod.p, N, ssym.p, slen32.p}, "dist.window_send");
+                    } else {
+                        slen.alloc(soff[N]);
+                        prim::for_each(soff[N], WindowSendFn<idx_t>{Tpos.p, term.p, abd.p, kc.p, sod.p, N, ssym.p, slen.p}, "dist.window_send");
+                    }
                     wsym.alloc(Rw); wlen.alloc(Rw);
                 } catch (const prim::Error &e) { C.fail(e); }
                 C.allgather_u64({});                             // (nothing but the failure flag: the bulk exchanges below have no way back)
                 C.alltoall(ssym.p, scnt, wsym.p, rcnt, sizeof(u32), maxw);
-                C.alltoall(slen.p, scnt, wlen.p, rcnt, sizeof(idx_t), maxw);
+                if (narrow) {
+                    C.alltoall(slen32.p, scnt, wlen32.p, rcnt, sizeof(u32), maxw);
+                    prim::for_each(Rw, WidenLenFn{wlen32.p, wlen.p}, "dist.window_send");
+                } else C.alltoall(slen.p, scnt, wlen.p, rcnt, sizeof(idx_t), maxw);
             }
             Tpos.release(); term.release();
             bwt.sym.release(); bwt.len.release(); bwt.pos.release();
