@@ -241,6 +241,11 @@ def test_partitioned_phrase_naming(sim, oracle_mod, monkeypatch, capfd):
         for _ in range(12):
             data, w = parity.rand_collection(rng, kind)
             parity.check_final(sim, data, w)
+    # (the records by the general hashing pass instead of the lean record kernel + list of long phrases)
+    monkeypatch.setenv("GRLBWT_PART_ONE_PASS", "1")
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=13).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=4).tobytes(), 1)
+    monkeypatch.delenv("GRLBWT_PART_ONE_PASS")
     monkeypatch.setenv("GRLBWT_SIM_PD_LIMIT", "3")
     monkeypatch.setenv("GRLBWT_TABLE_TRACE", "1")
     parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=12).tobytes(), 1)

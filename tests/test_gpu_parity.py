@@ -104,6 +104,9 @@ def test_partitioned_phrase_naming(hip, oracle_mod, monkeypatch, capfd):
         for _ in range(6):
             data, w = parity.rand_collection(rng, kind)
             parity.check_final(hip, data, w)
+    monkeypatch.setenv("GRLBWT_PART_ONE_PASS", "1")        # the records by the general hashing pass (HashInsertFn's own cut)
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=13).tobytes(), 1)
+    monkeypatch.delenv("GRLBWT_PART_ONE_PASS")
     monkeypatch.setenv("GRLBWT_PART_BITS", "1")
     monkeypatch.setenv("GRLBWT_TABLE_TRACE", "1")
     capfd.readouterr()
