@@ -772,27 +772,71 @@ struct SufKeep {
         return !(q + 1 == (u64)ph_off[k + 1] && !ph_lastT[k] && q != (u64)ph_off[k]);
     }
 };
-GRL_DEV u64 suffix_key0(const u32 *dict_sym, u64 q, u64 end, int K, int b) {     // first K symbols packed b bits each
-    const u64 sent = (1ull << b) - 1;
+// RUN-AWARE KEYS (levels whose phrases hold long runs of one symbol: a 2 M-cell run of N makes one phrase of 2 M cells, and its
+// 2 M suffixes a^rem X tie with those of every other copy of the run for rem / K rounds each -- quadratic: 311 s for a 20 MB
+// input).  Below the window of K symbols a key carries, whenever the window lies INSIDE a run (rem >= K cells of the symbol a
+// left in it), one class bit and the run's remaining length: the suffixes a^i x.. and a^j y.. (i < j) compare as x against a, so
+// all runs followed by a smaller symbol come first, shortest first, then the runs followed by a larger symbol (or the phrase
+// end, which compares as +infinity), longest first.  Equal keys then mean equal remaining runs, and the whole run is
+// consumed at once: skip[q] grows by rem - K.  rb = 0: plain keys (every ordinary level).
+struct RunKeys {
+    const u32 *rem = nullptr;     // [S] cells from q to the end of its run of equal symbols, inside its phrase
+    u32 *skip = nullptr;          // [S] cells the suffix at q has jumped beyond the rounds' common depth
+    int rb = 0;                   // bits below the window: 1 + bitlen(longest phrase)
+};
+GRL_DEV u64 suffix_key0(const u32 *dict_sym, u64 q, u64 end, int K, int b, const RunKeys &rk = RunKeys(), u32 *jump = nullptr) {
+    const u64 sent = (1ull << b) - 1;       // first K symbols packed b bits each
     u64 key = 0;
     for (int j = 0; j < K; j++) key = (key << b) | ((q + j < end) ? (u64)dict_sym[q + j] : sent);
+    if (rk.rb) {
+        u64 low = 0;
+        if (q < end) {
+            const u32 r = rk.rem[q];
+            if (r >= (u32)K) {
+                const u32 a = dict_sym[q];
+                const u64 xe = q + (u64)r;                              // (<= end: runs stay inside their phrase)
+                const bool up = xe >= end || dict_sym[xe] > a;
+                const int R = rk.rb - 1;
+                low = up ? ((1ull << R) | (((1ull << R) - 1ull) - (u64)r)) : (u64)r;
+                if (jump) *jump = r - (u32)K;
+            }
+        }
+        key = (key << rk.rb) | low;
+    }
     return key;
 }
+struct RunChangeIn {      // 1 at the last cell of every run of equal symbols (runs end with their phrase)
+    const u32 *dict_sym; const u64 *pw; u64 S;
+    GRL_DEV u32 operator()(u64 q) const { return (q + 1 >= S || bit_at(pw, q + 1) || dict_sym[q + 1] != dict_sym[q]) ? 1u : 0u; }
+};
+struct RunEndsEmitFn {    // rex[q] = run ends in front of q; ends[k] = position of the k-th run end
+    static constexpr bool kWaveEmit = false;
+    u32 *rex; u32 *ends;
+    GRL_DEV void operator()(u64 q, u32 ex, u32 v) const { rex[q] = ex; if (v) ends[ex] = (u32)q; }
+};
+struct RunRemFn {
+    const u32 *rex; const u32 *ends; u32 *rem;
+    GRL_DEV void operator()(u64 q) const { rem[q] = ends[rex[q]] - (u32)q + 1u; }
+};
+struct InitSkipFn {       // after the first sort: the suffixes whose first key lay inside a run have consumed that run
+    const u32 *perm; const u32 *rem; u32 K; u32 *skip;
+    GRL_DEV void operator()(u64 t) const { const u32 q = perm[t]; const u32 r = rem[q]; if (r >= K) skip[q] = r - K; }
+};
 struct SampleKey0Fn {     // keys at strided positions: the splitter sample of the sharded sort
-    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; int K, b; u64 stride; u64 *out;
-    GRL_DEV void operator()(u64 i) const { const u64 q = i * stride; out[i] = suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b); }
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; int K, b; u64 stride; u64 *out; RunKeys rk;
+    GRL_DEV void operator()(u64 i) const { const u64 q = i * stride; out[i] = suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b, rk); }
 };
 struct PhraseDropIn {     // 1 for a phrase whose last-cell suffix is left out (one scan over the PHRASES then places every kept suffix)
     const u32 *ph_off; const u8 *ph_lastT;
     GRL_DEV u32 operator()(u64 k) const { return (!ph_lastT[k] && ph_off[k + 1] - ph_off[k] > 1) ? 1u : 0u; }
 };
 struct Key0KeepFn {       // (key, position) of the kept suffixes at position - (suffixes left out in front of the phrase)
-    SufKeep keep; const u32 *dropcnt; const u32 *dict_sym; int K, b; u64 *ka; u32 *va;
+    SufKeep keep; const u32 *dropcnt; const u32 *dict_sym; int K, b; u64 *ka; u32 *va; RunKeys rk;
     GRL_DEV void operator()(u64 q) const {
         if (keep(q)) {
             const u32 k = keep.dict_phr[q];
             const u64 i = q - (u64)dropcnt[k];
-            ka[i] = suffix_key0(dict_sym, q, keep.ph_off[k + 1], K, b);
+            ka[i] = suffix_key0(dict_sym, q, keep.ph_off[k + 1], K, b, rk);
             va[i] = (u32)q;
         }
     }
@@ -803,12 +847,12 @@ struct KeepRangeIn {      // 1 for the kept suffixes (SufKeep) among the positio
 };
 struct KeyRangeFn {       // (key, position, owner of the key's range) of those, compacted
     SufKeep keep; const u32 *ex; u64 q0; const u32 *dict_sym; int K, b; const u64 *spl; int N;
-    u64 *lk; u32 *lp; u32 *own; u32 *idx;
+    u64 *lk; u32 *lp; u32 *own; u32 *idx; RunKeys rk;
     GRL_DEV void operator()(u64 i) const {
         const u64 q = q0 + i;
         if (keep(q)) {
             const u32 o = ex[i];
-            const u64 key = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b);
+            const u64 key = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b, rk);
             u32 d = 0;
             for (int r = 1; r < N; r++) if (key >= spl[r]) d = (u32)r;      // the LAST rank whose range starts at or below the key
             lk[o] = key; lp[o] = (u32)q; own[o] = d; idx[o] = o;
@@ -821,11 +865,11 @@ struct ByteIn {
 };
 // (the same without an exchange, for few ranks: every rank looks at ALL positions and keeps the records of its own key range)
 struct OwnKeyFlagFn {     // flag[q] = 1 for the kept suffixes whose key lies in the range of rank `me`
-    SufKeep keep; const u32 *dict_sym; int K, b; const u64 *spl; int N, me; u8 *flag;
+    SufKeep keep; const u32 *dict_sym; int K, b; const u64 *spl; int N, me; u8 *flag; RunKeys rk;
     GRL_DEV void operator()(u64 q) const {
         u8 f = 0;
         if (keep(q)) {
-            const u64 key = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b);
+            const u64 key = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b, rk);
             int d = 0;
             for (int r = 1; r < N; r++) if (key >= spl[r]) d = r;
             f = d == me ? 1 : 0;
@@ -835,9 +879,9 @@ struct OwnKeyFlagFn {     // flag[q] = 1 for the kept suffixes whose key lies in
 };
 struct OwnKeyEmitFn {     // ... and their (key, position) records, compacted (positions ascending)
     static constexpr bool kWaveEmit = false;
-    SufKeep keep; const u32 *dict_sym; int K, b; u64 *ka; u32 *perm;
+    SufKeep keep; const u32 *dict_sym; int K, b; u64 *ka; u32 *perm; RunKeys rk;
     GRL_DEV void operator()(u64 q, u32 ex, u32 v) const {
-        if (v) { ka[ex] = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b); perm[ex] = (u32)q; }
+        if (v) { ka[ex] = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b, rk); perm[ex] = (u32)q; }
     }
 };
 struct GatherKeyPosFn {   // records in owner order
@@ -880,10 +924,11 @@ struct ExtKeyFn {         // compact the unresolved slots; key = the next K symb
     const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag; const u32 *dict_sym; const u64 *pw; u64 S;
     u64 Lres; int K, b;
     u32 *uslot; u32 *uq; u64 *ukey; u8 *uhead;
+    RunKeys rk;
     GRL_DEV void operator()(u64 i) const {
         if (uflag[i]) {
             const u64 t = act ? (u64)act[i] : i;
-            const u64 q = perm[t], x = q + Lres;
+            const u64 q = perm[t], x = q + Lres + (rk.rb ? (u64)rk.skip[q] : 0ull);
             // bits x .. x+K-1 of the start vector (K <= 16; the vector has a spare word behind position S)
             u64 w = 0;
             if (x < S) {
@@ -897,6 +942,21 @@ struct ExtKeyFn {         // compact the unresolved slots; key = the next K symb
             const u64 sent = (1ull << b) - 1;
             u64 key = 0;
             for (int j = 0; j < K; j++) key = (key << b) | (((u32)j < valid) ? (u64)dict_sym[x + (u64)j] : sent);
+            if (rk.rb) {                           // (the run field of suffix_key0, with the phrase end taken from the start bits)
+                u64 low = 0;
+                if (valid == (u32)K) {
+                    const u32 r = rk.rem[x];
+                    if (r >= (u32)K) {
+                        const u32 a = dict_sym[x];
+                        const u64 xe = x + (u64)r;
+                        const bool up = xe >= S || bit_at(pw, xe) || dict_sym[xe] > a;
+                        const int R = rk.rb - 1;
+                        low = up ? ((1ull << R) | (((1ull << R) - 1ull) - (u64)r)) : (u64)r;
+                        rk.skip[q] += r - (u32)K;
+                    }
+                }
+                key = (key << rk.rb) | low;
+            }
             const u32 o = uex[i];
             uslot[o] = (u32)t; uq[o] = (u32)q; ukey[o] = key; uhead[o] = hflag[t];
         }
@@ -3044,11 +3104,27 @@ class Engine {
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
             // as many symbols as fit 64 key bits per pass (up to 8 radix passes over all suffixes in the first one)
-            int K = 64 / b;
+            // run-aware keys (RunKeys) for levels with long phrases, i.e. long runs of one symbol (GRLBWT_RUN_KEYS_MIN: from which
+            // phrase length on; the tests set 0)
+            static const u64 run_min = getenv("GRLBWT_RUN_KEYS_MIN") ? (u64)atoll(getenv("GRLBWT_RUN_KEYS_MIN")) : 512;
+            RunKeys rk;
+            DBuf<u32> run_rem, run_skip;
+            if ((u64)maxlen >= run_min && S > 0) rk.rb = 1 + (int)bitlen64((u64)maxlen);
+            int K = (64 - rk.rb) / b;
             if (K < 1) K = 1;
             if (K > 16) K = 16;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
-            const u64 sent = (1ull << b) - 1ull;
+            if (rk.rb && K * b + rk.rb > 64) rk.rb = 0;                     // (symbols too wide to share a key with a run field: plain keys)
+            if (rk.rb) {
+                DBuf<u32> rex(S), ends(S);
+                run_rem.alloc(S); run_skip.alloc(S);
+                run_skip.zero();
+                prim::exclusive_scan_emit<u32>(S, RunChangeIn{dict_sym.p, pbits.words.p, S}, RunEndsEmitFn{rex.p, ends.p}, "suffix_runs");
+                prim::for_each(S, RunRemFn{rex.p, ends.p, run_rem.p}, "suffix_runs");
+                rk.rem = run_rem.p; rk.skip = run_skip.p;
+            }
+            const int kbits = K * b + rk.rb;                                // sort bits of a key
+            const u64 sent = ((1ull << b) - 1ull) << rk.rb;                 // (the last symbol of a key's window: all ones = the phrase has ended)
             // (GRLBWT_SEG_CAP: the tests lower the limit so that ordinary inputs take the large-group path too)
             static const u32 cap = getenv("GRLBWT_SEG_CAP") ? (u32)atoi(getenv("GRLBWT_SEG_CAP")) : kSegCap;
             DBuf<u64> ka;
@@ -3059,7 +3135,7 @@ class Engine {
                     const u64 dropped = prim::exclusive_scan<u32>(D, PhraseDropIn{ph_off, ph_lastT}, dropcnt.p, true, "suffix_keep");
                     Sg = S - dropped;
                     ka.alloc(Sg); perm.alloc(Sg);
-                    prim::for_each(S, Key0KeepFn{keep, dropcnt.p, dict_sym.p, K, b, ka.p, perm.p}, "suffix_keys0");
+                    prim::for_each(S, Key0KeepFn{keep, dropcnt.p, dict_sym.p, K, b, ka.p, perm.p, rk}, "suffix_keys0");
                 } else {
                     // Sample-sort exchange.  Every rank makes the (key, position) records of ITS 1/N of the dictionary positions,
                     // groups them by the rank that owns their key range (splitters from a strided sample: replicated data, same
@@ -3083,24 +3159,24 @@ class Engine {
                         if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_SORT")) if (atoi(fr) == me) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
                         const u64 ns = S < 8192 ? S : 8192, stride = S / ns;
                         DBuf<u64> samp(ns), dspl(N);
-                        prim::for_each(ns, SampleKey0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, stride, samp.p}, "dist.sample_keys");
+                        prim::for_each(ns, SampleKey0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, stride, samp.p, rk}, "dist.sample_keys");
                         std::vector<u64> hs = samp.to_host(ns), spl(N, 0);
                         std::sort(hs.begin(), hs.end());
                         for (int d = 1; d < N; d++) spl[d] = hs[(u64)d * ns / N];          // rank d owns keys in [spl[d], spl[d + 1])
                         prim::h2d(dspl.p, spl.data(), (u64)N * 8);
                         if (!exchange) {
                             DBuf<u8> mine(S);
-                            prim::for_each(S, OwnKeyFlagFn{keep, dict_sym.p, K, b, dspl.p, N, me, mine.p}, "suffix_keys0");
+                            prim::for_each(S, OwnKeyFlagFn{keep, dict_sym.p, K, b, dspl.p, N, me, mine.p, rk}, "suffix_keys0");
                             Sown = prim::reduce_sum<u64>(S, ByteIn{mine.p}, "suffix_keep");
                             ka.alloc(Sown); perm.alloc(Sown);
-                            prim::exclusive_scan_emit<u32>(S, ByteIn{mine.p}, OwnKeyEmitFn{keep, dict_sym.p, K, b, ka.p, perm.p}, "suffix_keys0");
+                            prim::exclusive_scan_emit<u32>(S, ByteIn{mine.p}, OwnKeyEmitFn{keep, dict_sym.p, K, b, ka.p, perm.p, rk}, "suffix_keys0");
                         }
                         const u64 q0 = exchange ? S * (u64)me / (u64)N : 0, q1 = exchange ? S * (u64)(me + 1) / (u64)N : 0, nq = q1 - q0;
                         DBuf<u32> kex(nq + 1);
                         const u64 nk = prim::exclusive_scan<u32>(nq, KeepRangeIn{keep, q0}, kex.p, false, "suffix_keep");
                         DBuf<u64> lk(nk), bound(2 * ((u64)N + 1));
                         DBuf<u32> lp(nk), own(nk), own2(nk), idx(nk), idx2(nk);
-                        prim::for_each(nq, KeyRangeFn{keep, kex.p, q0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p}, "suffix_keys0");
+                        prim::for_each(nq, KeyRangeFn{keep, kex.p, q0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p, rk}, "suffix_keys0");
                         int obits = (int)bitlen64((u64)N - 1);
                         if (obits < 1) obits = 1;
                         const int res = prim::sort_pairs<u32, u32>(own.p, idx.p, own2.p, idx2.p, nk, 0, obits, "dist.key_owner_sort");
@@ -3133,10 +3209,11 @@ class Engine {
                 DBuf<u64> kb(Sg);
                 DBuf<u32> vb(Sg);
                 const u64 *ks = ka.p;
-                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, Sg, 0, K * b, "suffix_sort0")) {
+                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, Sg, 0, kbits, "suffix_sort0")) {
                     std::swap(perm, vb);         // the result sits in the second buffer: take it, no copy
                     ks = kb.p;
                 }
+                if (rk.rb) prim::for_each(Sg, InitSkipFn{perm.p, rk.rem, (u32)K, rk.skip}, "suffix_runs");
                 prim::for_each(Sg, HeadFlagFn{ks, hflag.p}, "suffix_heads");
                 prim::for_each(Sg, FirstUnresolvedFn{ks, hflag.p, Sg, sent, uflag.p}, "suffix_unresolved");
                 prim::sync();
@@ -3155,7 +3232,7 @@ class Engine {
                 DBuf<u64> ukey(U);
                 DBuf<u8> uhead(U), unext(U);
                 prim::for_each(A, ExtKeyFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, dict_sym.p, pbits.words.p, S, Lres, K, b,
-                                           uslot.p, uq.p, ukey.p, uhead.p}, "suffix_keys");
+                                           uslot.p, uq.p, ukey.p, uhead.p, rk}, "suffix_keys");
                 const u64 nseg = prim::exclusive_scan<u32>(U, ByteIn{uhead.p}, hex.p, false, "suffix_heads");
                 DBuf<u32> seg_start(nseg + 1), bex(U + 1);
                 prim::for_each(U, SegStartFn{uhead.p, hex.p, U, seg_start.p}, "suffix_gstart");
@@ -3165,7 +3242,7 @@ class Engine {
                     DBuf<u32> bitem(NB), bidx(NB), bidx2(NB), key2(NB), key2b(NB);
                     DBuf<u64> bkey(NB), bkey2(NB);
                     prim::for_each(U, SegBigGatherFn{uhead.p, hex.p, seg_start.p, bex.p, ukey.p, cap, bitem.p, bkey.p, bidx.p}, "suffix_sort.big_gather");
-                    const u32 *i1 = prim::sort_pairs<u64, u32>(bkey.p, bidx.p, bkey2.p, bidx2.p, NB, 0, K * b, "suffix_sort") ? bidx2.p : bidx.p;
+                    const u32 *i1 = prim::sort_pairs<u64, u32>(bkey.p, bidx.p, bkey2.p, bidx2.p, NB, 0, kbits, "suffix_sort") ? bidx2.p : bidx.p;
                     u32 *i1o = (i1 == bidx.p) ? bidx2.p : bidx.p;
                     prim::for_each(NB, SegBigSegKeyFn{i1, bitem.p, uhead.p, hex.p, key2.p}, "suffix_sort.big_groups");
                     int sbits = (int)bitlen64(nseg);

@@ -155,6 +155,43 @@ def test_one_word_cells_in_64_bits(sim, oracle_mod, monkeypatch):
     parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
+def _long_run_collection(run, copies, seed):
+    """strings that hold a run of `run` + k equal symbols between random flanks (every copy a little longer), plus runs that end
+    a string, runs followed by a smaller and by a larger symbol, and a run that is a whole string"""
+    rng = np.random.default_rng(seed)
+    fl = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8))
+    a, b = fl(300), fl(300)
+    parts = [a + b"N" * (run + k) + b + b"\n" for k in range(copies)]
+    parts += [fl(50) + b"T" * (run // 2) + b"\n", fl(40) + b"C" * (run // 3) + b"A" + fl(30) + b"\n", b"G" * (run // 4) + b"T" + fl(20) + b"\n",
+              b"A" * (run // 5) + b"\n", a + b"N" * run + b + b"\n"]
+    return b"".join(parts)
+
+
+def test_run_aware_suffix_keys(sim, oracle_mod, monkeypatch):
+    """Phrases that hold long runs of one symbol (an N gap is ONE phrase as long as the gap): the dictionary suffix sort switches
+    to run-aware keys (RunKeys: a class bit + the remaining run length below the key's window; a whole run is consumed per
+    refinement round).  Without them the refinement needs run / K rounds for each of the run's suffixes -- quadratic.  Against
+    the oracle: real long runs at the default threshold (and the number of refinement rounds stays small), then the run-aware
+    keys forced on for ordinary inputs of every kind."""
+    data = _long_run_collection(6000, 5, 3)
+    with engine.Context(0, 0, sim) as ctx:
+        ctx.upload(data, 1)
+        ctx.build()
+        nb, _ = ctx.result_size()
+        assert ctx.result_bytes() == oracle_mod.rl_bwt(data, 1)
+        assert max(ctx.round_info(r)["sort_iters"] for r in range(2)) <= 40          # (6000-cell runs: ~400 rounds of 16 symbols otherwise)
+    monkeypatch.setenv("GRLBWT_RUN_KEYS_MIN", "0")
+    parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=3).tobytes(), 1)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+    parity.check_final(sim, _long_run_collection(900, 3, 5), 1)
+    rng = np.random.default_rng(123)
+    for kind in parity.KINDS:
+        for _ in range(10):
+            d, w = parity.rand_collection(rng, kind)
+            parity.check_final(sim, d, w)
+
+
 def test_device_side_generators_match_host():
     """The torch generators of the large test inputs (run on the GPU there) produce the host generators' bytes."""
     a = workloads.repetitive_copies(5, 30011)

@@ -114,6 +114,45 @@ def test_partitioned_phrase_naming(hip, oracle_mod, monkeypatch, capfd):
     assert "falling back to the hash table" in capfd.readouterr().err
 
 
+def test_run_aware_suffix_keys(hip, oracle_mod, monkeypatch):
+    """Long runs of one symbol (an N gap of 150 k cells in six copies, runs ending a string, runs followed by smaller / larger
+    symbols): ONE phrase per run, and the dictionary suffix sort must not take run / K refinement rounds for each of the run's
+    suffixes (20 MB of such data took 311 s before the run-aware keys).  Against the oracle, with the rounds counted; then the
+    run-aware keys forced on for ordinary inputs."""
+    import time
+    import torch
+    from tests.test_engine_logic_sim import _long_run_collection
+    data = _long_run_collection(10000, 6, 7)                # (the oracle is itself quadratic in the run length: 4 s here)
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.upload(data, 1)
+        ctx.build()
+        assert ctx.result_bytes() == oracle_mod.rl_bwt(data, 1)
+        assert max(ctx.round_info(r)["sort_iters"] for r in range(2)) <= 40
+    # long runs proper: by the device round trip
+    big = np.frombuffer(_long_run_collection(600000, 8, 9), dtype=np.uint8)
+    t = torch.from_numpy(big.copy()).to("cuda:0")
+    out = torch.zeros_like(t)
+    with engine.Context(0, 0, hip) as ctx:
+        t0 = time.time()
+        ctx.attach_device(t.data_ptr(), t.numel(), 1, keepalive=t)
+        ctx.build()
+        torch.cuda.synchronize()
+        assert time.time() - t0 < 30.0
+        assert max(ctx.round_info(r)["sort_iters"] for r in range(2)) <= 40
+        nb, _ = ctx.result_size()
+        n = ctx.invert_image(ctx.result_device_ptr(), nb, 1, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    assert n == t.numel() and torch.equal(out, t)
+    monkeypatch.setenv("GRLBWT_RUN_KEYS_MIN", "0")
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+    rng = np.random.default_rng(77)
+    for kind in parity.KINDS:
+        for _ in range(6):
+            d, w = parity.rand_collection(rng, kind)
+            parity.check_final(hip, d, w)
+
+
 def test_stagewise_idx64(hip, oracle_mod):
     parity.check_stagewise(hip, workloads.sampled_reads(5000, 80, 30000, seed=2).tobytes(), 1, engine.FLAG_FORCE_IDX64)
 
