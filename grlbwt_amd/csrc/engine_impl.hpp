@@ -94,6 +94,22 @@ struct CellOps {
 };
 
 GRL_HD bool bit_at(const u64 *w, u64 i) { return (w[i >> 6] >> (i & 63)) & 1ull; }
+// smallest i in [p, n) whose bit is set, n if there is none: 64 positions per step (the ends of very long phrases -- an N gap of
+// 10^8 cells is ONE phrase -- are found through the bit-vectors, not cell by cell)
+GRL_HD u64 next_set_bit(const u64 *w, u64 p, u64 n) {
+    u64 r = n;
+    if (p < n) {
+        u64 wi = p >> 6;
+        u64 x = w[wi] >> (p & 63);
+        if (x) r = p + (u64)__builtin_ctzll(x);
+        else {
+            bool found = false;
+            for (wi++; !found && (wi << 6) < n; wi++) { x = w[wi]; if (x) { r = (wi << 6) + (u64)__builtin_ctzll(x); found = true; } }
+        }
+        if (r > n) r = n;
+    }
+    return r;
+}
 
 // ------------------------------------------------------- a2: phrase starts
 // A.1 of SURVEY.md: position p starts a phrase iff it starts a string or it is an
@@ -222,6 +238,7 @@ struct HashInsertFn {
     // does NOT touch the table; longer ones take the table as before and mark their slot entry with kLongMark
     u32 *rec_h = nullptr; prim::U128 *rec_v = nullptr; int rec_b = 0; u32 rec_cmax = 0;
     u32 *long_count = nullptr;     // (sample pass: how many phrases are longer than rec_cmax)
+    u64 walk_cap = ~0ull;          // (sample pass: a phrase longer than this is left out -- one lane walking a 10^8-cell phrase a second time: 6 s)
     // Byte cells: 4 phrases per lane at once through the exact-key path (process_batch).  A phrase of <= 7 cells is cut
     // out of ONE unaligned 8-byte load with the start bits and a zero-byte test for the terminator -- no loop -- its
     // bytes are the table key, so a probe that matches needs no look at a representative occurrence, and the text,
@@ -309,7 +326,9 @@ struct HashInsertFn {
         if (pack) rec_put(klo, khi, ops.sym(c), 0, rec_b);
         // cells are taken 8 bytes at a time while that stays inside the text (one load covers a whole DNA phrase;
         // phrases of millions of cells -- e.g. N-runs -- would otherwise pay one memory latency per cell)
+        bool capped = false;
         while (!done && e + 1 + kCh <= n) {
+            if (e - p >= walk_cap) { capped = true; done = true; }
             u64 chunk = load8(t + e + 1);
             u64 b0 = e + 1;
             u64 bits = startbits[b0 >> 6] >> (b0 & 63);
@@ -336,6 +355,7 @@ struct HashInsertFn {
                 done = bit_at(startbits, e) || ops.isT(c);
             }
         }
+        if (capped) ok = false;
         if (ok && ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; ok = false; }
         u32 found = prim::kNoBucket;
         if (ok && pack) {
@@ -638,6 +658,7 @@ struct CompactTableFn {
     const u64 *keys; const idx_t *counts;
     u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
     int ks; u64 cs; const u64 *rep_pos;
+    u64 n;                                         // cells of the text
     GRL_DEV void emit(u64 s, u64 k) const {        // table slot s is phrase k of the dictionary
         u64 k64 = keys[s << ks];
         // (one exit: an early return from the first branch cost the ends-a-string flag of a few phrases in the 64-bit build
@@ -651,10 +672,12 @@ struct CompactTableFn {
         } else {
             pos = key_pos(k64); len = key_len(k64);
             lastT = key_lastT(k64);                // carried in the key: no gather of the phrase's last cell
-            if (len == kLenSat) {                  // saturated: walk to the phrase end
-                u64 e = pos;
-                bool more = true;
-                while (more) { if (ops.isT(t[e])) more = false; else { e++; if (bit_at(startbits, e)) more = false; } }
+            if (len == kLenSat) {
+                // saturated: the phrase ends at the first terminator or AT the next phrase start (LMS phrases share that cell) --
+                // and the position behind a terminator is a start, so the next start bit behind pos decides (a walk cell by cell
+                // took 18.7 s for ONE phrase of 10^8 cells)
+                const u64 ns = next_set_bit(startbits, pos + 1, n);
+                const u64 e = (ns >= n || ops.isT(t[ns - 1])) ? ns - 1 : ns;
                 len = e - pos + 1;
             }
         }
@@ -1222,16 +1245,29 @@ struct ApplyMetaPairsFn {  // the same from (position << 32 | metasymbol) pairs 
     const u64 *pairs; u64 *dm;
     GRL_DEV void operator()(u64 i) const { const u64 p = pairs[i]; reinterpret_cast<u32 *>(dm)[2 * (p >> 32) + 1] = (u32)p; }
 };
+struct DmStopBitsFn {      // one lane per word: bit q = dm[q] is marked or the last cell of its phrase (where a grammar walk stops)
+    const u64 *dm; u64 S; u64 *bits;
+    GRL_DEV void operator()(u64 w) const {
+        u64 m = 0;
+        for (u64 j = 0; j < 64 && w * 64 + j < S; j++) { const u64 e = dm[w * 64 + j]; if ((e >> 32) || ((u32)e & kDmEnd)) m |= 1ull << j; }
+        bits[w] = m;
+    }
+};
 struct GrammarFn {
     const u32 *repq; const u64 *dm;
     u32 MD;
     u32 *g0; u32 *g1;
+    const u64 *stops = nullptr; u64 S = 0;      // levels with very long phrases: where the walks stop, as a bit-vector (DmStopBitsFn)
     GRL_DEV void operator()(u64 u) const {
         u64 x = repq[u];
         u64 prev = dm[x];
         u32 a = MD, b = 0;
         bool done = false;
         if ((u32)prev & kDmEnd) { b = (u32)prev & kDmSym; done = true; }               // the representative is the last cell of its phrase (:38-41)
+        if (!done && stops) {                      // jump to the cell in front of the stop (a walk over 10^8 cells took 14 s)
+            const u64 y = next_set_bit(stops, x + 1, S);
+            if (y > x + 1) { x = y - 1; prev = dm[x]; }
+        }
         while (!done) {
             const u64 e = dm[++x];
             const u32 m = (u32)(e >> 32);
@@ -2784,6 +2820,7 @@ class Engine {
                 typedef HashInsertFn<cell_t, FIRST> HF;
                 HF fs{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0, P.next_text.p, scal.p, n, n_occ, trep.p};
                 fs.rec_b = rec_b; fs.rec_cmax = rec_cmax;       // (partitioned naming: only the long phrases reach the sample's table)
+                fs.walk_cap = (u64)1 << 16;
                 prim::for_each_agg(n_s, SampledFn<HF>{fs, blk, stride}, SlotCountAdd{tc.p, 1}, true, "hash_sample");
                 const u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
                 const u64 occ_s = std::max<u64>(prim::reduce_sum<u64>(cap_s, IdxIn<idx_t>{tc.p}, "hash_sample_count"), 1);
@@ -2857,6 +2894,8 @@ class Engine {
                 if (part) { f.rec_h = P.rec_h.p; f.rec_v = rec_v.p; f.rec_b = rec_b; f.rec_cmax = rec_cmax; }
                 if (cap_hot) {
                     HF fh{t, ops, startbits.p, wordbase.p, keys.p, cap_hot - 1, cap_hot, 0, P.next_text.p, scal.p, n, n_occ, rep_pos.p, claim.p};
+                    fh.walk_cap = (u64)1 << 16;             // (a phrase of millions of cells has no business in the hot table: the pass over the text
+                                                            // would find it there and compare it cell by cell with itself)
                     prim::for_each_agg(s_n, SampledFn<HF>{fh, s_blk, s_stride, claim.p}, NoCountAdd{}, false, "hash_hot");
                     f.hot_keys = keys.p; f.hot_mask = cap_hot - 1; f.slot_base = (u32)cap_hot;
                 }
@@ -2955,7 +2994,7 @@ class Engine {
             // ... and the phrases of the table behind them
             prim::for_each(nwords, ClaimSlotsFn{claim.p, cbase.p, startbits.p, wordbase.p, P.next_text.p, P.ph_slot.p + Ds}, "table_compact");
             prim::for_each(Dl, ClaimCompactFn<cell_t, FIRST>{CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, P.ph_pos.p + Ds,
-                                                             P.ph_freq.p + Ds, P.ph_len.p + Ds, P.ph_slot.p + Ds, P.ph_lastT.p + Ds, ks, cs, rep_pos.p}}, "table_compact");
+                                                             P.ph_freq.p + Ds, P.ph_len.p + Ds, P.ph_slot.p + Ds, P.ph_lastT.p + Ds, ks, cs, rep_pos.p, n}}, "table_compact");
             wordbase.release(); claim.release();
             u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{P.ph_freq.p}, "dict_freq_check");
             if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
@@ -3351,10 +3390,15 @@ class Engine {
                     DBuf<u64> all = C->template allgather_v<u64>(mp.p, nm, bb);
                     prim::for_each(bb[C->size], ApplyMetaPairsFn{all.p, dm.p}, "grammar_marks");
                 }
-                if (!C) prim::for_each(M, GrammarFn{repq.p, dm.p, MD, L.g0.p, L.g1.p}, "grammar");
+                DBuf<u64> stops;                 // (very long phrases only: the walks jump to their stops)
+                if (maxlen >= 4096 || getenv("GRLBWT_GRAMMAR_JUMP")) {
+                    stops.alloc((S + 63) / 64 + 1);
+                    prim::for_each((S + 63) / 64, DmStopBitsFn{dm.p, S, stops.p}, "grammar_marks");
+                }
+                if (!C) prim::for_each(M, GrammarFn{repq.p, dm.p, MD, L.g0.p, L.g1.p, stops.p, S}, "grammar");
                 else {                           // every rank walks for its own metasymbols; the cells are all-gathered
                     DBuf<u32> g0l(Ml), g1l(Ml);
-                    prim::for_each(Ml, GrammarFn{repq.p, dm.p, MD, g0l.p, g1l.p}, "grammar");
+                    prim::for_each(Ml, GrammarFn{repq.p, dm.p, MD, g0l.p, g1l.p, stops.p, S}, "grammar");
                     C->template allgather_v<u32>(g0l.p, Ml, bbM, true, L.g0.p);
                     C->template allgather_v<u32>(g1l.p, Ml, bbM, true, L.g1.p);
                 }

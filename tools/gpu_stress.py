@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Lease script: inputs chosen to hit slow paths (long runs, tandem repeats, monotone ramps over a large alphabet, one giant string,
+millions of identical strings, one symbol only).  Each is built on the device and inverted back (device round trip); prints the
+build time, the refinement rounds per level and the verdict.   python tools/gpu_stress.py [case ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def cases():
+    rng = np.random.default_rng(2026)
+    dna = lambda n: rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+    nl = np.array([10], dtype=np.uint8)
+    out = {}
+    out["tandem_ACG_x700k_5_strings"] = (np.concatenate([np.concatenate([np.tile(np.frombuffer(b"ACG", dtype=np.uint8), 700000 + k), dna(50), nl]) for k in range(5)]), 1)
+    out["tandem_period7_x300k"] = (np.concatenate([np.concatenate([np.tile(np.frombuffer(b"ACGGTCA", dtype=np.uint8), 300000 + 3 * k), dna(20), nl]) for k in range(4)]), 1)
+    ramp = np.arange(1, 400001, dtype=np.uint32)
+    out["u32_shared_ramps_400k_x6"] = (np.concatenate([np.concatenate([ramp, np.array([500000 + k, 0], dtype=np.uint32)]) for k in range(6)]).view(np.uint8), 4)
+    out["one_string_64MB"] = (np.concatenate([dna(64 << 20), nl]), 1)
+    out["identical_strings_8M_x_ACGTACGT"] = (np.tile(np.frombuffer(b"ACGTACGT\n", dtype=np.uint8), 8 << 20), 1)
+    out["one_symbol_100M"] = (np.concatenate([np.full(100 << 20, ord("A"), dtype=np.uint8), nl]), 1)
+    tok = rng.integers(1, 300, size=20 << 20).astype(np.uint16)
+    tok[5 << 20: 9 << 20] = 77
+    tok[(np.arange(1, 40) * (1 << 19))] = 0
+    tok[-1] = 0
+    out["u16_tokens_with_a_4M_run"] = (tok.view(np.uint8), 2)
+    return out
+
+
+def main():
+    import torch
+    import __graft_entry__ as g
+    from grlbwt_amd import engine
+    lib = g.build_hip()
+    want = sys.argv[1:]
+    for name, (data, w) in cases().items():
+        if want and name not in want:
+            continue
+        t = torch.from_numpy(np.ascontiguousarray(data)).to("cuda:0")
+        view = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[w]
+        cells = t.view(view)
+        back = torch.zeros_like(cells)
+        with engine.Context(0, 0, lib) as ctx:
+            t0 = time.time()
+            ctx.attach_device(cells.data_ptr(), cells.numel(), w, keepalive=cells)
+            ctx.build()
+            torch.cuda.synchronize()
+            tb = time.time() - t0
+            nb, nr = ctx.result_size()
+            iters = []
+            r = 0
+            while True:
+                try:
+                    iters.append(ctx.round_info(r)["sort_iters"])
+                    r += 1
+                except engine.GrlbwtError:
+                    break
+            t0 = time.time()
+            n = ctx.invert_image(ctx.result_device_ptr(), nb, w, back.data_ptr(), back.numel())
+            torch.cuda.synchronize()
+            ti = time.time() - t0
+        ok = n == cells.numel() and bool(torch.equal(back, cells))
+        print("%-36s %8.1f MB  build %7.2f s (%8.1f MB/s)  runs %10d  rounds %2d  refinement rounds %s  invert %6.2f s  round trip %s"
+              % (name, data.nbytes / 1e6, tb, data.nbytes / 1e6 / tb, nr, len(iters), iters, ti, ok), flush=True)
+
+
+if __name__ == "__main__":
+    main()
