@@ -790,9 +790,10 @@ struct DictBuildFn {      // one lane per PER consecutive dictionary positions: 
 // the sort, and so of the group stage, altogether.
 struct SufKeep {
     const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
+    bool all = false;     // levels with long phrases keep every suffix: the doubling rounds (DoubleKeyFn) want a slot for every position
     GRL_DEV bool operator()(u64 q) const {
         const u32 k = dict_phr[q];
-        return !(q + 1 == (u64)ph_off[k + 1] && !ph_lastT[k] && q != (u64)ph_off[k]);
+        return all || !(q + 1 == (u64)ph_off[k + 1] && !ph_lastT[k] && q != (u64)ph_off[k]);
     }
 };
 // RUN-AWARE KEYS (levels whose phrases hold long runs of one symbol: a 2 M-cell run of N makes one phrase of 2 M cells, and its
@@ -850,8 +851,8 @@ struct SampleKey0Fn {     // keys at strided positions: the splitter sample of t
     GRL_DEV void operator()(u64 i) const { const u64 q = i * stride; out[i] = suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b, rk); }
 };
 struct PhraseDropIn {     // 1 for a phrase whose last-cell suffix is left out (one scan over the PHRASES then places every kept suffix)
-    const u32 *ph_off; const u8 *ph_lastT;
-    GRL_DEV u32 operator()(u64 k) const { return (!ph_lastT[k] && ph_off[k + 1] - ph_off[k] > 1) ? 1u : 0u; }
+    const u32 *ph_off; const u8 *ph_lastT; bool all = false;
+    GRL_DEV u32 operator()(u64 k) const { return (!all && !ph_lastT[k] && ph_off[k + 1] - ph_off[k] > 1) ? 1u : 0u; }
 };
 struct Key0KeepFn {       // (key, position) of the kept suffixes at position - (suffixes left out in front of the phrase)
     SufKeep keep; const u32 *dropcnt; const u32 *dict_sym; int K, b; u64 *ka; u32 *va; RunKeys rk;
@@ -1043,6 +1044,54 @@ struct SegBigWriteFn {    // large items now ordered by (group, key): back into 
         perm[dst] = uq[src];
         if (!first && !eq_prev) hflag[dst] = 1;
         unext[jt] = ((eq_prev || eq_next) && (k & sent) != sent) ? 1 : 0;
+    }
+};
+// DOUBLING ROUNDS (single-GPU rounds, levels with long phrases, once the symbol extension has run a few rounds without
+// finishing: long phrases that are NOT runs -- strictly monotone ramps over a large alphabet -- shared by several strings
+// keep their suffix groups tied for their whole length, K symbols per round).  The suffix at position q, sorted to depth
+// d(q) = Ld + skip[q], takes as its key the current group of the suffix at q + d(q) (Larsson-Sadakane): groups are totally
+// ordered consistently with the final order, so members whose targets lie in different groups are ordered for good, and
+// members whose targets share a group T agree on depth(T) more symbols.  Key = group number << 1 | (T resolved): equal keys
+// with a resolved T are equal suffixes (the segment sorts' "still unresolved" test reads the low bit: sent = 1); a suffix
+// that has ended takes the largest key.
+struct SlotOfFn {
+    const u32 *perm; u32 *slot_of;
+    GRL_DEV void operator()(u64 t) const { slot_of[perm[t]] = (u32)t; }
+};
+struct UresInitFn {       // the unresolved flags of the active list, by slot
+    const u32 *act; const u8 *uflag; u8 *ures;
+    GRL_DEV void operator()(u64 i) const { if (uflag[i]) ures[act ? (u64)act[i] : i] = 1; }
+};
+struct DoubleKeyFn {
+    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag;
+    const u32 *dict_phr; const u32 *ph_off; const u32 *slot_of; const u32 *rank_ex; const u8 *ures; const u32 *skip;
+    u64 Ld, Sg;
+    u32 *uslot; u32 *uq; u64 *ukey; u8 *uhead; u32 *nskip;
+    GRL_DEV void operator()(u64 i) const {
+        if (uflag[i]) {
+            const u64 t = act ? (u64)act[i] : i;
+            const u64 q = perm[t];
+            const u64 sk = skip[q], x = q + Ld + sk, end = ph_off[dict_phr[q] + 1];
+            u64 key = (Sg << 1) | 1ull;                     // the suffix has ended: behind every real group, resolved
+            u64 ns = sk;
+            if (x < end) {
+                const u32 st = slot_of[x];
+                const bool tu = ures[st] != 0;
+                key = ((u64)(rank_ex[st] + hflag[st] - 1) << 1) | (tu ? 0ull : 1ull);
+                if (tu) ns = sk + Ld + (u64)skip[x];
+            }
+            const u32 o = uex[i];
+            uslot[o] = (u32)t; uq[o] = (u32)q; ukey[o] = key; uhead[o] = hflag[t]; nskip[o] = (u32)ns;
+        }
+    }
+};
+struct AfterDoubleFn {    // item j: its position's new depth; place j: which position sits there now and whether it is still unresolved
+    const u32 *uq; const u32 *nskip; const u32 *uslot; const u32 *perm; const u8 *unext; u32 *skip; u32 *slot_of; u8 *ures;
+    GRL_DEV void operator()(u64 j) const {
+        skip[uq[j]] = nskip[j];
+        const u32 sl = uslot[j];
+        slot_of[perm[sl]] = sl;
+        ures[sl] = unext[j];
     }
 };
 struct DenseGidFn {       // final dense group id of every slot
@@ -3149,6 +3198,10 @@ class Engine {
             RunKeys rk;
             DBuf<u32> run_rem, run_skip;
             if ((u64)maxlen >= run_min && S > 0) rk.rb = 1 + (int)bitlen64((u64)maxlen);
+            // long phrases on one GPU: every suffix keeps its slot (no "last cell" suffixes left out), so that the refinement can
+            // switch to doubling rounds (DoubleKeyFn) when the symbol extension does not finish in GRLBWT_DOUBLING_AFTER rounds
+            const bool longmode = !C && (u64)maxlen >= run_min && S > 0;
+            static const u64 dbl_after = getenv("GRLBWT_DOUBLING_AFTER") ? (u64)atoll(getenv("GRLBWT_DOUBLING_AFTER")) : 24;
             int K = (64 - rk.rb) / b;
             if (K < 1) K = 1;
             if (K > 16) K = 16;
@@ -3168,10 +3221,10 @@ class Engine {
             static const u32 cap = getenv("GRLBWT_SEG_CAP") ? (u32)atoi(getenv("GRLBWT_SEG_CAP")) : kSegCap;
             DBuf<u64> ka;
             {
-                const SufKeep keep{dict_phr.p, ph_off, ph_lastT};
+                const SufKeep keep{dict_phr.p, ph_off, ph_lastT, longmode};
                 if (!C) {
                     DBuf<u32> dropcnt(D + 1);
-                    const u64 dropped = prim::exclusive_scan<u32>(D, PhraseDropIn{ph_off, ph_lastT}, dropcnt.p, true, "suffix_keep");
+                    const u64 dropped = prim::exclusive_scan<u32>(D, PhraseDropIn{ph_off, ph_lastT, longmode}, dropcnt.p, true, "suffix_keep");
                     Sg = S - dropped;
                     ka.alloc(Sg); perm.alloc(Sg);
                     prim::for_each(S, Key0KeepFn{keep, dropcnt.p, dict_sym.p, K, b, ka.p, perm.p, rk}, "suffix_keys0");
@@ -3262,39 +3315,63 @@ class Engine {
             DBuf<u32> act;                       // slots still unresolved (empty = all slots), ascending
             u64 A = Sg;
             bool refined = false;
+            bool doubling = false;               // (see DoubleKeyFn)
+            u64 Ld = 0, dbl_rounds = 0;
+            DBuf<u32> slot_of, rank_ex, nskip;
+            DBuf<u8> ures;
             for (;;) {
                 DBuf<u32> uex(A + 1);
                 const u64 U = prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan");
                 if (U == 0) break;
-                if (Lres > (u64)maxlen + (u64)K) throw prim::Error(-71, "suffix refinement does not terminate");
+                if (Lres > (u64)maxlen + (u64)K || dbl_rounds > 80) throw prim::Error(-71, "suffix refinement does not terminate");
+                if (!doubling && longmode && iters > dbl_after) {
+                    doubling = true;
+                    Ld = Lres;                   // depth of the suffix at q from here on: Ld + skip[q]
+                    if (!rk.rb) { run_skip.alloc(S); run_skip.zero(); rk.skip = run_skip.p; }
+                    slot_of.alloc(S); slot_of.fill_ff();
+                    prim::for_each(Sg, SlotOfFn{perm.p, slot_of.p}, "suffix_doubling");
+                    ures.alloc(Sg); ures.zero();
+                    prim::for_each(A, UresInitFn{refined ? act.p : nullptr, uflag.p, ures.p}, "suffix_doubling");
+                    rank_ex.alloc(Sg + 1);
+                }
                 DBuf<u32> uslot(U), uq(U), hex(U + 1);
                 DBuf<u64> ukey(U);
                 DBuf<u8> uhead(U), unext(U);
+                if (doubling) {
+                    prim::exclusive_scan_nosync<u32>(Sg, ByteIn{hflag.p}, rank_ex.p, false, "suffix_doubling");      // group numbers of all slots
+                    nskip.alloc(U);
+                    prim::for_each(A, DoubleKeyFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, dict_phr.p, ph_off, slot_of.p, rank_ex.p,
+                                                  ures.p, rk.skip, Ld, Sg, uslot.p, uq.p, ukey.p, uhead.p, nskip.p}, "suffix_doubling");
+                    dbl_rounds++;
+                } else
                 prim::for_each(A, ExtKeyFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, dict_sym.p, pbits.words.p, S, Lres, K, b,
                                            uslot.p, uq.p, ukey.p, uhead.p, rk}, "suffix_keys");
+                const u64 sent_r = doubling ? 1ull : sent;                    // "still unresolved" bit(s) of a key
+                const int kbits_r = doubling ? (int)bitlen64((Sg << 1) | 1ull) : kbits;
                 const u64 nseg = prim::exclusive_scan<u32>(U, ByteIn{uhead.p}, hex.p, false, "suffix_heads");
                 DBuf<u32> seg_start(nseg + 1), bex(U + 1);
                 prim::for_each(U, SegStartFn{uhead.p, hex.p, U, seg_start.p}, "suffix_gstart");
-                prim::for_each(U, SegSortSmallFn{uhead.p, hex.p, seg_start.p, uslot.p, uq.p, ukey.p, sent, cap, perm.p, hflag.p, unext.p}, "suffix_sort.small");
+                prim::for_each(U, SegSortSmallFn{uhead.p, hex.p, seg_start.p, uslot.p, uq.p, ukey.p, sent_r, cap, perm.p, hflag.p, unext.p}, "suffix_sort.small");
                 const u64 NB = prim::exclusive_scan<u32>(U, SegBigIn{uhead.p, hex.p, seg_start.p, cap}, bex.p, false, "suffix_sort.big_scan");
                 if (NB) {                        // groups above kSegCap: by key, then (stable) by group
                     DBuf<u32> bitem(NB), bidx(NB), bidx2(NB), key2(NB), key2b(NB);
                     DBuf<u64> bkey(NB), bkey2(NB);
                     prim::for_each(U, SegBigGatherFn{uhead.p, hex.p, seg_start.p, bex.p, ukey.p, cap, bitem.p, bkey.p, bidx.p}, "suffix_sort.big_gather");
-                    const u32 *i1 = prim::sort_pairs<u64, u32>(bkey.p, bidx.p, bkey2.p, bidx2.p, NB, 0, kbits, "suffix_sort") ? bidx2.p : bidx.p;
+                    const u32 *i1 = prim::sort_pairs<u64, u32>(bkey.p, bidx.p, bkey2.p, bidx2.p, NB, 0, kbits_r, "suffix_sort") ? bidx2.p : bidx.p;
                     u32 *i1o = (i1 == bidx.p) ? bidx2.p : bidx.p;
                     prim::for_each(NB, SegBigSegKeyFn{i1, bitem.p, uhead.p, hex.p, key2.p}, "suffix_sort.big_groups");
                     int sbits = (int)bitlen64(nseg);
                     if (sbits < 1) sbits = 1;
                     const int res = prim::sort_pairs<u32, u32>(key2.p, (u32 *)i1, key2b.p, i1o, NB, 0, sbits, "suffix_sort");
-                    prim::for_each(NB, SegBigWriteFn{res ? key2b.p : key2.p, res ? i1o : i1, bitem.p, ukey.p, uq.p, uslot.p, NB, sent,
+                    prim::for_each(NB, SegBigWriteFn{res ? key2b.p : key2.p, res ? i1o : i1, bitem.p, ukey.p, uq.p, uslot.p, NB, sent_r,
                                                      perm.p, hflag.p, unext.p}, "suffix_refine");
                 }
+                if (doubling) prim::for_each(U, AfterDoubleFn{uq.p, nskip.p, uslot.p, perm.p, unext.p, rk.skip, slot_of.p, ures.p}, "suffix_doubling");
                 act = std::move(uslot);
                 uflag = std::move(unext);
                 A = U;
                 refined = true;
-                Lres += (u64)K;
+                if (!doubling) Lres += (u64)K;
                 iters++;
             }
             pbits.base.release();

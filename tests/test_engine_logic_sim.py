@@ -173,6 +173,7 @@ def test_run_aware_suffix_keys(sim, oracle_mod, monkeypatch):
     refinement round).  Without them the refinement needs run / K rounds for each of the run's suffixes -- quadratic.  Against
     the oracle: real long runs at the default threshold (and the number of refinement rounds stays small), then the run-aware
     keys forced on for ordinary inputs of every kind."""
+    monkeypatch.delenv("GRLBWT_RUN_KEYS_MIN", raising=False)
     data = _long_run_collection(6000, 5, 3)
     with engine.Context(0, 0, sim) as ctx:
         ctx.upload(data, 1)
@@ -190,6 +191,44 @@ def test_run_aware_suffix_keys(sim, oracle_mod, monkeypatch):
         for _ in range(10):
             d, w = parity.rand_collection(rng, kind)
             parity.check_final(sim, d, w)
+
+
+def _shared_ramps(n, copies, dtype=np.uint32):
+    """strings that share one long strictly increasing ramp (ONE phrase each, no runs) and differ behind it, plus a decreasing one"""
+    ramp = np.arange(1, n + 1, dtype=dtype)
+    parts = [np.concatenate([ramp, np.array([n + 10 + 3 * k, 0], dtype=dtype)]) for k in range(copies)]
+    parts.append(np.concatenate([ramp[::-1], np.array([0], dtype=dtype)]))
+    parts.append(np.concatenate([ramp[: n // 2], np.array([n + 5, 0], dtype=dtype)]))
+    return np.concatenate(parts)
+
+
+def test_doubling_rounds_of_the_suffix_refinement(sim, oracle_mod, monkeypatch):
+    """Long phrases that are not runs (monotone ramps over a large alphabet) shared by several strings: their suffix groups stay tied
+    for the whole ramp, and the symbol extension would need ramp / K rounds.  After GRLBWT_DOUBLING_AFTER rounds (24) the refinement
+    of a long-phrase level switches to doubling rounds (DoubleKeyFn: the key of a suffix is the current group of the suffix behind
+    its sorted depth).  Real ramps at the defaults, with the rounds counted; then doubling from the first (third) round on for
+    ordinary inputs of every kind."""
+    monkeypatch.delenv("GRLBWT_RUN_KEYS_MIN", raising=False)
+    monkeypatch.delenv("GRLBWT_DOUBLING_AFTER", raising=False)
+    cells = _shared_ramps(3000, 5)
+    with engine.Context(0, 0, sim) as ctx:
+        ctx.upload(cells.tobytes(), 4)
+        ctx.build()
+        assert ctx.result_bytes() == oracle_mod.rl_bwt(cells.tobytes(), 4)
+        assert ctx.round_info(0)["sort_iters"] <= 45          # (24 rounds of 2 symbols, then ~12 doubling rounds; 1500 otherwise)
+    for after in ("0", "2"):               # doubling from the first refinement round on / after two rounds of symbol extension
+        monkeypatch.setenv("GRLBWT_RUN_KEYS_MIN", "0")
+        monkeypatch.setenv("GRLBWT_DOUBLING_AFTER", after)
+        parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes(), 1)
+        parity.check_stagewise(sim, workloads.repetitive_copies(30, 8000, seed=3).tobytes(), 1)
+        parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+        parity.check_final(sim, _long_run_collection(900, 3, 5), 1)
+        parity.check_final(sim, _shared_ramps(700, 4, np.uint16).tobytes(), 2)
+        rng = np.random.default_rng(321)
+        for kind in parity.KINDS:
+            for _ in range(8):
+                d, w = parity.rand_collection(rng, kind)
+                parity.check_final(sim, d, w)
 
 
 def test_device_side_generators_match_host():

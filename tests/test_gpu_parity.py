@@ -122,6 +122,7 @@ def test_run_aware_suffix_keys(hip, oracle_mod, monkeypatch):
     import time
     import torch
     from tests.test_engine_logic_sim import _long_run_collection
+    monkeypatch.delenv("GRLBWT_RUN_KEYS_MIN", raising=False)
     data = _long_run_collection(10000, 6, 7)                # (the oracle is itself quadratic in the run length: 4 s here)
     with engine.Context(0, 0, hip) as ctx:
         ctx.upload(data, 1)
@@ -147,6 +148,47 @@ def test_run_aware_suffix_keys(hip, oracle_mod, monkeypatch):
     parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
     parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
     rng = np.random.default_rng(77)
+    for kind in parity.KINDS:
+        for _ in range(6):
+            d, w = parity.rand_collection(rng, kind)
+            parity.check_final(hip, d, w)
+
+
+def test_doubling_rounds_of_the_suffix_refinement(hip, oracle_mod, monkeypatch):
+    """Shared monotone ramps over a u32 alphabet (long phrases without runs): the refinement switches to doubling rounds.  A small
+    instance against the oracle, a 400 k-cell ramp in six strings by the device round trip (20 s before, with 200 001 rounds), then
+    doubling forced from the first round on for ordinary inputs."""
+    import time
+    import torch
+    from tests.test_engine_logic_sim import _long_run_collection, _shared_ramps
+    monkeypatch.delenv("GRLBWT_RUN_KEYS_MIN", raising=False)
+    monkeypatch.delenv("GRLBWT_DOUBLING_AFTER", raising=False)
+    cells = _shared_ramps(3000, 5)
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.upload(cells.tobytes(), 4)
+        ctx.build()
+        assert ctx.result_bytes() == oracle_mod.rl_bwt(cells.tobytes(), 4)
+        assert ctx.round_info(0)["sort_iters"] <= 45
+    big = _shared_ramps(400000, 6)
+    t = torch.from_numpy(big.view(np.int32).copy()).to("cuda:0")
+    out = torch.zeros_like(t)
+    with engine.Context(0, 0, hip) as ctx:
+        t0 = time.time()
+        ctx.attach_device(t.data_ptr(), t.numel(), 4, keepalive=t)
+        ctx.build()
+        torch.cuda.synchronize()
+        assert time.time() - t0 < 10.0
+        assert ctx.round_info(0)["sort_iters"] <= 60
+        nb, _ = ctx.result_size()
+        n = ctx.invert_image(ctx.result_device_ptr(), nb, 4, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    assert n == t.numel() and torch.equal(out, t)
+    monkeypatch.setenv("GRLBWT_RUN_KEYS_MIN", "0")
+    monkeypatch.setenv("GRLBWT_DOUBLING_AFTER", "0")
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
+    parity.check_final(hip, _long_run_collection(2000, 4, 5), 1)
+    rng = np.random.default_rng(78)
     for kind in parity.KINDS:
         for _ in range(6):
             d, w = parity.rand_collection(rng, kind)
