@@ -29,6 +29,16 @@ def cases():
     tok[(np.arange(1, 40) * (1 << 19))] = 0
     tok[-1] = 0
     out["u16_tokens_with_a_4M_run"] = (tok.view(np.uint8), 2)
+    out["tiny_strings_40M_x_1_symbol"] = (np.tile(np.frombuffer(b"A\nC\nG\nT\nA\n", dtype=np.uint8), 8 << 20), 1)
+    out["random_bytes_100MB_255_symbols"] = (np.concatenate([rng.integers(1, 256, size=100 << 20).astype(np.uint8), np.zeros(1, dtype=np.uint8)]), 1)
+    prot = rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8), size=400 << 20)
+    prot[(np.arange(1, 800000) * 524)] = 10
+    prot[-1] = 10
+    out["protein_like_400MB"] = (prot, 1)
+    long_strings = dna(1 << 30)
+    long_strings[(np.arange(1, 200) * ((1 << 30) // 200))] = 10
+    long_strings[-1] = 10
+    out["dna_1GB_in_200_strings"] = (long_strings, 1)
     return out
 
 
