@@ -710,6 +710,20 @@ __global__ void __launch_bounds__(kBlock) k_start_bits(u64 n, const cell_t *t, O
                     const u32 sl = ops.sym(s_c[wv * 64 + 63]);
                     u64 q = base + (u64)wv * 64 + 64;                // t[q] continues the run (P bit 63), q < n
                     bool walking = true;
+                    {   // long runs (an N gap of millions of cells behind a larger symbol): 4 x 8 bytes per step while they repeat the
+                        // run's cell -- the walk below takes two dependent loads per cell: 1 s for 5 M cells
+                        constexpr u64 per = 8 / sizeof(cell_t);
+                        const cell_t rc = t[q];
+                        u64 pat = 0;
+                        for (u64 x = 0; x < per; x++) pat = sizeof(cell_t) == 8 ? (u64)rc : ((pat << (8 * sizeof(cell_t) % 64)) | (u64)rc);
+                        bool fast = !ops.isT(rc);
+                        while (fast && q + 4 * per + 1 < n) {
+                            u64 d = 0;
+#pragma unroll
+                            for (int x = 0; x < 4; x++) { u64 v; __builtin_memcpy(&v, t + q + 1 + (u64)x * per, 8); d |= v ^ pat; }
+                            if (d) fast = false; else q += 4 * per;
+                        }
+                    }
                     while (walking) {
                         const cell_t cq = t[q];
                         if (ops.isT(cq) || q + 1 >= n) walking = false;            // the run reaches the string end: type L
