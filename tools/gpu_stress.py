@@ -39,6 +39,14 @@ def cases():
     long_strings[(np.arange(1, 200) * ((1 << 30) // 200))] = 10
     long_strings[-1] = 10
     out["dna_1GB_in_200_strings"] = (long_strings, 1)
+    big = rng.integers(1, 1 << 29, size=200 << 20, dtype=np.int64).astype(np.uint32)
+    big[(np.arange(1, 2000) * 100003)] = 0
+    big[-1] = 0
+    out["u32_random_200M_cells_29_bits"] = (big.view(np.uint8), 4)
+    zipf = (rng.zipf(1.3, size=100 << 20) % 50000 + 1).astype(np.uint32)
+    zipf[(np.arange(1, 5000) * 20011)] = 0
+    zipf[-1] = 0
+    out["u32_zipf_100M_cells"] = (zipf.view(np.uint8), 4)
     return out
 
 
@@ -52,7 +60,7 @@ def main():
         if want and name not in want:
             continue
         t = torch.from_numpy(np.ascontiguousarray(data)).to("cuda:0")
-        view = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[w]
+        view = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[w]
         cells = t.view(view)
         back = torch.zeros_like(cells)
         with engine.Context(0, 0, lib) as ctx:
