@@ -1984,8 +1984,19 @@ struct PhraseOwnerFn {
         if (k < pDs) {
             const prim::U128 r = pkeys[k];
             for (u64 j = 0; j < l; j++) ph.add(rec_sym(r, (u32)j, pkb));
-        } else
-            for (u64 j = 0; j < l; j++) ph.add((u32)ops.sym(t[o + j]));
+        } else {
+            // (eight independent loads per step: one lane walks the whole phrase, and a load and its latency per cell made a 5 M-cell
+            // phrase -- an N gap -- a 0.36 s affair)
+            u64 j = 0;
+            for (; j + 8 <= l; j += 8) {
+                cell_t c[8];
+#pragma unroll
+                for (int x = 0; x < 8; x++) c[x] = t[o + j + (u64)x];
+#pragma unroll
+                for (int x = 0; x < 8; x++) ph.add((u32)ops.sym(c[x]));
+            }
+            for (; j < l; j++) ph.add((u32)ops.sym(t[o + j]));
+        }
         const u64 h = ph.finish(l) * 0x9E3779B97F4A7C15ull;        // remixed: the table below takes its slot and tag from the plain hash
         owner[k] = (u32)(((h >> 32) * (u64)size) >> 32);
         idx[k] = (u32)k;
@@ -2105,7 +2116,17 @@ struct ListInsertFn {
     GRL_DEV void operator()(u64 i) const {
         const u64 o = off[i], l = len[i];
         PhraseHash ph = PhraseHash::init();
-        for (u64 j = 0; j < l; j++) ph.add(cells[o + j] >> 2);
+        {
+            u64 j = 0;                           // (eight independent loads per step: see PhraseOwnerFn)
+            for (; j + 8 <= l; j += 8) {
+                u32 c[8];
+#pragma unroll
+                for (int x = 0; x < 8; x++) c[x] = cells[o + j + (u64)x];
+#pragma unroll
+                for (int x = 0; x < 8; x++) ph.add(c[x] >> 2);
+            }
+            for (; j < l; j++) ph.add(cells[o + j] >> 2);
+        }
         const u64 h = ph.finish(l);
         const u64 tag = h >> kPosBits;
         const u64 mine = (tag << kPosBits) | (i + 1);
@@ -2124,7 +2145,12 @@ struct ListInsertFn {
                 if (len[i2] == l) {
                     const u64 o2 = off[i2];
                     u32 diff = 0;
-                    for (u64 j = 0; j < l; j++) diff |= cells[o2 + j] ^ cells[o + j];
+                    u64 j = 0;
+                    for (; j + 8 <= l && diff == 0; j += 8) {
+#pragma unroll
+                        for (int x = 0; x < 8; x++) diff |= cells[o2 + j + (u64)x] ^ cells[o + j + (u64)x];
+                    }
+                    for (; j < l; j++) diff |= cells[o2 + j] ^ cells[o + j];
                     hit = diff == 0;
                 }
             }

@@ -51,6 +51,50 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if case.startswith("gaps_dev:"):
+        # gaps_dev:<Mbp per string>:<gap Mbp>: every rank holds two strings with a long N gap each (lease script: the sharded flow on
+        # very long phrases); rank 0 also builds the whole collection alone and compares
+        import time
+        _, mbp, gap = case.split(":")
+        mbp, gap = int(mbp), int(gap)
+        dev = torch.device(device)
+
+        def string(k):
+            rng = np.random.default_rng(100 + k)
+            s_ = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=mbp * 1000000 + 31 * k)
+            s_[len(s_) // 3: len(s_) // 3 + gap * 1000000 + 7 * k] = ord("N")
+            return np.concatenate([s_, np.array([10], dtype=np.uint8)])
+        mine = np.concatenate([string(2 * rank), string(2 * rank + 1)])
+        text = torch.from_numpy(mine).to(dev)
+        comm = gdist.Communicator(dev)
+        with engine.Context(dev.index or 0, gdist.pool_flags(comm), lib) as ctx:
+            for rep in range(2):
+                ctx.profile_enable(rep == 1)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+                gdist.dist_build(ctx, comm)
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+            out = ctx.result_bytes()
+            if rank == 0:
+                for k, (c, ms, nb) in sorted(ctx.profile().items(), key=lambda kv: -kv[1][1])[:8]:
+                    print("  %-32s %4d %10.2f ms" % (k, c, ms), flush=True)
+        msg = "rank %d: sharded build %.2f s, image md5 %s" % (rank, dt, hashlib.md5(out).hexdigest())
+        if rank == 0:
+            whole = torch.from_numpy(np.concatenate([string(k) for k in range(2 * world)])).to(dev)
+            with engine.Context(dev.index or 0, 0, lib) as ctx:
+                for rep in range(2):
+                    t0 = time.time()
+                    ctx.attach_device(whole.data_ptr(), whole.numel(), 1, keepalive=whole)
+                    ctx.build()
+                    torch.cuda.synchronize()
+                    d1 = time.time() - t0
+                msg += "; single-GPU build %.2f s, md5 %s" % (d1, hashlib.md5(ctx.result_bytes()).hexdigest())
+        print(msg, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if case == "illformed":
         # rank 1 holds a shard that does not end with the separator: EVERY rank must raise (no rank may be left waiting
         # in the first collective of the build)
