@@ -329,6 +329,10 @@ def main():
                     # (run 0 is a warm-up and is dropped: it backs ~90 GB of device memory this process has not touched.  A few
                     # seconds between runs: the driver scrubs a process's device memory after its exit, and a process that starts
                     # into that waits for it in its first allocations -- measured 2-3 s on some boxes, none on others)
+                    try:
+                        os.remove(fout)              # a fresh output file every run (replacing an existing 8 GB output costs the release
+                    except OSError:                  # of its cached pages inside rename(): ~0.6 s that belong to the previous run)
+                        pass
                     time.sleep(3.0)
                     tc = time.perf_counter()
                     p = subprocess.run([cli, fin, "-o", fout], capture_output=True, text=True)

@@ -16,6 +16,7 @@
 #include <atomic>
 
 #include <chrono>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -247,26 +248,42 @@ static int run_multi_gpu(const arguments &args) {
     }
     // Reap in completion order.  A rank that ends abnormally (non-zero exit, a signal) may leave its peers inside a
     // collective that will never complete: the page tells the ones still at the rendezvous, the others are killed.
-    int worst = 0;
+    // The exit code reported is the FIRST non-zero one (later ones are usually consequences: a peer killed here ends with 2).
+    int first_bad = 0;
     size_t left = kids.size();
     bool killed = false;
+    auto reap = [&](pid_t pid, int status) {
+        bool mine = false;
+        for (pid_t &k : kids) if (k == pid) { k = -1; mine = true; }
+        if (!mine) return false;
+        left--;
+        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 2;
+        if (code != 0 && first_bad == 0) first_bad = code;
+        return code != 0;
+    };
     while (left > 0) {
         int status = 0;
         const pid_t pid = waitpid(-1, &status, 0);
-        if (pid < 0) break;
-        bool mine = false;
-        for (pid_t &k : kids) if (k == pid) { k = -1; mine = true; }
-        if (!mine) continue;
-        left--;
-        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 2;
-        if (code > worst) worst = code;
-        if (code != 0 && !killed) {
+        if (pid < 0) {
+            if (errno == EINTR) continue;        // (a signal delivered to the parent: the ranks are still running)
+            break;                               // ECHILD: nothing left to wait for
+        }
+        if (reap(pid, status) && !killed) {
             sh->aborted.store(1);
-            usleep(300000);                      // ranks that fail together (an agreed error) print their message and leave by themselves
+            // ranks that fail together (an agreed error) print their message, tear their arenas down and leave by themselves:
+            // give them up to 2 s (polling), then kill what is still inside a collective that will never complete
+            for (int waited_ms = 0; left > 0 && waited_ms < 2000; ) {
+                const pid_t q = waitpid(-1, &status, WNOHANG);
+                if (q > 0) { reap(q, status); continue; }
+                if (q < 0 && errno != EINTR) break;
+                usleep(20000);
+                waited_ms += 20;
+            }
             for (pid_t k : kids) if (k > 0) kill(k, SIGKILL);
             killed = true;
         }
     }
+    const int worst = first_bad;
     return worst;
 }
 

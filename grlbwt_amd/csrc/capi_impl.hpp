@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -140,6 +141,7 @@ bool par_io(int fd, char *buf, uint64_t off, uint64_t len, bool write, int nthr)
     };
     if (nthr < 1) nthr = 1;
     if (len < ((uint64_t)4 << 20)) nthr = 1;
+    if (nthr == 1) { bool ok1 = true; one(off, off + len, &ok1); return ok1; }      // (no thread of its own)
     std::vector<std::thread> th;
     std::vector<char> oks(nthr, 1);
     const uint64_t part = (len + nthr - 1) / nthr;
@@ -389,19 +391,14 @@ void load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fx_flags, uint64_t *
 // pwrite() threads -- 8, 16, 32 measured alike on the 8.3 GB image of the 10 GB build: buffered writes to one file serialise on
 // its inode lock.  Filling a shared mapping of the file from 16 threads instead was 4x SLOWER: 4.1-4.5 s, page faults.)
 void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
-    // a fresh file: rewriting an existing 6.7 GB output in place (O_TRUNC) took 2.3 s against 0.9 s for a new one.  Dropping the
-    // old file's cached pages costs too (unlink of an 8.3 GB output: ~0.6 s of a 10 GB run): it is moved aside and removed by a
-    // thread of its own while the new file is written.
-    struct stat st0;
-    std::thread remover;
-    if (stat(path, &st0) == 0 && S_ISREG(st0.st_mode)) {
-        const std::string aside = std::string(path) + ".old~" + std::to_string((long)getpid());
-        if (rename(path, aside.c_str()) == 0) remover = std::thread([aside] { unlink(aside.c_str()); });
-        else unlink(path);
-    }
-    struct JoinAtExit { std::thread &t; ~JoinAtExit() { if (t.joinable()) t.join(); } } join_remover{remover};
-    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + path);
+    // The image goes to <path>.tmp~<pid> and is renamed over the target once it is complete and closed (the reference renames
+    // bwt_lev_0 to the output name, grl_bwt.hpp:77): an existing output stays intact until then, and a run that is killed or fails
+    // leaves at most the temporary behind -- removed on every error path here.  A fresh file is also the fast way to write:
+    // rewriting an existing 6.7 GB output in place (O_TRUNC) took 2.3 s against 0.9 s for a new one.  What replacing an existing
+    // output costs is the release of its cached pages inside rename() (~0.6 s for 8.3 GB).
+    const std::string tmp = std::string(path) + ".tmp~" + std::to_string((long)getpid());
+    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + tmp);
     char *bufs[2] = {nullptr, nullptr};
     prim::Fence fences[2];
     std::atomic<bool> ok(true);               // written by the writer thread, read by the loop
@@ -419,7 +416,11 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
             if (writer.joinable()) writer.join();
             prim::fence_wait(fences[k]);
             poff = off; plen = len; pk = k;
-            writer = std::thread([&, poff, plen, pk] { if (!par_io(fd, bufs[pk], poff, plen, true, io_threads())) ok = false; });
+            try {
+                writer = std::thread([&, poff, plen, pk] { if (!par_io(fd, bufs[pk], poff, plen, true, io_threads())) ok = false; });
+            } catch (const std::system_error &) {                     // no thread to be had: write this chunk here
+                if (!par_io(fd, bufs[pk], poff, plen, true, 1)) ok = false;
+            }
         }
         if (writer.joinable()) writer.join();
     } catch (...) {
@@ -427,11 +428,13 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
         try { prim::sync(); } catch (...) {}
         for (int k = 0; k < 2; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
         close(fd);
+        unlink(tmp.c_str());
         throw;
     }
     for (int k = 0; k < 2; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
     if (close(fd) != 0) ok = false;
-    if (!ok) throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path);
+    if (ok && rename(tmp.c_str(), path) != 0) ok = false;
+    if (!ok) { unlink(tmp.c_str()); throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path); }
 }
 
 // ---- primitive self-test (device vs host loops) -----------------------------

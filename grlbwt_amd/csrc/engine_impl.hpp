@@ -21,8 +21,8 @@
 //   a12 parse2bwt                   exact_ind_phase.cpp:603-672             -> Engine::first_bwt
 //   a13 compute_hocc_size           exact_ind_phase.cpp:42-109              -> Engine::expand_split: ChainGen through prim::expand_count
 //   a14 infer_lvl_bwt pass B        exact_ind_phase.cpp:143-258             -> ... and prim::expand_sort (expansion fused with the first split pass)
-//   a15 infer_lvl_bwt pass C        exact_ind_phase.cpp:287-361             -> Engine::assemble_t: TakeScanEmitFn, PrePlaceFn, CellAtomsFn,
-//                                                                               PreAtomsFn, BigAtomsFn, merge_atoms
+//   a15 infer_lvl_bwt pass C        exact_ind_phase.cpp:287-361             -> Engine::assemble_t: TermHeadEmitFn, PrePlaceFn, AsmSeg through
+//                                                                               prim::stream_merge_count / stream_merge_emit
 //   8e  collection-level mode       parsing_strategies.h:200-386 (thread ranges) -> Engine::dist_build (dist_round_t, dist_induce_level, dist_finish)
 //   8f2 .rl_bwt consumers           scripts/*.cpp                            -> image_plain / image_rle / image_stats / image_split_runs / invert_image
 //   8f3 FASTA/Q ingestion           external/bioparsers/lib/fastx_handler.cpp, kseq.h -> Engine::fastx_to_text
@@ -65,6 +65,14 @@ struct DBuf {
 };
 
 static inline unsigned bitlen64(u64 v) { return v == 0 ? 0 : 64 - (unsigned)__builtin_clzll(v); }
+
+// Fault injection for the multi-rank failure-agreement tests (tests/test_dist_gloo.py): compiled into the serial test stand-in
+// only (prim::kIsDevice is false there).  The product library never reads these variables: no environment can make a
+// production rank throw "injected by the test".
+static inline bool test_fail_rank(const char *var, int me) {
+    if constexpr (prim::kIsDevice) { (void)var; (void)me; return false; }
+    else { const char *fr = getenv(var); return fr && atoi(fr) == me; }
+}
 
 // ----------------------------------------------------------------- searches
 // first index i in [0,n) with a[i] > v  (n if none)
@@ -1539,42 +1547,6 @@ static inline Runs merge_runs(const u32 *sym, const idx_t *len, u64 n, u32 *merg
     return out;
 }
 
-// the same over packed atoms  sym << lbits | len  (pass C writes 8 bytes per atom instead of 4 + sizeof(idx_t))
-struct AtomHeadLenIn {
-    const u64 *a; int lbits;
-    GRL_DEV HeadLen operator()(u64 t) const {
-        const u64 x = a[t];
-        return HeadLen((t == 0 || (x >> lbits) != (a[t - 1] >> lbits)) ? (idx_t)1 : (idx_t)0, (idx_t)(x & ((1ull << lbits) - 1ull)));
-    }
-};
-struct AtomMergeEmitFn {
-    static constexpr bool kWaveEmit = false;
-    const u64 *a; int lbits; u64 n;
-    u32 *osym; idx_t *ostart;
-    GRL_DEV void operator()(u64 t, HeadLen ex, HeadLen v) const {
-        if (v.a) { osym[ex.a] = (u32)(a[t] >> lbits); ostart[ex.a] = ex.b; }
-        if (t == n - 1) ostart[ex.a + v.a] = ex.b + v.b;
-    }
-};
-static inline Runs merge_atoms(const u64 *atoms, u64 n, int lbits) {
-    Runs out;
-    if (n == 0) { out.sym.alloc(0); out.len.alloc(0); return out; }
-    DBuf<u32> hsym(n);
-    DBuf<idx_t> ostart(n + 1);
-    HeadLen tot = prim::exclusive_scan_emit<HeadLen>(n, AtomHeadLenIn{atoms, lbits}, AtomMergeEmitFn{atoms, lbits, n, hsym.p, ostart.p}, "merge_runs.scan");
-    u64 R = (u64)tot.a;
-    out.n = (u64)tot.b;
-    out.len.alloc(R);
-    prim::for_each(R, DiffFn{ostart.p, out.len.p}, "merge_runs.len");
-    // the heads' scratch (sized for the worst case) becomes the symbol array as it is, unless it is much larger than what it
-    // holds (a copy of 4 R bytes -- 6.6 GB at level 0 of the 10 GB build -- for nothing but a tighter allocation otherwise)
-    if (R * 2 >= n) out.sym = std::move(hsym);
-    else { out.sym.alloc(R); prim::d2d(out.sym.p, hsym.p, R * sizeof(u32)); }
-    out.pos = std::move(ostart);      // (pass C of the next level wants exactly this prefix: no scan of the lengths there)
-    out.R = R;
-    return out;
-}
-
 // --------------------------------------------------------- a12: parse2bwt
 struct CellSymFn {
     const u32 *t; u32 *sym; idx_t *len;
@@ -1687,21 +1659,31 @@ struct CellView {
         return fused32 ? (idx_t)((fused32[t] >> kb) & ((1u << lb) - 1u))
                        : fused ? (idx_t)((fused[t] >> kb) & ((1ull << lb) - 1ull)) : packed ? (idx_t)(packed[t] & 0xFFFFFFFFull) : slen[t];
     }
+    GRL_DEV void load(u64 t, u32 &s, idx_t &l) const {      // symbol and length from ONE load of the cell
+        if (fused32) { const u32 w = fused32[t]; s = w >> (kb + lb); l = (idx_t)((w >> kb) & ((1u << lb) - 1u)); }
+        else if (fused) { const u64 w = fused[t]; s = (u32)(w >> (kb + lb)); l = (idx_t)((w >> kb) & ((1ull << lb) - 1ull)); }
+        else if (packed) { const u64 w = packed[t]; s = (u32)(w >> 32); l = (idx_t)(w & 0xFFFFFFFFull); }
+        else { s = ssym[t]; l = slen[t]; }
+    }
 };
 struct CellHeadIn {     // 1 where a cell does not merge with its predecessor (other bucket or other symbol): the reference's n_runs
     CellView c;
     GRL_DEV u64 operator()(u64 t) const { return (t == 0 || c.key(t) != c.key(t - 1) || c.sym(t) != c.sym(t - 1)) ? 1ull : 0ull; }
 };
-// ---- pass C without materialised segments --------------------------------------------------------------------
+// ---- pass C as a stream merge (prim::stream_merge_*) -------------------------------------------------------------
 // Output order = pre-BWT order with every HOCC run replaced by the cells of its buckets.  A "segment" is a non-HOCC
 // pre-BWT run or a cell; segment index of cell t: nhb[j] + t (j = pre-BWT run of its bucket), of pre-BWT run j:
 // nhb[j] + #cells of buckets in front of it.  TAKE segments (TAKE cells, BWT-marker runs) tile the T axis (the symbols
-// of BWT_{r+1}); X = T prefix of a segment = (TAKE lengths of the cells before it) + (BWT-marker lengths of the pre-BWT
-// runs before it).  A TAKE segment [a, b) becomes one atom per run of BWT_{r+1} it touches.  First atom of a segment:
-//     abase = g + #(run starts of BWT_{r+1} strictly inside TAKE segments in front of it)
-//           = g + (#run starts in (0, X)) - (#positions in (0, X) that are a run start AND a TAKE segment start)
-// both counts are ranks in bit-vectors over the T axis (n_{r+1} bits): nothing of segment size is scanned twice, no
-// segment or atom-count arrays exist, and only the cells' TAKE prefix (one scan) is stored.
+// of the rewritten BWT_{r+1}) in output order, so the T position of a segment is the sum of the TAKE lengths in front of
+// it, and BWT_r is the stream of the literal segments and of the pieces of T the TAKE segments cut out, with equal
+// neighbours merged.  prim::stream_merge_* does exactly that in three forward passes over the segments; what it needs:
+//   * which segments are pre-BWT runs: a bit-vector over the segment axis with ranks (RankCell), the non-HOCC runs compacted
+//     in order (nh_sym / nh_len) -- the cells are the other segments, in their own order;
+//   * the MAXIMAL runs of the rewritten BWT_{r+1} (the chain walks rewrite symbols, neighbours may have become equal): esym /
+//     epos, and their starts as a bit-vector over T with ranks.
+// (Rounds 1-3: a scan gave every cell its T prefix (stored), two bit-vectors over T their first output atom through a rank
+// each, a kernel gathered five arrays per cell to place packed atoms, another scan merged the atoms: 346 GB of traffic for
+// 42 GB priced, 206 ms of the 10 GB build.)
 typedef prim::Pair<idx_t, idx_t> HoccBwt;      // (HOCC-marker symbols, BWT-marker symbols) scanned together over the pre-BWT
 struct PreScanIn {
     const u32 *sym; const idx_t *len; u32 hocc_code, bwt_code;
@@ -1710,89 +1692,42 @@ struct PreScanIn {
         return HoccBwt(s == hocc_code ? len[j] : (idx_t)0, s == bwt_code ? len[j] : (idx_t)0);
     }
 };
-template <class TC>
-struct CellTakeIn {       // TAKE length of a cell (0 for literal cells)
-    CellView c; u32 take_code;
-    GRL_DEV TC operator()(u64 t) const { return c.sym(t) == take_code ? (TC)c.len(t) : (TC)0; }
-};
 // first cell whose bucket is >= u (cells are sorted by bucket)
 GRL_DEV u64 cell_lower_bound(const CellView &c, u64 E, u32 u) {
     u64 lo = 0, hi = E;
     while (lo < hi) { u64 mid = (lo + hi) >> 1; if (c.key(mid) < u) lo = mid + 1; else hi = mid; }
     return lo;
 }
-// The two bit-vectors over the T axis and their ranks, interleaved: word i of both and the counts in front of it share one
-// 32-byte cell, so that "first atom of a segment" -- a rank in each vector at the same position -- is ONE gather instead of
-// four (the cell and atom kernels were bound by the number of gather instructions: 35 per pair of cells in round 2).
-struct alignas(32) TCell { u64 tw, tb, cw, cb; };        // run starts of BWT_{r+1} / their count in front; coincidences / their count
-struct alignas(16) TCellT { u64 tw, tb; };               // (the first half alone: 16-byte loads)
-GRL_DEV u64 trank(const TCell *tc, u64 x) {              // run starts in [0, x)
-    const TCellT c = *reinterpret_cast<const TCellT *>(&tc[x >> 6]);
-    return c.tb + (u64)__builtin_popcountll(c.tw & ((1ull << (x & 63)) - 1ull));
+struct alignas(16) RankCell { u64 w; u64 b; };        // a word of a bit-vector and the number of set bits in front of it: ONE 16-byte load per rank
+GRL_DEV u64 rank_in(const RankCell *rc, u64 x) {      // set bits in [0, x)
+    const RankCell c = rc[x >> 6];
+    return c.b + (u64)__builtin_popcountll(c.w & ((1ull << (x & 63)) - 1ull));
 }
-struct TCellPopcIn {      // popcount of one of the two vectors (which: 0 = tw, 2 = cw)
-    const TCell *tc; int which;
-    GRL_DEV u64 operator()(u64 i) const { return (u64)__builtin_popcountll(reinterpret_cast<const u64 *>(&tc[i])[which]); }
+struct RankCellPopcIn {
+    const RankCell *rc;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)__builtin_popcountll(rc[i].w); }
 };
-struct TCellBaseEmitFn {  // ... and its exclusive prefix into the neighbouring field
+struct RankCellBaseEmitFn {
     static constexpr bool kWaveEmit = false;
-    TCell *tc; int which;
-    GRL_DEV void operator()(u64 i, u64 ex, u64) const { reinterpret_cast<u64 *>(&tc[i])[which + 1] = ex; }
+    RankCell *rc;
+    GRL_DEV void operator()(u64 i, u64 ex, u64) const { rc[i].b = ex; }
 };
-GRL_DEV void mark_coincidence(TCell *tc, u64 x) {
-    if (x && ((tc[x >> 6].tw >> (x & 63)) & 1ull)) prim::atomic_or(&tc[x >> 6].cw, 1ull << (x & 63));
-}
-template <class TC>
-struct PrePlaceFn {       // non-HOCC pre-BWT runs: segment index, T prefix; BWT-marker runs mark their T start
-    const u32 *psym; const HoccBwt *PHB; const idx_t *nhb; const u32 *u_to_p; u64 M; CellView c; u64 E; const TC *Tc;
+struct PrePlaceFn {       // non-HOCC pre-BWT runs, compacted in order: segment index, symbol, length
+    const u32 *psym; const idx_t *plen; const idx_t *nhb; const u32 *u_to_p; u64 M; CellView c; u64 E;
     const u32 *p_to_u; const idx_t *first_cell;      // optional O(1) forms of the two searches (nullptr: search)
-    u32 hocc_code, bwt_code;
-    idx_t *pre_g; idx_t *pre_x; TCell *tc;
+    u32 hocc_code;
+    idx_t *seg_pos; u32 *nh_sym; idx_t *nh_len;
     GRL_DEV void operator()(u64 j) const {
         u32 s = psym[j];
         if (s != hocc_code) {
             u64 ustar = p_to_u ? (u64)p_to_u[j] : lower_bound<u32>(u_to_p, M, (u32)j);      // metasymbols whose pre-BWT run lies in front of j
             u64 cs = first_cell ? (u64)first_cell[ustar] : cell_lower_bound(c, E, (u32)ustar);   // ... and their cells
-            u64 x = (u64)PHB[j].b + (u64)Tc[cs];
-            pre_g[j] = (idx_t)((u64)nhb[j] + cs);
-            pre_x[j] = (idx_t)x;
-            if (s == bwt_code) mark_coincidence(tc, x);
+            const u64 i = (u64)nhb[j];
+            seg_pos[i] = (idx_t)(i + cs);
+            nh_sym[i] = s;
+            nh_len[i] = plen[j];
         }
     }
-};
-// Emit side of the TAKE-prefix scan over the cells: stores the prefix and marks, on the T axis, the TAKE cells whose
-// start is also a run start of BWT_{r+1} (the coincidences; a separate pass that marked every TAKE start and ANDed the
-// two bit-vectors afterwards cost 54 ms at level 0 of the 10 GB build, this costs one bit test per TAKE cell)
-template <class TC>
-struct TakeScanEmitFn {
-    CellView c; const u32 *u_to_p; const HoccBwt *PHB; u32 take_code; u64 E; TCell *tc; TC *Tc;
-    GRL_DEV void operator()(u64 t, TC ex, TC v) const {
-        Tc[t] = ex;
-        if (t == E - 1) Tc[E] = ex + v;
-        if (c.sym(t) == take_code) mark_coincidence(tc, (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b);
-    }
-#ifdef GRLBWT_PRIM_HIP
-    // Wave-cooperative form (prim::k_scan_tiles calls it with all lanes): the marks of 64 consecutive cells fall into a
-    // handful of words of cw -- TAKE segments start where runs of BWT_{r+1} start far more often than not, 738 M marks at
-    // level 0 of the 10 GB build -- so the wave ORs them together and issues one atomic per word (device atomics run at
-    // ~20-27 G/s whatever the footprint: tools/membench.hip; this scan took 37 ms there with one atomic per mark).
-    static constexpr bool kWaveEmit = true;
-    GRL_DEV void wave(u64 t, TC ex, TC v, bool valid) const {
-        u64 x = 0;
-        bool mk = false;
-        if (valid) {
-            Tc[t] = ex;
-            if (t == E - 1) Tc[E] = ex + v;
-            if (c.sym(t) == take_code) {
-                x = (u64)ex + (u64)PHB[u_to_p[c.key(t)]].b;
-                mk = x && ((tc[x >> 6].tw >> (x & 63)) & 1ull);
-            }
-        }
-        prim::wave_or_words(reinterpret_cast<u64 *>(tc), mk, (x >> 6) * 4 + 2, 1ull << (x & 63));      // (word index of TCell::cw)
-    }
-#else
-    static constexpr bool kWaveEmit = false;
-#endif
 };
 // first_cell[m] = first cell whose bucket is >= m (m in [0, M]) = exclusive prefix of the bucket sizes.  The bucket heads
 // record where their bucket starts (+1: 0 = empty) and where the bucket in front of them ends; sizes -> one scan.
@@ -1838,109 +1773,32 @@ struct BlockPlaceFn {
     const K *in; K kmask; u32 u0; const idx_t *off; K *out;
     GRL_DEV void operator()(u64 t) const { const K c = in[t]; out[(idx_t)(off[(u32)(c & kmask) - u0] + (idx_t)t)] = c; }
 };
-// atoms of one segment; a TAKE segment touching more than kInlineAtoms runs is queued for the wide kernel
-static constexpr u32 kInlineAtoms = 16;
-struct BigSeg { u64 abase, a, b, k0; };
-struct AtomEmitter {
-    const TCell *tc; const idx_t *Tpos; const u32 *term;
-    u32 *osym; idx_t *olen; u64 *oatom; int lbits;      // oatom != nullptr: packed atoms sym << lbits | len
-    BigSeg *big; u32 *big_n; u32 big_cap;
-    GRL_DEV u64 abase_of(u64 g, u64 x) const {
-        u64 o = g;
-        if (x) {
-            const TCell c = tc[x >> 6];
-            const u64 below = (1ull << (x & 63)) - 1ull;
-            o = g + (c.tb + (u64)__builtin_popcountll(c.tw & below) - 1) - (c.cb + (u64)__builtin_popcountll(c.cw & below));
-        }
-        return o;
-    }
-    GRL_DEV void put(u64 o, u32 sym, u64 len) const {
-        if (oatom) oatom[o] = ((u64)sym << lbits) | len;
-        else { osym[o] = sym; olen[o] = (idx_t)len; }
-    }
-    GRL_DEV void literal(u64 g, u64 x, u32 sym, idx_t len) const { put(abase_of(g, x), sym, (u64)len); }
-    GRL_DEV void take(u64 g, u64 a, u64 len) const {
-        const u64 k0 = trank(tc, a + 1) - 1;                         // run of BWT_{r+1} holding T position a
-        take_at(abase_of(g, a), a, len, k0, trank(tc, a + len) - k0);
-    }
-    // TAKE segment [a, a+len) whose first atom is o, first run k0, number of runs touched cnt
-    GRL_DEV void take_at(u64 o, u64 a, u64 len, u64 k0, u64 cnt) const {
-        const u64 b = a + len;
-        // (if / else, no early return: hipcc 7.2 has let lanes of a branch that returned run the stores behind it)
-        if (cnt > kInlineAtoms) {
-            u32 slot = prim::atomic_add(big_n, 1u);
-            if (slot < big_cap) big[slot] = BigSeg{o, a, b, k0};
-        } else {
-            u64 s = a;
-            for (u64 x = 0; x < cnt; x++) {
-                u64 e = (u64)Tpos[k0 + x + 1];
-                if (e > b) e = b;
-                put(o + x, term[k0 + x], e - s);
-                s = e;
-            }
-        }
-    }
+// the maximal runs of the rewritten BWT_{r+1}: run k starts one (exact_ind_phase.cpp:257 rewrites the symbols, the lengths stay)
+struct TermHeadIn {
+    const u32 *term;
+    GRL_DEV idx_t operator()(u64 k) const { return (k == 0 || term[k] != term[k - 1]) ? (idx_t)1 : (idx_t)0; }
 };
-// Two cells per lane: the address chain of a cell (bucket -> pre-BWT run -> T prefix -> rank words -> run index) is five
-// dependent gathers deep and the kernel waits on them at full occupancy; taking two cells through the chain together
-// keeps twice the loads in flight.  (Straight-line up to the emission, which loops over the runs a TAKE cell spans.)
-template <class TC, int NC = 2>
-struct CellAtomsFn {
-    CellView c; const u32 *u_to_p; const HoccBwt *PHB; const idx_t *nhb; const TC *Tc; u32 take_code; AtomEmitter em; u64 E;
-    GRL_DEV void operator()(u64 h) const {
-        u64 t[NC], g[NC], x[NC], l[NC], o[NC], f[NC], n[NC];
-        u32 k[NC], j[NC], s[NC];
-        bool tk[NC];
-#pragma unroll
-        for (int e = 0; e < NC; e++) { t[e] = NC * h + e < E ? NC * h + e : NC * h; k[e] = c.key(t[e]); }     // (a short tail repeats the first cell and is not emitted)
-#pragma unroll
-        for (int e = 0; e < NC; e++) j[e] = u_to_p[k[e]];
-#pragma unroll
-        for (int e = 0; e < NC; e++) {
-            g[e] = (u64)nhb[j[e]] + t[e];
-            x[e] = (u64)Tc[t[e]] + (u64)PHB[j[e]].b;
-            s[e] = c.sym(t[e]);
-            l[e] = (u64)c.len(t[e]);
-            tk[e] = s[e] == take_code;
-        }
-        // ranks of all cells: the loads of the chains are independent
-#pragma unroll
-        for (int e = 0; e < NC; e++) {
-            o[e] = em.abase_of(g[e], x[e]);                                         // (one 32-byte gather)
-            f[e] = tk[e] ? trank(em.tc, x[e] + 1) - 1 : 0;                          // run holding the TAKE start
-            n[e] = tk[e] ? trank(em.tc, x[e] + l[e]) - f[e] : 0;
-        }
-#pragma unroll
-        for (int e = 0; e < NC; e++) {
-            if (e == 0 || NC * h + e < E) { if (tk[e]) em.take_at(o[e], x[e], l[e], f[e], n[e]); else em.put(o[e], s[e], l[e]); }
-        }
-    }
+struct TermHeadEmitFn {
+    static constexpr bool kWaveEmit = false;
+    const u32 *term; const idx_t *Tpos; u32 *esym; idx_t *epos;
+    GRL_DEV void operator()(u64 k, idx_t ex, idx_t v) const { if (v) { esym[ex] = term[k]; epos[ex] = Tpos[k]; } }
 };
-struct PreAtomsFn {
-    const u32 *psym; const idx_t *plen; const idx_t *pre_g; const idx_t *pre_x; u32 hocc_code, bwt_code; AtomEmitter em;
-    GRL_DEV void operator()(u64 j) const {
-        const u32 s = psym[j];
-        if (s != hocc_code) {
-            if (s == bwt_code) em.take((u64)pre_g[j], (u64)pre_x[j], (u64)plen[j]);
-            else em.literal((u64)pre_g[j], (u64)pre_x[j], s, plen[j]);
-        }
+// the segment stream of one level (prim::stream_merge protocol)
+struct AsmSeg {
+    const RankCell *kinds;                      // over the segment axis: bit g = segment g is a (non-HOCC) pre-BWT run
+    const u32 *nh_sym; const idx_t *nh_len;     // those runs in order
+    CellView c; u32 take_code;
+    const RankCell *tstarts; const u32 *esym_; const idx_t *epos_;
+    GRL_DEV void load(u64 g, u32 &sym, idx_t &len, bool &take) const {
+        const RankCell kc = kinds[g >> 6];
+        const u64 ord = kc.b + (u64)__builtin_popcountll(kc.w & ((1ull << (g & 63)) - 1ull));
+        if ((kc.w >> (g & 63)) & 1ull) { sym = nh_sym[ord]; len = nh_len[ord]; }
+        else c.load(g - ord, sym, len);
+        take = sym == take_code;
     }
-};
-struct BigCountIn {
-    const BigSeg *big; const TCell *tc;
-    GRL_DEV u64 operator()(u64 i) const { return trank(tc, big[i].b) - big[i].k0; }
-};
-struct BigAtomsFn {       // one lane per atom of the queued segments
-    const BigSeg *big; const u64 *bbase; u64 nbig; const idx_t *Tpos; const u32 *term; AtomEmitter em;
-    GRL_DEV void operator()(u64 y) const {
-        const u64 i = upper_bound<u64>(bbase, nbig, y) - 1;
-        const BigSeg sg = big[i];
-        const u64 x = y - bbase[i], k = sg.k0 + x;
-        u64 s = (u64)Tpos[k], e = (u64)Tpos[k + 1];
-        if (s < sg.a) s = sg.a;
-        if (e > sg.b) e = sg.b;
-        em.put(sg.abase + x, term[k], e - s);
-    }
+    GRL_DEV u64 erank(u64 x) const { return rank_in(tstarts, x); }
+    GRL_DEV u32 esym(u64 k) const { return esym_[k]; }
+    GRL_DEV u64 epos(u64 k) const { return (u64)epos_[k]; }
 };
 
 // ------------------------------------------------------- a16: .rl_bwt image
@@ -2652,7 +2510,6 @@ template <int IB> struct RunRecT;
 template <> struct alignas(8) RunRecT<4> { u32 delta; u32 sym; };
 template <> struct alignas(16) RunRecT<8> { u64 delta; u32 sym; u32 pad; };
 typedef RunRecT<sizeof(idx_t)> RunRec;
-struct alignas(16) RankCell { u64 w; u64 b; };        // a word of the run-start bit-vector and the number of run starts in front of it: ONE gather per rank
 struct RankCellFn {
     const u64 *words; const idx_t *base; RankCell *rc;
     GRL_DEV void operator()(u64 i) const { rc[i] = RankCell{words[i], (u64)base[i]}; }
@@ -3309,7 +3166,7 @@ class Engine {
                     u64 Sown = 0;
                     try {
                         // (GRLBWT_TEST_FAIL_RANK_SORT=<rank>: the tests make one rank fail here)
-                        if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_SORT")) if (atoi(fr) == me) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
+                        if (test_fail_rank("GRLBWT_TEST_FAIL_RANK_SORT", me)) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
                         const u64 ns = S < 8192 ? S : 8192, stride = S / ns;
                         DBuf<u64> samp(ns), dspl(N);
                         prim::for_each(ns, SampleKey0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, stride, samp.p, rk}, "dist.sample_keys");
@@ -3832,8 +3689,7 @@ class Engine {
             Tpos.alloc(bwt.R + 1);
             Tsum = (u64)prim::exclusive_scan<idx_t>(bwt.R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "asm.Tpos");
         }
-        if (Tsum < 0xFFFFFFFFull) assemble_t<u32>(in, I, cells, E, Tpos, Tsum, term, r);      // the cells' TAKE prefix fits 32 bits
-        else assemble_t<u64>(in, I, cells, E, Tpos, Tsum, term, r);
+        assemble_t(in, I, cells, E, Tpos, Tsum, term, r);
     }
     void release_level(LevelData &L) {           // the level's grammar is no longer needed
         L.g0.release(); L.g1.release(); L.has_hocc.release(); L.u_to_p.release(); L.p_to_u.release(); L.prebwt.sym.release(); L.prebwt.len.release();
@@ -3866,34 +3722,27 @@ class Engine {
         release_level(L);
     }
     // pass C (exact_ind_phase.cpp:287-361): BWT_r from the pre-BWT, the induced cells and the rewritten BWT_{r+1}
-    template <class TC>
     void assemble_t(const AsmIn &L, LevelInfo &I, const CellView &cells, u64 E, DBuf<idx_t> &Tpos, u64 Tsum, DBuf<u32> &term, int r) {
         const u32 bwt_code = L.sigma + 1, hocc_code = L.sigma + 2, take_code = bwt_code;
         const u64 R = bwt.R, P = L.P, M = L.M;
-        // pre-BWT coordinates: (HOCC symbols, BWT-marker symbols) and the number of non-HOCC runs in front of every run
-        DBuf<HoccBwt> PHB(P + 1);
+        // ---- the maximal runs of the rewritten BWT_{r+1} and their starts over the T axis
+        DBuf<u32> esym(R ? R : 1);
+        DBuf<idx_t> epos(R + 1);
+        const u64 Re = R ? (u64)prim::exclusive_scan_emit<idx_t>(R, TermHeadIn{term.p}, TermHeadEmitFn{term.p, Tpos.p, esym.p, epos.p}, "asm.truns") : 0;
+        Tpos.release(); term.release();
+        bwt.sym.release(); bwt.len.release();
+        const u64 nwT = Tsum / 64 + 2;
+        DBuf<RankCell> tstarts(nwT);
+        tstarts.zero();
+        if (Re) prim::for_each((Re + 15) / 16, BuildBitsFn{epos.p, Re, reinterpret_cast<u64 *>(tstarts.p), 2}, "asm.tbits");
+        prim::exclusive_scan_emit<u64>(nwT, RankCellPopcIn{tstarts.p}, RankCellBaseEmitFn{tstarts.p}, "asm.tbits");
+        // ---- the non-HOCC pre-BWT runs, compacted, and where they sit among the segments
         DBuf<idx_t> nhb(P + 1);
-        prim::exclusive_scan_nosync<HoccBwt>(P, PreScanIn{L.psym, L.plen, hocc_code, bwt_code}, PHB.p, true, "asm.pre_scan");
         const u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.psym, hocc_code}, nhb.p, true, "asm.nhb");
-        const u64 PBsum = (u64)PHB.get(P).b;
-        // bit-vectors over the T axis (n_{r+1} bits): run starts of BWT_{r+1}; TAKE segment starts that are run starts too
-        const u64 nw = Tsum / 64 + 2;
-        DBuf<TCell> tcell(nw);
-        tcell.zero();
-        prim::for_each((R + 15) / 16, BuildBitsFn{Tpos.p, R, reinterpret_cast<u64 *>(tcell.p), 4}, "asm.tbits");
-        prim::exclusive_scan_emit<u64>(nw, TCellPopcIn{tcell.p, 0}, TCellBaseEmitFn{tcell.p, 0}, "asm.tbits");
-        // the cells' TAKE prefix (scan fused with the coincidence marks)
-        DBuf<TC> Tc(E + 1);
-        u64 TCsum = 0;
-        if (E) TCsum = (u64)prim::exclusive_scan_emit<TC>(E, CellTakeIn<TC>{cells, take_code},
-                                                           TakeScanEmitFn<TC>{cells, L.u_to_p, PHB.p, take_code, E, tcell.p, Tc.p},
-                                                           "asm.take_scan");
-        else Tc.zero();
-        if (PBsum + TCsum != Tsum) throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
-                                                              std::to_string(PBsum + TCsum) + " vs " + std::to_string(Tsum) + ")");
         const u64 G = NH + E;
         I.G = G;
-        DBuf<idx_t> pre_g(P), pre_x(P);
+        DBuf<idx_t> seg_pos(NH ? NH : 1), nh_len(NH ? NH : 1);
+        DBuf<u32> nh_sym(NH ? NH : 1);
         {
             // where the cells of the buckets in front of a pre-BWT run end: a table over the metasymbols when the runs are
             // many (one pass over the cells), a binary search per run when they are few (level 0: 45 k runs, 2.6 G cells)
@@ -3905,46 +3754,39 @@ class Engine {
                 prim::for_each(E, BucketEdgesFn{cells, E, bstart1.p, bend.p}, "asm.first_cell");
                 prim::exclusive_scan_nosync<idx_t>(M, BucketSizeIn{bstart1.p, bend.p}, first_cell.p, true, "asm.first_cell");
             }
-            prim::for_each(P, PrePlaceFn<TC>{L.psym, PHB.p, nhb.p, L.u_to_p, M, cells, E, Tc.p, L.p_to_u, first_cell.p,
-                                             hocc_code, bwt_code, pre_g.p, pre_x.p, tcell.p}, "asm.pre_place");
+            prim::for_each(P, PrePlaceFn{L.psym, L.plen, nhb.p, L.u_to_p, M, cells, E, L.p_to_u, first_cell.p, hocc_code,
+                                         seg_pos.p, nh_sym.p, nh_len.p}, "asm.pre_place");
         }
-        const u64 Ctot = prim::exclusive_scan_emit<u64>(nw, TCellPopcIn{tcell.p, 2}, TCellBaseEmitFn{tcell.p, 2}, "asm.coinc_rank");
-        const u64 A = G + (R ? R - 1 : 0) - Ctot;           // every run start in (0, Tsum) that is no TAKE segment start cuts one atom
-        I.A = A;
-        // atoms: one packed word  sym << lbits | len  whenever a symbol and a length of this level fit 64 bits together
-        const int lbits = (int)bitlen64(L.n_out), sbits = (int)bitlen64((u64)L.sigma + 3);
-        const bool packed_atoms = lbits + sbits <= 64;
-        DBuf<u32> osym;
-        DBuf<idx_t> olen;
-        DBuf<u64> oatom;
-        if (packed_atoms) oatom.alloc(A); else { osym.alloc(A); olen.alloc(A); }
-        const u32 big_cap = (u32)std::min<u64>(A / kInlineAtoms + 16, 0x7FFFFFFFull);
-        DBuf<BigSeg> big(big_cap);
-        DBuf<u32> big_n(1);
-        big_n.zero();
-        const AtomEmitter em{tcell.p, Tpos.p, term.p, osym.p, olen.p,
-                             packed_atoms ? oatom.p : nullptr, lbits, big.p, big_n.p, big_cap};
-        // (four cells per lane: 46.3 vs 43.2 ms at level 0 of the 10 GB build -- two it stays)
-        // (2 cells per lane; 1 and 4 were measured again in round 3 on the 10 GB build: 43.0 / 40.7 / 42.9 ms at level 0 for
-        // 1 / 2 / 4 -- the kernel is bound neither by loads in flight per lane nor by vector issue)
-        prim::for_each((E + 1) / 2, CellAtomsFn<TC, 2>{cells, L.u_to_p, PHB.p, nhb.p, Tc.p, take_code, em, E}, "asm.cell_atoms");
-        prim::for_each(P, PreAtomsFn{L.psym, L.plen, pre_g.p, pre_x.p, hocc_code, bwt_code, em}, "asm.pre_atoms");
-        const u64 nbig = (u64)big_n.get(0);
-        if (nbig > big_cap) throw prim::Error(-71, "induction: wide-segment queue overflow (level " + std::to_string(r) + ")");
-        if (nbig) {                                          // TAKE segments spanning many runs: one lane per atom
-            DBuf<u64> bbase(nbig + 1);
-            const u64 nb_atoms = prim::exclusive_scan<u64>(nbig, BigCountIn{big.p, tcell.p}, bbase.p, true, "asm.big_scan");
-            prim::for_each(nb_atoms, BigAtomsFn{big.p, bbase.p, nbig, Tpos.p, term.p, em}, "asm.big_atoms");
-        }
-        // everything but the atoms can go before the merge allocates its scan arrays (peak memory)
-        Tc.release(); pre_g.release(); pre_x.release(); PHB.release(); nhb.release(); big.release();
-        tcell.release();
-        Tpos.release(); term.release();
+        nhb.release();
+        const u64 nwG = G / 64 + 2;
+        DBuf<RankCell> kinds(nwG);
+        kinds.zero();
+        if (NH) prim::for_each((NH + 15) / 16, BuildBitsFn{seg_pos.p, NH, reinterpret_cast<u64 *>(kinds.p), 2}, "asm.kinds");
+        prim::exclusive_scan_emit<u64>(nwG, RankCellPopcIn{kinds.p}, RankCellBaseEmitFn{kinds.p}, "asm.kinds");
+        seg_pos.release();
+        // ---- the stream merge: count (T positions, run heads), then emit
+        const AsmSeg seg{kinds.p, nh_sym.p, nh_len.p, cells, take_code, tstarts.p, esym.p, epos.p};
+        prim::SmPlan<idx_t> plan;
+        prim::stream_merge_count<AsmSeg, idx_t>(G, seg, plan, "asm");
+        if (plan.take_total != Tsum) { plan.release(); throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
+                                                                                       std::to_string(plan.take_total) + " vs " + std::to_string(Tsum) + ")"); }
+        if (plan.len_total != L.n_out) { plan.release(); throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(plan.len_total) +
+                                                                                       " symbols, the level has " + std::to_string(L.n_out)); }
+        I.A = plan.atoms;
+        const u64 Ro = plan.heads;
+        Runs out;
+        out.sym.alloc(Ro); out.pos.alloc(Ro + 1);
+        try { prim::stream_merge_emit<AsmSeg, idx_t>(seg, plan, out.sym.p, out.pos.p, "asm"); } catch (...) { plan.release(); throw; }
+        plan.release();
+        const idx_t total = (idx_t)L.n_out;
+        prim::h2d(out.pos.p + Ro, &total, sizeof(idx_t));
+        // everything but the runs can go before their lengths are taken (peak memory)
+        kinds.release(); nh_sym.release(); nh_len.release(); tstarts.release(); esym.release(); epos.release();
         release_cells();
-        bwt.sym.release(); bwt.len.release();
-        bwt = packed_atoms ? merge_atoms(oatom.p, A, lbits) : merge_runs(osym.p, olen.p, A);
-        if (bwt.n != L.n_out) throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(bwt.n) +
-                                                              " symbols, the level has " + std::to_string(L.n_out));
+        out.len.alloc(Ro);
+        prim::for_each(Ro, DiffFn{out.pos.p, out.len.p}, "merge_runs.len");
+        out.R = Ro; out.n = L.n_out;
+        bwt = std::move(out);
     }
     // the induced cells of the level being assembled (owned here so that pass C can drop them before the run merge)
     DBuf<u32> c_skey, c_ssym, c_sfused32; DBuf<idx_t> c_slen; DBuf<u64> c_spack, c_sfused, c_gp;
@@ -4042,7 +3884,7 @@ class Engine {
             // counts: Comm::fail)
             try {
                 // (GRLBWT_TEST_FAIL_RANK=<rank>: the tests make one rank fail here)
-                if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK")) if (atoi(fr) == me) throw prim::Error(-28, "phrase hash table overflow (injected by the test)");
+                if (test_fail_rank("GRLBWT_TEST_FAIL_RANK", me)) throw prim::Error(-28, "phrase hash table overflow (injected by the test)");
                 // (levels above 0: partitioned naming as on one GPU -- short phrases are records in P.ph_key, not text positions)
                 hash_local<cell_t, FIRST>(t, n, ops, P, L, !getenv("GRLBWT_DIST_NO_PART"));
                 DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D), soff(P.D + 1);
@@ -4109,7 +3951,7 @@ class Engine {
             DBuf<u64> goff, o_pos; DBuf<idx_t> o_freq; DBuf<u32> o_len, o_off; DBuf<u8> o_lastT;
             try {
                 // (GRLBWT_TEST_FAIL_RANK_MERGE=<rank>: the tests make one rank fail here)
-                if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_MERGE")) if (atoi(fr) == me) throw prim::Error(-28, "merged phrase table overflow (injected by the test)");
+                if (test_fail_rank("GRLBWT_TEST_FAIL_RANK_MERGE", me)) throw prim::Error(-28, "merged phrase table overflow (injected by the test)");
                 goff.alloc(Dr + 1);
                 const u64 chk = prim::exclusive_scan<u64>(Dr, LenIn{rlen.p}, goff.p, true, "dist.list_offsets");
                 if (chk != Sr) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
@@ -4239,8 +4081,11 @@ class Engine {
             u64 mr = 0;
             try {
                 StageTimer st(&tm.ind_expand);
-                Tpos.alloc(R + 1);
-                Tlocal = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "dist.Tpos");
+                if (bwt.pos.p) { Tpos = std::move(bwt.pos); Tlocal = bwt.n; }      // pass C of the level above left my slice's prefix behind
+                else {
+                    Tpos.alloc(R + 1);
+                    Tlocal = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{bwt.len.p}, Tpos.p, true, "dist.Tpos");
+                }
                 mr = level_maxrun();
             } catch (const prim::Error &e) { C.fail(e); Tlocal = 0; mr = 0; }
             std::vector<u64> g1 = C.allgather_u64({mr, Tlocal});
@@ -4261,7 +4106,7 @@ class Engine {
             term.alloc(R);
             split.alloc(4 * ((u64)N + 1));
             // (GRLBWT_TEST_FAIL_RANK_INDUCE=<rank>: the tests make one rank fail here)
-            if (const char *fr = getenv("GRLBWT_TEST_FAIL_RANK_INDUCE")) if (atoi(fr) == me) throw prim::Error(-12, "out of device memory (injected by the test)");
+            if (test_fail_rank("GRLBWT_TEST_FAIL_RANK_INDUCE", me)) throw prim::Error(-12, "out of device memory (injected by the test)");
             E = expand_split(L, term, maxrun, kb, lb);
             I.E = E;
             StageTimer st(&tm.ind_assemble);

@@ -2344,4 +2344,268 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
     after_launch(name);
 }
 
+// ------------------------------------------------------------------ stream merge (induction pass C)
+// A sequence of G segments in OUTPUT order.  Segment g is a literal run (sym, len) or a TAKE of `len` symbols from an axis T
+// that the TAKE segments consume front to back, each where the one in front of it stopped.  T is given by its MAXIMAL runs
+// (neighbours differ in symbol): erank(x) = run starts in [0, x), esym(k) / epos(k) = symbol / first position of run k.
+// Result: the maximal runs of the concatenation, (symbol, first symbol position) per run -- written once, in order; nothing of
+// segment or atom size is stored in between.
+//     SEG:  void load(u64 g, u32 &sym, IDX &len, bool &take)       u64 erank(u64 x)      u32 esym(u64 k)      u64 epos(u64 k)
+// Three streaming passes over the segments, one workgroup per tile of kSmTile segments:
+//     k_sm_sums    (sum of TAKE lengths, sum of lengths) per tile      -> scans: T position / symbol position at every tile start
+//     k_sm_merge<false>  the tile's segments in LDS, a block scan gives every segment its T position; a TAKE segment
+//                  [x, x + len) touches the runs erank(x + 1) - 1 .. erank(x + len) - 1 (two rank loads; neighbouring lanes hit
+//                  the same words); a run head = an atom whose symbol differs from the atom in front of it -> heads per tile
+//     k_sm_merge<true>   the same once more, now with the run index at every tile start: the heads are stored
+// (Output order = segment order = T order: every access of the three passes runs forward through its array.  The form this
+// replaces computed the T prefix of every cell with a scan of its own, stored it, gathered five arrays per cell to place
+// packed atoms, wrote them, and merged them with another scan: 105 ms at level 0 of the 10 GB build against ~35.)
+static constexpr int kSmSpt = 4;                           // segments per thread
+static constexpr int kSmTile = kBlock * kSmSpt;            // 1024 segments per tile
+static constexpr u32 kSmNoSym = 0xFFFFFFFFu;
+static constexpr u32 kSmInline = 8;                        // atoms behind the first a lane stores by itself; a TAKE that spans more runs of T is queued
+                                                           // and copied by a kernel of its own, one lane per atom (a pre-BWT run of BWT markers can
+                                                           // take tens of millions of runs: the deep levels of a read collection)
+template <class IDX>
+struct SmWide { IDX r, L, x, cnt; u64 k; };                // run index / symbol position / T position of the segment, atoms behind the first, first of their runs
+template <class IDX>
+struct SmPlan {
+    u64 G = 0, tiles = 0;
+    IDX *xbase = nullptr, *lbase = nullptr, *hbase = nullptr;       // [tiles + 1] exclusive prefixes: TAKE symbols, symbols, run heads
+    u64 take_total = 0, len_total = 0, heads = 0, atoms = 0;
+    u64 wide_n = 0, wide_atoms = 0;                                 // queued TAKE segments and their atoms
+    void release() {
+        if (xbase) dev_free(xbase);
+        if (lbase) dev_free(lbase);
+        if (hbase) dev_free(hbase);
+        xbase = lbase = hbase = nullptr;
+    }
+};
+template <class SEG, class IDX>
+__global__ void __launch_bounds__(kBlock) k_sm_sums(u64 G, SEG seg, IDX *tile_take, IDX *tile_len) {
+    __shared__ IDX s_a[4], s_b[4];
+    const u64 base = (u64)blockIdx.x * kSmTile;
+    IDX a = 0, b = 0;
+#pragma unroll
+    for (int j = 0; j < kSmSpt; j++) {
+        const u64 g = base + (u64)j * kBlock + threadIdx.x;
+        if (g < G) {
+            u32 sym; IDX len; bool take;
+            seg.load(g, sym, len, take);
+            a += take ? len : (IDX)0;
+            b += len;
+        }
+    }
+    a = wave_reduce<IDX, Op::Sum>(a);
+    b = wave_reduce<IDX, Op::Sum>(b);
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_take[blockIdx.x] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        tile_len[blockIdx.x] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    }
+}
+// wide[]: [0] queued segments, [1] their atoms (count pass: totals; emit pass: wide[2] = queue fill)
+template <class SEG, class IDX, bool EMIT>
+__global__ void __launch_bounds__(kBlock) k_sm_merge(u64 G, SEG seg, const IDX *xbase, const IDX *lbase, const IDX *hbase, IDX *tile_heads, IDX *tile_atoms,
+                                                     unsigned long long *wide, SmWide<IDX> *queue, u64 queue_cap, u32 *osym, IDX *ostart) {
+    constexpr int TILE = kSmTile, SPT = kSmSpt;
+    typedef Pair<IDX, IDX> P2;
+    __shared__ u32 s_sym[TILE + TILE / 32];                 // bit 31: TAKE (symbols are < 2^30); skewed by one slot per 32
+    __shared__ IDX s_len[TILE + TILE / 32];
+    __shared__ P2 s_w2[4];
+    __shared__ IDX s_w1[4];
+    __shared__ u32 s_last[kBlock];
+    const u64 base = (u64)blockIdx.x * TILE;
+    // striped loads (neighbouring lanes, neighbouring segments) -> LDS -> blocked (a lane's segments are consecutive)
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        const u32 k = (u32)j * kBlock + threadIdx.x;
+        const u64 g = base + k;
+        u32 sym = 0; IDX len = 0; bool take = false;
+        if (g < G) seg.load(g, sym, len, take);
+        s_sym[k + (k >> 5)] = sym | (take ? 0x80000000u : 0u);
+        s_len[k + (k >> 5)] = len;
+    }
+    __syncthreads();
+    u32 sy[SPT]; IDX ln[SPT];
+    P2 acc(0);
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const u32 k = threadIdx.x * SPT + i;
+        sy[i] = s_sym[k + (k >> 5)];
+        ln[i] = s_len[k + (k >> 5)];
+        acc.a += (sy[i] & 0x80000000u) ? ln[i] : (IDX)0;
+        acc.b += ln[i];
+    }
+    P2 tot;
+    const P2 ex = block_excl_scan<P2>(acc, s_w2, &tot);
+    const u64 g0 = base + (u64)threadIdx.x * SPT;
+    IDX xs[SPT], Ls[SPT];
+    {
+        IDX x = xbase[blockIdx.x] + ex.a, L = lbase[blockIdx.x] + ex.b;
+#pragma unroll
+        for (int i = 0; i < SPT; i++) { xs[i] = x; Ls[i] = L; x += (sy[i] & 0x80000000u) ? ln[i] : (IDX)0; L += ln[i]; }
+    }
+    // runs of T every TAKE segment touches: two rank loads each, all of a lane's in flight together
+    u64 k0[SPT], k1[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const bool tk = (g0 + i < G) && (sy[i] & 0x80000000u);
+        k0[i] = tk ? seg.erank((u64)xs[i] + 1) - 1 : 0;
+        k1[i] = tk ? seg.erank((u64)xs[i] + (u64)ln[i]) : 0;
+    }
+    u32 fs[SPT], ls[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const bool tk = (g0 + i < G) && (sy[i] & 0x80000000u);
+        fs[i] = tk ? seg.esym(k0[i]) : (sy[i] & 0x7FFFFFFFu);
+        ls[i] = (tk && k1[i] - k0[i] > 1) ? seg.esym(k1[i] - 1) : fs[i];
+    }
+    // the symbol in front of my first segment: the last symbol of the lane in front of me; lane 0: of the segment in front of the tile
+    {
+        u32 mine = kSmNoSym;
+#pragma unroll
+        for (int i = 0; i < SPT; i++) if (g0 + i < G) mine = ls[i];
+        s_last[threadIdx.x] = mine;
+    }
+    __syncthreads();
+    u32 prev = kSmNoSym;
+    if (threadIdx.x > 0) prev = s_last[threadIdx.x - 1];
+    else if (base > 0) {
+        u32 sym; IDX len; bool take;
+        seg.load(base - 1, sym, len, take);
+        prev = take ? seg.esym(seg.erank((u64)xbase[blockIdx.x]) - 1) : sym;     // (a TAKE in front of the tile ends where the tile's T range starts)
+    }
+    bool head[SPT];
+    IDX nh = 0, na = 0;
+    u32 nwide = 0;
+    unsigned long long wide_atoms = 0;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const bool v = g0 + i < G;
+        const IDX inner = (v && (sy[i] & 0x80000000u)) ? (IDX)(k1[i] - k0[i] - 1) : (IDX)0;
+        head[i] = v && fs[i] != prev;
+        nh += (head[i] ? (IDX)1 : (IDX)0) + inner;
+        na += (v ? (IDX)1 : (IDX)0) + inner;
+        if (inner > (IDX)kSmInline) { nwide++; wide_atoms += (unsigned long long)inner; }
+        if (v) prev = ls[i];
+    }
+    if constexpr (!EMIT) {
+        nh = wave_reduce<IDX, Op::Sum>(nh);
+        na = wave_reduce<IDX, Op::Sum>(na);
+        const unsigned long long anyw = __ballot(nwide != 0);
+        if (anyw) {                            // (rare: one pair of atomics per wave that holds a wide segment)
+            nwide = wave_reduce<u32, Op::Sum>(nwide);
+            wide_atoms = wave_reduce<unsigned long long, Op::Sum>(wide_atoms);
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&wide[0], (unsigned long long)nwide); atomicAdd(&wide[1], wide_atoms); }
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { s_w2[threadIdx.x >> 6] = P2(nh, na); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tile_heads[blockIdx.x] = s_w2[0].a + s_w2[1].a + s_w2[2].a + s_w2[3].a;
+            tile_atoms[blockIdx.x] = s_w2[0].b + s_w2[1].b + s_w2[2].b + s_w2[3].b;
+        }
+    } else {
+        IDX htot;
+        IDX r = hbase[blockIdx.x] + block_excl_scan<IDX>(nh, s_w1, &htot);
+#pragma unroll
+        for (int i = 0; i < SPT; i++) {
+            if (g0 + i < G) {
+                if (head[i]) { osym[r] = fs[i]; ostart[r] = Ls[i]; r++; }
+                if (sy[i] & 0x80000000u) {
+                    const IDX inner = (IDX)(k1[i] - k0[i] - 1);
+                    if (inner > (IDX)kSmInline) {
+                        const u64 q = (u64)atomicAdd(&wide[2], 1ull);
+                        if (q < queue_cap) queue[q] = SmWide<IDX>{r, Ls[i], xs[i], inner, k0[i] + 1};
+                    } else {
+                        for (IDX a = 0; a < inner; a++) {
+                            const u64 k = k0[i] + 1 + (u64)a;
+                            osym[r + a] = seg.esym(k);
+                            ostart[r + a] = Ls[i] + (IDX)(seg.epos(k) - (u64)xs[i]);
+                        }
+                    }
+                    r += inner;
+                }
+            }
+        }
+    }
+}
+template <class IDX>
+struct SmWideCountIn {
+    const SmWide<IDX> *q;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)q[i].cnt; }
+};
+// the atoms of the queued TAKE segments, one lane per atom (entries in queue order, qbase = exclusive prefix of their counts)
+template <class SEG, class IDX>
+__global__ void __launch_bounds__(kBlock) k_sm_wide(u64 natoms, u64 nq, SEG seg, const SmWide<IDX> *queue, const u64 *qbase, u32 *osym, IDX *ostart) {
+    const u64 stride = (u64)gridDim.x * kBlock;
+    for (u64 y = (u64)blockIdx.x * kBlock + threadIdx.x; y < natoms; y += stride) {
+        u64 lo = 0, hi = nq;                   // last entry with qbase <= y
+        while (lo + 1 < hi) { const u64 mid = (lo + hi) >> 1; if (qbase[mid] <= y) lo = mid; else hi = mid; }
+        const SmWide<IDX> e = queue[lo];
+        const u64 a = y - qbase[lo], k = e.k + a;
+        osym[e.r + (IDX)a] = seg.esym(k);
+        ostart[e.r + (IDX)a] = e.L + (IDX)(seg.epos(k) - (u64)e.x);
+    }
+}
+// passes 1 + 2: the plan's prefixes and totals (one host synchronisation); pass 3 follows through stream_merge_emit
+template <class SEG, class IDX>
+inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *name = "stream_merge") {
+    plan.release();
+    plan = SmPlan<IDX>();
+    plan.G = G;
+    if (G == 0) return;
+    plan.tiles = (G + kSmTile - 1) / kSmTile;
+    const u64 T = plan.tiles;
+    plan.xbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    plan.lbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    plan.hbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    IDX *tatoms = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    prof_begin(std::string(name) + ".sums");
+    hipLaunchKernelGGL((k_sm_sums<SEG, IDX>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, plan.xbase, plan.lbase);
+    prof_end();
+    after_launch(name);
+    u64 *dres = (u64 *)dev_alloc(6 * sizeof(u64));      // [0] TAKE symbols, [1] symbols, [2] heads, [3] atoms, [4] wide segments, [5] their atoms
+    dev_memset(dres, 0, 6 * sizeof(u64));               // (the scans store IDX-wide totals into zeroed words)
+    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.xbase}, plan.xbase, (IDX *)(dres + 0), plan.xbase + T, name);
+    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.lbase}, plan.lbase, (IDX *)(dres + 1), plan.lbase + T, name);
+    prof_begin(std::string(name) + ".count");
+    hipLaunchKernelGGL((k_sm_merge<SEG, IDX, false>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
+                       (const IDX *)nullptr, plan.hbase, tatoms, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
+    prof_end();
+    after_launch(name);
+    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.hbase}, plan.hbase, (IDX *)(dres + 2), plan.hbase + T, name);
+    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{tatoms}, tatoms, (IDX *)(dres + 3), (IDX *)nullptr, name);
+    u64 h[6];
+    d2h(h, dres, 6 * sizeof(u64));
+    dev_free(dres); dev_free(tatoms);
+    plan.take_total = h[0]; plan.len_total = h[1]; plan.heads = h[2]; plan.atoms = h[3]; plan.wide_n = h[4]; plan.wide_atoms = h[5];
+}
+template <class SEG, class IDX>
+inline void stream_merge_emit(SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart, const char *name = "stream_merge") {
+    if (plan.G == 0) return;
+    const u64 nq = plan.wide_n;
+    SmWide<IDX> *queue = (SmWide<IDX> *)dev_alloc((nq ? nq : 1) * sizeof(SmWide<IDX>));
+    unsigned long long *wide = (unsigned long long *)dev_alloc(3 * sizeof(unsigned long long));
+    dev_memset(wide, 0, 3 * sizeof(unsigned long long));
+    prof_begin(std::string(name) + ".emit", plan.heads * (sizeof(u32) + sizeof(IDX)));
+    hipLaunchKernelGGL((k_sm_merge<SEG, IDX, true>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
+                       (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, wide, queue, nq, osym, ostart);
+    prof_end();
+    after_launch(name);
+    if (nq) {
+        u64 *qbase = (u64 *)dev_alloc((nq + 1) * sizeof(u64));
+        exclusive_scan_async<u64, SmWideCountIn<IDX>>(nq, SmWideCountIn<IDX>{queue}, qbase, (u64 *)nullptr, qbase + nq, name);
+        prof_begin(std::string(name) + ".wide", plan.wide_atoms * (sizeof(u32) + sizeof(IDX)));
+        hipLaunchKernelGGL((k_sm_wide<SEG, IDX>), dim3(grid_for(plan.wide_atoms, kBlock)), dim3(kBlock), 0, rt().stream, plan.wide_atoms, nq, seg,
+                           (const SmWide<IDX> *)queue, (const u64 *)qbase, osym, ostart);
+        prof_end();
+        after_launch(name);
+        dev_free(qbase);
+    }
+    dev_free(queue); dev_free(wide);
+}
+
 }   // namespace prim

@@ -339,4 +339,49 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
     }
 }
 
+// stream merge (serial form of prim_hip.hpp's: segments in output order -> maximal runs)
+template <class IDX>
+struct SmPlan {
+    u64 G = 0;
+    u64 take_total = 0, len_total = 0, heads = 0, atoms = 0;
+    void release() {}
+};
+template <class SEG, class IDX, class PUT>
+inline void sm_walk(u64 G, const SEG &seg, SmPlan<IDX> &plan, PUT put) {
+    u64 x = 0, L = 0, heads = 0, atoms = 0;
+    u32 prev = 0xFFFFFFFFu;
+    for (u64 g = 0; g < G; g++) {
+        u32 sym; IDX len; bool take;
+        seg.load(g, sym, len, take);
+        if (take) {
+            const u64 k0 = seg.erank(x + 1) - 1, k1 = seg.erank(x + (u64)len);
+            for (u64 k = k0; k < k1; k++) {
+                const u32 s = seg.esym(k);
+                atoms++;
+                if (k > k0 || s != prev) { put(heads, s, k == k0 ? L : L + (seg.epos(k) - x)); heads++; }
+                prev = s;
+            }
+            x += (u64)len;
+        } else {
+            atoms++;
+            if (sym != prev) { put(heads, sym, L); heads++; }
+            prev = sym;
+        }
+        L += (u64)len;
+    }
+    plan.take_total = x; plan.len_total = L; plan.heads = heads; plan.atoms = atoms;
+}
+template <class SEG, class IDX>
+inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char * = "") {
+    plan = SmPlan<IDX>();
+    plan.G = G;
+    sm_walk(G, seg, plan, [](u64, u32, u64) {});
+}
+template <class SEG, class IDX>
+inline void stream_merge_emit(SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart, const char * = "") {
+    SmPlan<IDX> again = plan;
+    sm_walk(plan.G, seg, again, [&](u64 r, u32 s, u64 at) { osym[r] = s; ostart[r] = (IDX)at; });
+    if (again.heads != plan.heads) throw Error(-71, "stream_merge_emit: the second walk found a different number of runs");
+}
+
 }   // namespace prim

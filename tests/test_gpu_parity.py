@@ -467,6 +467,25 @@ def test_result_pointer_is_complete_when_build_returns(hip, oracle_mod):
             assert bytes(img.cpu().numpy()) == exp
 
 
+def test_final_bytes_vs_oracle_250MB(hip, oracle_mod):
+    """The largest input compared byte for byte with the oracle ("What's weak" 3): 1.65 M Illumina-style reads of
+    150 bp from an 8.3 Mbp genome (249 MB, 30x coverage, 0.5 % substitutions -- the headline distribution at 1/40 of its
+    size), default switches, one build; the oracle takes about a minute of one host core."""
+    import torch
+    data = workloads.sampled_reads(1650000, 150, 8300000, seed=20260417)
+    assert data.size == 1650000 * 151
+    dev = torch.from_numpy(data).to("cuda:0")
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(dev.data_ptr(), dev.numel(), 1, keepalive=dev)
+        ctx.build()
+        got = ctx.result_bytes()
+    del dev
+    exp = oracle_mod.rl_bwt(data.tobytes(), 1)
+    assert len(got) == len(exp)
+    assert got == exp, "HIP .rl_bwt differs from the oracle on the 249 MB input"
+
+
 def test_idx64_build_round_trip_4_3GB(hip):
     """A TRUE 64-bit index build (n >= 2^32 - 256 cells, no FORCE flag): 28,443,491 x 150 bp Illumina-style reads
     (4,294,967,141 bytes), built and inverted on the device (grl2plain + reverse_bwt kernels), compared byte for byte."""

@@ -67,9 +67,12 @@ def main():
     torch.cuda.empty_cache()
     # (b) CLI end to end, file in page cache
     for rep in range(2):
-        p = subprocess.run([cli, path, "-o", "/tmp/fx_out"], capture_output=True, text=True)
+        # (--fastx: the conversion is opt-in, as in the reference; without it the file would be read as one-string-per-line cells)
+        p = subprocess.run([cli, path, "--fastx", "-o", "/tmp/fx_out"], capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("grlbwt-timing:")]
         out["cli_rc"] = p.returncode
+        assert p.returncode == 0, p.stderr[-500:]
+        assert "The input is in FASTA/Q format" in p.stdout, p.stdout[-500:]
         out["cli_timing_%d" % rep] = line[0] if line else p.stderr[-300:]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "fastx_e2e_%d%s.json" % (reads, "_gz" if gz else "")), "w") as f:
