@@ -1508,10 +1508,20 @@ struct DiffFn {
 
 struct Runs {
     DBuf<u32> sym;
-    DBuf<idx_t> len;
+    DBuf<idx_t> len;      // (pass C leaves only `pos` behind: what reads the lengths there goes through RunLen / Engine::need_len)
     DBuf<idx_t> pos;      // optional: first symbol position of every run + total (R + 1 entries), kept from the merge that made the runs
     u64 R = 0;
     u64 n = 0;            // symbols described (set by merge_runs)
+};
+// length of run i, from the lengths or from the runs' position prefix (a difference array of R entries, written and read once
+// per level, was 6 ms at level 0 of the 10 GB build)
+struct RunLen {
+    const idx_t *len; const idx_t *pos;
+    GRL_DEV idx_t operator()(u64 i) const { return len ? len[i] : (idx_t)(pos[i + 1] - pos[i]); }
+};
+struct RunLenIn64 {
+    RunLen l;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)l(i); }
 };
 
 // merge adjacent equal symbols (bwt_io.h push_back/inc_freq_last idiom): -> maximal runs.
@@ -1583,7 +1593,7 @@ struct TakeCountIn {      // 1 if the run's symbol has hidden occurrences (it dr
 enum { CELLS_SEPARATE = 0, CELLS_PACKED = 1, CELLS_FUSED = 2 };
 template <int MODE>
 struct ChainExpandFn {
-    const u32 *nsym; const idx_t *nlen; const u64 *gp; const idx_t *eoff;
+    const u32 *nsym; RunLen nlen; const u64 *gp; const idx_t *eoff;
     u32 sigma3, take_code;
     u32 *ekey; idx_t *eidx; u32 *esym; idx_t *elen; u64 *epack; u32 *term;
     int kb, lb;                                   // CELLS_FUSED: epack[e] = sym << (kb+lb) | len << kb | bucket
@@ -1595,7 +1605,7 @@ struct ChainExpandFn {
     }
     GRL_DEV void operator()(u64 i) const {
         u32 cur = nsym[i];
-        idx_t f = nlen[i];
+        idx_t f = nlen(i);
         u64 e = eoff[i];
         u64 c = gp[cur];
         if (c & 0x80000000ull) put(e++, cur, take_code, f);
@@ -1613,7 +1623,7 @@ struct ChainExpandFn {
 // bucket split; protocol in prim_hip.hpp): nodes are metasymbols, a node's record is its packed grammar cell, keys are
 // the fused cells sym << (kb+lb) | len << kb | bucket, finish() rewrites the run's symbol (exact_ind_phase.cpp:257).
 struct ChainGen {
-    const u32 *nsym; const idx_t *nlen; const u64 *gp;
+    const u32 *nsym; RunLen nlen; const u64 *gp;
     u32 sigma3, take_code;
     u32 *term;
     int kb, lb;
@@ -1622,7 +1632,7 @@ struct ChainGen {
     GRL_DEV bool owns(u64 rec) const { return (rec & 0x80000000ull) != 0; }
     GRL_DEV bool more(u64 rec) const { return (u32)(rec >> 32) >= sigma3; }
     GRL_DEV u32 next(u64 rec) const { return (u32)(rec >> 32) - sigma3; }
-    GRL_DEV u64 item_bits(u64 i) const { return (u64)nlen[i] << kb; }
+    GRL_DEV u64 item_bits(u64 i) const { return (u64)nlen(i) << kb; }
     GRL_DEV u64 key_own(u32 u, u64 ib) const { return ((u64)take_code << (kb + lb)) | ib | (u64)u; }
     GRL_DEV u64 key_step(u64 rec, u32 b, u64 ib) const { return ((u64)((u32)rec & 0x7FFFFFFFu) << (kb + lb)) | ib | (u64)b; }
     GRL_DEV void finish(u64 i, u64 rec) const { term[i] = (u32)(rec >> 32); }
@@ -1789,25 +1799,33 @@ struct AsmSeg {
     const u32 *nh_sym; const idx_t *nh_len;     // those runs in order
     CellView c; u32 take_code;
     const RankCell *tstarts; const u32 *esym_; const idx_t *epos_;
-    GRL_DEV void load(u64 g, u32 &sym, idx_t &len, bool &take) const {
+    struct Ref { u64 idx; bool pre; };          // where the record of a segment sits: pre-BWT run idx of the compacted ones, or cell idx
+    GRL_DEV Ref locate(u64 g) const {
         const RankCell kc = kinds[g >> 6];
         const u64 ord = kc.b + (u64)__builtin_popcountll(kc.w & ((1ull << (g & 63)) - 1ull));
-        if ((kc.w >> (g & 63)) & 1ull) { sym = nh_sym[ord]; len = nh_len[ord]; }
-        else c.load(g - ord, sym, len);
+        const bool pre = (kc.w >> (g & 63)) & 1ull;
+        return Ref{pre ? ord : g - ord, pre};
+    }
+    GRL_DEV void fetch(const Ref &r, u32 &sym, idx_t &len, bool &take) const {
+        if (r.pre) { sym = nh_sym[r.idx]; len = nh_len[r.idx]; }
+        else c.load(r.idx, sym, len);
         take = sym == take_code;
     }
+    GRL_DEV u64 pre_before(u64 g) const { return rank_in(kinds, g); }
+    GRL_DEV Ref plain(u64 t) const { return Ref{t, false}; }
     GRL_DEV u64 erank(u64 x) const { return rank_in(tstarts, x); }
+    GRL_DEV void eword(u64 w, u64 &bits, u64 &before) const { const RankCell c = tstarts[w]; bits = c.w; before = c.b; }
     GRL_DEV u32 esym(u64 k) const { return esym_[k]; }
     GRL_DEV u64 epos(u64 k) const { return (u64)epos_[k]; }
 };
 
 // ------------------------------------------------------- a16: .rl_bwt image
 struct PackRunsFn {
-    const u32 *sym; const idx_t *len; u32 sb, fb; u8 *out; u32 hdr;      // hdr: bytes in front of the first record (16, or 0 for a part)
+    const u32 *sym; RunLen len; u32 sb, fb; u8 *out; u32 hdr;      // hdr: bytes in front of the first record (16, or 0 for a part)
     GRL_DEV void operator()(u64 i) const {
         const u32 rec = sb + fb;
         u8 *p = out + hdr + i * (u64)rec;
-        u64 s = sym[i], l = len[i];
+        u64 s = sym[i], l = len(i);
         // records of 4 or 8 bytes (DNA: 1+3; tokens: 2+2 ... ) are one aligned store, not `rec` byte stores
         if (rec == 4 && ((uintptr_t)out & 3) == 0) { *reinterpret_cast<u32 *>(p) = (u32)(s | (l << (8 * sb))); return; }
         if (rec == 8 && ((uintptr_t)out & 7) == 0) { *reinterpret_cast<u64 *>(p) = s | (l << (8 * sb)); return; }
@@ -3515,7 +3533,12 @@ class Engine {
         linfo[bwt_level].n = cur_n;
         if (keep_texts) { kept_bwts.clear(); kept_bwts.resize(levels.size() + 1); keep_bwt(bwt_level); }
     }
+    RunLen run_len() const { return RunLen{bwt.len.p, bwt.pos.p}; }      // (one of the two is there)
+    void need_len() {                          // the lengths as an array (inspection, the collection-level mode's edges)
+        if (!bwt.len.p && bwt.pos.p) { bwt.len.alloc(bwt.R); prim::for_each(bwt.R, DiffFn{bwt.pos.p, bwt.len.p}, "merge_runs.len"); }
+    }
     void keep_bwt(int lvl) {
+        need_len();
         Runs c;
         c.sym.alloc(bwt.R); c.len.alloc(bwt.R); c.R = bwt.R;
         prim::d2d(c.sym.p, bwt.sym.p, bwt.R * sizeof(u32));
@@ -3565,7 +3588,7 @@ class Engine {
             if (fused) {
                 // chain expansion fused with the first pass of the bucket split (prim::expand_*): the cells are never
                 // written in run order, there is no offset array and no scan over the runs
-                const ChainGen gen{bwt.sym.p, bwt.len.p, gp.p, sigma3, take_code, term.p, kb, lb};
+                const ChainGen gen{bwt.sym.p, run_len(), gp.p, sigma3, take_code, term.p, kb, lb};
                 prim::XsPlan plan;
                 {
                     StageTimer st(&tm.ind_expand);
@@ -3601,7 +3624,7 @@ class Engine {
                 DBuf<u64> ef(E), ef2(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<CELLS_FUSED>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                    prim::for_each(R, ChainExpandFn<CELLS_FUSED>{bwt.sym.p, run_len(), gp.p, eoff.p, sigma3, take_code,
                                                                  nullptr, nullptr, nullptr, nullptr, ef.p, term.p, kb, lb}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
@@ -3616,7 +3639,7 @@ class Engine {
                 DBuf<u64> ep(E), ep2(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<CELLS_PACKED>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                    prim::for_each(R, ChainExpandFn<CELLS_PACKED>{bwt.sym.p, run_len(), gp.p, eoff.p, sigma3, take_code,
                                                                   ekey.p, nullptr, nullptr, nullptr, ep.p, term.p, 0, 0}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
@@ -3630,7 +3653,7 @@ class Engine {
                 DBuf<idx_t> eidx(E), eidx2(E), elen(E);
                 {
                     StageTimer st(&tm.ind_expand);
-                    prim::for_each(R, ChainExpandFn<CELLS_SEPARATE>{bwt.sym.p, bwt.len.p, gp.p, eoff.p, sigma3, take_code,
+                    prim::for_each(R, ChainExpandFn<CELLS_SEPARATE>{bwt.sym.p, run_len(), gp.p, eoff.p, sigma3, take_code,
                                                                     ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p, 0, 0}, "induce_expand");
                 }
                 StageTimer st(&tm.ind_sort);
@@ -3675,7 +3698,7 @@ class Engine {
     CellView cell_view(int kb, int lb, u32 u0 = 0) const { return CellView{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p, u0, c_sfused32.p}; }
     u64 level_maxrun() {
         StageTimer st(&tm.ind_expand);
-        return prim::reduce_max<u64>(bwt.R, IdxIn64{bwt.len.p}, "induce_maxrun");
+        return prim::reduce_max<u64>(bwt.R, RunLenIn64{run_len()}, "induce_maxrun");
     }
     // what pass C assembles: a contiguous piece of the level's pre-BWT, the metasymbols (buckets) whose HOCC runs lie in it
     // (indices relative to the piece), and the number of symbols the piece describes.  The whole level on one GPU.
@@ -3715,7 +3738,7 @@ class Engine {
         }
         assemble(AsmIn{L.prebwt.sym.p, L.prebwt.len.p, L.prebwt.R, L.u_to_p.p, L.p_to_u.p, L.M, L.sigma, L.info.n_in}, I, cells, E, term, r);
         bwt_level = r;
-        if (r == 0) bwt.pos.release();           // (no level below wants the prefix)
+        if (r == 0 && bwt.len.p) bwt.pos.release();      // (no level below wants the prefix -- unless it stands for the lengths)
         I.R = bwt.R;
         I.n = L.info.n_in;
         if (keep_texts) keep_bwt(r);
@@ -3783,9 +3806,7 @@ class Engine {
         // everything but the runs can go before their lengths are taken (peak memory)
         kinds.release(); nh_sym.release(); nh_len.release(); tstarts.release(); esym.release(); epos.release();
         release_cells();
-        out.len.alloc(Ro);
-        prim::for_each(Ro, DiffFn{out.pos.p, out.len.p}, "merge_runs.len");
-        out.R = Ro; out.n = L.n_out;
+        out.R = Ro; out.n = L.n_out;            // (no length array: RunLen reads the prefix)
         bwt = std::move(out);
     }
     // the induced cells of the level being assembled (owned here so that pass C can drop them before the run merge)
@@ -3808,7 +3829,7 @@ class Engine {
         u8 hdr[16] = {0};
         for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
         prim::h2d(image.p, hdr, 16);
-        prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, bwt.len.p, sb, fb, image.p, 16u}, "pack_rl_bwt");
+        prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, run_len(), sb, fb, image.p, 16u}, "pack_rl_bwt");
         image_runs = bwt.R;
         // "results are complete when a call returns" (include/grlbwt_hip.h): the image pointer may be handed to another
         // stream (torch, a copy engine) right after the build, so the engine's stream is drained here
@@ -4081,6 +4102,7 @@ class Engine {
             u64 mr = 0;
             try {
                 StageTimer st(&tm.ind_expand);
+                need_len();                      // (pass C leaves the prefix only; the passes below read lengths after the prefix has moved on)
                 if (bwt.pos.p) { Tpos = std::move(bwt.pos); Tlocal = bwt.n; }      // pass C of the level above left my slice's prefix behind
                 else {
                     Tpos.alloc(R + 1);
@@ -4296,6 +4318,7 @@ class Engine {
         StageTimer st(&tm.finish);
         const int N = C.size, me = C.rank;
         const u64 R = bwt.R;
+        need_len();
         std::vector<u64> mine(5, 0);             // runs, first (sym, len), last (sym, len)
         mine[0] = R;
         if (R) { mine[1] = bwt.sym.get(0); mine[2] = (u64)bwt.len.get(0); mine[3] = bwt.sym.get(R - 1); mine[4] = (u64)bwt.len.get(R - 1); }
@@ -4319,7 +4342,7 @@ class Engine {
         if (extra[me]) prim::for_each(1, AddLenFn{bwt.len.p + (R - 1), extra[me]}, "pack_rl_bwt");
         const u32 sb = (u32)stats.sb, fb = (u32)stats.fb, rec = sb + fb;
         DBuf<u8> part(Rm * rec);
-        prim::for_each(Rm, PackRunsFn{bwt.sym.p + first, bwt.len.p + first, sb, fb, part.p, 0u}, "pack_rl_bwt");
+        prim::for_each(Rm, PackRunsFn{bwt.sym.p + first, RunLen{bwt.len.p + first, nullptr}, sb, fb, part.p, 0u}, "pack_rl_bwt");
         std::vector<u64> cnt = C.allgather_u64({Rm * rec}), base(N + 1, 0);
         for (int g = 0; g < N; g++) base[g + 1] = base[g] + cnt[g];
         image_bytes = 16 + base[N];
@@ -4672,7 +4695,7 @@ class Engine {
         u8 hdr[16] = {0};
         for (int i = 0; i < 8; i++) { hdr[i] = (u8)(h.sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb2 >> (8 * i)); }
         prim::h2d(dev_out, hdr, 16);
-        prim::for_each(si.runs_after, PackRunsFn{osym.p, olen.p, (u32)h.sb, fb2, dev_out, 16u}, "split.pack");
+        prim::for_each(si.runs_after, PackRunsFn{osym.p, RunLen{olen.p, nullptr}, (u32)h.sb, fb2, dev_out, 16u}, "split.pack");
         prim::sync();
         return si;
     }

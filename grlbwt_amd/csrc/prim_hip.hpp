@@ -2350,7 +2350,10 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
 // (neighbours differ in symbol): erank(x) = run starts in [0, x), esym(k) / epos(k) = symbol / first position of run k.
 // Result: the maximal runs of the concatenation, (symbol, first symbol position) per run -- written once, in order; nothing of
 // segment or atom size is stored in between.
-//     SEG:  void load(u64 g, u32 &sym, IDX &len, bool &take)       u64 erank(u64 x)      u32 esym(u64 k)      u64 epos(u64 k)
+//     SEG:  REF locate(u64 g)  +  void fetch(REF, u32 &sym, IDX &len, bool &take)   (two dependent loads: the kernels issue all of a
+//           lane's first loads, then all of its second ones);  u64 pre_before(u64 g) = segments in [0, g) that are no cells, REF plain(u64 t)
+//           = cell t (tiles without such segments skip locate);  void eword(u64 w, u64 &bits, u64 &before) = word w of the run-start
+//           vector over T and the starts in front of it;  u32 esym(u64 k);  u64 epos(u64 k)
 // Three streaming passes over the segments, one workgroup per tile of kSmTile segments:
 //     k_sm_sums    (sum of TAKE lengths, sum of lengths) per tile      -> scans: T position / symbol position at every tile start
 //     k_sm_merge<false>  the tile's segments in LDS, a block scan gives every segment its T position; a TAKE segment
@@ -2360,8 +2363,8 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
 // (Output order = segment order = T order: every access of the three passes runs forward through its array.  The form this
 // replaces computed the T prefix of every cell with a scan of its own, stored it, gathered five arrays per cell to place
 // packed atoms, wrote them, and merged them with another scan: 105 ms at level 0 of the 10 GB build against ~35.)
-static constexpr int kSmSpt = 4;                           // segments per thread
-static constexpr int kSmTile = kBlock * kSmSpt;            // 1024 segments per tile
+static constexpr int kSmSpt = 8;                           // segments per thread
+static constexpr int kSmTile = kBlock * kSmSpt;            // 2048 segments per tile
 static constexpr u32 kSmNoSym = 0xFFFFFFFFu;
 static constexpr u32 kSmInline = 8;                        // atoms behind the first a lane stores by itself; a TAKE that spans more runs of T is queued
                                                            // and copied by a kernel of its own, one lane per atom (a pre-BWT run of BWT markers can
@@ -2372,166 +2375,266 @@ template <class IDX>
 struct SmPlan {
     u64 G = 0, tiles = 0;
     IDX *xbase = nullptr, *lbase = nullptr, *hbase = nullptr;       // [tiles + 1] exclusive prefixes: TAKE symbols, symbols, run heads
+    u32 *tlast = nullptr;                                           // [tiles] last symbol of every tile
     u64 take_total = 0, len_total = 0, heads = 0, atoms = 0;
     u64 wide_n = 0, wide_atoms = 0;                                 // queued TAKE segments and their atoms
     void release() {
         if (xbase) dev_free(xbase);
         if (lbase) dev_free(lbase);
         if (hbase) dev_free(hbase);
-        xbase = lbase = hbase = nullptr;
+        if (tlast) dev_free(tlast);
+        xbase = lbase = hbase = nullptr; tlast = nullptr;
     }
 };
+// (one WAVE per tile, eight loads in flight per lane, no barrier: with a workgroup per tile of 1024 segments this pass spent its
+// time starting workgroups that lived for two dependent loads -- 6.4 ms for the 2.65 G cells of level 0 of the 10 GB build)
 template <class SEG, class IDX>
-__global__ void __launch_bounds__(kBlock) k_sm_sums(u64 G, SEG seg, IDX *tile_take, IDX *tile_len) {
-    __shared__ IDX s_a[4], s_b[4];
-    const u64 base = (u64)blockIdx.x * kSmTile;
-    IDX a = 0, b = 0;
+__global__ void __launch_bounds__(kBlock) k_sm_sums(u64 G, u64 tiles, SEG seg, IDX *tile_take, IDX *tile_len) {
+    const int lane = threadIdx.x & 63;
+    const u64 tile = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (tile < tiles) {                              // (wave-uniform)
+        const u64 base = tile * kSmTile;
+        IDX a = 0, b = 0;
+        for (int j0 = 0; j0 < kSmTile / 64; j0 += 8) {
+            u32 sym[8]; IDX len[8]; bool take[8];
+            typename SEG::Ref ref[8];
 #pragma unroll
-    for (int j = 0; j < kSmSpt; j++) {
-        const u64 g = base + (u64)j * kBlock + threadIdx.x;
-        if (g < G) {
-            u32 sym; IDX len; bool take;
-            seg.load(g, sym, len, take);
-            a += take ? len : (IDX)0;
-            b += len;
+            for (int j = 0; j < 8; j++) { const u64 g = base + (u64)(j0 + j) * 64 + lane; ref[j] = seg.locate(g < G ? g : G - 1); }      // (clamped, not branched: all loads in flight)
+#pragma unroll
+            for (int j = 0; j < 8; j++) seg.fetch(ref[j], sym[j], len[j], take[j]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const bool v = base + (u64)(j0 + j) * 64 + lane < G;
+                a += (v && take[j]) ? len[j] : (IDX)0;
+                b += v ? len[j] : (IDX)0;
+            }
         }
-    }
-    a = wave_reduce<IDX, Op::Sum>(a);
-    b = wave_reduce<IDX, Op::Sum>(b);
-    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        tile_take[blockIdx.x] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
-        tile_len[blockIdx.x] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+        a = wave_reduce<IDX, Op::Sum>(a);
+        b = wave_reduce<IDX, Op::Sum>(b);
+        if (lane == 0) { tile_take[tile] = a; tile_len[tile] = b; }
     }
 }
-// wide[]: [0] queued segments, [1] their atoms (count pass: totals; emit pass: wide[2] = queue fill)
-template <class SEG, class IDX, bool EMIT>
-__global__ void __launch_bounds__(kBlock) k_sm_merge(u64 G, SEG seg, const IDX *xbase, const IDX *lbase, const IDX *hbase, IDX *tile_heads, IDX *tile_atoms,
-                                                     unsigned long long *wide, SmWide<IDX> *queue, u64 queue_cap, u32 *osym, IDX *ostart) {
+// wide[]: [0] queued segments, [1] their atoms (count pass: totals; emit pass: wide[2] = queue fill).
+// Count pass: the first segment of a tile counts as a head; tfirst / tlast (first and last symbol of the tile) let the caller
+// take that back where the tile in front ends with the same symbol -- no look at the neighbouring tile from inside the kernel
+// (three dependent loads on every tile's critical path when lane 0 worked it out by itself).
+// The passes are bound by their instruction count (~100 vector instructions per segment in the first form, half of them 64-bit
+// arithmetic in the 64-bit index build), so:
+//   * positions inside a tile are offsets of type LT from the tile's bases -- 32 bits whenever the tile describes < 2^32 symbols
+//     (a wave-uniform choice per tile);
+//   * a tile without pre-BWT runs (level 0 of a read collection: all but 45 k of 2.6 G segments are cells) skips the per-segment
+//     rank in the kinds vector;
+//   * the two ranks of a TAKE segment come from ONE word of the T vector whenever its ends share it;
+//   * the emit pass stages the tile's heads in LDS and writes them out linearly (a lane's heads are consecutive, so the direct
+//     stores of a wave were 64 addresses 40 bytes apart: 24 ms for level 0 of the 10 GB build against 12 for the count pass).
+template <class LT> struct SmShared {
+    u32 sym[kSmTile + kSmTile / 32];            // bit 31: TAKE (symbols are < 2^30); skewed by one slot per 32.  Emit: the staged heads' symbols
+    LT len[kSmTile + kSmTile / 32];             // ... and their positions
+    Pair<LT, LT> w2[4];
+    u32 w1[4];
+    u32 last[kBlock];
+};
+template <class LT, class SEG, class IDX, bool EMIT>
+GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const IDX lb, const IDX hb, const u32 prev_tile, const bool plain, const u64 ord0,
+                     SmShared<LT> &S, IDX *tile_heads, IDX *tile_atoms, u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue,
+                     u64 queue_cap, u32 *osym, IDX *ostart) {
     constexpr int TILE = kSmTile, SPT = kSmSpt;
-    typedef Pair<IDX, IDX> P2;
-    __shared__ u32 s_sym[TILE + TILE / 32];                 // bit 31: TAKE (symbols are < 2^30); skewed by one slot per 32
-    __shared__ IDX s_len[TILE + TILE / 32];
-    __shared__ P2 s_w2[4];
-    __shared__ IDX s_w1[4];
-    __shared__ u32 s_last[kBlock];
-    const u64 base = (u64)blockIdx.x * TILE;
+    typedef Pair<LT, LT> P2;
     // striped loads (neighbouring lanes, neighbouring segments) -> LDS -> blocked (a lane's segments are consecutive)
+    {
+        u32 sym[SPT]; IDX len[SPT]; bool take[SPT];
+        typename SEG::Ref ref[SPT];
+        if (plain) {
 #pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        const u32 k = (u32)j * kBlock + threadIdx.x;
-        const u64 g = base + k;
-        u32 sym = 0; IDX len = 0; bool take = false;
-        if (g < G) seg.load(g, sym, len, take);
-        s_sym[k + (k >> 5)] = sym | (take ? 0x80000000u : 0u);
-        s_len[k + (k >> 5)] = len;
+            for (int j = 0; j < SPT; j++) { const u64 g = base + (u32)j * kBlock + threadIdx.x; ref[j] = seg.plain((g < G ? g : G - 1) - ord0); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) { const u64 g = base + (u32)j * kBlock + threadIdx.x; ref[j] = seg.locate(g < G ? g : G - 1); }      // (clamped, not branched: all loads in flight)
+        }
+#pragma unroll
+        for (int j = 0; j < SPT; j++) seg.fetch(ref[j], sym[j], len[j], take[j]);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const u32 k = (u32)j * kBlock + threadIdx.x;
+            const bool v = base + k < G;
+            S.sym[k + (k >> 5)] = v ? (sym[j] | (take[j] ? 0x80000000u : 0u)) : 0u;
+            S.len[k + (k >> 5)] = v ? (LT)len[j] : (LT)0;
+        }
     }
     __syncthreads();
-    u32 sy[SPT]; IDX ln[SPT];
+    u32 sy[SPT]; LT ln[SPT];
     P2 acc(0);
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
         const u32 k = threadIdx.x * SPT + i;
-        sy[i] = s_sym[k + (k >> 5)];
-        ln[i] = s_len[k + (k >> 5)];
-        acc.a += (sy[i] & 0x80000000u) ? ln[i] : (IDX)0;
+        sy[i] = S.sym[k + (k >> 5)];
+        ln[i] = S.len[k + (k >> 5)];
+        acc.a += (sy[i] & 0x80000000u) ? ln[i] : (LT)0;
         acc.b += ln[i];
     }
     P2 tot;
-    const P2 ex = block_excl_scan<P2>(acc, s_w2, &tot);
+    const P2 ex = block_excl_scan<P2>(acc, S.w2, &tot);
     const u64 g0 = base + (u64)threadIdx.x * SPT;
-    IDX xs[SPT], Ls[SPT];
+    LT xs[SPT], Ls[SPT];                     // offsets from (xb, lb)
     {
-        IDX x = xbase[blockIdx.x] + ex.a, L = lbase[blockIdx.x] + ex.b;
+        LT x = ex.a, L = ex.b;
 #pragma unroll
-        for (int i = 0; i < SPT; i++) { xs[i] = x; Ls[i] = L; x += (sy[i] & 0x80000000u) ? ln[i] : (IDX)0; L += ln[i]; }
+        for (int i = 0; i < SPT; i++) { xs[i] = x; Ls[i] = L; x += (sy[i] & 0x80000000u) ? ln[i] : (LT)0; L += ln[i]; }
     }
-    // runs of T every TAKE segment touches: two rank loads each, all of a lane's in flight together
-    u64 k0[SPT], k1[SPT];
+    // runs of T every TAKE segment touches: the rank word of its first symbol, and of its end where that is another word
+    u64 k0[SPT]; u32 inner[SPT];             // first run touched; runs touched behind it (saturated: a segment with >= 2^32 - 1 inner runs is split by nobody -- see below)
+    u64 k1m[SPT];                            // last run touched
+    {
+        u64 aw[SPT], ab[SPT], bw[SPT], bb[SPT];
 #pragma unroll
-    for (int i = 0; i < SPT; i++) {
-        const bool tk = (g0 + i < G) && (sy[i] & 0x80000000u);
-        k0[i] = tk ? seg.erank((u64)xs[i] + 1) - 1 : 0;
-        k1[i] = tk ? seg.erank((u64)xs[i] + (u64)ln[i]) : 0;
+        for (int i = 0; i < SPT; i++) {
+            const bool tk = (g0 + i < G) && (sy[i] & 0x80000000u);
+            const u64 x1 = (u64)xb + (u64)xs[i] + 1;
+            aw[i] = 0; ab[i] = 0;
+            if (tk) seg.eword(x1 >> 6, aw[i], ab[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < SPT; i++) {
+            const bool tk = (g0 + i < G) && (sy[i] & 0x80000000u);
+            const u64 x1 = (u64)xb + (u64)xs[i] + 1, xe = x1 - 1 + (u64)ln[i];
+            bw[i] = aw[i]; bb[i] = ab[i];
+            if (tk && (xe >> 6) != (x1 >> 6)) seg.eword(xe >> 6, bw[i], bb[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < SPT; i++) {
+            const bool tk = (g0 + i < G) && (sy[i] & 0x80000000u);
+            const u64 x1 = (u64)xb + (u64)xs[i] + 1, xe = x1 - 1 + (u64)ln[i];
+            const u64 ka = ab[i] + (u64)__builtin_popcountll(aw[i] & ((1ull << (x1 & 63)) - 1ull)) - 1;       // run holding the first symbol
+            const u64 kb = bb[i] + (u64)__builtin_popcountll(bw[i] & ((1ull << (xe & 63)) - 1ull));           // run starts in [0, x + len)
+            k0[i] = tk ? ka : 0;
+            k1m[i] = tk ? kb - 1 : 0;
+            const u64 in64 = tk ? kb - 1 - ka : 0;
+            inner[i] = in64 > 0xFFFFFFFEull ? 0xFFFFFFFFu : (u32)in64;
+        }
     }
     u32 fs[SPT], ls[SPT];
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
         const bool tk = (g0 + i < G) && (sy[i] & 0x80000000u);
         fs[i] = tk ? seg.esym(k0[i]) : (sy[i] & 0x7FFFFFFFu);
-        ls[i] = (tk && k1[i] - k0[i] > 1) ? seg.esym(k1[i] - 1) : fs[i];
     }
-    // the symbol in front of my first segment: the last symbol of the lane in front of me; lane 0: of the segment in front of the tile
+#pragma unroll
+    for (int i = 0; i < SPT; i++) ls[i] = inner[i] ? seg.esym(k1m[i]) : fs[i];
+    // the symbol in front of my first segment: the last symbol of the lane in front of me; lane 0: of the tile in front
     {
         u32 mine = kSmNoSym;
 #pragma unroll
         for (int i = 0; i < SPT; i++) if (g0 + i < G) mine = ls[i];
-        s_last[threadIdx.x] = mine;
+        S.last[threadIdx.x] = mine;
     }
     __syncthreads();
-    u32 prev = kSmNoSym;
-    if (threadIdx.x > 0) prev = s_last[threadIdx.x - 1];
-    else if (base > 0) {
-        u32 sym; IDX len; bool take;
-        seg.load(base - 1, sym, len, take);
-        prev = take ? seg.esym(seg.erank((u64)xbase[blockIdx.x]) - 1) : sym;     // (a TAKE in front of the tile ends where the tile's T range starts)
-    }
+    u32 prev = threadIdx.x > 0 ? S.last[threadIdx.x - 1] : prev_tile;       // (count pass, lane 0: no symbol -> its first segment counts as a head)
     bool head[SPT];
-    IDX nh = 0, na = 0;
+    u64 nh = 0, na = 0;                      // (64 bits: a single segment can hold 2^32 runs in the 64-bit build)
     u32 nwide = 0;
     unsigned long long wide_atoms = 0;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
         const bool v = g0 + i < G;
-        const IDX inner = (v && (sy[i] & 0x80000000u)) ? (IDX)(k1[i] - k0[i] - 1) : (IDX)0;
+        const u64 in64 = inner[i] == 0xFFFFFFFFu ? k1m[i] - k0[i] : (u64)inner[i];
         head[i] = v && fs[i] != prev;
-        nh += (head[i] ? (IDX)1 : (IDX)0) + inner;
-        na += (v ? (IDX)1 : (IDX)0) + inner;
-        if (inner > (IDX)kSmInline) { nwide++; wide_atoms += (unsigned long long)inner; }
+        nh += (head[i] ? 1u : 0u) + in64;
+        na += (v ? 1u : 0u) + in64;
+        if (in64 > (u64)kSmInline) { nwide++; wide_atoms += in64; }
         if (v) prev = ls[i];
     }
     if constexpr (!EMIT) {
-        nh = wave_reduce<IDX, Op::Sum>(nh);
-        na = wave_reduce<IDX, Op::Sum>(na);
+        nh = wave_reduce<u64, Op::Sum>(nh);
+        na = wave_reduce<u64, Op::Sum>(na);
         const unsigned long long anyw = __ballot(nwide != 0);
         if (anyw) {                            // (rare: one pair of atomics per wave that holds a wide segment)
             nwide = wave_reduce<u32, Op::Sum>(nwide);
             wide_atoms = wave_reduce<unsigned long long, Op::Sum>(wide_atoms);
             if ((threadIdx.x & 63) == 0) { atomicAdd(&wide[0], (unsigned long long)nwide); atomicAdd(&wide[1], wide_atoms); }
         }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) { s_w2[threadIdx.x >> 6] = P2(nh, na); }
+        __shared__ u64 s_r[4][2];
+        if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6][0] = nh; s_r[threadIdx.x >> 6][1] = na; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            tile_heads[blockIdx.x] = s_w2[0].a + s_w2[1].a + s_w2[2].a + s_w2[3].a;
-            tile_atoms[blockIdx.x] = s_w2[0].b + s_w2[1].b + s_w2[2].b + s_w2[3].b;
+            tile_heads[blockIdx.x] = (IDX)(s_r[0][0] + s_r[1][0] + s_r[2][0] + s_r[3][0]);
+            tile_atoms[blockIdx.x] = (IDX)(s_r[0][1] + s_r[1][1] + s_r[2][1] + s_r[3][1]);
+            tfirst[blockIdx.x] = fs[0];
+            // the tile's last symbol: of the last lane that holds a segment (the lanes behind it hold none)
+            const u64 nin = G - base < (u64)TILE ? G - base : (u64)TILE;
+            tlast[blockIdx.x] = S.last[(nin - 1) / SPT];
         }
     } else {
-        IDX htot;
-        IDX r = hbase[blockIdx.x] + block_excl_scan<IDX>(nh, s_w1, &htot);
+        __shared__ u64 s_h[4];
+        u64 htot;
+        const u64 hl0 = block_excl_scan<u64>(nh, s_h, &htot);       // my first head, counted from the tile's
+        const bool staged = htot <= (u64)TILE;                       // (uniform) the tile's heads fit the LDS arrays the segments came through
+        if (staged) {
+            for (u32 k = threadIdx.x; k < (u32)htot; k += kBlock) S.sym[k] = kSmNoSym;      // (places of queued atoms stay marked: the wide kernel writes them)
+            __syncthreads();
+        }
+        u64 r = hl0;
 #pragma unroll
         for (int i = 0; i < SPT; i++) {
             if (g0 + i < G) {
-                if (head[i]) { osym[r] = fs[i]; ostart[r] = Ls[i]; r++; }
+                if (head[i]) {
+                    if (staged) { S.sym[r] = fs[i]; S.len[r] = Ls[i]; }
+                    else { osym[(u64)hb + r] = fs[i]; ostart[(u64)hb + r] = lb + (IDX)Ls[i]; }
+                    r++;
+                }
                 if (sy[i] & 0x80000000u) {
-                    const IDX inner = (IDX)(k1[i] - k0[i] - 1);
-                    if (inner > (IDX)kSmInline) {
+                    const u64 in64 = inner[i] == 0xFFFFFFFFu ? k1m[i] - k0[i] : (u64)inner[i];
+                    if (in64 > (u64)kSmInline) {
                         const u64 q = (u64)atomicAdd(&wide[2], 1ull);
-                        if (q < queue_cap) queue[q] = SmWide<IDX>{r, Ls[i], xs[i], inner, k0[i] + 1};
+                        if (q < queue_cap) queue[q] = SmWide<IDX>{(IDX)((u64)hb + r), lb + (IDX)Ls[i], xb + (IDX)xs[i], (IDX)in64, k0[i] + 1};
                     } else {
-                        for (IDX a = 0; a < inner; a++) {
+                        const u64 x = (u64)xb + (u64)xs[i];
+                        for (u32 a = 0; a < (u32)in64; a++) {
                             const u64 k = k0[i] + 1 + (u64)a;
-                            osym[r + a] = seg.esym(k);
-                            ostart[r + a] = Ls[i] + (IDX)(seg.epos(k) - (u64)xs[i]);
+                            const u32 sk = seg.esym(k);
+                            const u64 off = seg.epos(k) - x;            // (< the segment's length)
+                            if (staged) { S.sym[r + a] = sk; S.len[r + a] = Ls[i] + (LT)off; }
+                            else { osym[(u64)hb + r + a] = sk; ostart[(u64)hb + r + a] = lb + (IDX)Ls[i] + (IDX)off; }
                         }
                     }
-                    r += inner;
+                    r += in64;
                 }
+            }
+        }
+        if (staged) {
+            __syncthreads();
+            for (u32 k = threadIdx.x; k < (u32)htot; k += kBlock) {
+                const u32 sk = S.sym[k];
+                if (sk != kSmNoSym) { osym[(u64)hb + k] = sk; ostart[(u64)hb + k] = lb + (IDX)S.len[k]; }
             }
         }
     }
 }
+template <class SEG, class IDX, bool EMIT>
+__global__ void __launch_bounds__(kBlock) k_sm_merge(u64 G, SEG seg, const IDX *xbase, const IDX *lbase, const IDX *hbase, IDX *tile_heads, IDX *tile_atoms,
+                                                     u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue, u64 queue_cap, u32 *osym, IDX *ostart) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[sizeof(SmShared<IDX>)];
+    const u64 base = (u64)blockIdx.x * kSmTile;
+    // (loaded first: nothing below has to wait for them)
+    const IDX xb = xbase[blockIdx.x], lb = lbase[blockIdx.x], lnext = lbase[blockIdx.x + 1];
+    IDX hb = 0;
+    u32 prev_tile = kSmNoSym;
+    if constexpr (EMIT) { hb = hbase[blockIdx.x]; if (blockIdx.x > 0) prev_tile = tlast[blockIdx.x - 1]; }
+    const u64 gend = base + kSmTile < G ? base + kSmTile : G;
+    const u64 ord0 = seg.pre_before(base), ord1 = seg.pre_before(gend);
+    const bool plain = ord0 == ord1;                                   // (uniform) no pre-BWT run among the tile's segments
+    if (sizeof(IDX) == 4 || (u64)(lnext - lb) >= 0xFFFFFFFFull)        // (uniform) offsets inside the tile in the index width ...
+        sm_tile<IDX, SEG, IDX, EMIT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<IDX> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
+                                     wide, queue, queue_cap, osym, ostart);
+    else                                                               // ... or in 32 bits when the tile describes < 2^32 symbols
+        sm_tile<u32, SEG, IDX, EMIT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<u32> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
+                                     wide, queue, queue_cap, osym, ostart);
+}
+// heads of tile t without the provisional head of its first segment where the tile in front ends with the same symbol
+template <class IDX>
+struct SmHeadsIn {
+    const IDX *heads; const u32 *tfirst; const u32 *tlast;
+    GRL_DEV IDX operator()(u64 t) const { return heads[t] - ((t > 0 && tfirst[t] == tlast[t - 1]) ? (IDX)1 : (IDX)0); }
+};
 template <class IDX>
 struct SmWideCountIn {
     const SmWide<IDX> *q;
@@ -2562,9 +2665,11 @@ inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *na
     plan.xbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
     plan.lbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
     plan.hbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    plan.tlast = (u32 *)dev_alloc(T * sizeof(u32));
     IDX *tatoms = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    u32 *tfirst = (u32 *)dev_alloc(T * sizeof(u32));
     prof_begin(std::string(name) + ".sums");
-    hipLaunchKernelGGL((k_sm_sums<SEG, IDX>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, plan.xbase, plan.lbase);
+    hipLaunchKernelGGL((k_sm_sums<SEG, IDX>), dim3((unsigned)((T + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, rt().stream, G, T, seg, plan.xbase, plan.lbase);
     prof_end();
     after_launch(name);
     u64 *dres = (u64 *)dev_alloc(6 * sizeof(u64));      // [0] TAKE symbols, [1] symbols, [2] heads, [3] atoms, [4] wide segments, [5] their atoms
@@ -2573,14 +2678,14 @@ inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *na
     exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.lbase}, plan.lbase, (IDX *)(dres + 1), plan.lbase + T, name);
     prof_begin(std::string(name) + ".count");
     hipLaunchKernelGGL((k_sm_merge<SEG, IDX, false>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
-                       (const IDX *)nullptr, plan.hbase, tatoms, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
+                       (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
     prof_end();
     after_launch(name);
-    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.hbase}, plan.hbase, (IDX *)(dres + 2), plan.hbase + T, name);
+    exclusive_scan_async<IDX, SmHeadsIn<IDX>>(T, SmHeadsIn<IDX>{plan.hbase, tfirst, plan.tlast}, plan.hbase, (IDX *)(dres + 2), plan.hbase + T, name);
     exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{tatoms}, tatoms, (IDX *)(dres + 3), (IDX *)nullptr, name);
     u64 h[6];
     d2h(h, dres, 6 * sizeof(u64));
-    dev_free(dres); dev_free(tatoms);
+    dev_free(dres); dev_free(tatoms); dev_free(tfirst);
     plan.take_total = h[0]; plan.len_total = h[1]; plan.heads = h[2]; plan.atoms = h[3]; plan.wide_n = h[4]; plan.wide_atoms = h[5];
 }
 template <class SEG, class IDX>
@@ -2592,7 +2697,7 @@ inline void stream_merge_emit(SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart
     dev_memset(wide, 0, 3 * sizeof(unsigned long long));
     prof_begin(std::string(name) + ".emit", plan.heads * (sizeof(u32) + sizeof(IDX)));
     hipLaunchKernelGGL((k_sm_merge<SEG, IDX, true>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
-                       (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, wide, queue, nq, osym, ostart);
+                       (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart);
     prof_end();
     after_launch(name);
     if (nq) {

@@ -352,7 +352,7 @@ inline void sm_walk(u64 G, const SEG &seg, SmPlan<IDX> &plan, PUT put) {
     u32 prev = 0xFFFFFFFFu;
     for (u64 g = 0; g < G; g++) {
         u32 sym; IDX len; bool take;
-        seg.load(g, sym, len, take);
+        seg.fetch(seg.locate(g), sym, len, take);
         if (take) {
             const u64 k0 = seg.erank(x + 1) - 1, k1 = seg.erank(x + (u64)len);
             for (u64 k = k0; k < k1; k++) {

@@ -21,6 +21,10 @@ def main():
     cases = []
     if which in ("both", "rep"):
         cases.append(("configs2_repetitive_100x24Mbp", lambda: workloads.repetitive_copies_torch(100, 24000000, device=dev), 1))
+    if which == "chr1":
+        # SURVEY 8(d) item 3 at chromosome scale: 100 copies of a 248,956,422 bp sequence (the length of human chr1), 24.9 GB --
+        # the arena near device capacity (configs[2] exercised at the 2.4 GB pseudo-chromosome only)
+        cases.append(("configs2_repetitive_100x248956422bp", lambda: workloads.repetitive_copies_torch(100, 248956422, device=dev), 1))
     if which in ("both", "tok"):
         cases.append(("configs4_u16_tokens_1GB", lambda: workloads.zipf_tokens_torch(500000000, device=dev), 2))
     for name, gen, w in cases:
@@ -55,7 +59,7 @@ def main():
         del text, back
         torch.cuda.empty_cache()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "config_roundtrip.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "config_roundtrip%s.json" % ("" if which == "both" else "_" + which)), "w") as f:
         json.dump(out, f, indent=1)
 
 
