@@ -350,7 +350,9 @@ def main():
                             hh.update(blk)
                 if len(runs) > 1 and "wall_s" in runs[0]:
                     runs[0]["warm_up"] = True
-                best = min((r for r in runs if "wall_s" in r and not r.get("warm_up")), key=lambda r: r["wall_s"], default=None)
+                # (the MEDIAN of the timed runs is what is reported -- VERDICT r3: not the best of three)
+                timed = sorted((r for r in runs if "wall_s" in r and not r.get("warm_up")), key=lambda r: r["wall_s"])
+                best = timed[len(timed) // 2] if timed else None
                 cli_e2e = {"command": "grlbwt_amd/bin/grlbwt FILE -o OUT (file in the page cache, output to %s)" % tmpdir, "runs": runs,
                            "output_md5": hh.hexdigest(), "md5_equals_hbm_image": None}
                 if best:
@@ -516,7 +518,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
+            # value = the build with the input resident in HBM (the contract of this bench); value_cli = the same bytes through the
+            # grlbwt executable, file in the page cache -> .rl_bwt file closed (SURVEY 8(d)'s wording of the metric; median run)
+            "value_cli": (cli_e2e or {}).get("MBps_wall"),
             "config": {"workload": wl, "input_resident": "HBM", "output": ".rl_bwt image in HBM",
+                       "value_is": "HBM-resident build (value); value_cli = wall time of the CLI, file in -> .rl_bwt file closed, median of the timed runs",
                        "parallelism": ("1 GPU" if world == 1 else
                                        "the ONE collection sharded by record over %d GPUs (%d reads each): local LMS parsing/hashing/emission, "
                                        "hash-partitioned dictionary merge (all-to-all) + key-range-sharded dictionary stage per round, induction "

@@ -112,7 +112,17 @@ GRL_HD u64 next_set_bit(const u64 *w, u64 p, u64 n) {
         if (x) r = p + (u64)__builtin_ctzll(x);
         else {
             bool found = false;
-            for (wi++; !found && (wi << 6) < n; wi++) { x = w[wi]; if (x) { r = (wi << 6) + (u64)__builtin_ctzll(x); found = true; } }
+            wi++;
+            // eight words per step while they are empty (one lane walks the gap: a load and its latency per word made the 1.6 M empty
+            // words of a 10^8-cell phrase a 170 ms affair, five times per build)
+            bool fast = true;
+            while (fast && ((wi + 8) << 6) <= n) {
+                u64 any = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) any |= w[wi + k];
+                if (any) fast = false; else wi += 8;
+            }
+            for (; !found && (wi << 6) < n; wi++) { x = w[wi]; if (x) { r = (wi << 6) + (u64)__builtin_ctzll(x); found = true; } }
         }
         if (r > n) r = n;
     }
@@ -334,7 +344,51 @@ struct HashInsertFn {
         return res;
     }
     // the general form: walk the phrase cell by cell (any length), hash it, find/claim its slot -- or leave its record
-    GRL_DEV u32 process_walk(u64 p, u64 ord, bool pack) const {
+    // GIANT PHRASES (a string of 10^8 equal symbols is ONE phrase; so is the whole of a level whose text has become one phrase):
+    // one lane hashing 10^8 cells took 4 s.  A phrase that runs kGiantMin cells beyond the point where the walk switches to its
+    // long form is hashed by the whole wave instead: process_walk returns prim::kGiantBucket, the kernel (prim::for_each_agg)
+    // has the leader find the phrase's bounds (giant_bounds), every lane hash one of 64 equal pieces (giant_piece), mixes the
+    // piece hashes in lane order (giant_mix) and hands the result back to the leader (process_giant).  Which hash a phrase
+    // gets depends on its length only, so every occurrence gets the same one.
+    static constexpr bool kGiant = true;
+    static constexpr u64 kGiantMin = 1ull << 16;
+    GRL_DEV void giant_bounds(u64 item, u64 &p, u64 &ee) const {
+        p = item;
+        const u64 ns = next_set_bit(startbits, p + 1, n);
+        ee = (ns >= n || ops.isT(t[ns - 1])) ? ns - 1 : ns;
+    }
+    GRL_DEV u64 giant_piece(u64 p, u64 ee, int lane) const {
+        const u64 len = ee - p + 1, piece = (len + 63) / 64;
+        u64 x = p + (u64)lane * piece;
+        const u64 xe = x + piece < ee + 1 ? x + piece : ee + 1;      // my cells: [x, xe)
+        const u64 cnt = xe > x ? xe - x : 0;
+        PhraseHash ph = PhraseHash::init();
+        while (x + 4 * kCh <= xe) {
+            u64 ck[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) ck[q4] = load8(t + x + (u64)q4 * kCh);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+#pragma unroll
+                for (u64 j = 0; j < kCh; j++) ph.add(ops.sym((cell_t)(sizeof(cell_t) == 8 ? ck[q4] : (ck[q4] >> (8 * sizeof(cell_t) * j)))));
+            }
+            x += 4 * kCh;
+        }
+        while (x < xe) { ph.add(ops.sym(t[x])); x++; }
+        return ph.finish(cnt);
+    }
+    GRL_HD static u64 giant_mix(u64 acc, u64 h) {
+        acc = (acc ^ h) * 0xFF51AFD7ED558CCDull;
+        return acc ^ (acc >> 32);
+    }
+    GRL_DEV u32 process_giant(u64 item, u64 acc, u64 ee) const {
+        const u64 p = item;
+        const u64 w = startbits[p >> 6];
+        const u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+        const bool pack = !kExact && rec_cmax != 0;
+        return process_walk(p, ord, pack, &acc, ee);
+    }
+    GRL_DEV u32 process_walk(u64 p, u64 ord, bool pack, const u64 *giant_acc = nullptr, u64 known_end = 0) const {
         PhraseHash ph = PhraseHash::init();
         u64 e = p;                               // last cell taken so far
         cell_t c = t[p];
@@ -344,7 +398,7 @@ struct HashInsertFn {
         if (pack) rec_put(klo, khi, ops.sym(c), 0, rec_b);
         // cells are taken 8 bytes at a time while that stays inside the text (one load covers a whole DNA phrase;
         // phrases of millions of cells -- e.g. N-runs -- would otherwise pay one memory latency per cell)
-        bool capped = false;
+        bool capped = false, giant = false, use_giant = false;
         while (!done && e + 1 + kCh <= n) {
             if (e - p >= walk_cap) { capped = true; done = true; }
             if (!done && e - p >= 4096) {
@@ -352,21 +406,29 @@ struct HashInsertFn {
                 // cell behind a terminator starts a string, so the next start bit decides as in CompactTableFn -- and its cells are
                 // hashed from batches of four independent loads (one load and its latency per 8 cells: 77 ns per cell, 2.3 s for a
                 // 30 M-cell gap)
-                const u64 ns = next_set_bit(startbits, e + 1, n);
-                const u64 ee = (ns >= n || ops.isT(t[ns - 1])) ? ns - 1 : ns;
-                u64 x = e + 1;
-                while (x + 4 * kCh <= ee + 1) {
-                    u64 ck[4];
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) ck[q4] = load8(t + x + (u64)q4 * kCh);
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-#pragma unroll
-                        for (u64 j = 0; j < kCh; j++) ph.add(ops.sym((cell_t)(sizeof(cell_t) == 8 ? ck[q4] : (ck[q4] >> (8 * sizeof(cell_t) * j)))));
-                    }
-                    x += 4 * kCh;
+                u64 ee = known_end;                                       // (the wave's second visit knows where the phrase ends)
+                if (!giant_acc) {
+                    const u64 ns = next_set_bit(startbits, e + 1, n);
+                    ee = (ns >= n || ops.isT(t[ns - 1])) ? ns - 1 : ns;
                 }
-                while (x <= ee) { ph.add(ops.sym(t[x])); x++; }
+                if (ee - p >= walk_cap) capped = true;                  // (sample passes: too long to be worth a second walk)
+                else if (ee - e >= kGiantMin) {                          // the whole wave hashes it (see kGiant)
+                    if (giant_acc) use_giant = true; else giant = true;
+                } else {
+                    u64 x = e + 1;
+                    while (x + 4 * kCh <= ee + 1) {
+                        u64 ck[4];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) ck[q4] = load8(t + x + (u64)q4 * kCh);
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) {
+#pragma unroll
+                            for (u64 j = 0; j < kCh; j++) ph.add(ops.sym((cell_t)(sizeof(cell_t) == 8 ? ck[q4] : (ck[q4] >> (8 * sizeof(cell_t) * j)))));
+                        }
+                        x += 4 * kCh;
+                    }
+                    while (x <= ee) { ph.add(ops.sym(t[x])); x++; }
+                }
                 e = ee;
                 done = true;
             }
@@ -398,7 +460,7 @@ struct HashInsertFn {
                 done = bit_at(startbits, e) || ops.isT(c);
             }
         }
-        if (capped) ok = false;
+        if (capped || giant) ok = false;
         if (ok && ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; ok = false; }
         u32 found = prim::kNoBucket;
         if (ok && pack) {
@@ -422,9 +484,10 @@ struct HashInsertFn {
                 for (u64 j = 0; j < len; j++) content |= (u64)t[p + j] << (8 * j);
                 const u64 mine = kExactKey | (len << 60) | content;
                 found = insert_exact(mine, p, exact_hash(mine) & (hot_keys ? hot_mask : mask), 0, false);
-            } else found = find_or_insert(p, len, ph.finish(len), ops.isT(t[e]));
+            } else found = find_or_insert(p, len, use_giant ? PhraseHash{(u32)(*giant_acc >> 32), (u32)*giant_acc}.finish(len) : ph.finish(len), ops.isT(t[e]));
             if (found != prim::kNoBucket) out_slot[ord] = (found & ~prim::kClaimBit) | (pack ? kLongMark : 0u);
         }
+        if (giant) found = prim::kGiantBucket;
         return found;
     }
     GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const { process_batch_exact(item, valid, slot); }
@@ -589,6 +652,11 @@ struct SampledFn {
     GRL_DEV u64 claim_pos(u64 v) const { return map(v); }
     GRL_DEV bool is_start(u64 v) const { return f.is_start(map(v)); }
     GRL_DEV u32 process(u64 v) const { return f.process(map(v)); }
+    static constexpr bool kGiant = F::kGiant;
+    GRL_DEV void giant_bounds(u64 v, u64 &p, u64 &ee) const { f.giant_bounds(map(v), p, ee); }
+    GRL_DEV u64 giant_piece(u64 p, u64 ee, int lane) const { return f.giant_piece(p, ee, lane); }
+    GRL_HD static u64 giant_mix(u64 acc, u64 h) { return F::giant_mix(acc, h); }
+    GRL_DEV u32 process_giant(u64 v, u64 acc, u64 ee) const { return f.process_giant(map(v), acc, ee); }
     GRL_DEV u32 operator()(u64 v) const { return f(map(v)); }
     GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const {
         u64 m[kBatch];
@@ -688,6 +756,11 @@ struct ListedFn {
     GRL_DEV u64 claim_pos(u64 v) const { return pos[v]; }
     GRL_DEV bool is_start(u64) const { return true; }
     GRL_DEV u32 process(u64 v) const { return f.process(pos[v]); }
+    static constexpr bool kGiant = F::kGiant;
+    GRL_DEV void giant_bounds(u64 v, u64 &p, u64 &ee) const { f.giant_bounds(pos[v], p, ee); }
+    GRL_DEV u64 giant_piece(u64 p, u64 ee, int lane) const { return f.giant_piece(p, ee, lane); }
+    GRL_HD static u64 giant_mix(u64 acc, u64 h) { return F::giant_mix(acc, h); }
+    GRL_DEV u32 process_giant(u64 v, u64 acc, u64 ee) const { return f.process_giant(pos[v], acc, ee); }
     GRL_DEV u32 operator()(u64 v) const { return f.process(pos[v]); }
     GRL_DEV void process_batch(const u64 *, const bool *, u32 *) const {}
 };
@@ -1633,6 +1706,7 @@ struct ChainGen {
     GRL_DEV bool more(u64 rec) const { return (u32)(rec >> 32) >= sigma3; }
     GRL_DEV u32 next(u64 rec) const { return (u32)(rec >> 32) - sigma3; }
     GRL_DEV u64 item_bits(u64 i) const { return (u64)nlen(i) << kb; }
+    GRL_DEV u64 item_len(u64 i) const { return (u64)nlen(i); }
     GRL_DEV u64 key_own(u32 u, u64 ib) const { return ((u64)take_code << (kb + lb)) | ib | (u64)u; }
     GRL_DEV u64 key_step(u64 rec, u32 b, u64 ib) const { return ((u64)((u32)rec & 0x7FFFFFFFu) << (kb + lb)) | ib | (u64)b; }
     GRL_DEV void finish(u64 i, u64 rec) const { term[i] = (u32)(rec >> 32); }
@@ -2471,6 +2545,7 @@ struct SplitRunsFn {      // one lane per L-piece
 struct RunSymFn {         // for_each_agg protocol: every run is a work item, its bucket is its symbol
     static constexpr int kBatch = 1;
     static constexpr bool kClaims = false;
+    static constexpr bool kGiant = false;
     GRL_DEV u64 claim_pos(u64 i) const { return i; }
     const u32 *rsym;
     GRL_DEV bool is_start(u64) const { return true; }
@@ -2739,7 +2814,9 @@ class Engine {
         }
         P.n_occ = n_occ;
         L.info.parse_size = n_occ;
-        if (n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "parse too large for u32 phrase ordinals");
+        // (phrase ordinals are idx_t: the 64-bit build takes parses of 2^32 phrases and more -- level 0 of a 24.9 GB collection has
+        // 7.3 G; what stays 32 bits wide are slot ids, dictionary positions and a shard's frequencies on the wire: checked where they are made)
+        if (sizeof(idx_t) == 4 && n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "parse too large for u32 phrase ordinals");
 
         // ---- partitioned naming (levels above 0, single-GPU rounds): a phrase of <= cmax cells is a 128-bit record; the records
         // are grouped by a hash prefix into partitions that fit an LDS table (prim::PartSort), de-duplicated and counted there
@@ -3564,8 +3641,6 @@ class Engine {
         DBuf<u32> sfused32;                     // the same word in 32 bits when the three fields fit (kb + lb + sbits <= 32 < 2^32: kb < 32)
         kb = (int)bitlen64(L.M > 0 ? L.M - 1 : 0);
         if (kb < 1) kb = 1;
-        lb = (int)bitlen64(maxrun);
-        if (lb < 1) lb = 1;
         {
             const int bits = kb;
             {
@@ -3574,6 +3649,20 @@ class Engine {
                 prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
             }
             const int sbits = (int)bitlen64((u64)sigma3);
+            // maxrun == 0: the longest run is not known yet.  The counting walk of the fused path reads every run anyway and
+            // brings it back with its other totals (a reduction of its own over the runs was 2 ms and a host synchronisation
+            // per level); it runs whenever a fused layout is possible at all (bucket + symbol + 1 length bit in 64).
+            prim::XsPlan plan;
+            bool counted = false;
+            if (maxrun == 0 && kb + sbits + 1 <= 64 && !getenv("GRLBWT_CELL_LAYOUT")) {
+                const ChainGen gen0{bwt.sym.p, run_len(), gp.p, sigma3, take_code, term.p, kb, 0};
+                StageTimer st(&tm.ind_expand);
+                E = prim::expand_count(R, gen0, bits, plan, "induce");
+                maxrun = plan.maxlen;
+                counted = true;
+            } else if (maxrun == 0) maxrun = level_maxrun();
+            lb = (int)bitlen64(maxrun);
+            if (lb < 1) lb = 1;
             // Whenever bucket, run length and symbol fit 64 bits together (always at DNA scales), the cell IS the sort
             // key: the split moves 8 bytes per cell and pass instead of 12, and holds 16 instead of 24 bytes per cell.
             // (GRLBWT_CELL_LAYOUT=packed|separate: the tests take the wider layouts on inputs that would never need them)
@@ -3589,8 +3678,7 @@ class Engine {
                 // chain expansion fused with the first pass of the bucket split (prim::expand_*): the cells are never
                 // written in run order, there is no offset array and no scan over the runs
                 const ChainGen gen{bwt.sym.p, run_len(), gp.p, sigma3, take_code, term.p, kb, lb};
-                prim::XsPlan plan;
-                {
+                if (!counted) {
                     StageTimer st(&tm.ind_expand);
                     E = prim::expand_count(R, gen, bits, plan, "induce");
                 }
@@ -3610,9 +3698,9 @@ class Engine {
                     sfused = std::move(res ? ef2 : ef);
                     done = true;
                 }
-                plan.release();
                 if (done) prim::sync();
             }
+            plan.release();
             if (!done) {     // offsets of every run's cells (an item with more than 32 cells, or cells that do not fit one word)
                 StageTimer st(&tm.ind_expand);
                 eoff.alloc(R + 1);
@@ -3729,7 +3817,7 @@ class Engine {
         I.R_next = R; I.P = L.prebwt.R;
         DBuf<u32> term(R);
         int kb, lb;
-        const u64 E = expand_split(L, term, level_maxrun(), kb, lb);
+        const u64 E = expand_split(L, term, 0, kb, lb);      // (0: the longest run comes out of the counting walk)
         I.E = E;
         const CellView cells = cell_view(kb, lb);
         if (prim::rt().profile) {              // SURVEY 8d's E'_r and E_r for the roofline accounting (bench.py)
@@ -3758,7 +3846,7 @@ class Engine {
         DBuf<RankCell> tstarts(nwT);
         tstarts.zero();
         if (Re) prim::for_each((Re + 15) / 16, BuildBitsFn{epos.p, Re, reinterpret_cast<u64 *>(tstarts.p), 2}, "asm.tbits");
-        prim::exclusive_scan_emit<u64>(nwT, RankCellPopcIn{tstarts.p}, RankCellBaseEmitFn{tstarts.p}, "asm.tbits");
+        prim::exclusive_scan_emit_nosync<u64>(nwT, RankCellPopcIn{tstarts.p}, RankCellBaseEmitFn{tstarts.p}, "asm.tbits");
         // ---- the non-HOCC pre-BWT runs, compacted, and where they sit among the segments
         DBuf<idx_t> nhb(P + 1);
         const u64 NH = (u64)prim::exclusive_scan<idx_t>(P, NotCodeIn{L.psym, hocc_code}, nhb.p, true, "asm.nhb");
@@ -3785,7 +3873,7 @@ class Engine {
         DBuf<RankCell> kinds(nwG);
         kinds.zero();
         if (NH) prim::for_each((NH + 15) / 16, BuildBitsFn{seg_pos.p, NH, reinterpret_cast<u64 *>(kinds.p), 2}, "asm.kinds");
-        prim::exclusive_scan_emit<u64>(nwG, RankCellPopcIn{kinds.p}, RankCellBaseEmitFn{kinds.p}, "asm.kinds");
+        prim::exclusive_scan_emit_nosync<u64>(nwG, RankCellPopcIn{kinds.p}, RankCellBaseEmitFn{kinds.p}, "asm.kinds");
         seg_pos.release();
         // ---- the stream merge: count (T positions, run heads), then emit
         const AsmSeg seg{kinds.p, nh_sym.p, nh_len.p, cells, take_code, tstarts.p, esym.p, epos.p};
@@ -3908,6 +3996,7 @@ class Engine {
                 if (test_fail_rank("GRLBWT_TEST_FAIL_RANK", me)) throw prim::Error(-28, "phrase hash table overflow (injected by the test)");
                 // (levels above 0: partitioned naming as on one GPU -- short phrases are records in P.ph_key, not text positions)
                 hash_local<cell_t, FIRST>(t, n, ops, P, L, !getenv("GRLBWT_DIST_NO_PART"));
+                if (P.n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "a shard's parse has >= 2^32 phrases (its frequencies travel as u32): use more ranks");
                 DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D), soff(P.D + 1);
                 DBuf<u64> bound(2 * ((u64)N + 1));
                 prim::for_each(P.D, PhraseOwnerFn<cell_t, FIRST>{t, ops, P.ph_pos.p, P.ph_len.p, (u32)N, owner.p, idx.p, P.ph_key.p, P.Ds, P.rec_b},

@@ -40,7 +40,14 @@ extern "C" {
 #define GRLBWT_EDEVICE (-5)     /* HIP runtime error (no device, launch failure, ...)                */
 #define GRLBWT_ENOMEM (-12)     /* device or host allocation failed                                  */
 #define GRLBWT_EILLFORMED (-84) /* reference: "Error: the file is ill formed", exit(1) (utils.cpp:177-180) */
-#define GRLBWT_ERANGE (-75)     /* input beyond what this build supports (symbols >= 2^30, ...)      */
+#define GRLBWT_ERANGE (-75)     /* input beyond what this build supports -- the limits, all checked:
+                                 *   collection            < 2^40 cells (64-bit positions from 2^32 - 256 cells on);
+                                 *   symbols, and the alphabet of every level (metasymbols of a round)       < 2^30;
+                                 *   distinct phrases of one round < 2^32, their symbols (the round's dictionary) < 2^32;
+                                 *   phrase-table slots of one round <= 2^31 (2^30 with the hot table of level 0);
+                                 *   phrase OCCURRENCES of one round: no bound of their own in the 64-bit build (level 0 of a
+                                 *   24.9 GB collection has 7.3 G); a shard of the collection-level mode < 2^32 per round.
+                                 * The reference takes dictionaries up to 64-bit suffix-array cells (exact_par_phase.cpp:244-263). */
 #define GRLBWT_ENOSPC (-28)     /* phrase table overflow                                              */
 #define GRLBWT_EINTERNAL (-71)  /* internal consistency check failed                                  */
 #define GRLBWT_ENOTDNA (-86)    /* reference: "The input seems not to be DNA (invalid symbol:X)", exit(1) (fastx_handler.cpp:30-33) */

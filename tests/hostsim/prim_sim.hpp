@@ -117,6 +117,20 @@ inline u32 agg_take_claim(const F &f, u32 s, u64 item) {       // the claim prot
     }
     return s;
 }
+static constexpr u32 kGiantBucket = 0xFFFFFFFDu;
+template <class F>
+inline u32 agg_take_giant(const F &f, u32 s, u64 item) {       // the giant-item protocol of prim_hip.hpp, serially
+    if constexpr (F::kGiant) {
+        if (s == kGiantBucket) {
+            u64 p, ee;
+            f.giant_bounds(item, p, ee);
+            u64 acc = 0x9E3779B97F4A7C15ull;
+            for (int k = 0; k < 64; k++) acc = F::giant_mix(acc, f.giant_piece(p, ee, k));
+            s = f.process_giant(item, acc, ee);
+        }
+    }
+    return s;
+}
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     if constexpr (F::kBatch > 1) {       // the functor's batched form (what the HIP kernel calls), kBatch work items at a time
@@ -129,7 +143,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             f.process_batch(item, valid, slot);
             for (int j = 0; j < k; j++) {
                 slot[j] = agg_take_claim(f, slot[j], item[j]);
-                if (slot[j] == kDeferBucket) slot[j] = agg_take_claim(f, f.process(item[j]), item[j]);       // (the HIP kernel queues these up)
+                if (slot[j] == kDeferBucket) slot[j] = agg_take_claim(f, agg_take_giant(f, f.process(item[j]), item[j]), item[j]);       // (the HIP kernel queues these up)
                 if (slot[j] != kNoBucket) add(slot[j], 1u);
             }
             k = 0;
@@ -138,7 +152,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             if (f.is_start(i)) { item[k] = i; valid[k] = true; if (++k == F::kBatch) flush(); }
         if (k) flush();
     } else {
-        for (u64 i = 0; i < n; i++) { u32 s = agg_take_claim(f, f(i), i); if (s != kNoBucket) add(s, 1u); }
+        for (u64 i = 0; i < n; i++) { u32 s = agg_take_claim(f, agg_take_giant(f, f(i), i), i); if (s != kNoBucket) add(s, 1u); }
     }
 }
 // stage clocks: host wall time here (the HIP runtime uses event pairs on its stream)
@@ -202,6 +216,8 @@ inline T exclusive_scan_emit(u64 n, F in, E emit, const char * = "") {
     for (u64 i = 0; i < n; i++) { T v = (T)in(i); emit(i, acc, v); acc += v; }
     return acc;
 }
+template <class T, class F, class E>
+inline void exclusive_scan_emit_nosync(u64 n, F in, E emit, const char * = "") { (void)exclusive_scan_emit<T, F, E>(n, in, emit); }
 inline void byte_histogram_accumulate(const u8 *p, u64 n, u64 *d_hist) { for (u64 i = 0; i < n; i++) d_hist[p[i]]++; }
 inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
     std::memset(hist_host, 0, 256 * 8);
@@ -247,6 +263,7 @@ struct XsPlan {
     bool ok = false;
     u64 n = 0, E = 0;
     u32 maxc = 0;
+    u64 maxlen = 0;
     int bits = 0, db = 8;
     void release() {}
 };
@@ -272,6 +289,7 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char * = "
         xs_walk(gen, i, false, [&](u64) { c++; });
         plan.E += c;
         if (c > plan.maxc) plan.maxc = c;
+        if (gen.item_len(i) > plan.maxlen) plan.maxlen = gen.item_len(i);
     }
     // the stand-in has no staging limit; GRLBWT_SIM_XS_MAXC lets a test push items over the HIP limit's fallback branch
     const char *lim = getenv("GRLBWT_SIM_XS_MAXC");

@@ -94,6 +94,18 @@ def test_long_phrases_saturated_length(sim, oracle_mod):
     parity.check_stagewise(sim, data, 1, engine.FLAG_FORCE_IDX64)
 
 
+def test_giant_phrases_hashed_by_the_wave(sim, oracle_mod):
+    """Phrases far beyond the point where the walk switches to its long form (HashInsertFn::kGiantMin = 65536 cells more) are
+    hashed in 64 pieces by the whole wave: the same phrase twice (one table entry, count 2), a phrase that differs in its last
+    cell, one that is a cell longer, and a level that collapses into ONE phrase (a single long string of distinct-ish cells)."""
+    g = b"A" * 90000
+    data = g + b"\n" + g + b"\n" + b"A" * 89999 + b"C" + b"\n" + g + b"A\n" + b"CGT" * 10 + b"\n"
+    parity.check_final(sim, data, 1)
+    rng = np.random.default_rng(5)
+    one = bytes(rng.integers(1, 256, size=300000).astype(np.uint8)) + b"\x00"       # one string: level 2 is a single phrase
+    parity.check_final(sim, one, 1)
+
+
 def test_table_growth_when_prefix_is_unrepresentative(sim, oracle_mod):
     # > 2^20 repetitive cells first (the capacity estimate sees almost no distinct phrases), then diverse reads
     rep = (b"ACGTTGCA" * 16 + b"\n") * 8500

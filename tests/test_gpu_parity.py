@@ -467,6 +467,30 @@ def test_result_pointer_is_complete_when_build_returns(hip, oracle_mod):
             assert bytes(img.cpu().numpy()) == exp
 
 
+def test_giant_phrases_hashed_by_the_wave(hip, oracle_mod):
+    """(see tests/test_engine_logic_sim.py) phrases of 90 k - 2 M cells: hashed in 64 pieces by the whole wave, duplicates found.
+    Against the oracle where it finishes in seconds (it sorts the suffixes of a run of c equal cells in c^2 steps: 90 k yes, 2 M
+    no); the 2 M-cell gaps through the device-side inverter instead (every string comes back at its input index)."""
+    import torch
+    g = b"A" * 90000
+    data = g + b"\n" + g + b"\n" + b"A" * 89999 + b"C" + b"\n" + g + b"A\n" + b"CGT" * 10 + b"\n"
+    parity.check_final(hip, data, 1)
+    rng = np.random.default_rng(5)
+    one = bytes(rng.integers(1, 256, size=2000000).astype(np.uint8)) + b"\x00"      # one string: the deepest level is a single phrase
+    parity.check_final(hip, one, 1)
+    two = b"N" * 2000000
+    gaps = np.frombuffer(b"ACGT" + two + b"TTGA\n" + b"ACGT" + two + b"TTGA\n" + b"GG" + two + b"C\n" + b"ACGT" + two + b"TTGC\n", dtype=np.uint8)
+    text = torch.from_numpy(gaps.copy()).to("cuda:0")
+    back = torch.zeros_like(text)
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+        nb, nr = ctx.result_size()
+        n = ctx.invert_image(ctx.result_device_ptr(), nb, 1, back.data_ptr(), back.numel())
+    torch.cuda.synchronize()
+    assert n == text.numel() and torch.equal(back, text)
+
+
 def test_final_bytes_vs_oracle_250MB(hip, oracle_mod):
     """The largest input compared byte for byte with the oracle ("What's weak" 3): 1.65 M Illumina-style reads of
     150 bp from an 8.3 Mbp genome (249 MB, 30x coverage, 0.5 % substitutions -- the headline distribution at 1/40 of its
