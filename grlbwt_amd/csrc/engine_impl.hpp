@@ -112,9 +112,25 @@ GRL_HD u64 next_set_bit(const u64 *w, u64 p, u64 n) {
         if (x) r = p + (u64)__builtin_ctzll(x);
         else {
             bool found = false;
+            for (wi++; !found && (wi << 6) < n; wi++) { x = w[wi]; if (x) { r = (wi << 6) + (u64)__builtin_ctzll(x); found = true; } }
+        }
+        if (r > n) r = n;
+    }
+    return r;
+}
+// the same for the one-lane walkers of the cold kernels (table compaction, grammar walk, the bounds of a listed long phrase):
+// eight words per step while they are empty -- a load and its latency per word made the 1.6 M empty words of a 10^8-cell phrase
+// a 170 ms affair, five times per build.  (Not in the hashing kernels: inlined there, its sixteen registers of loads in flight
+// pushed the level-0 kernel of the 10 GB build from 105 to 148 registers and 328 bytes of scratch per lane: 46 -> 122 ms.)
+GRL_HD u64 next_set_bit_far(const u64 *w, u64 p, u64 n) {
+    u64 r = n;
+    if (p < n) {
+        u64 wi = p >> 6;
+        u64 x = w[wi] >> (p & 63);
+        if (x) r = p + (u64)__builtin_ctzll(x);
+        else {
+            bool found = false;
             wi++;
-            // eight words per step while they are empty (one lane walks the gap: a load and its latency per word made the 1.6 M empty
-            // words of a 10^8-cell phrase a 170 ms affair, five times per build)
             bool fast = true;
             while (fast && ((wi + 8) << 6) <= n) {
                 u64 any = 0;
@@ -344,17 +360,17 @@ struct HashInsertFn {
         return res;
     }
     // the general form: walk the phrase cell by cell (any length), hash it, find/claim its slot -- or leave its record
-    // GIANT PHRASES (a string of 10^8 equal symbols is ONE phrase; so is the whole of a level whose text has become one phrase):
-    // one lane hashing 10^8 cells took 4 s.  A phrase that runs kGiantMin cells beyond the point where the walk switches to its
-    // long form is hashed by the whole wave instead: process_walk returns prim::kGiantBucket, the kernel (prim::for_each_agg)
-    // has the leader find the phrase's bounds (giant_bounds), every lane hash one of 64 equal pieces (giant_piece), mixes the
-    // piece hashes in lane order (giant_mix) and hands the result back to the leader (process_giant).  Which hash a phrase
-    // gets depends on its length only, so every occurrence gets the same one.
-    static constexpr bool kGiant = true;
-    static constexpr u64 kGiantMin = 1ull << 16;
+    // LONG PHRASES (a string of 10^8 equal symbols is ONE phrase; so is the whole of a level whose text has become one phrase):
+    // one lane hashing 10^8 cells took 4 s.  A phrase the walk has followed for kLongWalk cells without reaching its end is LISTED
+    // (giant_list) and left; prim::for_each_giant then takes one WAVE per listed phrase: lane 0 finds its bounds
+    // (giant_bounds), every lane hashes one of 64 equal pieces (giant_piece), the piece hashes are mixed in lane order
+    // (giant_mix) and lane 0 finishes with the result (process_giant: table lookup / insertion).  Which hash a phrase gets
+    // depends on its length only, so every occurrence gets the same one -- and the hashing kernels hold no code for long phrases.
+    u64 *giant_list = nullptr; u32 *giant_n = nullptr; u32 giant_cap = 0;
+    static constexpr u64 kLongWalk = 4096;
     GRL_DEV void giant_bounds(u64 item, u64 &p, u64 &ee) const {
         p = item;
-        const u64 ns = next_set_bit(startbits, p + 1, n);
+        const u64 ns = next_set_bit_far(startbits, p + 1, n);
         ee = (ns >= n || ops.isT(t[ns - 1])) ? ns - 1 : ns;
     }
     GRL_DEV u64 giant_piece(u64 p, u64 ee, int lane) const {
@@ -401,35 +417,13 @@ struct HashInsertFn {
         bool capped = false, giant = false, use_giant = false;
         while (!done && e + 1 + kCh <= n) {
             if (e - p >= walk_cap) { capped = true; done = true; }
-            if (!done && e - p >= 4096) {
-                // a very long phrase (an N gap of millions of cells): its end comes from the start bits, 64 positions per step -- the
-                // cell behind a terminator starts a string, so the next start bit decides as in CompactTableFn -- and its cells are
-                // hashed from batches of four independent loads (one load and its latency per 8 cells: 77 ns per cell, 2.3 s for a
-                // 30 M-cell gap)
-                u64 ee = known_end;                                       // (the wave's second visit knows where the phrase ends)
-                if (!giant_acc) {
-                    const u64 ns = next_set_bit(startbits, e + 1, n);
-                    ee = (ns >= n || ops.isT(t[ns - 1])) ? ns - 1 : ns;
+            if (!done && e - p >= kLongWalk) {
+                if (giant_acc) { e = known_end; use_giant = true; }      // (the wave's visit: it knows the end and brings the hash)
+                else {
+                    giant = true;
+                    const u32 gs = giant_n ? prim::atomic_add(giant_n, 1u) : giant_cap;
+                    if (gs < giant_cap) giant_list[gs] = p; else scal[1] = 6;      // (the list takes every phrase that can be this long: see hash_local)
                 }
-                if (ee - p >= walk_cap) capped = true;                  // (sample passes: too long to be worth a second walk)
-                else if (ee - e >= kGiantMin) {                          // the whole wave hashes it (see kGiant)
-                    if (giant_acc) use_giant = true; else giant = true;
-                } else {
-                    u64 x = e + 1;
-                    while (x + 4 * kCh <= ee + 1) {
-                        u64 ck[4];
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; q4++) ck[q4] = load8(t + x + (u64)q4 * kCh);
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; q4++) {
-#pragma unroll
-                            for (u64 j = 0; j < kCh; j++) ph.add(ops.sym((cell_t)(sizeof(cell_t) == 8 ? ck[q4] : (ck[q4] >> (8 * sizeof(cell_t) * j)))));
-                        }
-                        x += 4 * kCh;
-                    }
-                    while (x <= ee) { ph.add(ops.sym(t[x])); x++; }
-                }
-                e = ee;
                 done = true;
             }
             if (!done) {
@@ -487,7 +481,6 @@ struct HashInsertFn {
             } else found = find_or_insert(p, len, use_giant ? PhraseHash{(u32)(*giant_acc >> 32), (u32)*giant_acc}.finish(len) : ph.finish(len), ops.isT(t[e]));
             if (found != prim::kNoBucket) out_slot[ord] = (found & ~prim::kClaimBit) | (pack ? kLongMark : 0u);
         }
-        if (giant) found = prim::kGiantBucket;
         return found;
     }
     GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const { process_batch_exact(item, valid, slot); }
@@ -652,11 +645,6 @@ struct SampledFn {
     GRL_DEV u64 claim_pos(u64 v) const { return map(v); }
     GRL_DEV bool is_start(u64 v) const { return f.is_start(map(v)); }
     GRL_DEV u32 process(u64 v) const { return f.process(map(v)); }
-    static constexpr bool kGiant = F::kGiant;
-    GRL_DEV void giant_bounds(u64 v, u64 &p, u64 &ee) const { f.giant_bounds(map(v), p, ee); }
-    GRL_DEV u64 giant_piece(u64 p, u64 ee, int lane) const { return f.giant_piece(p, ee, lane); }
-    GRL_HD static u64 giant_mix(u64 acc, u64 h) { return F::giant_mix(acc, h); }
-    GRL_DEV u32 process_giant(u64 v, u64 acc, u64 ee) const { return f.process_giant(map(v), acc, ee); }
     GRL_DEV u32 operator()(u64 v) const { return f(map(v)); }
     GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const {
         u64 m[kBatch];
@@ -756,11 +744,6 @@ struct ListedFn {
     GRL_DEV u64 claim_pos(u64 v) const { return pos[v]; }
     GRL_DEV bool is_start(u64) const { return true; }
     GRL_DEV u32 process(u64 v) const { return f.process(pos[v]); }
-    static constexpr bool kGiant = F::kGiant;
-    GRL_DEV void giant_bounds(u64 v, u64 &p, u64 &ee) const { f.giant_bounds(pos[v], p, ee); }
-    GRL_DEV u64 giant_piece(u64 p, u64 ee, int lane) const { return f.giant_piece(p, ee, lane); }
-    GRL_HD static u64 giant_mix(u64 acc, u64 h) { return F::giant_mix(acc, h); }
-    GRL_DEV u32 process_giant(u64 v, u64 acc, u64 ee) const { return f.process_giant(pos[v], acc, ee); }
     GRL_DEV u32 operator()(u64 v) const { return f.process(pos[v]); }
     GRL_DEV void process_batch(const u64 *, const bool *, u32 *) const {}
 };
@@ -792,7 +775,7 @@ struct CompactTableFn {
                 // saturated: the phrase ends at the first terminator or AT the next phrase start (LMS phrases share that cell) --
                 // and the position behind a terminator is a start, so the next start bit behind pos decides (a walk cell by cell
                 // took 18.7 s for ONE phrase of 10^8 cells)
-                const u64 ns = next_set_bit(startbits, pos + 1, n);
+                const u64 ns = next_set_bit_far(startbits, pos + 1, n);
                 const u64 e = (ns >= n || ops.isT(t[ns - 1])) ? ns - 1 : ns;
                 len = e - pos + 1;
             }
@@ -1430,7 +1413,7 @@ struct GrammarFn {
         bool done = false;
         if ((u32)prev & kDmEnd) { b = (u32)prev & kDmSym; done = true; }               // the representative is the last cell of its phrase (:38-41)
         if (!done && stops) {                      // jump to the cell in front of the stop (a walk over 10^8 cells took 14 s)
-            const u64 y = next_set_bit(stops, x + 1, S);
+            const u64 y = next_set_bit_far(stops, x + 1, S);
             if (y > x + 1) { x = y - 1; prev = dm[x]; }
         }
         while (!done) {
@@ -1706,7 +1689,6 @@ struct ChainGen {
     GRL_DEV bool more(u64 rec) const { return (u32)(rec >> 32) >= sigma3; }
     GRL_DEV u32 next(u64 rec) const { return (u32)(rec >> 32) - sigma3; }
     GRL_DEV u64 item_bits(u64 i) const { return (u64)nlen(i) << kb; }
-    GRL_DEV u64 item_len(u64 i) const { return (u64)nlen(i); }
     GRL_DEV u64 key_own(u32 u, u64 ib) const { return ((u64)take_code << (kb + lb)) | ib | (u64)u; }
     GRL_DEV u64 key_step(u64 rec, u32 b, u64 ib) const { return ((u64)((u32)rec & 0x7FFFFFFFu) << (kb + lb)) | ib | (u64)b; }
     GRL_DEV void finish(u64 i, u64 rec) const { term[i] = (u32)(rec >> 32); }
@@ -2545,7 +2527,6 @@ struct SplitRunsFn {      // one lane per L-piece
 struct RunSymFn {         // for_each_agg protocol: every run is a work item, its bucket is its symbol
     static constexpr int kBatch = 1;
     static constexpr bool kClaims = false;
-    static constexpr bool kGiant = false;
     GRL_DEV u64 claim_pos(u64 i) const { return i; }
     const u32 *rsym;
     GRL_DEV bool is_start(u64) const { return true; }
@@ -2851,7 +2832,9 @@ class Engine {
         u64 cap_max = 1024;
         while (cap_max < 2 * n_occ && cap_max < (1ull << 31)) cap_max <<= 1;      // slot ids are u32 with bit 31 spare (prim::kClaimBit)
         P.next_text.alloc(n_occ);
-        DBuf<u32> scal(4);
+        DBuf<u32> scal(8);                        // [1] error flag, [2..3] debug, [4] giant phrases listed
+        const u64 giant_cap = n / HashInsertFn<cell_t, FIRST>::kLongWalk + 2;      // (a listed phrase has more than kLongWalk cells of its own)
+        DBuf<u64> giant_list(giant_cap);
         u64 cap = cap_max;
         double frac = 1.0;
         u64 s_blk = 0, s_stride = 0, s_n = 0, s_distinct = 0;      // the sample (blocks of s_blk cells, s_stride apart) and its distinct phrases
@@ -2882,7 +2865,7 @@ class Engine {
                 typedef HashInsertFn<cell_t, FIRST> HF;
                 HF fs{t, ops, startbits.p, wordbase.p, tk.p, cap_s - 1, cap_s, 0, P.next_text.p, scal.p, n, n_occ, trep.p};
                 fs.rec_b = rec_b; fs.rec_cmax = rec_cmax;       // (partitioned naming: only the long phrases reach the sample's table)
-                fs.walk_cap = (u64)1 << 16;
+                fs.walk_cap = HF::kLongWalk;        // (the sample leaves the long phrases out: they are listed and hashed by waves in the real pass)
                 prim::for_each_agg(n_s, SampledFn<HF>{fs, blk, stride}, SlotCountAdd{tc.p, 1}, true, "hash_sample");
                 const u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
                 const u64 occ_s = std::max<u64>(prim::reduce_sum<u64>(cap_s, IdxIn<idx_t>{tc.p}, "hash_sample_count"), 1);
@@ -2954,9 +2937,10 @@ class Engine {
                 HF f{t, ops, startbits.p, wordbase.p, keys.p + cap_hot, cap - 1, probe_limit, ks,
                      P.next_text.p, scal.p, n, n_occ, rep_pos.p ? rep_pos.p + cap_hot : nullptr, claim.p};
                 if (part) { f.rec_h = P.rec_h.p; f.rec_v = rec_v.p; f.rec_b = rec_b; f.rec_cmax = rec_cmax; }
+                f.giant_list = giant_list.p; f.giant_n = scal.p + 4; f.giant_cap = (u32)std::min<u64>(giant_cap, 0xFFFFFFFFull);
                 if (cap_hot) {
                     HF fh{t, ops, startbits.p, wordbase.p, keys.p, cap_hot - 1, cap_hot, 0, P.next_text.p, scal.p, n, n_occ, rep_pos.p, claim.p};
-                    fh.walk_cap = (u64)1 << 16;             // (a phrase of millions of cells has no business in the hot table: the pass over the text
+                    fh.walk_cap = HF::kLongWalk;            // (a phrase of thousands of cells has no business in the hot table: the pass over the text
                                                             // would find it there and compare it cell by cell with itself)
                     prim::for_each_agg(s_n, SampledFn<HF>{fh, s_blk, s_stride, claim.p}, NoCountAdd{}, false, "hash_hot");
                     f.hot_keys = keys.p; f.hot_mask = cap_hot - 1; f.slot_base = (u32)cap_hot;
@@ -2987,7 +2971,11 @@ class Engine {
                         if (nl) prim::for_each_agg(nl, ListedFn<HF>{f, lpos.p, claim.p}, SlotCountAdd{cnt, cs}, false, "hash_long_phrases");
                     } else launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
                 } else launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
-                std::vector<u32> sc = scal.to_host(4);
+                std::vector<u32> sc = scal.to_host(8);
+                if (sc[4] && !sc[1]) {            // the phrases too long for one lane: one wave each
+                    prim::for_each_giant((u64)sc[4], giant_list.p, f, SlotCountAdd{cnt, cs}, "hash_giant_phrases");
+                    sc = scal.to_host(8);
+                }
                 if (sc[1] == 1) {
                     if (cap == cap_max) throw prim::Error(-28, "phrase hash table overflow");
                     cap = cap * 4 > cap_max ? cap_max : cap * 4;
@@ -3649,18 +3637,7 @@ class Engine {
                 prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
             }
             const int sbits = (int)bitlen64((u64)sigma3);
-            // maxrun == 0: the longest run is not known yet.  The counting walk of the fused path reads every run anyway and
-            // brings it back with its other totals (a reduction of its own over the runs was 2 ms and a host synchronisation
-            // per level); it runs whenever a fused layout is possible at all (bucket + symbol + 1 length bit in 64).
             prim::XsPlan plan;
-            bool counted = false;
-            if (maxrun == 0 && kb + sbits + 1 <= 64 && !getenv("GRLBWT_CELL_LAYOUT")) {
-                const ChainGen gen0{bwt.sym.p, run_len(), gp.p, sigma3, take_code, term.p, kb, 0};
-                StageTimer st(&tm.ind_expand);
-                E = prim::expand_count(R, gen0, bits, plan, "induce");
-                maxrun = plan.maxlen;
-                counted = true;
-            } else if (maxrun == 0) maxrun = level_maxrun();
             lb = (int)bitlen64(maxrun);
             if (lb < 1) lb = 1;
             // Whenever bucket, run length and symbol fit 64 bits together (always at DNA scales), the cell IS the sort
@@ -3678,7 +3655,7 @@ class Engine {
                 // chain expansion fused with the first pass of the bucket split (prim::expand_*): the cells are never
                 // written in run order, there is no offset array and no scan over the runs
                 const ChainGen gen{bwt.sym.p, run_len(), gp.p, sigma3, take_code, term.p, kb, lb};
-                if (!counted) {
+                {
                     StageTimer st(&tm.ind_expand);
                     E = prim::expand_count(R, gen, bits, plan, "induce");
                 }
@@ -3817,7 +3794,7 @@ class Engine {
         I.R_next = R; I.P = L.prebwt.R;
         DBuf<u32> term(R);
         int kb, lb;
-        const u64 E = expand_split(L, term, 0, kb, lb);      // (0: the longest run comes out of the counting walk)
+        const u64 E = expand_split(L, term, level_maxrun(), kb, lb);
         I.E = E;
         const CellView cells = cell_view(kb, lb);
         if (prim::rt().profile) {              // SURVEY 8d's E'_r and E_r for the roofline accounting (bench.py)

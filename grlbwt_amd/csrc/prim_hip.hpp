@@ -808,29 +808,46 @@ static constexpr u32 kDeferBucket = 0xFFFFFFFEu;   // process_batch: "take this 
 // the lanes of a wave hold neighbouring items, so the wave ORs its marks together and issues one atomic per word.  The set bits
 // are the distinct buckets, each once: the caller compacts from them instead of scanning a sparse table.  (Bucket ids < 2^31.)
 static constexpr u32 kClaimBit = 0x80000000u;
-// GIANT work items (functors with F::kGiant): process() may answer kGiantBucket for an item too long for one lane (a phrase of
-// 10^8 cells); the wave then takes it together -- the item's lane finds its bounds, every lane hashes one of 64 pieces, the
-// piece hashes are mixed in lane order and the item's lane finishes with the result.  Call from converged code.
+// GIANT work items (a phrase of 10^8 cells is too long for one lane: 4 s).  The functor of a hashing pass lists them
+// (positions, in f.giant_list) instead of processing them; for_each_giant then takes one WAVE per listed item: lane 0 finds
+// the item's bounds, every lane hashes one of 64 pieces, the piece hashes are mixed in lane order and lane 0 finishes with the
+// result (slot lookup / insertion, claim mark, count).  A kernel of its own: with the same steps inside the hashing kernel the
+// level-0 pass of the 10 GB build went from 46 to 142 ms (registers), although it never meets such a phrase.
 static constexpr u32 kGiantBucket = 0xFFFFFFFDu;
-template <class F>
-GRL_DEV u32 agg_take_giant(const F &f, u32 s, u64 item, bool valid) {
-    if constexpr (F::kGiant) {
-        const int lane = threadIdx.x & 63;
-        unsigned long long gm = __ballot(valid && s == kGiantBucket);
-        while (gm) {
-            const int leader = __ffsll((long long)gm) - 1;
-            gm &= gm - 1;
-            u64 p = 0, ee = 0;
-            if (lane == leader) f.giant_bounds(item, p, ee);
-            p = (u64)__shfl((unsigned long long)p, leader);
-            ee = (u64)__shfl((unsigned long long)ee, leader);
-            const u64 mine = f.giant_piece(p, ee, lane);
-            u64 acc = 0x9E3779B97F4A7C15ull;
-            for (int k = 0; k < 64; k++) acc = F::giant_mix(acc, (u64)__shfl((unsigned long long)mine, k));
-            if (lane == leader) s = f.process_giant(item, acc, ee);
+template <class F, class A>
+__global__ void __launch_bounds__(64) k_giant(u64 n_items, const u64 *items, F f, A add) {
+    const int lane = threadIdx.x & 63;
+    for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const u64 item = items[it];
+        u64 p = 0, ee = 0;
+        if (lane == 0) f.giant_bounds(item, p, ee);
+        p = (u64)__shfl((unsigned long long)p, 0);
+        ee = (u64)__shfl((unsigned long long)ee, 0);
+        const u64 mine = f.giant_piece(p, ee, lane);
+        u64 acc = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < 64; k++) acc = F::giant_mix(acc, (u64)__shfl((unsigned long long)mine, k));
+        if (lane == 0) {
+            u32 s = f.process_giant(item, acc, ee);
+            if (s != kNoBucket && s != kGiantBucket) {
+                if constexpr (F::kClaims) {
+                    if (f.claim_bits) {
+                        const u64 cp = f.claim_pos(item);
+                        if (s & kClaimBit) atomicOr(reinterpret_cast<unsigned long long *>(&f.claim_bits[cp >> 6]), 1ull << (cp & 63));
+                        s &= ~kClaimBit;
+                    }
+                }
+                add(s, 1u);
+            }
         }
     }
-    return s;
+}
+template <class F, class A>
+inline void for_each_giant(u64 n_items, const u64 *items, F f, A add, const char *name = "giant_items") {
+    if (n_items == 0) return;
+    prof_begin(name);
+    hipLaunchKernelGGL((k_giant<F, A>), dim3((unsigned)(n_items < 65536 ? n_items : 65536)), dim3(64), 0, rt().stream, n_items, items, f, add);
+    prof_end();
+    after_launch(name);
 }
 template <class F>
 GRL_DEV u32 agg_take_claim(const F &f, u32 s, u64 item, bool valid) {
@@ -894,7 +911,6 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 u32 s = kNoBucket;
                 const u64 it = start + (v ? defer[k & (DCAP - 1)] : 0u);
                 if (v) s = f.process(it);
-                s = agg_take_giant(f, s, it, v);
                 s = agg_take_claim(f, s, it, v);
                 if (v) count(s);
                 dh = dt - dh >= 64u ? dh + 64u : dt;
@@ -961,7 +977,6 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 const u64 it = base + (v ? queue[q] : 0u);
                 u32 s = kNoBucket;
                 if (v) s = f.process(it);
-                s = agg_take_giant(f, s, it, v);
                 s = agg_take_claim(f, s, it, v);
                 if (v) count(s);
             }
@@ -980,15 +995,6 @@ struct NoAggFn {
     F f; A add;
     GRL_DEV void operator()(u64 i) const {
         u32 s = f(i);
-        if constexpr (F::kGiant) {
-            if (s == kGiantBucket) {           // (debug path: the item's lane does the 64 pieces by itself)
-                u64 p, ee;
-                f.giant_bounds(i, p, ee);
-                u64 acc = 0x9E3779B97F4A7C15ull;
-                for (int k = 0; k < 64; k++) acc = F::giant_mix(acc, f.giant_piece(p, ee, k));
-                s = f.process_giant(i, acc, ee);
-            }
-        }
         if (s != kNoBucket) {
             if constexpr (F::kClaims) {
                 if (f.claim_bits) {
@@ -1741,7 +1747,6 @@ struct XsPlan {
     bool ok = false;         // false: the fused path does not apply (an item with more than 32 keys); E is still valid
     u64 n = 0, E = 0;
     u32 maxc = 0, tiles = 0;
-    u64 maxlen = 0;          // largest gen.item_len(i)
     int bits = 0, db = 8;    // sort bits, bits of the first digit
     int md = 0;              // widest digit of the passes behind the fused one (0: the default)
     u8 *cnt8 = nullptr; u32 *counts = nullptr; u64 *offsets = nullptr;
@@ -1770,7 +1775,6 @@ __global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, 
     u32 *h = s_h[threadIdx.x >> 6];
     const u64 base = (u64)blockIdx.x * kXsTileItems;
     u32 mx = 0;
-    u64 ml = 0;
     for (int b = 0; b < kXsTileItems / kBlock; b++) {
         const u64 i = base + (u64)b * kBlock + threadIdx.x;
         if (i < n) {
@@ -1786,14 +1790,10 @@ __global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, 
             }
             cnt8[i] = (u8)(c < 255u ? c : 255u);
             mx = c > mx ? c : mx;
-            const u64 il = gen.item_len(i);
-            ml = il > ml ? il : ml;
         }
     }
     mx = wave_reduce<u32, Op::Max>(mx);
-    ml = wave_reduce<u64, Op::Max>(ml);
     if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_max, mx);
-    if ((threadIdx.x & 63) == 0 && ml) atomicMax(reinterpret_cast<unsigned long long *>(scal + 4), (unsigned long long)ml);      // (scal[4..5]: one atomic per wave)
     __syncthreads();
     for (int d = threadIdx.x; d < NB; d += kBlock) {
         u32 t = 0;
@@ -2005,8 +2005,8 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char *name
     u32 chunks = (plan.tiles + kRsChunk - 1) / kRsChunk;
     u32 *chunk_sums = (u32 *)dev_alloc((u64)NB * chunks * sizeof(u32));
     u64 *chunk_off = (u64 *)dev_alloc((u64)NB * chunks * sizeof(u64));
-    u64 *scal = (u64 *)dev_alloc(24);       // [0] most keys of an item (u32), [1] keys, [2] longest item
-    dev_memset(scal, 0, 24);
+    u64 *scal = (u64 *)dev_alloc(16);
+    dev_memset(scal, 0, 16);
     prof_begin(std::string(name) + ".xcount");
     if (plan.db == 9) hipLaunchKernelGGL((k_xs_count<GEN, 9>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, n, gen, dmask, plan.cnt8, plan.counts, (u32 *)scal);
     else hipLaunchKernelGGL((k_xs_count<GEN, 8>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, n, gen, dmask, plan.cnt8, plan.counts, (u32 *)scal);
@@ -2014,12 +2014,11 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char *name
     after_launch(name);
     if (plan.db == 9) rs_offsets<512>(plan.counts, plan.tiles, chunk_sums, chunk_off, plan.offsets, scal + 1, name);
     else rs_offsets<256>(plan.counts, plan.tiles, chunk_sums, chunk_off, plan.offsets, scal + 1, name);
-    u64 h[3];
-    d2h(h, scal, 24);
+    u64 h[2];
+    d2h(h, scal, 16);
     dev_free(chunk_sums); dev_free(chunk_off); dev_free(scal);
     plan.maxc = (u32)h[0];
     plan.E = h[1];
-    plan.maxlen = h[2];
     // (GRLBWT_XS_MAXC: the tests lower the limit so that ordinary inputs take the caller's unfused branch)
     const char *lim = getenv("GRLBWT_XS_MAXC");
     plan.ok = plan.maxc <= (lim ? (u32)atoi(lim) : 32u);

@@ -118,18 +118,26 @@ inline u32 agg_take_claim(const F &f, u32 s, u64 item) {       // the claim prot
     return s;
 }
 static constexpr u32 kGiantBucket = 0xFFFFFFFDu;
-template <class F>
-inline u32 agg_take_giant(const F &f, u32 s, u64 item) {       // the giant-item protocol of prim_hip.hpp, serially
-    if constexpr (F::kGiant) {
-        if (s == kGiantBucket) {
-            u64 p, ee;
-            f.giant_bounds(item, p, ee);
-            u64 acc = 0x9E3779B97F4A7C15ull;
-            for (int k = 0; k < 64; k++) acc = F::giant_mix(acc, f.giant_piece(p, ee, k));
-            s = f.process_giant(item, acc, ee);
+template <class F, class A>
+inline void for_each_giant(u64 n_items, const u64 *items, F f, A add, const char * = "") {       // the giant-item kernel of prim_hip.hpp, serially
+    for (u64 it = 0; it < n_items; it++) {
+        const u64 item = items[it];
+        u64 p, ee;
+        f.giant_bounds(item, p, ee);
+        u64 acc = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < 64; k++) acc = F::giant_mix(acc, f.giant_piece(p, ee, k));
+        u32 s = f.process_giant(item, acc, ee);
+        if (s != kNoBucket && s != kGiantBucket) {
+            if constexpr (F::kClaims) {
+                if (f.claim_bits) {
+                    const u64 cp = f.claim_pos(item);
+                    if (s & kClaimBit) f.claim_bits[cp >> 6] |= 1ull << (cp & 63);
+                    s &= ~kClaimBit;
+                }
+            }
+            add(s, 1u);
         }
     }
-    return s;
 }
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
@@ -143,7 +151,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             f.process_batch(item, valid, slot);
             for (int j = 0; j < k; j++) {
                 slot[j] = agg_take_claim(f, slot[j], item[j]);
-                if (slot[j] == kDeferBucket) slot[j] = agg_take_claim(f, agg_take_giant(f, f.process(item[j]), item[j]), item[j]);       // (the HIP kernel queues these up)
+                if (slot[j] == kDeferBucket) slot[j] = agg_take_claim(f, f.process(item[j]), item[j]);       // (the HIP kernel queues these up)
                 if (slot[j] != kNoBucket) add(slot[j], 1u);
             }
             k = 0;
@@ -152,7 +160,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             if (f.is_start(i)) { item[k] = i; valid[k] = true; if (++k == F::kBatch) flush(); }
         if (k) flush();
     } else {
-        for (u64 i = 0; i < n; i++) { u32 s = agg_take_claim(f, agg_take_giant(f, f(i), i), i); if (s != kNoBucket) add(s, 1u); }
+        for (u64 i = 0; i < n; i++) { u32 s = agg_take_claim(f, f(i), i); if (s != kNoBucket) add(s, 1u); }
     }
 }
 // stage clocks: host wall time here (the HIP runtime uses event pairs on its stream)
@@ -263,7 +271,6 @@ struct XsPlan {
     bool ok = false;
     u64 n = 0, E = 0;
     u32 maxc = 0;
-    u64 maxlen = 0;
     int bits = 0, db = 8;
     void release() {}
 };
@@ -289,7 +296,6 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char * = "
         xs_walk(gen, i, false, [&](u64) { c++; });
         plan.E += c;
         if (c > plan.maxc) plan.maxc = c;
-        if (gen.item_len(i) > plan.maxlen) plan.maxlen = gen.item_len(i);
     }
     // the stand-in has no staging limit; GRLBWT_SIM_XS_MAXC lets a test push items over the HIP limit's fallback branch
     const char *lim = getenv("GRLBWT_SIM_XS_MAXC");

@@ -95,7 +95,7 @@ def test_long_phrases_saturated_length(sim, oracle_mod):
 
 
 def test_giant_phrases_hashed_by_the_wave(sim, oracle_mod):
-    """Phrases far beyond the point where the walk switches to its long form (HashInsertFn::kGiantMin = 65536 cells more) are
+    """Phrases the walk has followed for HashInsertFn::kLongWalk = 4096 cells without reaching their end are listed and
     hashed in 64 pieces by the whole wave: the same phrase twice (one table entry, count 2), a phrase that differs in its last
     cell, one that is a cell longer, and a level that collapses into ONE phrase (a single long string of distinct-ish cells)."""
     g = b"A" * 90000
