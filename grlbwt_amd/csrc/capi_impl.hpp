@@ -8,9 +8,12 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -161,16 +164,78 @@ int io_threads() {
     static const int n = [] {
         if (const char *e = getenv("GRLBWT_IO_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) return v; }
         const unsigned hc = std::thread::hardware_concurrency();
-        return (int)std::min<unsigned>(std::max<unsigned>(hc / 2, 4u), 8u);       // (8 and 16 measured alike on a 256-core host, 4 a little slower)
+        return (int)std::min<unsigned>(std::max<unsigned>(hc / 2, 4u), 16u);      // (pread from the page cache: 99 GB/s with 8 threads, 118 with 16, 97 with 32 on a 256-core host)
     }();
     return n;
 }
 
 // file -> HBM: chunk k+1 is read from the file while chunk k travels over PCIe; for byte cells the histogram of
 // collection_stats is taken from every chunk on the device as soon as it has landed (no second pass over the text)
+// Reader threads that live for one load: a chunk is cut into 4 MiB pieces which the threads take one by one (pread from the
+// page cache: 14 GB/s with one thread, 100-118 GB/s with 8-16 on the GPU box, tools/io_probe.cpp).  (Eight new threads per
+// 64 MiB chunk, joined before the next chunk, read the 10 GB input at 43 GB/s.)
+struct ReadPool {
+    static constexpr uint64_t kPiece = (uint64_t)4 << 20;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    int fd = -1; char *buf = nullptr; uint64_t off = 0, len = 0;       // the chunk being read
+    uint64_t next = 0, done = 0, pieces = 0, generation = 0;
+    bool stop = false, ok = true;
+    explicit ReadPool(int n) {
+        try { for (int i = 0; i < n; i++) th.emplace_back([this] { run(); }); } catch (const std::system_error &) {}      // (as many as there are; none: read() reads in line)
+    }
+    ~ReadPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t p, a, b; int f; char *dst; uint64_t base;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_work.wait(g, [&] { return stop || (generation != seen && next < pieces) ; });
+                if (stop) return;
+                if (next >= pieces) { seen = generation; continue; }
+                p = next++;
+                f = fd; dst = buf; base = off;
+                a = p * kPiece; b = a + kPiece < len ? a + kPiece : len;
+            }
+            bool good = true;
+            for (uint64_t x = a; x < b && good;) {
+                const ssize_t r = pread(f, dst + x, b - x, (off_t)(base + x));
+                if (r <= 0) good = false; else x += (uint64_t)r;
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (!good) ok = false;
+                if (++done == pieces) cv_done.notify_all();
+            }
+        }
+    }
+    // bytes [off_, off_ + len_) of the file into buf_; returns when they are all there
+    bool read(int fd_, char *buf_, uint64_t off_, uint64_t len_) {
+        if (th.empty()) return par_io(fd_, buf_, off_, len_, false, 1);
+        std::unique_lock<std::mutex> g(mu);
+        fd = fd_; buf = buf_; off = off_; len = len_;
+        pieces = (len_ + kPiece - 1) / kPiece; next = 0; done = 0; generation++;
+        if (pieces == 0) return ok;
+        cv_work.notify_all();
+        cv_done.wait(g, [&] { return done == pieces; });
+        return ok;
+    }
+};
+// GRLBWT_IO_TRACE=1: where the loader and the image writer spend their time (stderr)
+inline bool io_trace() { static const bool on = getenv("GRLBWT_IO_TRACE") != nullptr; return on; }
+inline double io_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 template <class E>
 void load_file_into(E &e, int fd, uint64_t base, uint64_t bytes, int w) {      // bytes [base, base + bytes) of the file
+    const double t_a = io_now();
     e.own0.alloc(bytes + 16);
+    const double t_b = io_now();
+    double t_read = 0, t_wait = 0;
     char *bufs[kIoBufs] = {nullptr, nullptr, nullptr};
     prim::Fence fences[kIoBufs];
     uint64_t *d_hist = nullptr;
@@ -181,20 +246,30 @@ void load_file_into(E &e, int fd, uint64_t base, uint64_t bytes, int w) {      /
     };
     try {
         const uint64_t chunk = bytes < kIoChunk ? (bytes + 15) / 16 * 16 : kIoChunk;
-        for (int k = 0; k < kIoBufs; k++) bufs[k] = (char *)prim::pinned_alloc(chunk ? chunk : 16);
+        // (the pinned buffers are made as the ring reaches them: pinning 3 x 64 MiB takes 60 ms, and the second and third are not
+        // needed before the first chunk is on its way)
         if (w == 1) { d_hist = (uint64_t *)prim::dev_alloc(256 * 8); prim::dev_memset(d_hist, 0, 256 * 8); }
         int k = 0;
+        ReadPool pool(bytes > ReadPool::kPiece ? io_threads() : 0);
         for (uint64_t off = 0; off < bytes; off += chunk, k = (k + 1) % kIoBufs) {
             const uint64_t len = bytes - off < chunk ? bytes - off : chunk;
+            const double t0 = io_now();
+            if (!bufs[k]) bufs[k] = (char *)prim::pinned_alloc(chunk ? chunk : 16);
             prim::fence_wait(fences[k]);                                // the copy that last used this buffer is done
-            if (!par_io(fd, bufs[k], base + off, len, false, io_threads())) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+            const double t1 = io_now();
+            if (!pool.read(fd, bufs[k], base + off, len)) throw prim::Error(GRLBWT_EINVAL, "cannot read the input file");
+            t_wait += t1 - t0; t_read += io_now() - t1;
             prim::h2d_async(e.own0.p + off, bufs[k], len);
             if (d_hist) prim::byte_histogram_accumulate(e.own0.p + off, len, d_hist);
             prim::fence_record(fences[k]);
         }
         uint64_t hist[256];
+        const double t_c = io_now();
         if (d_hist) prim::d2h(hist, d_hist, sizeof hist); else prim::sync();
+        const double t_d = io_now();
         cleanup();
+        if (io_trace()) fprintf(stderr, "[grlbwt] load: device buffer %.3f s, pinned buffers + loop %.3f s (reading %.3f s, waiting for copies %.3f s), drain %.3f s, "
+                                        "free %.3f s, %d reader threads\n", t_b - t_a, t_c - t_b, t_read, t_wait, t_d - t_c, io_now() - t_d, io_threads());
         e.load_text(e.own0.p, bytes / (uint64_t)w, w, w == 1 ? hist : nullptr);
     } catch (...) {
         try { prim::sync(); } catch (...) {}
@@ -387,51 +462,100 @@ void load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fx_flags, uint64_t *
         ctx->e32 = std::move(e);
     }
 }
-// HBM image -> file: chunk k is written while chunk k+1 comes down.  (The write side runs at ~9 GB/s whatever the number of
-// pwrite() threads -- 8, 16, 32 measured alike on the 8.3 GB image of the 10 GB build: buffered writes to one file serialise on
-// its inode lock.  Filling a shared mapping of the file from 16 threads instead was 4x SLOWER: 4.1-4.5 s, page faults.)
+// HBM image -> file.  A buffered write to ONE file runs at the rate of one thread copying into the page cache, whatever the
+// number of threads (the inode's lock; tools/io_probe.cpp on the GPU box, 8 GiB to /tmp: 1 thread 10.9 GB/s, 4-16 threads with
+// pwrite on disjoint ranges 9.3-9.7, 64 threads 3.8, preallocated with posix_fallocate 11.1, O_DIRECT 7.1 -- and 64 GB/s into
+// EIGHT files; a shared mapping filled by 16 threads was 4x slower: page faults).  So: the blocks are preallocated, ONE writer
+// thread lives for the whole image and writes the chunks in order as their copies land in a ring of pinned buffers; the device
+// copies (50+ GB/s) stay ahead of it.  (Before: a writer thread per 64 MiB chunk that started eight more: 0.97-1.17 s for the
+// 8.3 GB image of the 10 GB build.)
 void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
     // The image goes to <path>.tmp~<pid> and is renamed over the target once it is complete and closed (the reference renames
     // bwt_lev_0 to the output name, grl_bwt.hpp:77): an existing output stays intact until then, and a run that is killed or fails
-    // leaves at most the temporary behind -- removed on every error path here.  A fresh file is also the fast way to write:
-    // rewriting an existing 6.7 GB output in place (O_TRUNC) took 2.3 s against 0.9 s for a new one.  What replacing an existing
-    // output costs is the release of its cached pages inside rename() (~0.6 s for 8.3 GB).
+    // leaves at most the temporary behind -- removed on every error path here.  What replacing an existing output costs is the
+    // release of its cached pages inside rename() (~0.6 s for 8.3 GB).
+    const double t_a = io_now();
     const std::string tmp = std::string(path) + ".tmp~" + std::to_string((long)getpid());
     int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + tmp);
-    char *bufs[2] = {nullptr, nullptr};
-    prim::Fence fences[2];
-    std::atomic<bool> ok(true);               // written by the writer thread, read by the loop
+    constexpr int NBUF = 4;
+    char *bufs[NBUF] = {nullptr, nullptr, nullptr, nullptr};
+    prim::Fence fences[NBUF];
+    struct Job { uint64_t off, len; };
+    Job jobs[NBUF];
+    std::mutex mu;
+    std::condition_variable cv;
+    int filled = 0, written = 0;              // chunks handed to the writer / chunks it has finished (ring positions = count % NBUF)
+    bool stop = false;
+    std::atomic<bool> ok(true);
     std::thread writer;                       // outside the try block: a failing copy must not unwind past a joinable thread
+    double t_wait_copy = 0, t_pwrite = 0;
+    auto finish_writer = [&] {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv.notify_all();
+        if (writer.joinable()) writer.join();
+    };
     try {
         const uint64_t chunk = nb < kIoChunk ? nb : kIoChunk;
-        for (int k = 0; k < 2; k++) bufs[k] = (char *)prim::pinned_alloc(chunk ? chunk : 16);
-        if (ftruncate(fd, (off_t)nb) != 0) ok = false;
-        uint64_t poff = 0, plen = 0;
-        int k = 0, pk = 0;
-        for (uint64_t off = 0; off < nb && ok; off += chunk, k ^= 1) {
+        if (nb && posix_fallocate(fd, 0, (off_t)nb) != 0 && ftruncate(fd, (off_t)nb) != 0) ok = false;
+        const double t_b = io_now();
+        auto body = [&] {
+            prim::thread_attach();
+            for (;;) {
+                int k;
+                Job j;
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return stop || written < filled; });
+                    if (written >= filled) return;                   // (stop, nothing left)
+                    k = written % NBUF;
+                    j = jobs[k];
+                }
+                const double t0 = io_now();
+                try { prim::fence_wait(fences[k]); } catch (...) { ok = false; }
+                const double t1 = io_now();
+                if (ok && !par_io(fd, bufs[k], j.off, j.len, true, 1)) ok = false;
+                t_wait_copy += t1 - t0; t_pwrite += io_now() - t1;
+                { std::lock_guard<std::mutex> g(mu); written++; }
+                cv.notify_all();
+            }
+        };
+        try { writer = std::thread(body); } catch (const std::system_error &) { /* no thread to be had: the chunks are written below */ }
+        for (uint64_t off = 0; off < nb && ok; off += chunk) {
             const uint64_t len = nb - off < chunk ? nb - off : chunk;
-            prim::d2h_async(bufs[k], dev_image + off, len);           // buffer k was written out two chunks ago (joined below)
+            int k;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return filled - written < NBUF; });         // a free buffer
+                k = filled % NBUF;
+            }
+            if (!bufs[k]) bufs[k] = (char *)prim::pinned_alloc(chunk ? chunk : 16);      // (made as the ring reaches them: the writer is busy by then)
+            prim::d2h_async(bufs[k], dev_image + off, len);
             prim::fence_record(fences[k]);
-            if (writer.joinable()) writer.join();
-            prim::fence_wait(fences[k]);
-            poff = off; plen = len; pk = k;
-            try {
-                writer = std::thread([&, poff, plen, pk] { if (!par_io(fd, bufs[pk], poff, plen, true, io_threads())) ok = false; });
-            } catch (const std::system_error &) {                     // no thread to be had: write this chunk here
-                if (!par_io(fd, bufs[pk], poff, plen, true, 1)) ok = false;
+            if (writer.joinable()) {
+                { std::lock_guard<std::mutex> g(mu); jobs[k] = Job{off, len}; filled++; }
+                cv.notify_all();
+            } else {                                                          // (no writer thread: in line)
+                prim::fence_wait(fences[k]);
+                if (!par_io(fd, bufs[k], off, len, true, 1)) ok = false;
             }
         }
-        if (writer.joinable()) writer.join();
+        {   // everything handed over: wait for the writer to drain
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return written >= filled; });
+        }
+        finish_writer();
+        if (io_trace()) fprintf(stderr, "[grlbwt] write: open + buffers + preallocation %.3f s, chunks %.3f s (writer: waiting for copies %.3f s, writing %.3f s)\n",
+                                t_b - t_a, io_now() - t_b, t_wait_copy, t_pwrite);
     } catch (...) {
-        if (writer.joinable()) writer.join();
+        finish_writer();
         try { prim::sync(); } catch (...) {}
-        for (int k = 0; k < 2; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
+        for (int k = 0; k < NBUF; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
         close(fd);
         unlink(tmp.c_str());
         throw;
     }
-    for (int k = 0; k < 2; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
+    for (int k = 0; k < NBUF; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
     if (close(fd) != 0) ok = false;
     if (ok && rename(tmp.c_str(), path) != 0) ok = false;
     if (!ok) { unlink(tmp.c_str()); throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path); }

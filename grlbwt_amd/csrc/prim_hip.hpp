@@ -543,6 +543,7 @@ inline void fence_record(Fence &f) {
     f.armed = true;
 }
 inline void fence_wait(Fence &f) { if (f.armed) { GRL_HIP_CHECK(hipEventSynchronize(f.e)); f.armed = false; } }
+inline void thread_attach() { if (rt().device >= 0) (void)hipSetDevice(rt().device); }      // a helper thread that is going to wait for fences
 inline void fence_destroy(Fence &f) { if (f.e) (void)hipEventDestroy(f.e); f.e = nullptr; f.armed = false; }
 inline void d2d(void *dst, const void *src, size_t n) {
     if (n) GRL_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, rt().stream));

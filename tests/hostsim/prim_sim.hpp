@@ -71,6 +71,7 @@ inline void d2h_async(void *h, const void *d, size_t n) { if (n) std::memcpy(h, 
 struct Fence { bool armed = false; };
 inline void fence_record(Fence &f) { f.armed = true; }
 inline void fence_wait(Fence &f) { f.armed = false; }
+inline void thread_attach() {}
 inline void fence_destroy(Fence &) {}
 inline void dev_memset(void *d, int v, size_t n) { if (n) std::memset(d, v, n); }
 

@@ -67,6 +67,11 @@ def main():
         torch.cuda.empty_cache()
         runs = []
         for rep in range(int(os.environ.get("GRLBWT_E2E_REPS", "2"))):
+            try:
+                os.remove(fout)                  # a fresh output file (replacing an existing 8 GB one costs ~0.7 s inside rename())
+            except OSError:
+                pass
+            time.sleep(float(os.environ.get("GRLBWT_E2E_PAUSE", "2")))
             t0 = time.time()
             p = subprocess.run([cli, fin, "-o", fout], capture_output=True, text=True)
             wall = time.time() - t0

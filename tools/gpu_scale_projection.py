@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 STAGES = [
-    ("parse.local (LMS breaks, hashing, table compaction)", lambda s: s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases", "hash_nocount", "hash_hot", "byte_hist", "table_compact", "dict_freq_check", "dict_maxlen", "dict_syms", "dict_offsets", "hash_long_list", "hash_long_phrases") or s.startswith(("phrase_part", "phrase_dedupe"))),
+    ("parse.local (LMS breaks, hashing, table compaction)", lambda s: s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases", "hash_nocount", "hash_hot", "byte_hist", "table_compact", "dict_freq_check", "dict_maxlen", "dict_syms", "dict_offsets", "hash_long_list", "hash_long_phrases", "hash_giant_phrases") or s.startswith(("phrase_part", "phrase_dedupe"))),
     ("parse.dictionary exchange + merge", lambda s: s.startswith("dist.") and not any(k in s for k in ("Tpos", "Ppos", "pre_scan", "owners", "cell_bounds", "take_sums", "window", "merge_cells", "piece_maps", "sample_keys", "mark_", "full_", "apply_phrase"))),
     ("parse.dictionary stage (sort, groups, grammar)", lambda s: s.startswith(("dict_build", "suffix_", "group_", "prebwt_", "grammar", "phrase_values", "merge_runs")) or s in ("dist.sample_keys", "dist.mark_scan", "dist.mark_pairs", "dist.full_scan", "dist.full_pairs", "dist.apply_phrase_ranks")),
     ("parse.emit", lambda s: s in ("slot_values", "emit_parse", "dist.list_values", "dist.local_values") or s.startswith("emit_part")),
@@ -131,7 +131,7 @@ def worker(args):
         out["peak_bytes"] = ctx.memory_usage()["peak_live_bytes"]
         nb, nr = ctx.result_size()
         import hashlib
-        out["image_md5"] = workloads.md5_device(gdist._view(ctx.result_device_ptr(), nb, dev)) if rank == 0 and nb < (2 << 30) else None
+        out["image_md5"] = workloads.md5_device(gdist._view(ctx.result_device_ptr(), nb, dev)) if rank == 0 else None
         out["image_bytes"] = nb
     comm.give()
     ag = [b for k, b, _ in comm.log if k == "allgather"]
@@ -176,7 +176,8 @@ def main():
             t0 = time.time()
             p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
             if p.returncode != 0:
-                res["runs"].append({"ranks": n, "failed": p.returncode, "stderr": p.stderr[-1500:]})
+                err = [l for l in p.stderr.splitlines() if "rror" in l and "Signal 15" not in l and "error_file" not in l]
+                res["runs"].append({"ranks": n, "failed": p.returncode, "errors": err[:12], "stderr": p.stderr[-1500:]})
                 print(json.dumps(res["runs"][-1]), flush=True)
                 continue
             ranks = [json.load(open(os.path.join(td, "rank%d.json" % r))) for r in range(n)]
