@@ -100,7 +100,7 @@ def parse_bytes(rounds, cell_bytes):
 def _is_hash_emit(s):
     # (round 3: the partitioned naming of the levels above 0 -- record pass, partition sort, LDS de-duplication, the values' way back)
     return s in ("lms_breaks", "phrase_ordinals", "hash_sample", "hash_sample_count", "hash_phrases", "slot_values", "emit_parse",
-                 "hash_prepare", "hash_lookup", "hash_hot", "hash_long_list", "hash_long_phrases") or \
+                 "hash_prepare", "hash_lookup", "hash_hot", "hash_long_list", "hash_long_phrases", "hash_giant_phrases") or \
         s.startswith(("phrase_part", "phrase_dedupe", "emit_part"))
 
 
@@ -115,9 +115,9 @@ GROUP_SITES = {
 # rocprofv3 kernel-name fragments of the kernels a group launches (PMC traffic lookup)
 GROUP_KERNELS = {
     "induce_AB": ["k_xs_count", "k_xs_scatter", "PackGrammarFn", "ChainCountFn", "ChainExpandFn", "NoVal, 1>", "k_rs_hist<unsigned long, 1>", "k_rs_hist<unsigned int, 1>"],
-    "induce_C": ["TakeScanEmitFn", "CellTakeIn", "PrePlaceFn", "BucketEdgesFn", "BucketSizeIn", "CellAtomsFn", "PreAtomsFn", "BigAtomsFn",
-                 "BigCountIn", "AtomHeadLenIn", "PreScanIn", "NotCodeIn"],
-    "hash_emit": ["HashInsertFn", "k_start_bits", "MapFn", "ScatterValFn", "PhraseRecordFn", "BitPositionsFn", "k_part_dedupe", "k_rs_unscatter",
+    "induce_C": ["k_sm_sums", "k_sm_merge", "k_sm_wide", "SmHeadsIn", "SmWideCountIn", "TermHeadIn", "RankCellPopcIn", "PrePlaceFn", "BucketEdgesFn",
+                 "BucketSizeIn", "NotCodeIn", "BuildBitsFn"],
+    "hash_emit": ["HashInsertFn", "k_giant", "k_start_bits", "MapFn", "ScatterValFn", "PhraseRecordFn", "BitPositionsFn", "k_part_dedupe", "k_rs_unscatter",
                   "prim::U128, 2,", "k_rs_hist<unsigned int, 2>", "k_rs_hist_wide<unsigned int, 2", "PartBoundsFn", "PartPhraseFn", "PartValFn", "PartCombineFn"],
     "dict_stage": ["ClaimCompactFn", "DictBuildFn", "Key0KeepFn", "unsigned int, 0>", "k_rs_hist<unsigned long, 0>", "HeadFlagFn", "FirstUnresolvedFn",
                    "ExtKeyFn", "SegStartFn", "SegSortSmallFn", "SegBig", "GroupStartsFn", "DenseGidFn", "SuffixRecFn", "GroupAccum", "GroupDecideFn",

@@ -87,3 +87,11 @@ def test_hip_library_identifies_itself(hip_lib):
     lib = ctypes.CDLL(hip_lib)
     lib.grlbwt_backend_name.restype = ctypes.c_char_p
     assert lib.grlbwt_backend_name() == b"hip-gfx950"
+
+
+def test_fault_injection_is_not_in_the_product(hip_lib):
+    """The failure-agreement tests inject faults through GRLBWT_TEST_FAIL_RANK* -- in the serial test stand-in only: the product
+    library never reads those variables (an environment variable could make a production rank throw)."""
+    blob = open(hip_lib, "rb").read()
+    assert b"GRLBWT_TEST_FAIL_RANK" not in blob
+    assert b"injected by the test" not in blob

@@ -16,7 +16,8 @@ import sys
 out, tag = sys.argv[1], sys.argv[2]
 builds = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 STREAMING = ("k_rs_scatter", "k_rs_hist", "k_scan_tiles", "k_scan_tile_sums", "k_start_bits", "k_byte_hist", "k_rs_chunk_sums",
-             "k_rs_tile_offsets", "k_reduce", "PackRunsFn", "DiffFn")
+             "k_rs_tile_offsets", "k_reduce", "PackRunsFn", "DiffFn", "k_sm_sums")      # (k_sm_merge / k_sm_wide read 4-8 bytes per lane
+                                                                                       # forward and gather a few words per segment: counted as gather kernels, factor 1)
 res = {"tag": tag, "builds_profiled": builds,
        "note": "per kernel over the whole PMC run (builds_profiled builds of the bench workload): FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 "
                "reports them; hbm_bytes_total = fetch_factor * FETCH * 1024 + WRITE * 1024 with fetch_factor 2 for streaming kernels "
