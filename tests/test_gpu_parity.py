@@ -491,6 +491,29 @@ def test_giant_phrases_hashed_by_the_wave(hip, oracle_mod):
     assert n == text.numel() and torch.equal(back, text)
 
 
+def test_runs_and_parse_beyond_2_pow_32(hip):
+    """4.4 G copies of the string "A": 8.8 G cells, a parse of 4.4 G phrase occurrences in ONE round (>= 2^32: the 64-bit
+    build has no bound on them) and two BWT runs of 4.4 G symbols each (>= 2^32: the tiles of the stream merge that hold
+    them take their 64-bit form).  The image is known in closed form: every "$"-suffix is preceded by A, every "A$"-suffix by
+    the separator -- header (1, 5), then (A, k), (separator, k)."""
+    import torch
+    k = (1 << 32) + (1 << 27) + 12345
+    text = torch.empty(2 * k, dtype=torch.uint8, device="cuda:0")
+    text[0::2] = 65
+    text[1::2] = 10
+    torch.cuda.synchronize()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+        st = ctx.stats()
+        assert st["n_strings"] == k and st["n_syms"] == 2 * k and (st["sb"], st["fb"]) == (1, 5)
+        got = ctx.result_bytes()
+        assert ctx.round_info(0)["parse_size"] == k
+    del text
+    exp = (1).to_bytes(8, "little") + (5).to_bytes(8, "little") + bytes([65]) + k.to_bytes(5, "little") + bytes([10]) + k.to_bytes(5, "little")
+    assert got == exp, (len(got), got[:40])
+
+
 def test_final_bytes_vs_oracle_250MB(hip, oracle_mod):
     """The largest input compared byte for byte with the oracle ("What's weak" 3): 1.65 M Illumina-style reads of
     150 bp from an 8.3 Mbp genome (249 MB, 30x coverage, 0.5 % substitutions -- the headline distribution at 1/40 of its
