@@ -3864,7 +3864,7 @@ class Engine {
         // ---- the stream merge: count (T positions, run heads), then emit
         const AsmSeg seg{kinds.p, nh_sym.p, nh_len.p, cells, take_code, tstarts.p, esym.p, epos.p};
         prim::SmPlan<idx_t> plan;
-        prim::stream_merge_count<AsmSeg, idx_t>(G, seg, plan, "asm");
+        prim::stream_merge_count<AsmSeg, idx_t>(G, seg, plan, "asm", NH * 64 < G);      // (few pre-BWT runs among the segments: small tiles, see prim_hip.hpp)
         if (plan.take_total != Tsum) { plan.release(); throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
                                                                                        std::to_string(plan.take_total) + " vs " + std::to_string(Tsum) + ")"); }
         if (plan.len_total != L.n_out) { plan.release(); throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(plan.len_total) +

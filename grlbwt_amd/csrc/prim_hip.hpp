@@ -2415,8 +2415,10 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
 // (Output order = segment order = T order: every access of the three passes runs forward through its array.  The form this
 // replaces computed the T prefix of every cell with a scan of its own, stored it, gathered five arrays per cell to place
 // packed atoms, wrote them, and merged them with another scan: 105 ms at level 0 of the 10 GB build against ~35.)
-static constexpr int kSmSpt = 8;                           // segments per thread
-static constexpr int kSmTile = kBlock * kSmSpt;            // 2048 segments per tile
+// segments per thread SPT = 4 or 8 (tiles of 1024 / 2048 segments), chosen per call: tiles of plain cells (level 0 of a read
+// collection) run faster small -- 143 registers and three waves per SIMD at 8, seven at 4: emit 24.7 -> 19.9 ms, count 11.9 -> 9.9 --
+// tiles that mix cells and pre-BWT runs faster large (the per-tile work -- two ranks in the kinds vector, the bases, four block
+// barriers -- weighs more there: count 10.3 ms at 8, 13.7 at 4 on level 1 of the 10 GB build)
 static constexpr u32 kSmNoSym = 0xFFFFFFFFu;
 static constexpr u32 kSmInline = 8;                        // atoms behind the first a lane stores by itself; a TAKE that spans more runs of T is queued
                                                            // and copied by a kernel of its own, one lane per atom (a pre-BWT run of BWT markers can
@@ -2426,6 +2428,7 @@ struct SmWide { IDX r, L, x, cnt; u64 k; };                // run index / symbol
 template <class IDX>
 struct SmPlan {
     u64 G = 0, tiles = 0;
+    int spt = 8;
     IDX *xbase = nullptr, *lbase = nullptr, *hbase = nullptr;       // [tiles + 1] exclusive prefixes: TAKE symbols, symbols, run heads
     u32 *tlast = nullptr;                                           // [tiles] last symbol of every tile
     u64 take_total = 0, len_total = 0, heads = 0, atoms = 0;
@@ -2440,30 +2443,35 @@ struct SmPlan {
 };
 // (one WAVE per tile, eight loads in flight per lane, no barrier: with a workgroup per tile of 1024 segments this pass spent its
 // time starting workgroups that lived for two dependent loads -- 6.4 ms for the 2.65 G cells of level 0 of the 10 GB build)
-template <class SEG, class IDX>
+template <class SEG, class IDX, int SPT>
 __global__ void __launch_bounds__(kBlock) k_sm_sums(u64 G, u64 tiles, SEG seg, IDX *tile_take, IDX *tile_len) {
+    constexpr int kSmTile = kBlock * SPT;
+    constexpr int TPW = 1;                          // tiles per wave (two small tiles per wave was measured slower: 7.2 vs 5.9 ms at level 0 of the 10 GB build)
     const int lane = threadIdx.x & 63;
-    const u64 tile = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (tile < tiles) {                              // (wave-uniform)
-        const u64 base = tile * kSmTile;
-        IDX a = 0, b = 0;
-        for (int j0 = 0; j0 < kSmTile / 64; j0 += 8) {
-            u32 sym[8]; IDX len[8]; bool take[8];
-            typename SEG::Ref ref[8];
+    const u64 tile0 = ((u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * TPW;
+    for (int tw = 0; tw < TPW; tw++) {
+        const u64 tile = tile0 + tw;
+        if (tile < tiles) {                              // (wave-uniform)
+            const u64 base = tile * kSmTile;
+            IDX a = 0, b = 0;
+            for (int j0 = 0; j0 < kSmTile / 64; j0 += 8) {
+                u32 sym[8]; IDX len[8]; bool take[8];
+                typename SEG::Ref ref[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const u64 g = base + (u64)(j0 + j) * 64 + lane; ref[j] = seg.locate(g < G ? g : G - 1); }      // (clamped, not branched: all loads in flight)
+                for (int j = 0; j < 8; j++) { const u64 g = base + (u64)(j0 + j) * 64 + lane; ref[j] = seg.locate(g < G ? g : G - 1); }      // (clamped, not branched: all loads in flight)
 #pragma unroll
-            for (int j = 0; j < 8; j++) seg.fetch(ref[j], sym[j], len[j], take[j]);
+                for (int j = 0; j < 8; j++) seg.fetch(ref[j], sym[j], len[j], take[j]);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const bool v = base + (u64)(j0 + j) * 64 + lane < G;
-                a += (v && take[j]) ? len[j] : (IDX)0;
-                b += v ? len[j] : (IDX)0;
+                for (int j = 0; j < 8; j++) {
+                    const bool v = base + (u64)(j0 + j) * 64 + lane < G;
+                    a += (v && take[j]) ? len[j] : (IDX)0;
+                    b += v ? len[j] : (IDX)0;
+                }
             }
+            a = wave_reduce<IDX, Op::Sum>(a);
+            b = wave_reduce<IDX, Op::Sum>(b);
+            if (lane == 0) { tile_take[tile] = a; tile_len[tile] = b; }
         }
-        a = wave_reduce<IDX, Op::Sum>(a);
-        b = wave_reduce<IDX, Op::Sum>(b);
-        if (lane == 0) { tile_take[tile] = a; tile_len[tile] = b; }
     }
 }
 // wide[]: [0] queued segments, [1] their atoms (count pass: totals; emit pass: wide[2] = queue fill).
@@ -2479,18 +2487,19 @@ __global__ void __launch_bounds__(kBlock) k_sm_sums(u64 G, u64 tiles, SEG seg, I
 //   * the two ranks of a TAKE segment come from ONE word of the T vector whenever its ends share it;
 //   * the emit pass stages the tile's heads in LDS and writes them out linearly (a lane's heads are consecutive, so the direct
 //     stores of a wave were 64 addresses 40 bytes apart: 24 ms for level 0 of the 10 GB build against 12 for the count pass).
-template <class LT> struct SmShared {
+template <class LT, int SPT> struct SmShared {
+    static constexpr int kSmTile = kBlock * SPT;
     u32 sym[kSmTile + kSmTile / 32];            // bit 31: TAKE (symbols are < 2^30); skewed by one slot per 32.  Emit: the staged heads' symbols
     LT len[kSmTile + kSmTile / 32];             // ... and their positions
     Pair<LT, LT> w2[4];
     u32 w1[4];
     u32 last[kBlock];
 };
-template <class LT, class SEG, class IDX, bool EMIT>
+template <class LT, class SEG, class IDX, bool EMIT, int SPT>
 GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const IDX lb, const IDX hb, const u32 prev_tile, const bool plain, const u64 ord0,
-                     SmShared<LT> &S, IDX *tile_heads, IDX *tile_atoms, u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue,
+                     SmShared<LT, SPT> &S, IDX *tile_heads, IDX *tile_atoms, u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue,
                      u64 queue_cap, u32 *osym, IDX *ostart) {
-    constexpr int TILE = kSmTile, SPT = kSmSpt;
+    constexpr int TILE = kBlock * SPT;
     typedef Pair<LT, LT> P2;
     // striped loads (neighbouring lanes, neighbouring segments) -> LDS -> blocked (a lane's segments are consecutive)
     {
@@ -2535,7 +2544,7 @@ GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const 
     }
     // runs of T every TAKE segment touches: the rank word of its first symbol, and of its end where that is another word
     u64 k0[SPT]; u32 inner[SPT];             // first run touched; runs touched behind it (saturated: a segment with >= 2^32 - 1 inner runs is split by nobody -- see below)
-    u64 k1m[SPT];                            // last run touched
+    u64 k1m[SPT];                            // last run touched  (dropping this array for a recount in the saturated case made the compiler use MORE registers: 143 -> 160)
     {
         u64 aw[SPT], ab[SPT], bw[SPT], bb[SPT];
 #pragma unroll
@@ -2639,6 +2648,8 @@ GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const 
                         const u64 q = (u64)atomicAdd(&wide[2], 1ull);
                         if (q < queue_cap) queue[q] = SmWide<IDX>{(IDX)((u64)hb + r), lb + (IDX)Ls[i], xb + (IDX)xs[i], (IDX)in64, k0[i] + 1};
                     } else {
+                        // (all of a segment's loads in flight first, clamped instead of branched, was tried: no faster -- 18.9 vs 19.4 ms on
+                        // level 1 of the 10 GB build -- and 24 more registers)
                         const u64 x = (u64)xb + (u64)xs[i];
                         for (u32 a = 0; a < (u32)in64; a++) {
                             const u64 k = k0[i] + 1 + (u64)a;
@@ -2661,10 +2672,11 @@ GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const 
         }
     }
 }
-template <class SEG, class IDX, bool EMIT>
+template <class SEG, class IDX, bool EMIT, int SPT>
 __global__ void __launch_bounds__(kBlock) k_sm_merge(u64 G, SEG seg, const IDX *xbase, const IDX *lbase, const IDX *hbase, IDX *tile_heads, IDX *tile_atoms,
                                                      u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue, u64 queue_cap, u32 *osym, IDX *ostart) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[sizeof(SmShared<IDX>)];
+    constexpr int kSmTile = kBlock * SPT;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[sizeof(SmShared<IDX, SPT>)];
     const u64 base = (u64)blockIdx.x * kSmTile;
     // (loaded first: nothing below has to wait for them)
     const IDX xb = xbase[blockIdx.x], lb = lbase[blockIdx.x], lnext = lbase[blockIdx.x + 1];
@@ -2675,10 +2687,10 @@ __global__ void __launch_bounds__(kBlock) k_sm_merge(u64 G, SEG seg, const IDX *
     const u64 ord0 = seg.pre_before(base), ord1 = seg.pre_before(gend);
     const bool plain = ord0 == ord1;                                   // (uniform) no pre-BWT run among the tile's segments
     if (sizeof(IDX) == 4 || (u64)(lnext - lb) >= 0xFFFFFFFFull)        // (uniform) offsets inside the tile in the index width ...
-        sm_tile<IDX, SEG, IDX, EMIT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<IDX> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
+        sm_tile<IDX, SEG, IDX, EMIT, SPT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<IDX, SPT> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
                                      wide, queue, queue_cap, osym, ostart);
     else                                                               // ... or in 32 bits when the tile describes < 2^32 symbols
-        sm_tile<u32, SEG, IDX, EMIT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<u32> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
+        sm_tile<u32, SEG, IDX, EMIT, SPT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<u32, SPT> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
                                      wide, queue, queue_cap, osym, ostart);
 }
 // heads of tile t without the provisional head of its first segment where the tile in front ends with the same symbol
@@ -2707,11 +2719,13 @@ __global__ void __launch_bounds__(kBlock) k_sm_wide(u64 natoms, u64 nq, SEG seg,
 }
 // passes 1 + 2: the plan's prefixes and totals (one host synchronisation); pass 3 follows through stream_merge_emit
 template <class SEG, class IDX>
-inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *name = "stream_merge") {
+inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *name = "stream_merge", bool mostly_plain = false) {
     plan.release();
     plan = SmPlan<IDX>();
     plan.G = G;
     if (G == 0) return;
+    plan.spt = mostly_plain ? 4 : 8;
+    const u64 kSmTile = (u64)kBlock * plan.spt;
     plan.tiles = (G + kSmTile - 1) / kSmTile;
     const u64 T = plan.tiles;
     plan.xbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
@@ -2721,7 +2735,8 @@ inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *na
     IDX *tatoms = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
     u32 *tfirst = (u32 *)dev_alloc(T * sizeof(u32));
     prof_begin(std::string(name) + ".sums");
-    hipLaunchKernelGGL((k_sm_sums<SEG, IDX>), dim3((unsigned)((T + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, rt().stream, G, T, seg, plan.xbase, plan.lbase);
+    if (plan.spt == 4) hipLaunchKernelGGL((k_sm_sums<SEG, IDX, 4>), dim3((unsigned)((T + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, rt().stream, G, T, seg, plan.xbase, plan.lbase);
+    else hipLaunchKernelGGL((k_sm_sums<SEG, IDX, 8>), dim3((unsigned)((T + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, rt().stream, G, T, seg, plan.xbase, plan.lbase);
     prof_end();
     after_launch(name);
     u64 *dres = (u64 *)dev_alloc(6 * sizeof(u64));      // [0] TAKE symbols, [1] symbols, [2] heads, [3] atoms, [4] wide segments, [5] their atoms
@@ -2729,8 +2744,12 @@ inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *na
     exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.xbase}, plan.xbase, (IDX *)(dres + 0), plan.xbase + T, name);
     exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.lbase}, plan.lbase, (IDX *)(dres + 1), plan.lbase + T, name);
     prof_begin(std::string(name) + ".count");
-    hipLaunchKernelGGL((k_sm_merge<SEG, IDX, false>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
-                       (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
+    if (plan.spt == 4)
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, false, 4>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
+                           (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
+    else
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, false, 8>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
+                           (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
     prof_end();
     after_launch(name);
     exclusive_scan_async<IDX, SmHeadsIn<IDX>>(T, SmHeadsIn<IDX>{plan.hbase, tfirst, plan.tlast}, plan.hbase, (IDX *)(dres + 2), plan.hbase + T, name);
@@ -2748,8 +2767,12 @@ inline void stream_merge_emit(SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart
     unsigned long long *wide = (unsigned long long *)dev_alloc(3 * sizeof(unsigned long long));
     dev_memset(wide, 0, 3 * sizeof(unsigned long long));
     prof_begin(std::string(name) + ".emit", plan.heads * (sizeof(u32) + sizeof(IDX)));
-    hipLaunchKernelGGL((k_sm_merge<SEG, IDX, true>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
-                       (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart);
+    if (plan.spt == 4)
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, true, 4>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
+                           (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart);
+    else
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, true, 8>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
+                           (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart);
     prof_end();
     after_launch(name);
     if (nq) {

@@ -397,7 +397,7 @@ inline void sm_walk(u64 G, const SEG &seg, SmPlan<IDX> &plan, PUT put) {
     plan.take_total = x; plan.len_total = L; plan.heads = heads; plan.atoms = atoms;
 }
 template <class SEG, class IDX>
-inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char * = "") {
+inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char * = "", bool = false) {
     plan = SmPlan<IDX>();
     plan.G = G;
     sm_walk(G, seg, plan, [](u64, u32, u64) {});
