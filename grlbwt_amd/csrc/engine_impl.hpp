@@ -629,6 +629,10 @@ struct NoCountAdd {            // (experiments: the hashing pass without its cou
     GRL_DEV void operator()(u32, u32) const {}
 };
 
+struct SampleCountIn {    // (slot occupied, its count): distinct phrases and occurrences of a sample's table
+    const u64 *keys; const idx_t *counts;
+    GRL_DEV prim::Pair<u64, u64> operator()(u64 i) const { return prim::Pair<u64, u64>(keys[i] != 0 ? 1ull : 0ull, (u64)counts[i]); }
+};
 struct OccIn {
     const u64 *keys; int ks;
     GRL_DEV u32 operator()(u64 i) const { return keys[i << ks] != 0 ? 1u : 0u; }
@@ -839,6 +843,10 @@ struct PartCombineFn {     // the parse: occurrences that went through the table
 struct LenIn {
     const u32 *l;
     GRL_DEV u32 operator()(u64 i) const { return l[i]; }
+};
+struct FreqLenIn {        // (frequency, length) of phrase i
+    const idx_t *f; const u32 *l;
+    GRL_DEV prim::Pair<u64, u64> operator()(u64 i) const { return prim::Pair<u64, u64>((u64)f[i], (u64)l[i]); }
 };
 GRL_HD u64 rank1(const u64 *words, const idx_t *base, u64 x);      // (defined with the rank bit-vectors below)
 template <class cell_t, bool FIRST, int PER = 4>
@@ -1312,6 +1320,15 @@ struct GroupDecideFn {
 struct FlagIn {
     const u8 *f; u8 m;
     GRL_DEV u32 operator()(u64 i) const { return (f[i] & m) ? 1u : 0u; }
+};
+struct RankedValidIn {    // (group is ranked, group is valid)
+    const u8 *f;
+    GRL_DEV prim::Pair<u32, u32> operator()(u64 i) const { const u8 x = f[i]; return prim::Pair<u32, u32>((x & GF_RANKED) ? 1u : 0u, (x & GF_VALID) ? 1u : 0u); }
+};
+struct SplitPairEmitFn {  // the two prefixes into arrays of their own
+    static constexpr bool kWaveEmit = false;
+    u32 *a; u32 *b;
+    GRL_DEV void operator()(u64 i, prim::Pair<u32, u32> ex, prim::Pair<u32, u32>) const { a[i] = ex.a; b[i] = ex.b; }
 };
 struct GroupEmitFn {      // (m_off, p_off: metasymbols / pre-BWT entries of the ranks in front of me when the groups are sharded)
     const u8 *gflag; const u32 *grank; const u32 *pidx; const u32 *gmin; const idx_t *gacc; const u32 *gstart; const u32 *perm;
@@ -2876,8 +2893,9 @@ class Engine {
                 fs.rec_b = rec_b; fs.rec_cmax = rec_cmax;       // (partitioned naming: only the long phrases reach the sample's table)
                 fs.walk_cap = HF::kLongWalk;        // (the sample leaves the long phrases out: they are listed and hashed by waves in the real pass)
                 prim::for_each_agg(n_s, SampledFn<HF>{fs, blk, stride}, SlotCountAdd{tc.p, 1}, true, "hash_sample");
-                const u64 d_s = prim::reduce_sum<u64>(cap_s, OccIn{tk.p, 0}, "hash_sample_count");
-                const u64 occ_s = std::max<u64>(prim::reduce_sum<u64>(cap_s, IdxIn<idx_t>{tc.p}, "hash_sample_count"), 1);
+                const prim::Pair<u64, u64> so = prim::reduce_sum<prim::Pair<u64, u64>>(cap_s, SampleCountIn{tk.p, tc.p}, "hash_sample_count");      // (one reduction: one synchronisation)
+                const u64 d_s = so.a;
+                const u64 occ_s = std::max<u64>(so.b, 1);
                 if (part) s_long = occ_s;
                 frac = (double)d_s / (double)occ_s;
                 if (frac > 1.0) frac = 1.0;
@@ -3055,13 +3073,16 @@ class Engine {
             prim::for_each(Dl, ClaimCompactFn<cell_t, FIRST>{CompactTableFn<cell_t, FIRST>{t, ops, startbits.p, keys.p, counts_p, P.ph_pos.p + Ds,
                                                              P.ph_freq.p + Ds, P.ph_len.p + Ds, P.ph_slot.p + Ds, P.ph_lastT.p + Ds, ks, cs, rep_pos.p, n}}, "table_compact");
             wordbase.release(); claim.release();
-            u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{P.ph_freq.p}, "dict_freq_check");
-            if (fsum != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fsum) + ") do not add up to the parse size (" +
+            // (frequencies and lengths summed by ONE reduction, the offsets by a scan whose total is known already: two host
+            // synchronisations instead of four)
+            const prim::Pair<u64, u64> fl = prim::reduce_sum<prim::Pair<u64, u64>>(D, FreqLenIn{P.ph_freq.p, P.ph_len.p}, "dict_totals");
+            if (fl.a != n_occ) throw prim::Error(-71, "phrase frequencies (" + std::to_string(fl.a) + ") do not add up to the parse size (" +
                                                            std::to_string(n_occ) + ")");
             P.maxlen = prim::reduce_max<u32>(D, LenIn{P.ph_len.p}, "dict_maxlen");   // (an atomicMax per insert serialised on one address)
-            u64 S64 = prim::reduce_sum<u64>(D, LenIn{P.ph_len.p}, "dict_syms");
+            const u64 S64 = fl.b;
             if (S64 >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
-            P.S = prim::exclusive_scan<u32>(D, LenIn{P.ph_len.p}, P.ph_off.p, true, "dict_offsets");
+            prim::exclusive_scan_nosync<u32>(D, LenIn{P.ph_len.p}, P.ph_off.p, true, "dict_offsets");
+            P.S = S64;
         }
     }
 
@@ -3318,8 +3339,7 @@ class Engine {
                 if (rk.rb) prim::for_each(Sg, InitSkipFn{perm.p, rk.rem, (u32)K, rk.skip}, "suffix_runs");
                 prim::for_each(Sg, HeadFlagFn{ks, hflag.p}, "suffix_heads");
                 prim::for_each(Sg, FirstUnresolvedFn{ks, hflag.p, Sg, sent, uflag.p}, "suffix_unresolved");
-                prim::sync();
-            }
+            }                                   // (no host synchronisation: the buffers that go out of scope here are reused in stream order)
             ka.release();
             u64 Lres = (u64)K, iters = 1;        // Lres symbols (incl. a possible sentinel) resolved so far
             DBuf<u32> act;                       // slots still unresolved (empty = all slots), ascending
@@ -3388,7 +3408,6 @@ class Engine {
             G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
             prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
             prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
-            prim::sync();
             L.info.sort_iters = iters;
         };
         if (!C) sort_local();
@@ -3422,8 +3441,10 @@ class Engine {
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
-            Ml = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_RANKED}, grank.p, false, "group_ranks");
-            P0l = prim::exclusive_scan<u32>(G, FlagIn{gflag.p, GF_VALID}, pidx.p, false, "prebwt_index");
+            {   // ranks of the ranked groups and pre-BWT index of the valid ones: one scan of pairs (one host synchronisation)
+                const prim::Pair<u32, u32> tot = prim::exclusive_scan_emit<prim::Pair<u32, u32>>(G, RankedValidIn{gflag.p}, SplitPairEmitFn{grank.p, pidx.p}, "group_ranks");
+                Ml = tot.a; P0l = tot.b;
+            }
             };
             if (!C) groups_local();
             else if (!C->pending) { try { groups_local(); } catch (const prim::Error &e) { C->fail(e); Ml = 0; P0l = 0; } }
@@ -3533,7 +3554,6 @@ class Engine {
             prim::for_each(P.n_occ, PartCombineFn{sv, vc.p, P.next_text.p}, "emit_parse");
             P.psort.release(); P.lid.release(); P.pbase.release(); P.rec_h.release(); P.ph_key.release();
         } else prim::for_each((P.n_occ + 3) / 4, MapFn{sv, P.next_text.p, P.n_occ}, "emit_parse");
-        prim::sync();
     }
 
     void finish_round(LocalParse &P, LevelData &L, u64 n_strings_for_termination, u64 n_occ_for_termination) {
@@ -3684,7 +3704,6 @@ class Engine {
                     sfused = std::move(res ? ef2 : ef);
                     done = true;
                 }
-                if (done) prim::sync();
             }
             plan.release();
             if (!done) {     // offsets of every run's cells (an item with more than 32 cells, or cells that do not fit one word)

@@ -1026,9 +1026,8 @@ inline void for_each_agg(u64 n, F f, A add, bool aggregate, const char *name = "
 enum class Op { Sum, Min, Max };
 template <class T, Op OP>
 GRL_HD T op_identity() {
-    if (OP == Op::Sum) return T(0);
-    if (OP == Op::Min) return ~T(0);
-    return T(0);
+    if constexpr (OP == Op::Min) return ~T(0);
+    else return T(0);
 }
 template <class T, Op OP>
 GRL_HD T op_apply(T a, T b) {
