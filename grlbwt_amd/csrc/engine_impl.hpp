@@ -1902,6 +1902,10 @@ struct AsmSeg {
 };
 
 // ------------------------------------------------------- a16: .rl_bwt image
+struct RunRecordFn {      // sym | len << (8 sb): the record of run i as one word (sb + fb <= 8)
+    const u32 *sym; RunLen len; u32 sb;
+    GRL_DEV u64 operator()(u64 i) const { return (u64)sym[i] | ((u64)len(i) << (8 * sb)); }
+};
 struct PackRunsFn {
     const u32 *sym; RunLen len; u32 sb, fb; u8 *out; u32 hdr;      // hdr: bytes in front of the first record (16, or 0 for a part)
     GRL_DEV void operator()(u64 i) const {
@@ -3922,9 +3926,11 @@ class Engine {
         u8 hdr[16] = {0};
         for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
         prim::h2d(image.p, hdr, 16);
-        // (four runs per lane, their 4 x 5 bytes put together in registers and stored as five aligned words, was measured at 15.5 ms
-        // against 6.5-9 for this form on the 1.66 G runs of the 10 GB image: the loads of a lane's four runs are what is 20 bytes apart then)
-        prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, run_len(), sb, fb, image.p, 16u}, "pack_rl_bwt");
+        // records of up to 8 bytes go through prim::pack_records (tiles assembled in LDS, 16-byte stores); wider ones one lane per run.
+        // (Four runs per lane, their 4 x 5 bytes put together in registers, was measured at 15.5 ms against 9 for one lane per run on
+        // the 1.66 G runs of the 10 GB image: the loads of a lane's four runs are what is 20 bytes apart then.)
+        if (sb + fb <= 8 && fb < 8) prim::pack_records(bwt.R, RunRecordFn{bwt.sym.p, run_len(), sb}, sb + fb, image.p + 16, "pack_rl_bwt");
+        else prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, run_len(), sb, fb, image.p, 16u}, "pack_rl_bwt");
         image_runs = bwt.R;
         // "results are complete when a call returns" (include/grlbwt_hip.h): the image pointer may be handed to another
         // stream (torch, a copy engine) right after the build, so the engine's stream is drained here

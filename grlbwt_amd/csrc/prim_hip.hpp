@@ -2395,6 +2395,50 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
     after_launch(name);
 }
 
+// ------------------------------------------------------------------ fixed-width record packing
+// out[i * rec .. (i + 1) * rec) = the low `rec` bytes (1..8, little endian) of f(i).  A tile of 1024 records is assembled in LDS
+// (the loads of f are coalesced: lane = record) and leaves as aligned 16-byte stores when `out` is 16-byte aligned (a tile is
+// 1024 * rec bytes: always a multiple of 16).  (One lane per record with `rec` byte stores -- 64 lanes 5 bytes apart -- took 9 ms
+// for the 1.66 G five-byte records of the 10 GB image.)
+static constexpr int kPackTile = 1024;
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_pack_records(u64 n, F f, u32 rec, u8 *out) {
+    __shared__ __attribute__((aligned(16))) u8 s_b[kPackTile * 8];
+    const u64 tiles = (n + kPackTile - 1) / kPackTile;
+    for (u64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const u64 base = tile * kPackTile;
+        const u32 cnt = n - base < (u64)kPackTile ? (u32)(n - base) : (u32)kPackTile;
+#pragma unroll
+        for (int j = 0; j < kPackTile / kBlock; j++) {
+            const u32 k = (u32)j * kBlock + threadIdx.x;
+            if (k < cnt) {
+                const u64 v = f(base + k);
+                for (u32 b = 0; b < rec; b++) s_b[k * rec + b] = (u8)(v >> (8 * b));
+            }
+        }
+        __syncthreads();
+        const u32 bytes = cnt * rec;
+        u8 *dst = out + base * (u64)rec;
+        if (((uintptr_t)dst & 15) == 0) {
+            const u32 vecs = bytes / 16;
+            for (u32 x = threadIdx.x; x < vecs; x += kBlock) reinterpret_cast<uint4 *>(dst)[x] = reinterpret_cast<const uint4 *>(s_b)[x];
+            for (u32 x = vecs * 16 + threadIdx.x; x < bytes; x += kBlock) dst[x] = s_b[x];
+        } else {
+            for (u32 x = threadIdx.x; x < bytes; x += kBlock) dst[x] = s_b[x];
+        }
+        __syncthreads();
+    }
+}
+template <class F>
+inline void pack_records(u64 n, F f, u32 rec, u8 *out, const char *name = "pack_records") {
+    if (n == 0) return;
+    if (rec < 1 || rec > 8) throw Error(-22, "pack_records: record width out of range");
+    prof_begin(name, n * rec);
+    hipLaunchKernelGGL((k_pack_records<F>), dim3(grid_for((n + kPackTile - 1) / kPackTile, 1)), dim3(kBlock), 0, rt().stream, n, f, rec, out);
+    prof_end();
+    after_launch(name);
+}
+
 // ------------------------------------------------------------------ stream merge (induction pass C)
 // A sequence of G segments in OUTPUT order.  Segment g is a literal run (sym, len) or a TAKE of `len` symbols from an axis T
 // that the TAKE segments consume front to back, each where the one in front of it stopped.  T is given by its MAXIMAL runs

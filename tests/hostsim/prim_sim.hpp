@@ -364,6 +364,10 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
     }
 }
 
+template <class F>
+inline void pack_records(u64 n, F f, u32 rec, u8 *out, const char * = "") {       // out[i * rec ..] = the low rec bytes of f(i)
+    for (u64 i = 0; i < n; i++) { const u64 v = f(i); for (u32 b = 0; b < rec; b++) out[i * rec + b] = (u8)(v >> (8 * b)); }
+}
 // stream merge (serial form of prim_hip.hpp's: segments in output order -> maximal runs)
 template <class IDX>
 struct SmPlan {
