@@ -3240,6 +3240,9 @@ class Engine {
             int K = (64 - rk.rb) / b;
             if (K < 1) K = 1;
             if (K > 16) K = 16;
+            // (GRLBWT_SORT_KMAX: fewer symbols in the first sort's key -- fewer radix passes, more left to the refinement)
+            static const int kmax = getenv("GRLBWT_SORT_KMAX") ? atoi(getenv("GRLBWT_SORT_KMAX")) : 16;
+            if (kmax >= 1 && K > kmax) K = kmax;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
             if (rk.rb && K * b + rk.rb > 64) rk.rb = 0;                     // (symbols too wide to share a key with a run field: plain keys)
             if (rk.rb) {
