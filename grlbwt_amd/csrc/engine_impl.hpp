@@ -1500,7 +1500,7 @@ struct RankBits {
 };
 struct BuildBitsFn {      // one lane per 16 consecutive (sorted, distinct) positions: OR them into their words
     const idx_t *pos; u64 count; u64 *words;
-    u64 ws = 1;           // word i of the bit-vector sits at words[i * ws] (interleaved layouts: TCell)
+    u64 ws = 1;           // word i of the bit-vector sits at words[i * ws] (interleaved layouts: RankCell keeps a word and its rank side by side)
     struct alignas(16) Chunk { idx_t v[16 / sizeof(idx_t)]; };     // 16 bytes of positions per load
     GRL_DEV void operator()(u64 j) const {
         u64 i0 = j * 16, i1 = i0 + 16 < count ? i0 + 16 : count;
