@@ -1417,97 +1417,149 @@ inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
 // store requests; the LDS-staged form below 3.8 ms.  One wave per 1024-key tile without workgroup barriers was
 // 1.3x slower than the first of those.)
 static constexpr int kRsItems = 16;                 // keys per lane (24 and 32 measured slower: registers, LDS)
-static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup
+static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup of 256 threads (PartSort, k_rs_unscatter; the plain sorts: sort_pairs)
 
-// Counting without LDS atomics: per row of 64 keys the wave takes one ballot per digit bit; lane l owns the four bins
-// l, l+64, l+128, l+192: the keys whose low six digit bits equal l are the AND of the six ballots (or their
-// complements) selected by l's own bits, and the two high bits split that set four ways with wave-uniform masks.
-// (Measured equal to the form with one LDS atomic per key, and to 4/8-byte instead of 16-byte key loads, within 6 %:
-// 29 M 8-byte keys in 64 us either way.  Kept because its cost does not depend on how skewed the digits are.)
+// The lanes of the wave whose digit equals mine (valid lanes only): how many of them sit below me, and how many there are.
+// The mismatch mask is the OR over the digit bits of ballot ^ (my bit ? ~0 : 0): two vector instructions per bit and half.
+// (BATCH: all bit spreads, then all ballots, then the folds.  A vector compare that writes a scalar pair and the vector
+// instruction that reads it need two instructions between them or the compiler pads with s_nop: 199 of them in the histogram
+// kernel, 30 in batch order.  The ranking kernels keep the bit-by-bit order: there the compiler finds that schedule itself,
+// and written in batch order it hoists the ballots of all sixteen rows -- scalar registers spilled to vector lanes, 250 bytes
+// of scratch per lane.)
+template <int DB, bool BATCH = false>
+GRL_DEV void wave_match(u32 d, bool valid, u32 &below, u32 &count) {
+    u32 mlo = 0, mhi = 0;
+    if constexpr (BATCH) {
+        u32 e[DB];
+        unsigned long long m[DB];
+#pragma unroll
+        for (int b = 0; b < DB; b++) asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(e[b]) : "v"(d), "n"(b));
+#pragma unroll
+        for (int b = 0; b < DB; b++) m[b] = __ballot(e[b] != 0u);
+#pragma unroll
+        for (int b = 0; b < DB; b++) {
+            mlo |= (u32)m[b] ^ e[b];
+            mhi |= (u32)(m[b] >> 32) ^ e[b];
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < DB; b++) {
+            u32 e;                                                    // my bit b, spread over the word (0 or ~0): ONE instruction
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(e) : "v"(d), "n"(b));     // (the compiler turns the builtin into shift + shift)
+            const unsigned long long m = __ballot(e != 0u);
+            mlo |= (u32)m ^ e;
+            mhi |= (u32)(m >> 32) ^ e;
+        }
+    }
+    const unsigned long long vm = __ballot(valid);
+    const u32 plo = (u32)vm & ~mlo, phi = (u32)(vm >> 32) & ~mhi;
+    below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    count = (u32)__popc(plo) + (u32)__popc(phi);
+}
+// Per-tile digit counts.  Per row of 64 keys the wave finds the lanes of equal digit (wave_match) and the FIRST lane of every
+// digit adds the digit's count to the wave's LDS table: one conflict-free LDS add per distinct digit, so the cost does not
+// depend on how skewed the digits are (one LDS atomic per key serialises on a 5-symbol alphabet), any digit width.
+// (Rounds 1-4: lane l owned the bins l, l+64, l+128, l+192 and built their member masks from six ballots AND-ed per lane plus
+// two more -- ~64 vector instructions per row against ~45 here; digits above 8 bits took one LDS atomic per key.)
 // (SITE: a tag that only names the instantiation -- the induction's bucket split gets kernels of its own in profiler
-// output, apart from the other keys-only 64-bit sorts)
-template <class K, int SITE = 0>
-__global__ void __launch_bounds__(kBlock) k_rs_hist(const K *keys, u64 n, int shift, u32 dmask, u32 *counts, u32 tiles) {
-    __shared__ u32 s_h[kBlock / 64][256];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const u64 base = (u64)blockIdx.x * kRsTile;
+// output, apart from the other keys-only 64-bit sorts; TB = threads per workgroup: the tile is TB x kRsItems keys, 4096 at
+// 256 threads, 8192 at 512; hist and scatter of a pass agree)
+template <class K, int SITE = 0, int DB = 8, int TB = kBlock>
+__global__ void __launch_bounds__(TB) k_rs_hist(const K *keys, u64 n, int shift, u32 dmask, u32 *counts, u32 tiles) {
+    constexpr int TILE = TB * kRsItems, NB = 1 << DB;
+    __shared__ u32 s_h[TB / 64][NB];
+    for (int i = threadIdx.x; i < (TB / 64) * NB; i += TB) (&s_h[0][0])[i] = 0;
+    u32 *h = s_h[threadIdx.x >> 6];
+    const u64 base = (u64)blockIdx.x * TILE;
     K k[kRsItems];
-    const bool full = base + kRsTile <= n;
+    const bool full = base + TILE <= n;
     constexpr int per = 16 / (int)sizeof(K);            // keys per 16-byte load (a count does not care which lane sees a key)
     struct alignas(16) Vec { K v[per]; };
-    if (full && ((uintptr_t)keys & 15) == 0) {
+    const bool vec = full && ((uintptr_t)keys & 15) == 0;
+    if (vec) {
 #pragma unroll
         for (int j = 0; j < kRsItems / per; j++) {
-            Vec x = *reinterpret_cast<const Vec *>(keys + base + ((u64)j * kBlock + threadIdx.x) * per);
+            Vec x = *reinterpret_cast<const Vec *>(keys + base + ((u64)j * TB + threadIdx.x) * per);
 #pragma unroll
             for (int e = 0; e < per; e++) k[j * per + e] = x.v[e];
         }
     } else {
 #pragma unroll
         for (int r = 0; r < kRsItems; r++) {
-            u64 i = base + (u64)r * kBlock + threadIdx.x;
+            u64 i = base + (u64)r * TB + threadIdx.x;
             k[r] = (i < n) ? keys[i] : K(0);
         }
     }
-    u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < kRsItems; r++) {
-        const u64 i = base + (u64)r * kBlock + threadIdx.x;      // only meaningful on the guarded path
+        const u64 i = base + (u64)r * TB + threadIdx.x;      // only meaningful on the guarded path
         const u32 d = (u32)(k[r] >> shift) & dmask;
-        unsigned long long lm = __ballot(full || i < n);
-#pragma unroll
-        for (int b = 0; b < 6; b++) {
-            unsigned long long m = __ballot((d >> b) & 1u);
-            lm &= ((lane >> b) & 1) ? m : ~m;
-        }
-        const unsigned long long b6 = __ballot((d >> 6) & 1u), b7 = __ballot((d >> 7) & 1u);
-        c0 += (u32)__popcll(lm & ~b6 & ~b7);
-        c1 += (u32)__popcll(lm & b6 & ~b7);
-        c2 += (u32)__popcll(lm & ~b6 & b7);
-        c3 += (u32)__popcll(lm & b6 & b7);
-    }
-    s_h[w][lane] = c0; s_h[w][lane + 64] = c1; s_h[w][lane + 128] = c2; s_h[w][lane + 192] = c3;
-    __syncthreads();
-    u32 tot = 0;
-#pragma unroll
-    for (int q = 0; q < kBlock / 64; q++) tot += s_h[q][threadIdx.x];
-    counts[(u64)blockIdx.x * 256 + threadIdx.x] = tot;      // tile-major: one coalesced row per tile
-}
-
-// Digits wider than 8 bits (9 or 10: one pass fewer over 51-56-bit suffix keys and 18-19-bit bucket residues): per-wave LDS tables,
-// one LDS atomic per key (measured equal to the ballot form at 8 bits).
-template <class K, int SITE, int DB>
-__global__ void __launch_bounds__(kBlock) k_rs_hist_wide(const K *keys, u64 n, int shift, u32 dmask, u32 *counts, u32 tiles) {
-    constexpr int NB = 1 << DB;
-    __shared__ u32 s_h[kBlock / 64][NB];
-    for (int i = threadIdx.x; i < (kBlock / 64) * NB; i += kBlock) (&s_h[0][0])[i] = 0;
-    __syncthreads();
-    u32 *h = s_h[threadIdx.x >> 6];
-    const u64 base = (u64)blockIdx.x * kRsTile;
-    const bool full = base + kRsTile <= n;
-    constexpr int per = 16 / (int)sizeof(K);
-    struct alignas(16) Vec { K v[per]; };
-    if (full && ((uintptr_t)keys & 15) == 0) {
-#pragma unroll
-        for (int j = 0; j < kRsItems / per; j++) {
-            Vec x = *reinterpret_cast<const Vec *>(keys + base + ((u64)j * kBlock + threadIdx.x) * per);
-#pragma unroll
-            for (int e = 0; e < per; e++) atomicAdd(&h[(u32)(x.v[e] >> shift) & dmask], 1u);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < kRsItems; r++) {
-            u64 i = base + (u64)r * kBlock + threadIdx.x;
-            if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & dmask], 1u);
-        }
+        const bool valid = vec || i < n;
+        u32 below, count;
+        wave_match<DB, true>(d, valid, below, count);
+        if (valid && below == 0u) (void)__hip_atomic_fetch_add(&h[d], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < NB; d += kBlock) {
+    for (int d = threadIdx.x; d < NB; d += TB) {
         u32 tot = 0;
 #pragma unroll
-        for (int q = 0; q < kBlock / 64; q++) tot += s_h[q][d];
-        counts[(u64)blockIdx.x * NB + d] = tot;
+        for (int q = 0; q < TB / 64; q++) tot += s_h[q][d];
+        counts[(u64)blockIdx.x * NB + d] = tot;         // tile-major: one coalesced row per tile
     }
+}
+
+// In-wave stable ranking of ROWS rows of 64 digits (the shared body of k_rs_scatter, k_xs_scatter and k_rs_unscatter):
+// idx[q] = number of keys of the same digit in front of key (row q, this lane) among this wave's rows 0..q, `cnt` = the
+// wave's own NB running counters in LDS (zeroed by the caller, barrier behind the zeroing).  Row q of a lane is valid when
+// t0 + 64 q < limit; rows at and behind `nrows` (wave-uniform) hold nothing.
+// Three phases instead of one loop (round 5).  The one-loop form read and rewrote the wave's counter through LDS and
+// broadcast the old value with a shuffle ROW BY ROW -- sixteen dependent LDS round trips per wave, each behind the row's
+// eight ballots.  Here (A) the match masks of all rows are computed first (wave_match: pure vector/scalar work, rows independent), (B) every row issues ONE plain LDS read of its digit's counter by all its lanes (equal addresses broadcast) and
+// ONE no-return LDS add by the first lane of every digit -- the add does not depend on the read, LDS operations of one
+// wave execute in issue order, so the 2 x ROWS operations go out back to back and are waited for once -- and (C) adds.
+// (dig(q): the digit of row q -- an array read, or recomputed from the key where registers are short)
+template <int DB, int ROWS, class DIG>
+GRL_DEV void wave_rank(DIG dig, u32 t0, u32 limit, u32 nrows, u32 *cnt, u32 (&idx)[ROWS]) {
+    u32 info[ROWS];                       // keys of my digit in front of me in the row | all of them << 8 | valid << 16
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) {
+        info[q] = 0;
+        if ((u32)q < nrows) {
+            const bool valid = t0 + 64u * (u32)q < limit;
+            // (wave_match spelled out, bit by bit: through the function the compiler schedules the sixteen rows as ONE block --
+            // ballots of all rows live at once, scalar registers spilled to vector lanes, 192 vector registers; here the
+            // select on `valid` below leaves a branch per row and the rows stay apart: 100 registers, no spills)
+            const u32 d = dig(q);
+            u32 mlo = 0, mhi = 0;
+#pragma unroll
+            for (int b = 0; b < DB; b++) {
+                u32 e;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(e) : "v"(d), "n"(b));
+                const unsigned long long m = __ballot(e != 0u);
+                mlo |= (u32)m ^ e;
+                mhi |= (u32)(m >> 32) ^ e;
+            }
+            const unsigned long long vm = __ballot(valid);
+            const u32 plo = (u32)vm & ~mlo, phi = (u32)(vm >> 32) & ~mhi;
+            const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const u32 count = (u32)__popc(plo) + (u32)__popc(phi);
+            info[q] = valid ? (below | count << 8 | 1u << 16) : 0u;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) {
+        idx[q] = 0;
+        if ((u32)q < nrows) {
+            if (info[q] >> 16) {
+                u32 *c = &cnt[dig(q)];
+                idx[q] = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if ((info[q] & 0xFFu) == 0u) (void)__hip_atomic_fetch_add(c, (info[q] >> 8) & 0xFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) idx[q] += info[q] & 0xFFu;
 }
 
 // Global write positions from the tile-major counts.  The order of a stable pass is digit-major (all tiles of digit
@@ -1562,21 +1614,22 @@ inline void rs_offsets(const u32 *counts, u32 tiles, u32 *chunk_sums, u64 *chunk
 static constexpr int kRsKeys = kRsTile / kBlock;
 struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays are read or written
 // (DB = digit bits, 8-10: thread t owns the BPT = 2^DB / 256 neighbouring bins [t * BPT, (t + 1) * BPT) in the offset phase)
-template <class K, class V, int SITE = 0, int DB = 8>
-__global__ void __launch_bounds__(kBlock)
+// (second launch bound: 4 waves per SIMD = 4 / 2 / 1 workgroups of 256 / 512 / 1024 threads per CU, what the LDS tile leaves room for)
+template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock>
+__global__ void __launch_bounds__(TB)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
                         const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles) {
-    constexpr int NB = 1 << DB, BPT = NB / kBlock;
+    constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
     constexpr int EB = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
-    __shared__ __attribute__((aligned(16))) unsigned char s_buf[kRsTile * EB];
-    __shared__ u32 s_cnt[4][NB];      // per wave: running count, then exclusive base, of each digit
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[TILE * EB];
+    __shared__ u32 s_cnt[NW][NB];      // per wave: running count, then exclusive base, of each digit
     __shared__ u64 s_gbase[NB];       // global position of tile-local index 0 of the digit's run (may wrap; mod 2^64)
-    __shared__ u32 s_wsum[4];
+    __shared__ u32 s_wsum[NW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * NB; i += kBlock) (&s_cnt[0][0])[i] = 0;
-    const u64 base = (u64)blockIdx.x * kRsTile;
+    for (int i = threadIdx.x; i < NW * NB; i += TB) (&s_cnt[0][0])[i] = 0;
+    const u64 base = (u64)blockIdx.x * TILE;
     const u64 left = n - base;
-    const u32 tile_n = left < (u64)kRsTile ? (u32)left : (u32)kRsTile;
+    const u32 tile_n = left < (u64)TILE ? (u32)left : (u32)TILE;
     const u32 wbase = (u32)w * (64 * kRsKeys);
     K key[kRsKeys];
     V val[std::is_same<V, NoVal>::value ? 1 : kRsKeys];
@@ -1588,37 +1641,20 @@ __global__ void __launch_bounds__(kBlock)
         key[q] = valid ? keys_in[base + t] : K(0);
     }
     __syncthreads();
-    volatile u32 *cnt = &s_cnt[w][0];
+    u32 dig[kRsKeys];
 #pragma unroll
-    for (int q = 0; q < kRsKeys; q++) {
-        u32 t = wbase + q * 64 + lane;
-        bool valid = t < tile_n;
-        u32 d = (u32)(key[q] >> shift) & dmask;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < DB; b++) {
-            unsigned long long m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-        u32 old = 0;
-        if (valid && below == 0) {
-            old = cnt[d];
-            cnt[d] = old + (u32)__popcll(peers);
-        }
-        int leader = valid ? __ffsll((long long)peers) - 1 : lane;
-        old = (u32)__shfl((int)old, leader);
-        idx[q] = old + below;            // rank among this wave's keys of digit d
-    }
+    for (int q = 0; q < kRsKeys; q++) dig[q] = (u32)(key[q] >> shift) & dmask;
+    wave_rank<DB, kRsKeys>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
     __syncthreads();
-    {   // thread t, bins [t*BPT, (t+1)*BPT): wave bases, tile-local digit starts, global bases
-        u32 cw[BPT][4], tt[BPT], sum = 0;
+    {   // thread t, bins [t*BPT, (t+1)*BPT): wave bases, tile-local digit starts, global bases (threads behind the last bin idle)
+        u32 cw[BPT][NW], tt[BPT], sum = 0;
+        const bool has = (int)threadIdx.x * BPT < NB;
 #pragma unroll
         for (int e = 0; e < BPT; e++) {
             const int d = threadIdx.x * BPT + e;
             tt[e] = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { cw[e][k] = s_cnt[k][d]; tt[e] += cw[e][k]; }
+            for (int k = 0; k < NW; k++) { cw[e][k] = has ? s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
             sum += tt[e];
         }
         u32 incl = sum;
@@ -1631,15 +1667,16 @@ __global__ void __launch_bounds__(kBlock)
         __syncthreads();
         u32 start = incl - sum;
         for (int k = 0; k < w; k++) start += s_wsum[k];
+        if (has) {
 #pragma unroll
-        for (int e = 0; e < BPT; e++) {
-            const int d = threadIdx.x * BPT + e;
-            s_cnt[0][d] = start;
-            s_cnt[1][d] = start + cw[e][0];
-            s_cnt[2][d] = start + cw[e][0] + cw[e][1];
-            s_cnt[3][d] = start + cw[e][0] + cw[e][1] + cw[e][2];
-            s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
-            start += tt[e];
+            for (int e = 0; e < BPT; e++) {
+                const int d = threadIdx.x * BPT + e;
+                u32 run = start;
+#pragma unroll
+                for (int k = 0; k < NW; k++) { s_cnt[k][d] = run; run += cw[e][k]; }
+                s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
+                start += tt[e];
+            }
         }
     }
     __syncthreads();
@@ -1648,8 +1685,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int q = 0; q < kRsKeys; q++) {
         u32 t = wbase + q * 64 + lane;
         if (t < tile_n) {
-            u32 d = (u32)(key[q] >> shift) & dmask;
-            idx[q] += s_cnt[w][d];
+            idx[q] += s_cnt[w][dig[q]];
             kb[idx[q]] = key[q];
         }
     }
@@ -1666,7 +1702,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < (kRsKeys + 1) / 2; j++) dpack[j] = 0;
 #pragma unroll
     for (int j = 0; j < kRsKeys; j++) {
-        u32 t = (u32)j * kBlock + threadIdx.x;
+        u32 t = (u32)j * TB + threadIdx.x;
         if (t < tile_n) {
             K k = kb[t];
             u32 d = (u32)(k >> shift) & dmask;
@@ -1685,7 +1721,7 @@ __global__ void __launch_bounds__(kBlock)
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kRsKeys; j++) {
-            u32 t = (u32)j * kBlock + threadIdx.x;
+            u32 t = (u32)j * TB + threadIdx.x;
             if (t < tile_n) {
                 u32 d = (dpack[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
                 vals_out[s_gbase[d] + t] = vb[t];
@@ -1898,32 +1934,9 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
                 key[q] = ((u32)q < rpw && t < hn) ? s_cells[t] : K(0);
             }
             __syncthreads();
-            volatile u32 *cnt = &s_cnt[w][0];
-#pragma unroll
-            for (int q = 0; q < ROWS; q++) {
-                // (rows behind rpw hold nothing: skipped by a workgroup-uniform branch -- a sub-batch of 1024 runs drops about
-                // 1600 keys at level 0, 7 of the 16 rows)
-                if ((u32)q < rpw) {
-                    const u32 t = ((u32)w * rpw + q) * 64 + lane;
-                    const bool valid = t < hn;
-                    const u32 d = (u32)key[q] & dmask;
-                    unsigned long long peers = __ballot(valid);
-#pragma unroll
-                    for (int bb = 0; bb < DB; bb++) {
-                        unsigned long long mk = __ballot((d >> bb) & 1u);
-                        peers &= ((d >> bb) & 1u) ? mk : ~mk;
-                    }
-                    const u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-                    u32 old = 0;
-                    if (valid && below == 0) {
-                        old = cnt[d];
-                        cnt[d] = old + (u32)__popcll(peers);
-                    }
-                    const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
-                    old = (u32)__shfl((int)old, leader);
-                    idx[q] = old + below;
-                }
-            }
+            // (rows behind rpw hold nothing: skipped by a workgroup-uniform branch -- a sub-batch of 1024 runs drops about
+            // 1600 keys at level 0, 7 of the 16 rows)
+            wave_rank<DB, ROWS>([&](int q) { return (u32)key[q] & dmask; }, (u32)w * rpw * 64u + (u32)lane, hn, rpw, &s_cnt[w][0], idx);
             __syncthreads();
             {   // thread t owns bins [t*BPT, (t+1)*BPT): wave bases, round-local digit starts, global bases
                 u32 cw[BPT][4], tt[BPT], sum = 0;
@@ -2050,32 +2063,40 @@ inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *na
     return sort_keys_fwd(buf_a, buf_b, plan.E, plan.db, plan.bits, name);
 }
 
-template <class K, class V, int SITE, int DB>
+template <class K, class V, int SITE, int DB, int TB = kBlock>
 inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shift, u32 dmask, u32 tiles, u32 *counts, u64 *offsets,
                     u32 *chunk_sums, u64 *chunk_off, const char *name) {
     prof_begin(std::string(name) + ".hist", n * sizeof(K));
-    if constexpr (DB == 8) hipLaunchKernelGGL((k_rs_hist<K, SITE>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
-    else hipLaunchKernelGGL((k_rs_hist_wide<K, SITE, DB>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
+    hipLaunchKernelGGL((k_rs_hist<K, SITE, DB, TB>), dim3(tiles), dim3(TB), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
     prof_end();
     after_launch(name);
     rs_offsets<(1 << DB)>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
     prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
-    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB>), dim3(tiles), dim3(kBlock), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles);
+    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles);
     prof_end();
     after_launch(name);
 }
-// Sorts n pairs by key bits [begin_bit, end_bit).  Buffers a/b ping-pong; returns
-// 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b).
-template <class K, class V, int SITE = 0>
-inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit,
-                      const char *name = "radix_sort") {
-    if (n == 0 || end_bit <= begin_bit) return 0;
+// Threads per workgroup of the plain sorts (GRLBWT_RS_THREADS=256|512; 0 = by record size).  512 threads = tiles of 8192 keys:
+// a tile leaves 32 instead of 16 keys per bin on average, i.e. runs of 256 instead of 128 bytes at the write front of a pass
+// over 8-byte keys -- the passes run at the rate of their scattered writes (tools/sortbench.hip: uniform digits 2.2-2.5 TB/s,
+// skewed digits 4.5 TB/s with the same kernel).  Records above 12 bytes keep 4096-key tiles (LDS).
+inline int rs_threads_override() {
+    static const int v = [] { const char *e = getenv("GRLBWT_RS_THREADS"); return e ? atoi(e) : 0; }();
+    return v;
+}
+inline int rs_threads_override_xs() {      // (SITE 1: the passes behind the fused expansion of the induction)
+    static const int v = [] { const char *e = getenv("GRLBWT_RS_THREADS_XS"); return e ? atoi(e) : 0; }();
+    return v;
+}
+template <class K, class V, int SITE, int TB>
+inline int sort_pairs_tb(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit, const char *name) {
     int widths[16];
     const int passes = rs_plan(end_bit - begin_bit, widths);
     int maxw = 8;
     for (int p = 0; p < passes; p++) if (widths[p] > maxw) maxw = widths[p];
     const u64 NBmax = (u64)1 << maxw;
-    u32 tiles = (u32)((n + kRsTile - 1) / kRsTile);
+    constexpr u64 TILE = (u64)TB * kRsItems;
+    u32 tiles = (u32)((n + TILE - 1) / TILE);
     u32 *counts = (u32 *)dev_alloc(NBmax * tiles * sizeof(u32));
     u64 *offsets = (u64 *)dev_alloc(NBmax * tiles * sizeof(u64));
     u32 chunks = (tiles + kRsChunk - 1) / kRsChunk;
@@ -2091,9 +2112,11 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         V *vin = cur ? vals_b : vals_a;
         K *kout = cur ? keys_a : keys_b;
         V *vout = cur ? vals_a : vals_b;
-        if (wd <= 8) rs_pass<K, V, SITE, 8>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
-        else if (wd == 9) rs_pass<K, V, SITE, 9>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
-        else rs_pass<K, V, SITE, 10>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+        if (wd <= 8) rs_pass<K, V, SITE, 8, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+        else if constexpr (TB <= 512) {      // (1024-thread workgroups: 8-bit digits only -- the per-wave counters of a wider digit do not fit LDS)
+            if (wd == 9) rs_pass<K, V, SITE, 9, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+            else rs_pass<K, V, SITE, 10, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+        } else throw Error(-71, "sort_pairs: digit too wide for 1024-thread workgroups");
         shift += wd;
         cur ^= 1;
     }
@@ -2102,6 +2125,26 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
     dev_free(chunk_sums);
     dev_free(chunk_off);
     return cur;
+}
+// Sorts n pairs by key bits [begin_bit, end_bit).  Buffers a/b ping-pong; returns
+// 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b).
+template <class K, class V, int SITE = 0>
+inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int begin_bit, int end_bit,
+                      const char *name = "radix_sort") {
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    constexpr int rec = (int)sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : (int)sizeof(V));
+    if constexpr (rec <= 12) {
+        const int ov = SITE == 1 ? rs_threads_override_xs() : rs_threads_override();
+        const int tb = ov ? ov : (SITE == 1 ? 256 : 1024);
+        if (n >= (u64)1 << 20) {
+            int widths[16], maxw = 0;
+            const int passes = rs_plan(end_bit - begin_bit, widths);
+            for (int p = 0; p < passes; p++) if (widths[p] > maxw) maxw = widths[p];
+            if (tb >= 1024 && maxw <= 8) return sort_pairs_tb<K, V, SITE, 1024>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, name);
+            if (tb >= 512) return sort_pairs_tb<K, V, SITE, 512>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, name);
+        }
+    }
+    return sort_pairs_tb<K, V, SITE, kBlock>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, name);
 }
 
 // keys only: returns 0 if the result is in keys_a, 1 if in keys_b
@@ -2156,28 +2199,7 @@ __global__ void __launch_bounds__(kBlock)
         dig[q] = t < tile_n ? ((u32)(keys_in[base + t] >> shift) & dmask) : 0u;
     }
     __syncthreads();
-    volatile u32 *cnt = &s_cnt[w][0];
-#pragma unroll
-    for (int q = 0; q < kRsKeys; q++) {
-        u32 t = wbase + q * 64 + lane;
-        bool valid = t < tile_n;
-        const u32 d = dig[q];
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < DB; b++) {
-            unsigned long long m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        u32 below = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-        u32 old = 0;
-        if (valid && below == 0) {
-            old = cnt[d];
-            cnt[d] = old + (u32)__popcll(peers);
-        }
-        int leader = valid ? __ffsll((long long)peers) - 1 : lane;
-        old = (u32)__shfl((int)old, leader);
-        idx[q] = old + below;
-    }
+    wave_rank<DB, kRsKeys>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
     __syncthreads();
     {
         u32 cw[BPT][4], tt[BPT], sum = 0;
