@@ -2185,6 +2185,10 @@ struct PhraseValDistFn {
 // holds the buckets (metasymbols) whose HOCC runs lie in its piece, so it receives exactly those cells from every rank,
 // and the stretch of the rewritten BWT_{r+1} its piece consumes (consumption is monotone in output order).  With cells
 // and that stretch in hand a piece is an ordinary single-GPU pass C.
+struct PreBwtLenIn {      // length of pre-BWT run j if it is a BWT-marker run (what a piece takes straight from the rewritten BWT_{r+1})
+    const u32 *sym; const idx_t *len; u32 bwt_code;
+    GRL_DEV u64 operator()(u64 j) const { return sym[j] == bwt_code ? (u64)len[j] : 0ull; }
+};
 struct OwnerSplitFn {     // lane d in [0, size]: first pre-BWT run of owner d, its first bucket, symbols and BWT-marker symbols in front
     const idx_t *Ppos; const HoccBwt *PHB; const u32 *u_to_p; u64 P, M, n_r; int size;
     u64 *out /*[size+1][4]*/;
@@ -2686,6 +2690,10 @@ struct LevelData {
     DBuf<u32> u_to_p;        // metasymbol -> index of the (merged) pre-BWT run emitted by its group
     DBuf<u32> p_to_u;        // (merged) pre-BWT run -> number of metasymbols whose run lies in front of it (single-GPU dictionary stage)
     Runs prebwt;
+    // collection-level mode: the pre-BWT stays with the rank whose key range produced it (round 5) -- prebwt, u_to_p and p_to_u
+    // then describe MY part only (run indices and metasymbol counts relative to it), metasymbols [u0, u0 + Ml) are mine
+    bool pre_local = false;
+    u32 u0 = 0, Ml = 0;
     RoundInfo info;
 };
 
@@ -2697,10 +2705,11 @@ static inline double now_s() {
 struct StageTimer {
     double *acc;
     u64 peak0;
-    explicit StageTimer(double *a) : acc(a) { prim::stage_begin(); peak0 = prim::pool_stage_begin(); }
+    const char *name;
+    explicit StageTimer(double *a, const char *nm = "?") : acc(a), name(nm) { prim::stage_begin(); peak0 = prim::pool_stage_begin(); }
     ~StageTimer() {
         prim::stage_end(acc);
-        prim::pool_stage_end(peak0, acc);
+        prim::pool_stage_end(peak0, name);
     }
 };
 
@@ -2731,7 +2740,7 @@ class Engine {
     // ---- a1 ------------------------------------------------------------
     template <class cell_t>
     void stats_t(const cell_t *t, u64 n, const u64 *hist256 = nullptr) {
-        StageTimer st(&tm.stats);
+        StageTimer st(&tm.stats, "stats");
         cell_t sep;
         prim::d2h(&sep, t + (n - 1), sizeof(cell_t));
         u64 mn, mx, F = n;
@@ -2819,7 +2828,7 @@ class Engine {
         DBuf<idx_t> wordbase(nwords + 1);
         u64 n_occ;
         {
-            StageTimer st(&tm.classify);
+            StageTimer st(&tm.classify, "classify");
             prim::start_bitvector(n, t, ops, StartPred<cell_t, FIRST>{t, ops}, startbits.p, "lms_breaks");
             n_occ = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{startbits.p}, wordbase.p, true, "phrase_ordinals");
         }
@@ -2879,7 +2888,7 @@ class Engine {
             // sample's abundance classes (Chao1) was tried and is 10-20x too low on this data (heterogeneous abundances):
             // two overflow re-runs per level.  An exact count (one more hashing pass over a 1/64 slice of the hash space)
             // costs about what a right-sized table saves.
-            StageTimer st(&tm.hash);
+            StageTimer st(&tm.hash, "hash");
             // (first level of a large text: 2^22 cells, so that the sample's phrases -- the hot table below -- cover the occurrences well)
             const u64 want_s = (FIRST && n >= (1ull << 26)) ? (1ull << 22) : (1ull << 20);
             const u64 n_s = n < want_s ? n : want_s;
@@ -2948,7 +2957,7 @@ class Engine {
                                                       (unsigned long long)cap_hot, (unsigned long long)s_distinct);
         }
         {
-            StageTimer st(&tm.hash);
+            StageTimer st(&tm.hash, "hash");
             typedef HashInsertFn<cell_t, FIRST> HF;
             for (;;) {
                 idx_t *cnt;
@@ -3026,7 +3035,7 @@ class Engine {
         DBuf<u32> dcnt;
         const prim::U128 *dval = nullptr;
         if (part) {
-            StageTimer st(&tm.hash);
+            StageTimer st(&tm.hash, "hash");
             rec_v2.alloc(n_occ);
             const int res = P.psort.forward(P.rec_h.p, rec_v.p, rec_v2.p, n_occ, 32 - part_bits, 32, "phrase_part");
             const prim::U128 *svals = res ? rec_v2.p : rec_v.p;
@@ -3059,7 +3068,7 @@ class Engine {
 
         // ---- a5: distinct phrases of this text (from the claim bits: the table itself is not scanned) -------------------
         {
-            StageTimer st(&tm.dict_sort);
+            StageTimer st(&tm.dict_sort, "dict_sort");
             DBuf<idx_t> cbase(nwords + 1);
             const u64 Dl = (u64)prim::exclusive_scan<idx_t>(nwords, PopcIn{claim.p}, cbase.p, false, "table_compact");
             const u64 D = Ds + Dl;
@@ -3097,6 +3106,17 @@ class Engine {
         int (*ag)(void *, const void *, void *, u64) = nullptr;
         int (*a2a)(void *, const void *, const u64 *, const u64 *, void *, const u64 *, const u64 *) = nullptr;
         bool stream_ordered = false;      // callbacks enqueue on the engine's stream: no host synchronisation around them
+        // bytes this rank sends to OTHER ranks, by exchange site (profiling builds: "@xfer:<site>" entries of the launch profile,
+        // what tools/gpu_scale_projection.py prices the fabric with); named("...") tags the next exchange
+        mutable const char *what = "unnamed";
+        const Comm &named(const char *w) const { what = w; return *this; }
+        void account(u64 bytes_to_others) const {
+            if (prim::rt().profile) {
+                auto &a = prim::rt().prof[std::string("@xfer:") + what + (prim::rt().tag >= 0 ? "#" + (prim::rt().phase ? std::string(1, prim::rt().phase) : std::string()) + std::to_string(prim::rt().tag) : std::string())];
+                a.launches += 1; a.bytes += bytes_to_others;
+            }
+            what = "unnamed";
+        }
         void allgather(const void *send, void *recv, u64 bytes) const {
             if (!stream_ordered) prim::sync();
             if (ag(user, send, recv, bytes) != 0) throw prim::Error(-5, "allgather callback failed");
@@ -3134,6 +3154,7 @@ class Engine {
             const u64 rounds = std::max<u64>((max_block + per - 1) / per, 1);
             std::vector<u64> sb(size), so(size), rb(size), ro(size), sbase(size + 1, 0), rbase(size + 1, 0);
             for (int g = 0; g < size; g++) { sbase[g + 1] = sbase[g] + scnt[g]; rbase[g + 1] = rbase[g] + rcnt[g]; }
+            account((sbase[size] - scnt[rank]) * elem);
             // my own block never leaves the device: a plain copy (GRLBWT_A2A_SELF_VIA_COMM=1: through the callback like the
             // others -- the tests do that so that a one-rank RCCL run still moves data through RCCL)
             static const bool self_via_comm = getenv("GRLBWT_A2A_SELF_VIA_COMM") != nullptr;
@@ -3167,6 +3188,7 @@ class Engine {
                 for (int g = 0; g < size; g++) base[g + 1] = base[g] + cnt[g];
             }
             if (base[rank + 1] - base[rank] != count) throw prim::Error(-71, "allgather_v: counts changed between calls");
+            account(count * sizeof(T) * (u64)(size - 1));
             DBuf<T> dense;
             if (!dest) { dense.alloc(base[size]); dest = dense.p; }
             static const bool self_via_comm = getenv("GRLBWT_A2A_SELF_VIA_COMM") != nullptr;
@@ -3204,12 +3226,13 @@ class Engine {
     void dict_stage(const Comm *C, const cell_t *t, CellOps<cell_t, FIRST> ops, u64 D, u64 S, u32 maxlen, const u64 *ph_pos, const idx_t *ph_freq,
                     const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val,
                     const u32 *fused_ph_slot = nullptr, u32 *fused_slot_val = nullptr,        // (both set: the values go straight to the slots)
-                    const prim::U128 *pkeys = nullptr, u64 pDs = 0, int pkb = 0) {            // (phrases [0, pDs) given by their records)
+                    const prim::U128 *pkeys = nullptr, u64 pDs = 0, int pkb = 0,              // (phrases [0, pDs) given by their records)
+                    const std::vector<u64> *dbase = nullptr) {        // (collection-level mode: rank g merged the phrases [dbase[g], dbase[g + 1]))
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
         DBuf<u32> dict_sym(S), dict_phr(S);
         RankBits pbits;                          // phrase starts over the dictionary positions (dictionary build, suffix refinement)
         {
-            StageTimer st(&tm.dict_sort);
+            StageTimer st(&tm.dict_sort, "dict_sort");
             build_rankbits32(pbits, ph_off, D, S + 1, "dict_build");
             // (4 positions per lane: 16 per lane, four phrases walked one after the other, was latency-bound -- 42 ms at 10 GB)
             prim::for_each((S + 3) / 4, DictBuildFn<cell_t, FIRST, 4>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p,
@@ -3223,7 +3246,7 @@ class Engine {
         // termination differ from rank to rank: a failure is recorded (Comm::fail) and raised by every rank at the counter
         // exchange behind the group stage)
         auto sort_local = [&] {
-            StageTimer st(&tm.dict_sort);
+            StageTimer st(&tm.dict_sort, "dict_sort");
             int b = (int)bitlen64(sigma);
             if (b < 1) b = 1;
             // as many symbols as fit 64 key bits per pass (up to 8 radix passes over all suffixes in the first one)
@@ -3327,8 +3350,8 @@ class Engine {
                         }
                         try { ka.alloc(Sg); perm.alloc(Sg); } catch (const prim::Error &e) { C->fail(e); }
                         C->allgather_u64({});                                // (the bulk exchanges below have no way back)
-                        C->alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
-                        C->alltoall(sp.p, scnt, perm.p, rcnt, 4, maxb);
+                        C->named("sort.sample_keys").alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
+                        C->named("sort.sample_pos").alltoall(sp.p, scnt, perm.p, rcnt, 4, maxb);
                     } else Sg = Sown;
                 }
             }
@@ -3430,7 +3453,7 @@ class Engine {
         const bool fused_vals = !C && fused_ph_slot && fused_slot_val;
         u64 M, P0;
         {
-            StageTimer st(&tm.dict_groups);
+            StageTimer st(&tm.dict_groups, "dict_groups");
             u64 Ml = 0, P0l = 0;
             auto groups_local = [&] {
             grank.alloc(G + 1); pidx.alloc(G + 1); gmin.alloc(G); gmax.alloc(G); gacc.alloc(G); gfull.alloc(G); gflag.alloc(G);
@@ -3471,22 +3494,35 @@ class Engine {
             DBuf<u32> psym0(P0l);
             DBuf<idx_t> plen0(P0l);
             DBuf<u32> u_to_p0(Ml), pu0(P0l);
-            prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code, (u32)Moff, (u32)P0off,
-                                          psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p, pu0.p}, "prebwt_emit");
+            // Collection-level mode: the pre-BWT stays where its groups were sorted (round 5).  My key range's groups are a
+            // contiguous piece of the sorted order, so what they emit is a contiguous piece of the level's pre-BWT: the induction
+            // takes exactly these pieces as the ranks' output pieces (dist_induce_level) and nobody needs anybody else's runs.
+            // (Rounds 1-4 all-gathered the emitted runs, their metasymbol counts and the metasymbol -> run map to every rank --
+            // 8.9 GB sent per rank of the 10 GB collection at N = 2, 17.8 GB received at any N -- and every rank merged and
+            // scanned the WHOLE pre-BWT; GRLBWT_DIST_REPLICATED_PREBWT=1 keeps that form.)  Runs are merged inside a piece
+            // only: a run cut by a piece boundary stays two runs, which describe the same symbols.
+            static const bool replicated_pre = getenv("GRLBWT_DIST_REPLICATED_PREBWT") != nullptr || getenv("GRLBWT_DIST_REPLICATED_INDUCTION") != nullptr;      // (the replicated induction wants the whole pre-BWT)
+            const bool pre_local = C && !replicated_pre;
+            prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code, pre_local ? 0u : (u32)Moff,
+                                          pre_local ? 0u : (u32)P0off, psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p, pu0.p}, "prebwt_emit");
             if (C) {                             // every rank's (Ml, P0l) is known: one exchange per array
-                psym0 = C->template allgather_v<u32>(psym0.p, P0l, bbP, true);
-                plen0 = C->template allgather_v<idx_t>(plen0.p, P0l, bbP, true);
-                pu0 = C->template allgather_v<u32>(pu0.p, P0l, bbP, true);
-                L.has_hocc = C->template allgather_v<u8>(L.has_hocc.p, Ml, bbM, true);
-                u_to_p0 = C->template allgather_v<u32>(u_to_p0.p, Ml, bbM, true);
+                if (!pre_local) {
+                    psym0 = C->named("prebwt.sym").template allgather_v<u32>(psym0.p, P0l, bbP, true);
+                    plen0 = C->named("prebwt.len").template allgather_v<idx_t>(plen0.p, P0l, bbP, true);
+                    pu0 = C->named("prebwt.pu").template allgather_v<u32>(pu0.p, P0l, bbP, true);
+                }
+                L.has_hocc = C->named("grammar.has_hocc").template allgather_v<u8>(L.has_hocc.p, Ml, bbM, true);
+                if (!pre_local) u_to_p0 = C->named("prebwt.u_to_p").template allgather_v<u32>(u_to_p0.p, Ml, bbM, true);
             }
-            DBuf<u32> merged(P0);
-            L.prebwt = merge_runs(psym0.p, plen0.p, P0, merged.p);
+            const u64 P0e = pre_local ? P0l : P0, Me = pre_local ? Ml : M;      // what this rank's pre-BWT arrays describe
+            L.pre_local = pre_local; L.u0 = pre_local ? (u32)Moff : 0u; L.Ml = (u32)Me;
+            DBuf<u32> merged(P0e);
+            L.prebwt = merge_runs(psym0.p, plen0.p, P0e, merged.p);
             L.prebwt.pos.release();
-            L.u_to_p.alloc(M);
-            prim::for_each(M, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
+            L.u_to_p.alloc(Me);
+            prim::for_each(Me, ComposeMapFn{u_to_p0.p, merged.p, L.u_to_p.p}, "prebwt_map");
             L.p_to_u.alloc(L.prebwt.R);
-            prim::for_each(P0, PreToMetaFn{pu0.p, merged.p, L.p_to_u.p}, "prebwt_map");
+            prim::for_each(P0e, PreToMetaFn{pu0.p, merged.p, L.p_to_u.p}, "prebwt_map");
             // ---- a8: grammar ------------------------------------------------
             L.g0.alloc(M); L.g1.alloc(M);
             u32 MD = sigma3 + (u32)M + 1;
@@ -3502,7 +3538,7 @@ class Engine {
                     DBuf<u64> mp(nm);
                     prim::for_each(Sg, MetaPairFn{perm.p, gid.p, ginfo.p, mex.p, sigma3, mp.p}, "dist.mark_pairs");
                     std::vector<u64> bb;
-                    DBuf<u64> all = C->template allgather_v<u64>(mp.p, nm, bb);
+                    DBuf<u64> all = C->named("grammar.mark_pairs").template allgather_v<u64>(mp.p, nm, bb);
                     prim::for_each(bb[C->size], ApplyMetaPairsFn{all.p, dm.p}, "grammar_marks");
                 }
                 DBuf<u64> stops;                 // (very long phrases only: the walks jump to their stops)
@@ -3514,8 +3550,8 @@ class Engine {
                 else {                           // every rank walks for its own metasymbols; the cells are all-gathered
                     DBuf<u32> g0l(Ml), g1l(Ml);
                     prim::for_each(Ml, GrammarFn{repq.p, dm.p, MD, g0l.p, g1l.p, stops.p, S}, "grammar");
-                    C->template allgather_v<u32>(g0l.p, Ml, bbM, true, L.g0.p);
-                    C->template allgather_v<u32>(g1l.p, Ml, bbM, true, L.g1.p);
+                    C->named("grammar.g0").template allgather_v<u32>(g0l.p, Ml, bbM, true, L.g0.p);
+                    C->named("grammar.g1").template allgather_v<u32>(g1l.p, Ml, bbM, true, L.g1.p);
                 }
             }
             // ---- a9: metasymbol of every phrase --------------------------------
@@ -3528,14 +3564,36 @@ class Engine {
             else if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, grank.p, phrase_val.p}, "phrase_values");
             else {                               // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
                 DBuf<u32> phrase_rank(D), fex(D + 1);
-                const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{pslot.p}, fex.p, false, "dist.full_scan");
+                const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{pslot.p}, fex.p, true, "dist.full_scan");
                 DBuf<u64> fp(nf);
                 prim::for_each(D, OwnPhrasePairFn{pslot.p, fex.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
+                if (dbase) {
+                    // The value of a phrase is wanted by ONE rank: the one that merged it and answers its senders (dist_round_t).  The
+                    // pairs are in phrase order and the owners' phrases are contiguous ranges, so every owner's pairs are one block:
+                    // an all-to-all of 8 bytes per phrase in all, where rounds 1-4 all-gathered all D pairs to every rank.
+                    const int N = C->size, me = C->rank;
+                    std::vector<u64> scnt(N, 0), rcnt(N, 0);
+                    u64 prev = 0;
+                    for (int g = 0; g < N; g++) {
+                        const u64 hi = (*dbase)[g + 1] ? (u64)fex.get((*dbase)[g + 1]) : 0;
+                        scnt[g] = hi - prev; prev = hi;
+                    }
+                    std::vector<u64> mat = C->allgather_u64(scnt);
+                    u64 got = 0, maxb = 0;
+                    for (int g = 0; g < N; g++) { rcnt[g] = mat[(u64)g * N + me]; got += rcnt[g]; for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]); }
+                    if (got != (*dbase)[me + 1] - (*dbase)[me]) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+                    DBuf<u64> mine(got);
+                    C->named("phrase.rank_pairs").alltoall(fp.p, scnt, mine.p, rcnt, 8, maxb);
+                    prim::for_each(got, ApplyPairsFn{mine.p, phrase_rank.p}, "dist.apply_phrase_ranks");
+                    // (only my own range of phrase_val is filled and read)
+                    prim::for_each(got, PhraseValDistFn{phrase_rank.p + (*dbase)[me], ph_freq + (*dbase)[me], ph_lastT + (*dbase)[me], phrase_val.p + (*dbase)[me]}, "phrase_values");
+                } else {
                 std::vector<u64> bb;
-                DBuf<u64> allf = C->template allgather_v<u64>(fp.p, nf, bb);
+                DBuf<u64> allf = C->named("phrase.rank_pairs").template allgather_v<u64>(fp.p, nf, bb);
                 if (bb[C->size] != D) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
                 prim::for_each(D, ApplyPairsFn{allf.p, phrase_rank.p}, "dist.apply_phrase_ranks");
                 prim::for_each(D, PhraseValDistFn{phrase_rank.p, ph_freq, ph_lastT, phrase_val.p}, "phrase_values");
+                }
             }
         }
         L.info.M = M;
@@ -3544,7 +3602,7 @@ class Engine {
     // a10: the local parse: slot id of every occurrence -> (rank<<2 | rep<<1 | T) of its phrase
     // (slot_val given: the dictionary stage has already put every phrase's value at its slot)
     void emit_local(LocalParse &P, const u32 *val_of_local_phrase, DBuf<u32> *slot_val_filled = nullptr) {
-        StageTimer st(&tm.emit);
+        StageTimer st(&tm.emit, "emit");
         DBuf<u32> own;
         if (!slot_val_filled) {
             own.alloc(P.cap);
@@ -3622,7 +3680,7 @@ class Engine {
         if (!parse_done) throw prim::Error(-22, "parse phase not finished");
         prim::rt().tag = (int)levels.size();
         prim::rt().phase = 'i';
-        StageTimer st(&tm.ind_assemble);
+        StageTimer st(&tm.ind_assemble, "ind_assemble");
         DBuf<u32> s(cur_n);
         DBuf<idx_t> l(cur_n);
         prim::for_each(cur_n, CellSymFn{cur_text.p, s.p, l.p}, "parse2bwt");
@@ -3668,7 +3726,7 @@ class Engine {
         {
             const int bits = kb;
             {
-                StageTimer st(&tm.ind_expand);
+                StageTimer st(&tm.ind_expand, "ind_expand");
                 gp.alloc(M);
                 prim::for_each(M, PackGrammarFn{L.g0.p, L.g1.p, L.has_hocc.p, gp.p}, "induce_pack_grammar");
             }
@@ -3692,7 +3750,7 @@ class Engine {
                 // written in run order, there is no offset array and no scan over the runs
                 const ChainGen gen{bwt.sym.p, run_len(), gp.p, sigma3, take_code, term.p, kb, lb};
                 {
-                    StageTimer st(&tm.ind_expand);
+                    StageTimer st(&tm.ind_expand, "ind_expand");
                     E = prim::expand_count(R, gen, bits, plan, "induce");
                 }
                 // 4-byte cells when everything fits (level 0 of the 10 GB DNA build: 17 + 8 + 7 bits): every pass of the split, pass C
@@ -3700,13 +3758,13 @@ class Engine {
                 // the ranks of a collection-level build agree on it.)
                 if (plan.ok && cell32) {
                     DBuf<u32> ef(E), ef2(E);
-                    StageTimer st(&tm.ind_sort);
+                    StageTimer st(&tm.ind_sort, "ind_sort");
                     int res = prim::expand_sort<ChainGen, u32>(gen, plan, ef.p, ef2.p, "induce");
                     sfused32 = std::move(res ? ef2 : ef);
                     done = true;
                 } else if (plan.ok) {
                     DBuf<u64> ef(E), ef2(E);
-                    StageTimer st(&tm.ind_sort);
+                    StageTimer st(&tm.ind_sort, "ind_sort");
                     int res = prim::expand_sort(gen, plan, ef.p, ef2.p, "induce");
                     sfused = std::move(res ? ef2 : ef);
                     done = true;
@@ -3714,7 +3772,7 @@ class Engine {
             }
             plan.release();
             if (!done) {     // offsets of every run's cells (an item with more than 32 cells, or cells that do not fit one word)
-                StageTimer st(&tm.ind_expand);
+                StageTimer st(&tm.ind_expand, "ind_expand");
                 eoff.alloc(R + 1);
                 prim::for_each(R, StoreFn<ChainCountFn>{ChainCountFn{bwt.sym.p, gp.p, sigma3}, eoff.p}, "induce_count");
                 E = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{eoff.p}, eoff.p, true, "induce_count_scan");
@@ -3723,11 +3781,11 @@ class Engine {
             } else if (fused) {
                 DBuf<u64> ef(E), ef2(E);
                 {
-                    StageTimer st(&tm.ind_expand);
+                    StageTimer st(&tm.ind_expand, "ind_expand");
                     prim::for_each(R, ChainExpandFn<CELLS_FUSED>{bwt.sym.p, run_len(), gp.p, eoff.p, sigma3, take_code,
                                                                  nullptr, nullptr, nullptr, nullptr, ef.p, term.p, kb, lb}, "induce_expand");
                 }
-                StageTimer st(&tm.ind_sort);
+                StageTimer st(&tm.ind_sort, "ind_sort");
                 int res = prim::sort_keys<u64, 1>(ef.p, ef2.p, E, 0, bits, "induce_split");
                 if (cell32) {                    // (the same form as the fused kernel's: the layout decides, not the path taken)
                     sfused32.alloc(E);
@@ -3738,11 +3796,11 @@ class Engine {
                 DBuf<u32> ekey(E), ekey2(E);
                 DBuf<u64> ep(E), ep2(E);
                 {
-                    StageTimer st(&tm.ind_expand);
+                    StageTimer st(&tm.ind_expand, "ind_expand");
                     prim::for_each(R, ChainExpandFn<CELLS_PACKED>{bwt.sym.p, run_len(), gp.p, eoff.p, sigma3, take_code,
                                                                   ekey.p, nullptr, nullptr, nullptr, ep.p, term.p, 0, 0}, "induce_expand");
                 }
-                StageTimer st(&tm.ind_sort);
+                StageTimer st(&tm.ind_sort, "ind_sort");
                 int res = prim::sort_pairs<u32, u64>(ekey.p, ep.p, ekey2.p, ep2.p, E, 0, bits, "induce_split");
                 skey = std::move(res ? ekey2 : ekey);
                 spack = std::move(res ? ep2 : ep);
@@ -3752,11 +3810,11 @@ class Engine {
                 DBuf<u32> esym(E);
                 DBuf<idx_t> eidx(E), eidx2(E), elen(E);
                 {
-                    StageTimer st(&tm.ind_expand);
+                    StageTimer st(&tm.ind_expand, "ind_expand");
                     prim::for_each(R, ChainExpandFn<CELLS_SEPARATE>{bwt.sym.p, run_len(), gp.p, eoff.p, sigma3, take_code,
                                                                     ekey.p, eidx.p, esym.p, elen.p, nullptr, term.p, 0, 0}, "induce_expand");
                 }
-                StageTimer st(&tm.ind_sort);
+                StageTimer st(&tm.ind_sort, "ind_sort");
                 ssym.alloc(E); slen.alloc(E);
                 int res = prim::sort_pairs<u32, idx_t>(ekey.p, eidx.p, ekey2.p, eidx2.p, E, 0, bits, "induce_split");
                 prim::for_each(E, GatherCellFn{res ? eidx2.p : eidx.p, esym.p, elen.p, ssym.p, slen.p}, "induce_gather");
@@ -3797,14 +3855,14 @@ class Engine {
     }
     CellView cell_view(int kb, int lb, u32 u0 = 0) const { return CellView{c_sfused.p, kb, lb, c_skey.p, c_spack.p, c_ssym.p, c_slen.p, u0, c_sfused32.p}; }
     u64 level_maxrun() {
-        StageTimer st(&tm.ind_expand);
+        StageTimer st(&tm.ind_expand, "ind_expand");
         return prim::reduce_max<u64>(bwt.R, RunLenIn64{run_len()}, "induce_maxrun");
     }
     // what pass C assembles: a contiguous piece of the level's pre-BWT, the metasymbols (buckets) whose HOCC runs lie in it
     // (indices relative to the piece), and the number of symbols the piece describes.  The whole level on one GPU.
     struct AsmIn { const u32 *psym; const idx_t *plen; u64 P; const u32 *u_to_p; const u32 *p_to_u; u64 M; u32 sigma; u64 n_out; };
     void assemble(const AsmIn &in, LevelInfo &I, const CellView &cells, u64 E, DBuf<u32> &term, int r) {
-        StageTimer st(&tm.ind_assemble);
+        StageTimer st(&tm.ind_assemble, "ind_assemble");
         DBuf<idx_t> Tpos;
         u64 Tsum;
         if (bwt.pos.p) { Tpos = std::move(bwt.pos); Tsum = bwt.n; }       // the run merge that produced BWT_{r+1} left its prefix behind
@@ -3922,7 +3980,7 @@ class Engine {
     void finish() {
         if (bwt_level != 0) throw prim::Error(-22, "induction not finished");
         prim::rt().tag = -1; prim::rt().phase = 0;
-        StageTimer st(&tm.finish);
+        StageTimer st(&tm.finish, "finish");
         u32 sb = (u32)stats.sb, fb = (u32)stats.fb;
         image_bytes = 16 + bwt.R * (u64)(sb + fb);
         image.alloc(image_bytes);
@@ -4001,7 +4059,7 @@ class Engine {
         DBuf<u32> rfreq;
         u64 Dr = 0, Sr = 0, occ_total = 0, n_total = 0, maxp = 0;     // maxp: largest phrase block of the exchange (all ranks agree)
         {
-            StageTimer st(&tm.hash);
+            StageTimer st(&tm.hash, "hash");
             DBuf<u32> slen, scells;
             DBuf<u32> sfreq;
             std::vector<u64> mine(2 * (u64)N + 2, 0);
@@ -4053,9 +4111,9 @@ class Engine {
                 for (int d = 0; d < N; d++) { maxp = std::max(maxp, mat[g * w + d]); maxc = std::max(maxc, mat[g * w + N + d]); }
             }
             rlen.alloc(Dr); rfreq.alloc(Dr); rcells.alloc(Sr);
-            C.alltoall(slen.p, pc, rlen.p, rpc, 4, maxp);
-            C.alltoall(sfreq.p, pc, rfreq.p, rpc, 4, maxp);
-            C.alltoall(scells.p, cc, rcells.p, rcc, 4, maxc);
+            C.named("dict.phrase_len").alltoall(slen.p, pc, rlen.p, rpc, 4, maxp);
+            C.named("dict.phrase_freq").alltoall(sfreq.p, pc, rfreq.p, rpc, 4, maxp);
+            C.named("dict.phrase_cells").alltoall(scells.p, cc, rcells.p, rcc, 4, maxc);
         }
         L.info.n_in = n_total;
         L.info.parse_size = occ_total;
@@ -4070,7 +4128,7 @@ class Engine {
         u64 D, S;
         u32 maxlen;
         {
-            StageTimer st(&tm.hash);
+            StageTimer st(&tm.hash, "hash");
             // (rank-local, sized by what THIS rank received: a failure here -- memory, table overflow -- is recorded and
             // travels with the counter exchange below, where every rank raises)
             u64 Do = 0, So64 = 0;
@@ -4114,16 +4172,16 @@ class Engine {
                 prim::for_each((So64 + 15) / 16, ListCellsFn{o_pos.p, o_off.p, Do, So64, rcells.p, ocells.p, obits.words.p, obits.base.p}, "dist.owner_cells");
             }
             rcells.release(); rlen.release(); rfreq.release();
-            gcells = C.allgather_v<u32>(ocells.p, So64, sbase, true);
-            ph_len = C.allgather_v<u32>(o_len.p, Do, dbase, true);
+            gcells = C.named("dict.merged_cells").allgather_v<u32>(ocells.p, So64, sbase, true);
+            ph_len = C.named("dict.merged_len").allgather_v<u32>(o_len.p, Do, dbase, true);
             if (sizeof(idx_t) == 8 && occ_total < 0xFFFFFFFFull) {      // (every merged frequency fits u32: 4 instead of 8 bytes per phrase on the wire)
                 DBuf<u32> of32(Do);
                 prim::for_each(Do, NarrowIdxFn{o_freq.p, of32.p}, "dist.dict_offsets");
-                DBuf<u32> all32 = C.allgather_v<u32>(of32.p, Do, dbase, true);
+                DBuf<u32> all32 = C.named("dict.merged_freq").allgather_v<u32>(of32.p, Do, dbase, true);
                 ph_freq.alloc(D);
                 prim::for_each(D, WidenLenFn{all32.p, ph_freq.p}, "dist.dict_offsets");
-            } else ph_freq = C.allgather_v<idx_t>(o_freq.p, Do, dbase, true);
-            ph_lastT = C.allgather_v<u8>(o_lastT.p, Do, dbase, true);
+            } else ph_freq = C.named("dict.merged_freq").allgather_v<idx_t>(o_freq.p, Do, dbase, true);
+            ph_lastT = C.named("dict.merged_lastT").allgather_v<u8>(o_lastT.p, Do, dbase, true);
             const u64 fsum = prim::reduce_sum<u64>(D, IdxIn<idx_t>{ph_freq.p}, "dist.freq_check");
             if (fsum != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
             maxlen = prim::reduce_max<u32>(D, LenIn{ph_len.p}, "dist.maxlen");
@@ -4135,14 +4193,14 @@ class Engine {
         // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar replicated ----
         DBuf<u32> gval;
         dict_stage<u32, false>(getenv("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
-                               ph_off.p, ph_lastT.p, sigma, L, gval);
+                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase);
         // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
         {
-            StageTimer st(&tm.emit);
+            StageTimer st(&tm.emit, "emit");
             DBuf<u32> rval(Dr), sval(P.D);
             prim::for_each(Dr, ListValFn{list_slot.p, slot_min.p, rep_ex.p, gval.p, dbase[me], rval.p}, "dist.list_values");
-            C.alltoall(rval.p, rpc, sval.p, pc, 4, maxp);
+            C.named("emit.phrase_values").alltoall(rval.p, rpc, sval.p, pc, 4, maxp);
             prim::for_each(P.D, ScatterU32Fn{order.p, sval.p, lval.p}, "dist.local_values");
         }
         emit_local(P, lval.p);
@@ -4203,10 +4261,11 @@ class Engine {
         // exchange, where every rank raises: nobody is left waiting for a rank that gave up)
         DBuf<idx_t> Tpos;
         u64 Tlocal = 0, maxrun = 0, Toff = 0, Ttotal = 0;
+        std::vector<u64> piece;                  // (pre_local) per rank boundary: -, first metasymbol, symbols and BWT-marker symbols in front
         {
             u64 mr = 0;
             try {
-                StageTimer st(&tm.ind_expand);
+                StageTimer st(&tm.ind_expand, "ind_expand");
                 need_len();                      // (pass C leaves the prefix only; the passes below read lengths after the prefix has moved on)
                 if (bwt.pos.p) { Tpos = std::move(bwt.pos); Tlocal = bwt.n; }      // pass C of the level above left my slice's prefix behind
                 else {
@@ -4215,11 +4274,31 @@ class Engine {
                 }
                 mr = level_maxrun();
             } catch (const prim::Error &e) { C.fail(e); Tlocal = 0; mr = 0; }
-            std::vector<u64> g1 = C.allgather_u64({mr, Tlocal});
+            // (pre-BWT kept by key range: my piece's symbols, BWT-marker symbols, metasymbols and runs travel with this exchange)
+            u64 pn = 0, pb = 0;
+            if (L.pre_local) {
+                try {
+                    pn = prim::reduce_sum<u64>(P, IdxIn<idx_t>{L.prebwt.len.p}, "dist.piece_sums");
+                    pb = prim::reduce_sum<u64>(P, PreBwtLenIn{L.prebwt.sym.p, L.prebwt.len.p, bwt_code}, "dist.piece_sums");
+                } catch (const prim::Error &e) { C.fail(e); }
+            }
+            std::vector<u64> g1 = C.allgather_u64({mr, Tlocal, pn, pb, (u64)L.Ml, P});
             for (int g = 0; g < N; g++) {
-                if (g1[2 * g] > maxrun) maxrun = g1[2 * g];
-                if (g < me) Toff += g1[2 * g + 1];
-                Ttotal += g1[2 * g + 1];
+                if (g1[6 * g] > maxrun) maxrun = g1[6 * g];
+                if (g < me) Toff += g1[6 * g + 1];
+                Ttotal += g1[6 * g + 1];
+            }
+            if (L.pre_local) {
+                piece.assign(4 * ((u64)N + 1), 0);
+                u64 Psum = 0;
+                for (int g = 0; g < N; g++) {
+                    piece[4 * (g + 1) + 1] = piece[4 * g + 1] + g1[6 * g + 4];
+                    piece[4 * (g + 1) + 2] = piece[4 * g + 2] + g1[6 * g + 2];
+                    piece[4 * (g + 1) + 3] = piece[4 * g + 3] + g1[6 * g + 3];
+                    Psum += g1[6 * g + 5];
+                }
+                if (piece[4 * (u64)N + 1] != M) throw prim::Error(-71, "dist induction: the pieces' metasymbols do not add up (level " + std::to_string(r) + ")");
+                I.P = Psum;
             }
         }
         DBuf<u32> term;
@@ -4236,9 +4315,15 @@ class Engine {
             if (test_fail_rank("GRLBWT_TEST_FAIL_RANK_INDUCE", me)) throw prim::Error(-12, "out of device memory (injected by the test)");
             E = expand_split(L, term, maxrun, kb, lb);
             I.E = E;
-            StageTimer st(&tm.ind_assemble);
+            StageTimer st(&tm.ind_assemble, "ind_assemble");
             // (2) owners of the output: pre-BWT run ranges of about n_r / size symbols, and the buckets inside them
-            {
+            if (L.pre_local) {                   // the pieces are the ranks' own parts of the pre-BWT: nothing to look up
+                sp = piece;
+                sp[4 * (u64)me] = 0; sp[4 * ((u64)me + 1)] = P;          // (run indices are relative to my part)
+                n_r = piece[4 * (u64)N + 2];
+                if (n_r != L.info.n_in) throw prim::Error(-71, "dist induction: the pre-BWT of level " + std::to_string(r) + " does not describe the level");
+                prim::h2d(split.p, sp.data(), 4 * ((u64)N + 1) * 8);
+            } else {
                 DBuf<idx_t> Ppos(P + 1);
                 DBuf<HoccBwt> PHB(P + 1);
                 n_r = (u64)prim::exclusive_scan<idx_t>(P, IdxIn<idx_t>{L.prebwt.len.p}, Ppos.p, true, "dist.Ppos");
@@ -4261,7 +4346,7 @@ class Engine {
             }
         } catch (const prim::Error &e) { C.fail(e); std::fill(v.begin(), v.end(), 0); }
         {
-            StageTimer st(&tm.ind_assemble);
+            StageTimer st(&tm.ind_assemble, "ind_assemble");
             std::vector<u64> mat = C.allgather_u64(v);           // mat[s*2N + d] cells, mat[s*2N + N + d] TAKE symbols of rank s for owner d
             // symbols of the rewritten BWT_{r+1} consumed in front of every owner's piece (output order = consumption order)
             std::vector<u64> Tc((u64)N + 1);
@@ -4310,11 +4395,11 @@ class Engine {
                     wsym.alloc(Rw); wlen.alloc(Rw);
                 } catch (const prim::Error &e) { C.fail(e); }
                 C.allgather_u64({});                             // (nothing but the failure flag: the bulk exchanges below have no way back)
-                C.alltoall(ssym.p, scnt, wsym.p, rcnt, sizeof(u32), maxw);
+                C.named("induce.window_sym").alltoall(ssym.p, scnt, wsym.p, rcnt, sizeof(u32), maxw);
                 if (narrow) {
-                    C.alltoall(slen32.p, scnt, wlen32.p, rcnt, sizeof(u32), maxw);
+                    C.named("induce.window_len").alltoall(slen32.p, scnt, wlen32.p, rcnt, sizeof(u32), maxw);
                     prim::for_each(Rw, WidenLenFn{wlen32.p, wlen.p}, "dist.window_send");
-                } else C.alltoall(slen.p, scnt, wlen.p, rcnt, sizeof(idx_t), maxw);
+                } else C.named("induce.window_len").alltoall(slen.p, scnt, wlen.p, rcnt, sizeof(idx_t), maxw);
             }
             Tpos.release(); term.release();
             bwt.sym.release(); bwt.len.release(); bwt.pos.release();
@@ -4332,7 +4417,7 @@ class Engine {
                 const u32 mu0 = (u32)sp[4 * me + 1], mu1 = (u32)sp[4 * (me + 1) + 1];
                 if (c_sfused32.p) {
                     DBuf<u32> rf(Er);
-                    C.alltoall(c_sfused32.p, scnt, rf.p, rcnt, 4, maxc);
+                    C.named("induce.cells").alltoall(c_sfused32.p, scnt, rf.p, rcnt, 4, maxc);
                     c_sfused32 = std::move(rf);
                     if (N > 1 && Er) {
                         if (merge_by_blocks) merge_cell_blocks<u32>(c_sfused32, rcnt, kb, lb, mu0, (u64)(mu1 - mu0), Er);
@@ -4343,7 +4428,7 @@ class Engine {
                     }
                 } else if (c_sfused.p) {
                     DBuf<u64> rf(Er);
-                    C.alltoall(c_sfused.p, scnt, rf.p, rcnt, 8, maxc);
+                    C.named("induce.cells").alltoall(c_sfused.p, scnt, rf.p, rcnt, 8, maxc);
                     c_sfused = std::move(rf);
                     if (N > 1 && Er) {
                         if (merge_by_blocks) merge_cell_blocks<u64>(c_sfused, rcnt, kb, lb, mu0, (u64)(mu1 - mu0), Er);
@@ -4354,8 +4439,8 @@ class Engine {
                     }
                 } else if (c_spack.p) {
                     DBuf<u32> rk(Er); DBuf<u64> rp(Er);
-                    C.alltoall(c_skey.p, scnt, rk.p, rcnt, 4, maxc);
-                    C.alltoall(c_spack.p, scnt, rp.p, rcnt, 8, maxc);
+                    C.named("induce.cells_key").alltoall(c_skey.p, scnt, rk.p, rcnt, 4, maxc);
+                    C.named("induce.cells_pack").alltoall(c_spack.p, scnt, rp.p, rcnt, 8, maxc);
                     c_skey = std::move(rk); c_spack = std::move(rp);
                     if (N > 1 && Er) {
                         DBuf<u32> k2(Er); DBuf<u64> p2(Er);
@@ -4363,9 +4448,9 @@ class Engine {
                     }
                 } else {
                     DBuf<u32> rk(Er), rs(Er); DBuf<idx_t> rl(Er);
-                    C.alltoall(c_skey.p, scnt, rk.p, rcnt, 4, maxc);
-                    C.alltoall(c_ssym.p, scnt, rs.p, rcnt, 4, maxc);
-                    C.alltoall(c_slen.p, scnt, rl.p, rcnt, sizeof(idx_t), maxc);
+                    C.named("induce.cells_key").alltoall(c_skey.p, scnt, rk.p, rcnt, 4, maxc);
+                    C.named("induce.cells_sym").alltoall(c_ssym.p, scnt, rs.p, rcnt, 4, maxc);
+                    C.named("induce.cells_len").alltoall(c_slen.p, scnt, rl.p, rcnt, sizeof(idx_t), maxc);
                     c_skey = std::move(rk);
                     if (N > 1 && Er) {
                         DBuf<u32> k2(Er); DBuf<idx_t> ix(Er), ix2(Er);
@@ -4397,11 +4482,16 @@ class Engine {
                 bwt.sym.alloc(0); bwt.len.alloc(0);
             } else {
                 const u64 Pm = p1 - p0, Mm = u1 - u0;
+                if (L.pre_local) {               // my part's maps are relative to it already
+                    if (Mm != (u64)L.Ml) throw prim::Error(-71, "dist induction: piece and key range disagree (level " + std::to_string(r) + ")");
+                    assemble(AsmIn{L.prebwt.sym.p, L.prebwt.len.p, Pm, L.u_to_p.p, L.p_to_u.p, Mm, L.sigma, n_out}, I, cell_view(kb, lb, u0), E, term, r);
+                } else {
                 DBuf<u32> u2p(Mm), p2u(Pm);
                 prim::for_each(Mm, RebaseFn{L.u_to_p.p + u0, p0, u2p.p}, "dist.piece_maps");
                 if (L.p_to_u.p) prim::for_each(Pm, RebaseFn{L.p_to_u.p + p0, u0, p2u.p}, "dist.piece_maps");
                 else prim::for_each(Pm, PieceMetaFn{L.u_to_p.p, M, p0, u0, p2u.p}, "dist.piece_maps");
                 assemble(AsmIn{L.prebwt.sym.p + p0, L.prebwt.len.p + p0, Pm, u2p.p, p2u.p, Mm, L.sigma, n_out}, I, cell_view(kb, lb, u0), E, term, r);
+                }
             }
         } catch (const prim::Error &e) {          // the next counter exchange (next level, or the image assembly) raises on every rank
             C.fail(e);
@@ -4420,7 +4510,7 @@ class Engine {
     void dist_finish(const Comm &C) {
         if (bwt_level != 0) throw prim::Error(-22, "induction not finished");
         prim::rt().tag = -1; prim::rt().phase = 0;
-        StageTimer st(&tm.finish);
+        StageTimer st(&tm.finish, "finish");
         const int N = C.size, me = C.rank;
         const u64 R = bwt.R;
         need_len();
@@ -4456,7 +4546,7 @@ class Engine {
         u8 hdr[16] = {0};
         for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
         prim::h2d(image.p, hdr, 16);
-        C.allgather_v<u8>(part.p, Rm * rec, base, true, image.p + 16);
+        C.named("image.parts").allgather_v<u8>(part.p, Rm * rec, base, true, image.p + 16);
         stats.n_strings = g_n_strings;
         stats.n_syms = g_n_syms;
         linfo[0].R = image_runs;
@@ -4473,7 +4563,7 @@ class Engine {
     // every rank induces the whole collection's BWT from the replicated grammar.
     void dist_induce_replicated(const Comm &C) {
         std::vector<u64> base;
-        DBuf<u32> all = C.allgather_v<u32>(cur_text.p, cur_n, base);
+        DBuf<u32> all = C.named("replicated.text").allgather_v<u32>(cur_text.p, cur_n, base);
         cur_n = base[C.size];
         if (cur_n != g_n_strings) throw prim::Error(-71, "deepest parse does not have one cell per string");
         cur_text = std::move(all);

@@ -238,10 +238,10 @@ inline u64 pool_stage_begin() {
     P.peak_bytes = P.live_bytes;
     return old;
 }
-inline void pool_stage_end(u64 old_peak, const void *stage_id) {
+inline void pool_stage_end(u64 old_peak, const void *stage_name) {
     Pool &P = pool();
     static const bool trace = getenv("GRLBWT_MEM_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "[grlbwt] stage %p level %d: peak live %.2f GB (live at end %.2f GB)\n", stage_id, rt().tag,
+    if (trace) fprintf(stderr, "[grlbwt] stage %-12s %c%d: peak live %.2f GB (live at end %.2f GB)\n", (const char *)stage_name, rt().phase ? rt().phase : '-', rt().tag,
                        P.peak_bytes / 1e9, P.live_bytes / 1e9);
     if (old_peak > P.peak_bytes) P.peak_bytes = old_peak;
 }
@@ -1519,8 +1519,40 @@ __global__ void __launch_bounds__(TB) k_rs_hist(const K *keys, u64 n, int shift,
 // ONE no-return LDS add by the first lane of every digit -- the add does not depend on the read, LDS operations of one
 // wave execute in issue order, so the 2 x ROWS operations go out back to back and are waited for once -- and (C) adds.
 // (dig(q): the digit of row q -- an array read, or recomputed from the key where registers are short)
-template <int DB, int ROWS, class DIG>
+// (PHASED = false: row by row -- match, LDS read, LDS add, sum -- with nothing kept per row but idx: for k_xs_scatter, whose
+// four interleaved chain walks leave no registers for a second per-row array (phased there: 22.3 -> 26.1 ms at level 0 of the
+// 10 GB build, spills in the ranking loop); one LDS round trip per row instead of the three of rounds 1-4)
+template <int DB, int ROWS, bool PHASED = true, class DIG>
 GRL_DEV void wave_rank(DIG dig, u32 t0, u32 limit, u32 nrows, u32 *cnt, u32 (&idx)[ROWS]) {
+    if constexpr (!PHASED) {
+#pragma unroll
+        for (int q = 0; q < ROWS; q++) {
+            idx[q] = 0;
+            if ((u32)q < nrows) {
+                const bool valid = t0 + 64u * (u32)q < limit;
+                const u32 d = dig(q);
+                u32 mlo = 0, mhi = 0;
+#pragma unroll
+                for (int b = 0; b < DB; b++) {
+                    u32 e;
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(e) : "v"(d), "n"(b));
+                    const unsigned long long m = __ballot(e != 0u);
+                    mlo |= (u32)m ^ e;
+                    mhi |= (u32)(m >> 32) ^ e;
+                }
+                const unsigned long long vm = __ballot(valid);
+                const u32 plo = (u32)vm & ~mlo, phi = (u32)(vm >> 32) & ~mhi;
+                const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+                if (valid) {
+                    u32 *c = &cnt[d];
+                    const u32 old = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (below == 0u) (void)__hip_atomic_fetch_add(c, (u32)__popc(plo) + (u32)__popc(phi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    idx[q] = old + below;
+                }
+            }
+        }
+        return;
+    }
     u32 info[ROWS];                       // keys of my digit in front of me in the row | all of them << 8 | valid << 16
 #pragma unroll
     for (int q = 0; q < ROWS; q++) {
@@ -1936,7 +1968,7 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
             __syncthreads();
             // (rows behind rpw hold nothing: skipped by a workgroup-uniform branch -- a sub-batch of 1024 runs drops about
             // 1600 keys at level 0, 7 of the 16 rows)
-            wave_rank<DB, ROWS>([&](int q) { return (u32)key[q] & dmask; }, (u32)w * rpw * 64u + (u32)lane, hn, rpw, &s_cnt[w][0], idx);
+            wave_rank<DB, ROWS, false>([&](int q) { return (u32)key[q] & dmask; }, (u32)w * rpw * 64u + (u32)lane, hn, rpw, &s_cnt[w][0], idx);
             __syncthreads();
             {   // thread t owns bins [t*BPT, (t+1)*BPT): wave bases, round-local digit starts, global bases
                 u32 cw[BPT][4], tt[BPT], sum = 0;

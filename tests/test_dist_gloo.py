@@ -109,8 +109,9 @@ def test_replicated_induction_fallback_agrees(sim, oracle_mod, tmp_path, monkeyp
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
     n_a2a = int(open(tmp_path / "reads.rank0.comm").read().split()[1])
     monkeypatch.delenv("GRLBWT_DIST_REPLICATED_INDUCTION")
-    _run(2, sim, "reads", tmp_path, 29592)           # (the parse rounds exchange all-to-all in both modes; the induction adds its own)
-    assert n_a2a < int(open(tmp_path / "reads.rank0.comm").read().split()[1])
+    _run(2, sim, "reads", tmp_path, 29592)           # (the two modes exchange different things: the fallback all-gathers the
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)      # pre-BWT, the sharded induction windows and cells)
+    assert n_a2a != int(open(tmp_path / "reads.rank0.comm").read().split()[1])
 
 
 def test_sharded_large_group_refinement(sim, oracle_mod, tmp_path, monkeypatch):
@@ -119,6 +120,15 @@ def test_sharded_large_group_refinement(sim, oracle_mod, tmp_path, monkeypatch):
     _run(2, sim, "tokens", tmp_path, 29594)
     data = open(tmp_path / "tokens.input", "rb").read()
     assert open(tmp_path / "tokens.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 2)
+
+
+def test_replicated_prebwt_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
+    """Rounds 1-4 all-gathered every level's pre-BWT and cut the output pieces by symbol count; since round 5 a rank keeps the
+    pre-BWT of its key range and that IS its piece.  The older form stays behind a switch and gives the same image."""
+    monkeypatch.setenv("GRLBWT_DIST_REPLICATED_PREBWT", "1")
+    _run(3, sim, "reads", tmp_path, 29596)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
 
 
 def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):

@@ -90,6 +90,7 @@ def worker(args):
     comm.take()
     text = workloads.sampled_reads_torch(args.reads, 150, args.genome, seed=20260003, device=dev, read_lo=lo, read_hi=hi)
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()                     # (the generator's temporaries: N ranks share ONE device here, what torch caches is lost to the others)
     flags = engine.FLAG_FORCE_IDX64 if args.reads * 151 >= 0xFFFFFF00 else 0
     out = {"rank": rank, "shard_bytes": int(text.numel())}
     with engine.Context(0, flags, lib) as ctx:
@@ -108,6 +109,12 @@ def worker(args):
         out["wall_s_serialised"] = round(time.time() - t0, 3)
         prof = ctx.profile()
         prof.pop("@host_sync", None)
+        xfer = {}                                    # bytes this rank sends to other ranks, by exchange site (engine-side accounting)
+        for k in [k for k in prof if k.startswith("@xfer:")]:
+            c, ms, nb = prof.pop(k)
+            site = k[6:].partition("#")[0]
+            xfer[site] = xfer.get(site, 0) + nb
+        out["sent_bytes_by_site"] = sorted(xfer.items(), key=lambda kv: -kv[1])
         st = {}
         for k, (c, ms, nb) in prof.items():
             site, _, tag = k.partition("#")
@@ -175,6 +182,10 @@ def main():
                    "--lock", lock, "--out", td]
             t0 = time.time()
             p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+            if os.environ.get("GRLBWT_MEM_TRACE"):      # per-stage peak memory of every rank (stderr of the workers)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "scale_projection%s_n%d.stderr" % (args.tag, n)), "w") as f:
+                    f.write("\n".join(l for l in p.stderr.splitlines() if "[grlbwt] stage" in l or "rror" in l))
             if p.returncode != 0:
                 err = [l for l in p.stderr.splitlines() if "rror" in l and "Signal 15" not in l and "error_file" not in l]
                 res["runs"].append({"ranks": n, "failed": p.returncode, "errors": err[:12], "stderr": p.stderr[-1500:]})
@@ -191,7 +202,10 @@ def main():
         # all-to-all: a rank's bytes leave over its 7 links in parallel when the peers are distinct (N-1 of them); all-gather of B
         # bytes in total: every rank receives B*(N-1)/N over its links
         links = max(1, min(7, n - 1))
-        xfer_ms = 0.0 if n == 1 else (sent * (n - 1) / n / (links * link) + recv_ag * (n - 1) / n / (links * link)) * 1e3
+        # (`sent` = bytes to OTHER ranks: a rank's own block of an exchange is a local copy and never reaches the callback.  Rounds
+        # 3-4 multiplied by (n - 1) / n once more -- right when the own block still went through the callback, too optimistic since:
+        # by 2 x at N = 2, 4/3 x at N = 4)
+        xfer_ms = 0.0 if n == 1 else (sent / (links * link) + recv_ag * (n - 1) / n / (links * link)) * 1e3
         xfer_slow_ms = xfer_ms * link / link_slow
         lat_ms = 0.0 if n == 1 else ncoll * 0.03
         run = {"ranks": n, "wall_s": round(time.time() - t0, 1), "kernel_ms_by_stage": by_stage, "critical_path_kernel_ms": round(crit, 2),
@@ -202,7 +216,9 @@ def main():
                "projected_transfer_ms_slow_links": round(xfer_slow_ms, 2), "projected_step_ms_slow_links": round(crit + xfer_slow_ms + lat_ms, 2),
                "image_md5": ranks[0].get("image_md5"), "image_bytes": ranks[0]["image_bytes"],
                "top_sites_rank0": ranks[0]["top_sites"], "dictionary_sites_rank0": ranks[0]["dictionary_sites"],
-               "sites_rank0": ranks[0].get("sites"), "large_exchanges_rank0": ranks[0].get("exchanges")}
+               "sites_rank0": ranks[0].get("sites"), "large_exchanges_rank0": ranks[0].get("exchanges"),
+               "sent_bytes_by_site_max_rank": sorted({k: max(dict(r.get("sent_bytes_by_site", [])).get(k, 0) for r in ranks) for k in
+                                                      {k for r in ranks for k, _ in r.get("sent_bytes_by_site", [])}}.items(), key=lambda kv: -kv[1])}
         if n == 1:
             base_ms = run["projected_step_ms"]
         if base_ms:
