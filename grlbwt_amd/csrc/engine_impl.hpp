@@ -1217,6 +1217,25 @@ typedef SufRecT<sizeof(idx_t)> SufRec;      // one 8/16-byte gather per sorted s
 // left carries two flags above the symbol (symbols are < 2^30): the suffix is the last cell of its phrase, and that
 // phrase ends a string -- what the group decision needs from the group's first member.
 static constexpr u32 kRecSym = 0x3FFFFFFFu, kRecFinal = 0x40000000u, kRecLastT = 0x80000000u;
+// What the group fold reads per sorted suffix: from the array SuffixRecFn streamed out (RecArray), or computed where it is
+// needed (RecCompute: five gathers per member instead of one, no array over the whole dictionary -- the collection-level mode
+// from GRLBWT_DIST_REC_FLY_MIN ranks on (default 8), where a rank folds 1/N of the suffixes and the array would still be S
+// records of 8-16 bytes: 9.9 GB at level 2 of the 10 GB collection)
+struct RecArray {
+    const SufRec *rec;
+    GRL_DEV SufRec operator()(u32 q) const { return rec[q]; }
+};
+struct RecCompute {
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; u32 bwt_code;
+    GRL_DEV SufRec operator()(u32 q) const {
+        const u32 k = dict_phr[q];
+        SufRec r;
+        r.freq = ph_freq[k];
+        r.left = (((u64)q == (u64)ph_off[k]) ? bwt_code : dict_sym[q - 1]) | (((u64)q + 1 == (u64)ph_off[k + 1]) ? kRecFinal : 0u) | (ph_lastT[k] ? kRecLastT : 0u);
+        r.set_phr(k);
+        return r;
+    }
+};
 struct SuffixRecFn {
     const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; u32 bwt_code;
     SufRec *rec;
@@ -1235,8 +1254,9 @@ struct SuffixRecFn {
 // of kGroupChunk consecutive members, each folded by its first lane and combined with one set of
 // atomics per chunk (GroupAccumLargeFn; 32x fewer same-address atomics than one per member).
 static constexpr u32 kGroupChunk = 32;
+template <class REC>
 struct GroupAccumSmallFn {
-    const u32 *perm; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
+    const u32 *perm; const u32 *gstart; REC rec; const u32 *dict_phr;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag; u32 *pslot;
     u32 *gphr;            // non-null: the whole phrase of a group is recorded BY GROUP (sequential store) instead of pslot[phrase] = group
@@ -1250,7 +1270,7 @@ struct GroupAccumSmallFn {
         const u32 te = large ? t0 : t1;
         for (u32 j = t0; j < te; j++) {
             const u32 q = perm[j];
-            SufRec r = rec[q];
+            SufRec r = rec(q);
             if (j == t0) first = r.left;
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
@@ -1274,8 +1294,9 @@ struct GroupChunksIn {    // chunks of a group above kGroupChunk members (0 for 
     const u32 *gstart;
     GRL_DEV u32 operator()(u64 g) const { const u32 sz = gstart[g + 1] - gstart[g]; return sz > kGroupChunk ? (sz + kGroupChunk - 1) / kGroupChunk : 0u; }
 };
+template <class REC>
 struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per slot spent 27 ms at 10 GB finding out it had nothing to do)
-    const u32 *perm; const u32 *coff; u64 G; const u32 *gstart; const SufRec *rec; const u32 *dict_phr;
+    const u32 *perm; const u32 *coff; u64 G; const u32 *gstart; REC rec; const u32 *dict_phr;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u32 *pslot; u32 *gphr;
     GRL_DEV void operator()(u64 c) const {
@@ -1285,7 +1306,7 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = t; j < te; j++) {
             const u32 q = perm[j];
-            SufRec r = rec[q];
+            SufRec r = rec(q);
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
             acc += r.freq;
@@ -1391,12 +1412,13 @@ struct MetaPairFn {        // (position << 32 | metasymbol) of the marked slots,
 // meta[], dict_sym[], the phrase-start bit-vector, dict_phr[] and ph_lastT[] apart: five random lines for 8 bytes of
 // output, 161 GB fetched to write 4 GB at 10 GB -- 46 ms.)
 static constexpr u32 kDmEnd = 0x80000000u, kDmLastT = 0x40000000u, kDmSym = 0x3FFFFFFFu;
-struct DictMetaInitFn {    // streaming: low half of dm[] from the dictionary, meta = 0
-    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT; u64 *dm;
-    GRL_DEV void operator()(u64 q) const {
+struct DictMetaInitFn {    // streaming: low half of dm[] from the dictionary, meta = 0  (q0: dm[] describes the positions from q0 on)
+    const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT; u64 *dm; u64 q0 = 0;
+    GRL_DEV void operator()(u64 i) const {
+        const u64 q = q0 + i;
         const u32 k = dict_phr[q];
         const bool end = q + 1 == (u64)ph_off[k + 1];
-        dm[q] = (u64)(dict_sym[q] | (end ? kDmEnd : 0u) | ((end && ph_lastT[k]) ? kDmLastT : 0u));
+        dm[i] = (u64)(dict_sym[q] | (end ? kDmEnd : 0u) | ((end && ph_lastT[k]) ? kDmLastT : 0u));
     }
 };
 struct MetaPosFn {         // by sorted slot t: gid[] and ginfo[] are read in order, only the marked suffixes scatter (the high halves of dm[])
@@ -1406,9 +1428,29 @@ struct MetaPosFn {         // by sorted slot t: gid[] and ginfo[] are read in or
         if (gi & 1u) reinterpret_cast<u32 *>(dm)[2 * (u64)perm[t] + 1] = (gi >> 1) + sigma3;
     }
 };
-struct ApplyMetaPairsFn {  // the same from (position << 32 | metasymbol) pairs (sharded dictionary stage)
-    const u64 *pairs; u64 *dm;
-    GRL_DEV void operator()(u64 i) const { const u64 p = pairs[i]; reinterpret_cast<u32 *>(dm)[2 * (p >> 32) + 1] = (u32)p; }
+struct ApplyMetaPairsFn {  // the same from (position << 32 | metasymbol) pairs (sharded dictionary stage; q0: first position of dm[])
+    const u64 *pairs; u64 *dm; u64 q0 = 0;
+    GRL_DEV void operator()(u64 i) const { const u64 p = pairs[i]; reinterpret_cast<u32 *>(dm)[2 * ((p >> 32) - q0) + 1] = (u32)p; }
+};
+// Collection-level mode, grammar passes sharded by the OWNER of a dictionary position (round 5): rank g merged -- and holds the
+// walk array dm[] of -- the positions [sbase[g], sbase[g + 1]).  Marks and walk requests travel as 64-bit records with the
+// position in the high half; a record goes to the rank whose part holds its position.
+struct PosOwnerFn {        // own[i] = that rank, for record i
+    const u64 *rec; const u64 *sbase; int N; u32 *own;
+    GRL_DEV void operator()(u64 i) const {
+        const u64 q = rec[i] >> 32;
+        u32 d = 0;
+        for (int r = 1; r < N; r++) if (q >= sbase[r]) d = (u32)r;      // the LAST rank whose part starts at or below q (empty parts in front of it share the start)
+        own[i] = d;
+    }
+};
+struct WalkRequestFn {     // (position of the representative << 32 | my metasymbol) for every metasymbol of my key range
+    const u32 *repq; u64 *req;
+    GRL_DEV void operator()(u64 u) const { req[u] = ((u64)repq[u] << 32) | u; }
+};
+struct WalkAnswerFn {      // answers come back in the order the requests left: g1 << 32 | g0 of the metasymbol in the request's low half
+    const u64 *req; const u64 *ans; u32 *g0; u32 *g1;
+    GRL_DEV void operator()(u64 i) const { const u32 u = (u32)req[i]; const u64 a = ans[i]; g0[u] = (u32)a; g1[u] = (u32)(a >> 32); }
 };
 struct DmStopBitsFn {      // one lane per word: bit q = dm[q] is marked or the last cell of its phrase (where a grammar walk stops)
     const u64 *dm; u64 S; u64 *bits;
@@ -1423,8 +1465,9 @@ struct GrammarFn {
     u32 MD;
     u32 *g0; u32 *g1;
     const u64 *stops = nullptr; u64 S = 0;      // levels with very long phrases: where the walks stop, as a bit-vector (DmStopBitsFn)
+    const u64 *req = nullptr; u64 q0 = 0; u64 *ans = nullptr;      // walks asked for by other ranks: start at (req[u] >> 32) - q0, answer g1 << 32 | g0
     GRL_DEV void operator()(u64 u) const {
-        u64 x = repq[u];
+        u64 x = req ? (req[u] >> 32) - q0 : (u64)repq[u];
         u64 prev = dm[x];
         u32 a = MD, b = 0;
         bool done = false;
@@ -1442,7 +1485,8 @@ struct GrammarFn {
                 done = true;
             } else prev = e;
         }
-        g0[u] = a; g1[u] = b;
+        if (ans) ans[u] = ((u64)b << 32) | (u64)a;
+        else { g0[u] = a; g1[u] = b; }
     }
 };
 
@@ -3227,7 +3271,8 @@ class Engine {
                     const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val,
                     const u32 *fused_ph_slot = nullptr, u32 *fused_slot_val = nullptr,        // (both set: the values go straight to the slots)
                     const prim::U128 *pkeys = nullptr, u64 pDs = 0, int pkb = 0,              // (phrases [0, pDs) given by their records)
-                    const std::vector<u64> *dbase = nullptr) {        // (collection-level mode: rank g merged the phrases [dbase[g], dbase[g + 1]))
+                    const std::vector<u64> *dbase = nullptr,          // (collection-level mode: rank g merged the phrases [dbase[g], dbase[g + 1])
+                    const std::vector<u64> *sbase = nullptr) {        //  = the dictionary positions [sbase[g], sbase[g + 1]))
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
         DBuf<u32> dict_sym(S), dict_phr(S);
         RankBits pbits;                          // phrase starts over the dictionary positions (dictionary build, suffix refinement)
@@ -3460,14 +3505,25 @@ class Engine {
             if (fused_vals) gphr.alloc(G); else pslot.alloc(D);
             if (C) pslot.fill_ff();              // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
             {
-                DBuf<SufRec> rec(S);
-                prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
-                prim::for_each(G, GroupAccumSmallFn{perm.p, gstart.p, rec.p, dict_phr.p, bwt_code,
-                                                    gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
+                static const int fly_min = getenv("GRLBWT_DIST_REC_FLY_MIN") ? atoi(getenv("GRLBWT_DIST_REC_FLY_MIN")) : 8;
+                const bool fly = C && C->size >= fly_min;
+                DBuf<SufRec> rec;
                 DBuf<u32> coff(G + 1);
+                if (!fly) {
+                    rec.alloc(S);
+                    prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
+                    prim::for_each(G, GroupAccumSmallFn<RecArray>{perm.p, gstart.p, RecArray{rec.p}, dict_phr.p, bwt_code,
+                                                                  gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
+                } else {
+                    const RecCompute rc{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code};
+                    prim::for_each(G, GroupAccumSmallFn<RecCompute>{perm.p, gstart.p, rc, dict_phr.p, bwt_code,
+                                                                    gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
+                }
                 const u64 NC = prim::exclusive_scan<u32>(G, GroupChunksIn{gstart.p}, coff.p, true, "group_accum_large");
-                prim::for_each(NC, GroupAccumLargeFn{perm.p, coff.p, G, gstart.p, rec.p, dict_phr.p, bwt_code,
-                                                     gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
+                if (!fly) prim::for_each(NC, GroupAccumLargeFn<RecArray>{perm.p, coff.p, G, gstart.p, RecArray{rec.p}, dict_phr.p, bwt_code,
+                                                                         gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
+                else prim::for_each(NC, GroupAccumLargeFn<RecCompute>{perm.p, coff.p, G, gstart.p, RecCompute{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code},
+                                                                      dict_phr.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
             }
             prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
                                             gflag.p}, "group_decide");
@@ -3528,8 +3584,78 @@ class Engine {
             u32 MD = sigma3 + (u32)M + 1;
             {
                 DBuf<u32> ginfo(G);
-                DBuf<u64> dm(S);
                 prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, (u32)Moff, ginfo.p}, "grammar_ginfo");
+                static const bool replicated_grammar = getenv("GRLBWT_DIST_REPLICATED_GRAMMAR") != nullptr;
+                if (C && sbase && !replicated_grammar) {
+                    // Sharded by the owner of the dictionary position (round 5): I hold dm[] of MY part of the dictionary only.  The marks
+                    // of my groups go to the owners of their positions, the walks of my metasymbols are done by the owners of their
+                    // representatives and the answers come back.  (Rounds 1-4: dm[] of the WHOLE dictionary on every rank, every rank's
+                    // marks all-gathered to everybody and applied by everybody -- at every N: 24 + 8 ms and 10 GB per rank at N = 8 of the
+                    // 10 GB collection, 4.8 GB of pairs sent per rank.)
+                    const int N = C->size, me = C->rank;
+                    const u64 s0 = (*sbase)[me], Sme = (*sbase)[me + 1] - s0;
+                    DBuf<u64> dm, dsb((u64)N + 1);
+                    int obits = (int)bitlen64((u64)N - 1);
+                    if (obits < 1) obits = 1;
+                    // records (position << 32 | payload) -> sorted by the owner of the position, counts per owner
+                    auto by_owner = [&](DBuf<u64> &rec, u64 n, std::vector<u64> &cnt, const char *name) {
+                        DBuf<u32> own(n), own2(n);
+                        DBuf<u64> rec2(n), bound(2 * ((u64)N + 1));
+                        prim::for_each(n, PosOwnerFn{rec.p, dsb.p, N, own.p}, name);
+                        const int res = prim::sort_pairs<u32, u64>(own.p, rec.p, own2.p, rec2.p, n, 0, obits, name);
+                        prim::for_each((u64)N + 1, KeyBoundFn{res ? own2.p : own.p, n, nullptr, bound.p}, name);
+                        std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
+                        for (int d = 0; d < N; d++) cnt[d] = bh[2 * (d + 1)] - bh[2 * d];
+                        if (res) rec = std::move(rec2);
+                    };
+                    std::vector<u64> mcnt(N, 0), wcnt(N, 0), mrc(N, 0), wrc(N, 0);
+                    DBuf<u64> mp, wq;
+                    try {
+                        prim::h2d(dsb.p, sbase->data(), ((u64)N + 1) * 8);
+                        dm.alloc(Sme);
+                        prim::for_each(Sme, DictMetaInitFn{dict_sym.p, dict_phr.p, ph_off, ph_lastT, dm.p, s0}, "grammar_init");
+                        DBuf<u32> mex(Sg + 1);
+                        const u64 nm = prim::exclusive_scan<u32>(Sg, MarkedIn{gid.p, ginfo.p}, mex.p, false, "dist.mark_scan");
+                        mp.alloc(nm);
+                        prim::for_each(Sg, MetaPairFn{perm.p, gid.p, ginfo.p, mex.p, sigma3, mp.p}, "dist.mark_pairs");
+                        by_owner(mp, nm, mcnt, "dist.mark_owner_sort");
+                        wq.alloc(Ml);
+                        prim::for_each(Ml, WalkRequestFn{repq.p, wq.p}, "dist.walk_requests");
+                        by_owner(wq, Ml, wcnt, "dist.walk_owner_sort");
+                    } catch (const prim::Error &e) { C->fail(e); std::fill(mcnt.begin(), mcnt.end(), 0); std::fill(wcnt.begin(), wcnt.end(), 0); }
+                    std::vector<u64> both(mcnt);
+                    both.insert(both.end(), wcnt.begin(), wcnt.end());
+                    std::vector<u64> mat = C->allgather_u64(both);           // (raises on every rank if one of them failed above)
+                    u64 nmr = 0, nwr = 0, maxm = 0, maxw = 0;
+                    for (int g = 0; g < N; g++) {
+                        mrc[g] = mat[(u64)g * 2 * N + me]; wrc[g] = mat[(u64)g * 2 * N + N + me];
+                        nmr += mrc[g]; nwr += wrc[g];
+                        for (int d = 0; d < N; d++) { maxm = std::max(maxm, mat[(u64)g * 2 * N + d]); maxw = std::max(maxw, mat[(u64)g * 2 * N + N + d]); }
+                    }
+                    DBuf<u64> mine, wmine, wans, wback;
+                    try { mine.alloc(nmr); wmine.alloc(nwr); wans.alloc(nwr); wback.alloc(Ml); } catch (const prim::Error &e) { C->fail(e); }
+                    C->allgather_u64({});                                    // (the bulk exchanges below have no way back)
+                    C->named("grammar.mark_pairs").alltoall(mp.p, mcnt, mine.p, mrc, 8, maxm);
+                    C->named("grammar.walk_requests").alltoall(wq.p, wcnt, wmine.p, wrc, 8, maxw);
+                    mp.release();
+                    try {
+                        prim::for_each(nmr, ApplyMetaPairsFn{mine.p, dm.p, s0}, "grammar_marks");
+                        mine.release();
+                        DBuf<u64> stops;             // (very long phrases only: the walks jump to their stops)
+                        if (maxlen >= 4096 || getenv("GRLBWT_GRAMMAR_JUMP")) {
+                            stops.alloc((Sme + 63) / 64 + 1);
+                            prim::for_each((Sme + 63) / 64, DmStopBitsFn{dm.p, Sme, stops.p}, "grammar_marks");
+                        }
+                        prim::for_each(nwr, GrammarFn{nullptr, dm.p, MD, nullptr, nullptr, stops.p, Sme, wmine.p, s0, wans.p}, "grammar");
+                    } catch (const prim::Error &e) { C->fail(e); }
+                    C->allgather_u64({});
+                    C->named("grammar.walk_answers").alltoall(wans.p, wrc, wback.p, wcnt, 8, maxw);
+                    DBuf<u32> g0l(Ml), g1l(Ml);
+                    prim::for_each(Ml, WalkAnswerFn{wq.p, wback.p, g0l.p, g1l.p}, "grammar");
+                    C->named("grammar.g0").template allgather_v<u32>(g0l.p, Ml, bbM, true, L.g0.p);
+                    C->named("grammar.g1").template allgather_v<u32>(g1l.p, Ml, bbM, true, L.g1.p);
+                } else {
+                DBuf<u64> dm(S);
                 prim::for_each(S, DictMetaInitFn{dict_sym.p, dict_phr.p, ph_off, ph_lastT, dm.p}, "grammar_init");
                 if (!C) prim::for_each(Sg, MetaPosFn{perm.p, gid.p, ginfo.p, sigma3, dm.p}, "grammar_marks");
                 else {                           // the marked positions of every rank's groups, as (position, metasymbol) pairs
@@ -3552,6 +3678,7 @@ class Engine {
                     prim::for_each(Ml, GrammarFn{repq.p, dm.p, MD, g0l.p, g1l.p, stops.p, S}, "grammar");
                     C->named("grammar.g0").template allgather_v<u32>(g0l.p, Ml, bbM, true, L.g0.p);
                     C->named("grammar.g1").template allgather_v<u32>(g1l.p, Ml, bbM, true, L.g1.p);
+                }
                 }
             }
             // ---- a9: metasymbol of every phrase --------------------------------
@@ -4193,7 +4320,7 @@ class Engine {
         // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar replicated ----
         DBuf<u32> gval;
         dict_stage<u32, false>(getenv("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
-                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase);
+                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase);
         // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
         {

@@ -131,6 +131,37 @@ def test_replicated_prebwt_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatc
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
 
 
+def test_replicated_grammar_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
+    """Since round 5 the grammar passes run where a dictionary position lives (marks and walk requests go to the owner of the
+    position); the older form -- every rank applies every mark to a walk array of the whole dictionary -- stays behind a switch."""
+    monkeypatch.setenv("GRLBWT_DIST_REPLICATED_GRAMMAR", "1")
+    _run(3, sim, "reads", tmp_path, 29597)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+
+
+def test_owner_sharded_grammar_with_stop_bits(sim, oracle_mod, tmp_path, monkeypatch):
+    """The walks of the owner-sharded grammar passes through the stop bit-vector (the form levels with very long phrases take)."""
+    monkeypatch.setenv("GRLBWT_GRAMMAR_JUMP", "1")
+    for kind, w, port in (("reads", 1, 29598), ("tokens", 2, 29599)):
+        _run(4, sim, kind, tmp_path, port)
+        data = open(tmp_path / ("%s.input" % kind), "rb").read()
+        assert open(tmp_path / ("%s.rl_bwt" % kind), "rb").read() == oracle_mod.rl_bwt(data, w)
+
+
+def test_group_fold_with_computed_suffix_records(sim, oracle_mod, tmp_path, monkeypatch):
+    """From 8 ranks on the group fold computes what it needs of a suffix where it needs it (no record array over the whole
+    dictionary); forced here at 2 and 3 ranks, with the large-group path taken by every group."""
+    monkeypatch.setenv("GRLBWT_DIST_REC_FLY_MIN", "2")
+    _run(2, sim, "reads", tmp_path, 29600)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
+    monkeypatch.setenv("GRLBWT_SEG_CAP", "1")
+    _run(3, sim, "tokens", tmp_path, 29601)
+    data = open(tmp_path / "tokens.input", "rb").read()
+    assert open(tmp_path / "tokens.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 2)
+
+
 def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
     monkeypatch.setenv("GRLBWT_DIST_REPLICATED_DICT", "1")
     _run(2, sim, "uniform", tmp_path, 29591)
