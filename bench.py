@@ -125,12 +125,22 @@ GROUP_KERNELS = {
 }
 
 
+def pmc_traffic_files():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
+
+
+def pmc_traffic_source():
+    """Where `traffic` comes from: NOT measured in this run -- the newest committed rocprofv3 PMC summary of this same command."""
+    files = pmc_traffic_files()
+    return os.path.relpath(files[-1], ROOT) if files else None
+
+
 def pmc_traffic(kernel_fragments):
     """HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected as the microarchitecture guide prescribes) summed over the
     kernels whose names contain one of `kernel_fragments`, per build, from the committed rocprofv3 PMC passes of
     this same command (profiles/<round>/pmc_traffic.json).  None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
+    files = pmc_traffic_files()
     if not files:
         return None
     try:
@@ -286,6 +296,21 @@ def main():
             dt = float(t.item())
         return dt
 
+    # which device every rank runs on (a SCALE record must show N distinct GPUs: VERDICT r4 13c)
+    def device_id():
+        pr = torch.cuda.get_device_properties(dev)
+        d = {"rank": rank, "local_rank": local_rank, "hip_device": torch.cuda.current_device(), "name": pr.name,
+             "total_memory": int(pr.total_memory)}
+        for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+            if hasattr(pr, k):
+                d[k] = str(getattr(pr, k))
+        return d
+    devices = [device_id()]
+    if dist is not None and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
+
     dt = timed(step, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = total_bytes * args.steps / dt / 1e6
@@ -426,6 +451,7 @@ def main():
             tr = pmc_traffic(GROUP_KERNELS[gname])
             return {"bound": "hbm", "kernel": gname, "launches": launches, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr,
+                    "traffic_source": (pmc_traffic_source() + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)") if tr else None,
                     "algorithmic_bytes": nb, "kernel_ms_total": round(ms, 4),
                     "share_of_kernel_time": round(ms / max(total_kernel_ms, 1e-9), 4)}
 
@@ -516,7 +542,7 @@ def main():
         out = {
             "metric": "input MB/s building BCR BWT on 10 GB DNA reads, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "single",      # (one collection of fixed size: strong scaling at N > 1; at N = 1 neither) "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             # value = the build with the input resident in HBM (the contract of this bench); value_cli = the same bytes through the
             # grlbwt executable, file in the page cache -> .rl_bwt file closed (SURVEY 8(d)'s wording of the metric; median run)
@@ -543,6 +569,8 @@ def main():
             # includes the replicated parts of the dictionary stage, which do not shrink with N)
             "per_gpu": {"shard_bytes_rank0": n_bytes, "value_per_gpu": round(value / world, 3)},
         }
+        out["devices"] = devices
+        out["distinct_devices"] = len({d.get("uuid") or d.get("pci_bus_id") or (d["local_rank"], d["hip_device"]) for d in devices})
         if comm is not None:     # totals over warmup + timed + profile steps on rank 0
             nsteps = args.warmup + args.steps + 1
             out["collectives_per_step"] = {"allgather": comm.n_allgather // nsteps, "alltoallv": comm.n_alltoall // nsteps,

@@ -810,9 +810,34 @@ const char *grlbwt_strerror(int code) {
 }
 const char *grlbwt_last_error(const grlbwt_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
 
+// The GRLBWT_* environment switches choose between forms of one computation (tests force most of them and compare the image
+// with the oracle: none changes the output) -- but several change what a run COSTS by integer factors (GRLBWT_NOPOOL,
+// GRLBWT_NO_PART, GRLBWT_DIST_REPLICATED_*).  A run that has any of them set says so, once per process, on stderr.
+// (GRLBWT_QUIET_ENV=1 silences the note: the test suites set switches on purpose.)
+static void warn_env_switches_once() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (getenv("GRLBWT_QUIET_ENV")) return;
+    extern char **environ;
+    std::string names;
+    int n = 0;
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "GRLBWT_", 7) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+        // the bench's / tests' own bookkeeping variables are not switches of the library
+        if (name.rfind("GRLBWT_BENCH_", 0) == 0 || name == "GRLBWT_HIP_LIB" || name == "GRLBWT_E2E_TMP" || name == "GRLBWT_SIM_LIB") continue;
+        names += (n++ ? ", " : "") + name;
+    }
+    if (n) fprintf(stderr, "[grlbwt] note: %d GRLBWT_* switch%s set in the environment (%s): the image is the same, time and memory of this run may not be\n",
+                   n, n == 1 ? "" : "es", names.c_str());
+}
+
 int grlbwt_ctx_create(int device_id, uint32_t flags, grlbwt_ctx **out) {
     if (!out) return GRLBWT_EINVAL;
     *out = nullptr;
+    warn_env_switches_once();
     grlbwt_ctx *c = new (std::nothrow) grlbwt_ctx();
     if (!c) return GRLBWT_ENOMEM;
     c->flags = flags;
