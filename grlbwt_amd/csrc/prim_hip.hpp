@@ -2167,8 +2167,9 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
     constexpr int rec = (int)sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : (int)sizeof(V));
     if constexpr (rec <= 12) {
         const int ov = SITE == 1 ? rs_threads_override_xs() : rs_threads_override();
-        const int tb = ov ? ov : (SITE == 1 ? 256 : 1024);
-        if (n >= (u64)1 << 20) {
+        // (large tiles want many of them: 16384-key tiles from 2^24 keys on -- 1024 tiles, four per CU --, 8192-key tiles from 2^22)
+        const int tb = ov ? ov : (SITE == 1 ? 256 : (n >= ((u64)1 << 24) ? 1024 : 512));
+        if (n >= (u64)1 << 22 || (ov && n >= (u64)1 << 20)) {
             int widths[16], maxw = 0;
             const int passes = rs_plan(end_bit - begin_bit, widths);
             for (int p = 0; p < passes; p++) if (widths[p] > maxw) maxw = widths[p];

@@ -58,6 +58,16 @@ def test_stagewise_reads(hip, oracle_mod):
     parity.check_stagewise(hip, workloads.uniform_reads(20000, 100, seed=5).tobytes(), 1)
 
 
+def test_stagewise_50MB_default_thresholds(hip, oracle_mod):
+    """Stage by stage at a size where the DEFAULT thresholds switch the large-input paths on: 330 k reads of
+    150 bp from a 1.7 Mbp genome, 49.8 MB -- levels 1-2 name their phrases through the partition sort (>= 2^20 occurrences), the
+    dictionary sorts run on 16384-key tiles, large equal-suffix groups go through the chunked fold.  Every level's parse,
+    grammar, has_hocc flags, pre-BWT and BWT against the oracle (about 15 s of one host core)."""
+    data = workloads.sampled_reads(330000, 150, 1660000, seed=20260508)
+    assert data.size == 330000 * 151
+    parity.check_stagewise(hip, data.tobytes(), 1)
+
+
 def test_stagewise_repetitive(hip, oracle_mod):
     parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1)
 
