@@ -957,6 +957,10 @@ struct SampleKey0Fn {     // keys at strided positions: the splitter sample of t
     const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; int K, b; u64 stride; u64 *out; RunKeys rk;
     GRL_DEV void operator()(u64 i) const { const u64 q = i * stride; out[i] = suffix_key0(dict_sym, q, ph_off[dict_phr[q] + 1], K, b, rk); }
 };
+struct SampleWeightFn {   // ... and the frequency of the phrase each sampled suffix belongs to (splitters by symbols described, not by suffixes)
+    const u32 *dict_phr; const idx_t *ph_freq; u64 stride; u64 *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = (u64)ph_freq[dict_phr[i * stride]]; }
+};
 struct PhraseDropIn {     // 1 for a phrase whose last-cell suffix is left out (one scan over the PHRASES then places every kept suffix)
     const u32 *ph_off; const u8 *ph_lastT; bool all = false;
     GRL_DEV u32 operator()(u64 k) const { return (!all && !ph_lastT[k] && ph_off[k + 1] - ph_off[k] > 1) ? 1u : 0u; }
@@ -3359,8 +3363,31 @@ class Engine {
                         DBuf<u64> samp(ns), dspl(N);
                         prim::for_each(ns, SampleKey0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, stride, samp.p, rk}, "dist.sample_keys");
                         std::vector<u64> hs = samp.to_host(ns), spl(N, 0);
+                        // A key range is also the rank's piece of the level's OUTPUT (the pre-BWT stays where it was sorted, round 5).
+                        // Where the dictionary is small against the text -- level 0 of read collections: 10^6 suffixes for 10^10 symbols --
+                        // the dictionary stage costs nothing and the induction everything: the splitters then cut the sample by the
+                        // symbols its suffixes stand for (phrase frequencies), not by their number.  Measured on the 10 GB collection at
+                        // N = 8 (profiles/r05): pass C of a piece costs by its cells and runs, not by its symbols -- slowest / fastest rank of
+                        // the induction 55 / 35 ms by count, 55 / 32 ms by mass, largest image part 1.9 -> 2.5 GB: left off.
+                        if (S * 16 < L.info.n_in && getenv("GRLBWT_DIST_SPLIT_BY_MASS")) {      // (opt-in: measured no better -- see below)
+                            DBuf<u64> sw(ns);
+                            prim::for_each(ns, SampleWeightFn{dict_phr.p, ph_freq, stride, sw.p}, "dist.sample_keys");
+                            std::vector<u64> hw = sw.to_host(ns);
+                            std::vector<std::pair<u64, u64>> kw(ns);
+                            u64 tot = 0;
+                            for (u64 i = 0; i < ns; i++) { kw[i] = {hs[i], hw[i]}; tot += hw[i]; }
+                            std::sort(kw.begin(), kw.end());
+                            u64 acc = 0;
+                            int d = 1;
+                            for (u64 i = 0; i < ns && d < N; i++) {
+                                while (d < N && acc >= tot / (u64)N * (u64)d) { spl[d] = kw[i].first; d++; }
+                                acc += kw[i].second;
+                            }
+                            for (; d < N; d++) spl[d] = ~0ull;                             // (nothing left for the last ranks)
+                        } else {
                         std::sort(hs.begin(), hs.end());
                         for (int d = 1; d < N; d++) spl[d] = hs[(u64)d * ns / N];          // rank d owns keys in [spl[d], spl[d + 1])
+                        }
                         prim::h2d(dspl.p, spl.data(), (u64)N * 8);
                         if (!exchange) {
                             DBuf<u8> mine(S);
