@@ -542,7 +542,8 @@ def main():
         out = {
             "metric": "input MB/s building BCR BWT on 10 GB DNA reads, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "single",      # (one collection of fixed size: strong scaling at N > 1; at N = 1 neither) "vs_baseline": None, "dtype": "u8",
+            # (scaling: ONE collection of fixed size -- strong scaling at N > 1; at N = 1 neither word applies)
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "single", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             # value = the build with the input resident in HBM (the contract of this bench); value_cli = the same bytes through the
             # grlbwt executable, file in the page cache -> .rl_bwt file closed (SURVEY 8(d)'s wording of the metric; median run)
