@@ -1036,6 +1036,20 @@ int grlbwt_get_counters(const grlbwt_ctx *ctx, grlbwt_counters *out) {
     return GRLBWT_OK;
 }
 
+int grlbwt_invert_image_tails(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int cell_bytes, uint64_t tail_cells,
+                              void *dev_out, uint64_t capacity_cells, uint64_t *n_strings_out, uint64_t *n_cells_out) {
+    if (!ctx || !dev_image || !dev_out || tail_cells == 0) return GRLBWT_EINVAL;
+    return guarded(ctx, [&] {
+        const uint64_t total = grl64::Engine::image_total_symbols(dev_image, image_bytes);
+        const bool big = total >= 0xFFFFFF00ull || (ctx->flags & GRLBWT_FLAG_FORCE_IDX64);
+        uint64_t k = 0;
+        const uint64_t n = big ? grl64::Engine::invert_image_tails(dev_image, image_bytes, cell_bytes, tail_cells, dev_out, capacity_cells, &k)
+                               : grl32::Engine::invert_image_tails(dev_image, image_bytes, cell_bytes, tail_cells, dev_out, capacity_cells, &k);
+        if (n_strings_out) *n_strings_out = k;
+        if (n_cells_out) *n_cells_out = n;
+    });
+}
+
 int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int cell_bytes,
                         void *dev_text_out, uint64_t capacity_cells, uint64_t *n_cells_out) {
     if (!ctx || !dev_image || !dev_text_out) return GRLBWT_EINVAL;

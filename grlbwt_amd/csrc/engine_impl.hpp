@@ -2715,6 +2715,19 @@ struct RunInvertWriteFn {
     }
 };
 
+template <class cell_t>
+struct RunInvertTailFn {    // the last `tail` cells of string i (separator included), right-aligned in slot i of `tail` cells; the rest of the slot stays as it was
+    const RankCell *rc; const RunRec *rec; u32 sep; u64 tail; cell_t *out; idx_t *got;
+    GRL_DEV void operator()(u64 i) const {
+        u64 end = (i + 1) * tail - 1, l = 1;
+        idx_t row = (idx_t)i;
+        out[end] = (cell_t)sep;
+        RunRec r = rec[run_of_row(rc, (u64)row)];
+        while (r.sym != sep && l < tail) { out[--end] = (cell_t)r.sym; l++; row = (idx_t)(row + (idx_t)r.delta); r = rec[run_of_row(rc, (u64)row)]; }
+        got[i] = (idx_t)l;
+    }
+};
+
 // =========================================================================
 struct RoundInfo {
     u64 n_in = 0, D = 0, S = 0, M = 0, parse_size = 0, sigma = 0, max_phrase_len = 0, sort_iters = 0, table_retries = 0;
@@ -4773,12 +4786,12 @@ class Engine {
     static void d2d_copy(T *dst, const T *src, u64 n) { prim::d2d(dst, src, n * sizeof(T)); }
     // the run-indexed form (functor block "the same inversion indexed by RUNS")
     template <class cell_t>
-    static u64 invert_runs_t(const u8 *img, u64 R, u32 sb, u32 fb, cell_t *text_out, u64 capacity) {
+    static u64 invert_runs_t(const u8 *img, u64 R, u32 sb, u32 fb, cell_t *text_out, u64 capacity, u64 tail = 0, u64 *n_strings_out = nullptr) {
         DBuf<u32> rsym(R);
         DBuf<idx_t> rlen(R), rpos(R + 1);
         prim::for_each(R, UnpackRunsFn{img, sb, fb, rsym.p, rlen.p}, "inv.unpack");
         const u64 n = (u64)prim::exclusive_scan<idx_t>(R, IdxIn<idx_t>{rlen.p}, rpos.p, true, "inv.positions");
-        if (n > capacity) throw prim::Error(-22, "inversion: output buffer too small");
+        if (!tail && n > capacity) throw prim::Error(-22, "inversion: output buffer too small");
         const u32 sep = prim::reduce_min<u32>(R, PtrU32In{rsym.p}, "inv.sep");
         const u32 mx = prim::reduce_max<u32>(R, PtrU32In{rsym.p}, "inv.max");
         const u64 k = prim::reduce_sum<u64>(R, SepLenIn{rsym.p, rlen.p, sep}, "inv.nstrings");      // strings = separators
@@ -4806,6 +4819,16 @@ class Engine {
             if (tot != n) throw prim::Error(-71, "inversion: run lengths do not add up");
         }
         rsym.release(); rlen.release(); rpos.release();
+        if (tail) {
+            // the ends of the strings only (collections whose strings are too long to walk in a test's time -- 100
+            // strings of 249 M cells are 249 M dependent steps each): `tail` LF steps per string from its terminator's row
+            if (k * tail > capacity) throw prim::Error(-22, "inversion: output buffer too small");
+            DBuf<idx_t> got(k);
+            prim::for_each(k, RunInvertTailFn<cell_t>{rc.p, rec.p, sep, tail, text_out, got.p}, "inv.tails");
+            prim::sync();
+            if (n_strings_out) *n_strings_out = k;
+            return (u64)prim::reduce_sum<u64>(k, IdxIn<idx_t>{got.p}, "inv.tails");
+        }
         DBuf<idx_t> slen(k + 1);
         prim::for_each(k, RunInvertLenFn{rc.p, rec.p, sep, slen.p}, "inv.lengths");
         const u64 tot = (u64)prim::exclusive_scan<idx_t>(k, IdxIn<idx_t>{slen.p}, slen.p, true, "inv.offsets");
@@ -4813,6 +4836,24 @@ class Engine {
         prim::for_each(k, RunInvertWriteFn<cell_t>{rc.p, rec.p, slen.p, sep, text_out}, "inv.write");
         prim::sync();
         return n;
+    }
+
+    // the last `tail` cells of every string (slot i of `tail` cells holds string i's end, right-aligned); returns the cells written
+    static u64 invert_image_tails(const void *dev_image, u64 image_bytes, int cell_bytes, u64 tail, void *dev_out, u64 capacity_cells, u64 *n_strings_out) {
+        if (image_bytes < 16 || tail == 0) throw prim::Error(-22, "not an .rl_bwt image, or no tail length");
+        u64 hdr[2];
+        prim::d2h(hdr, dev_image, 16);
+        const u64 sb = hdr[0], fb = hdr[1];
+        if (sb == 0 || sb > 8 || fb == 0 || fb > 8 || (image_bytes - 16) % (sb + fb)) throw prim::Error(-22, "bad .rl_bwt header");
+        const u64 R = (image_bytes - 16) / (sb + fb);
+        const u8 *img = (const u8 *)dev_image;
+        switch (cell_bytes) {
+            case 1: return invert_runs_t<u8>(img, R, (u32)sb, (u32)fb, (u8 *)dev_out, capacity_cells, tail, n_strings_out);
+            case 2: return invert_runs_t<u16>(img, R, (u32)sb, (u32)fb, (u16 *)dev_out, capacity_cells, tail, n_strings_out);
+            case 4: return invert_runs_t<u32>(img, R, (u32)sb, (u32)fb, (u32 *)dev_out, capacity_cells, tail, n_strings_out);
+            case 8: return invert_runs_t<u64>(img, R, (u32)sb, (u32)fb, (u64 *)dev_out, capacity_cells, tail, n_strings_out);
+            default: throw prim::Error(-22, "bad cell width");
+        }
     }
 
     static u64 invert_image(const void *dev_image, u64 image_bytes, int cell_bytes, void *dev_text_out, u64 capacity_cells, u64 n_total_hint = 0) {

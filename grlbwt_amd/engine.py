@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
     "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
     "grlbwt_level_text_download", "grlbwt_level_bwt_size", "grlbwt_level_bwt_download", "grlbwt_get_counters",
-    "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump", "grlbwt_dist_build", "grlbwt_memory_usage", "grlbwt_invert_image",
+    "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump", "grlbwt_dist_build", "grlbwt_memory_usage", "grlbwt_invert_image", "grlbwt_invert_image_tails",
     "grlbwt_image_plain", "grlbwt_image_rle", "grlbwt_image_stats_get", "grlbwt_image_split_runs",
     "grlbwt_level_grammar_size", "grlbwt_level_grammar_download",
 ]
@@ -167,6 +167,7 @@ def load_library(path=None, allow_test_standin=False):
     L.grlbwt_selftest.argtypes = [vp, u64, u64]
     L.grlbwt_memory_usage.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.grlbwt_invert_image.argtypes = [vp, vp, u64, i32, vp, u64, C.POINTER(u64)]
+    L.grlbwt_invert_image_tails.argtypes = [vp, vp, u64, i32, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.grlbwt_image_plain.argtypes = [vp, vp, u64, vp, u64, i32, C.POINTER(u64)]
     L.grlbwt_image_rle.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.grlbwt_image_stats_get.argtypes = [vp, vp, u64, C.POINTER(ImageStats)]
@@ -353,6 +354,14 @@ class Context:
         self._ck(self.L.grlbwt_invert_image(self._h, C.c_void_p(dev_image_ptr), image_bytes, cell_bytes,
                                             C.c_void_p(dev_out_ptr), capacity_cells, C.byref(n)))
         return n.value
+
+    def invert_image_tails(self, dev_image_ptr, image_bytes, cell_bytes, tail_cells, dev_out_ptr, capacity_cells):
+        """The last `tail_cells` cells of every string (slot i of the output: string i's end, right-aligned); returns
+        (strings, cells written)."""
+        k, n = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.grlbwt_invert_image_tails(self._h, C.c_void_p(dev_image_ptr), image_bytes, cell_bytes, tail_cells,
+                                                  C.c_void_p(dev_out_ptr), capacity_cells, C.byref(k), C.byref(n)))
+        return k.value, n.value
 
     def image_plain(self, dev_image_ptr, image_bytes, dev_out_ptr, capacity, null_char=-1):
         """grl2plain on the device (scripts/grl2plain.cpp): plain BWT bytes; returns their number."""

@@ -186,6 +186,14 @@ int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path);
 int grlbwt_invert_image(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int cell_bytes,
                         void *dev_text_out, uint64_t capacity_cells, uint64_t *n_cells_out);
 
+/* The same LF walk (scripts/reverse_bwt.cpp:36-52), stopped after tail_cells steps per string: slot i of dev_out (tail_cells cells wide)
+ * receives the LAST min(length, tail_cells) cells of string i, separator included, right-aligned; the cells in front of them are
+ * left as they were.  *n_strings_out = strings, *n_cells_out = cells written.  For collections whose strings are too long to walk
+ * end to end in a test's time (100 strings of 249 M cells: 249 M dependent steps each): the ends of all strings check the ORDER of
+ * the BWT, which a symbol-count comparison does not.  capacity_cells >= strings * tail_cells. */
+int grlbwt_invert_image_tails(grlbwt_ctx *ctx, const void *dev_image, uint64_t image_bytes, int cell_bytes, uint64_t tail_cells,
+                              void *dev_out, uint64_t capacity_cells, uint64_t *n_strings_out, uint64_t *n_cells_out);
+
 /* The other .rl_bwt consumers of the reference's scripts/ (SURVEY 8f-2), on an image in device memory:
  * grl2plain  (scripts/grl2plain.cpp:18-50): plain BWT, one byte per symbol ((char)sym); null_char >= 0 replaces
  *            symbol 0, -1 leaves it.

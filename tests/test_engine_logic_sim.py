@@ -142,6 +142,32 @@ def test_invert_image_round_trip(sim, kind, w, form, monkeypatch):
             assert n == data.size and np.array_equal(out, data)
 
 
+@pytest.mark.parametrize("tail", [1, 3, 17, 400])
+def test_invert_image_tails(sim, tail):
+    """grlbwt_invert_image_tails: slot i of the output holds the last min(length, tail) cells of string i, right-aligned; what
+    lies in front of them is left untouched (the form the chromosome-scale GPU test checks the order of a 24.9 GB image with)."""
+    for data, w in ((np.frombuffer(b"A\n\nA\nGATTACA\nGATTACA\nT\n\nACGTACGTACGTACGTACGTAAAAAAC\n", dtype=np.uint8), 1),
+                    (workloads.sampled_reads(300, 100, 2000, seed=14), 1), (workloads.zipf_tokens(5000, doc_len=60, vocab=500), 2)):
+        sep = data[-1]
+        ends = np.flatnonzero(data == sep)
+        starts = np.concatenate([[0], ends[:-1] + 1])
+        for flags in (0, engine.FLAG_FORCE_IDX64):
+            with engine.Context(0, flags, sim) as ctx:
+                ctx.upload(data.tobytes(), w)
+                ctx.build()
+                nb, _ = ctx.result_size()
+                out = np.full(len(ends) * tail, 0x5A, dtype=data.dtype)
+                k, n = ctx.invert_image_tails(ctx.result_device_ptr(), nb, w, tail, out.ctypes.data, out.size)
+            assert k == len(ends)
+            want = np.full(len(ends) * tail, 0x5A, dtype=data.dtype)
+            tot = 0
+            for i, (a, b) in enumerate(zip(starts, ends)):
+                m = min(int(b - a + 1), tail)
+                want[(i + 1) * tail - m:(i + 1) * tail] = data[b + 1 - m:b + 1]
+                tot += m
+            assert n == tot and np.array_equal(out, want)
+
+
 def test_unfused_expansion_branch(sim, oracle_mod, monkeypatch):
     """The HIP engine falls back to count + scan + expand + split when a run would drop more cells than the fused
     kernel stages in LDS (> 32); the stand-in's limit is lowered to take that branch on ordinary inputs."""

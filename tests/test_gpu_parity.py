@@ -459,6 +459,38 @@ def test_baseline_configs_at_stated_size_round_trip(hip, config):
     assert n == text.numel() and torch.equal(back, text)
 
 
+def test_configs2_at_chromosome_scale_order_checked(hip):
+    """BASELINE configs[2] at the size SURVEY 8(d) calls optional: 100 copies of a 248,956,422 bp sequence (the length of human
+    chr1), 1e-3 substitutions per copy, 24.9 GB, 7.3 G phrase occurrences at level 0 (>= 2^32), 171 GB of device memory.  A full
+    inversion walks 249 M dependent steps per string (minutes); the image is checked by (i) header widths, maximal
+    runs and lengths through torch, (ii) every symbol's total against its count in the text, and (iii) **the ORDER: the last
+    4 M cells of every string decoded by the per-run LF walk (grlbwt_invert_image_tails) and compared with the text** -- a BWT with
+    the right symbol counts in a wrong order does not survive 400 M LF steps."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230 << 30:
+        pytest.skip("needs ~230 GB of free device memory")
+    L, k, tail = 248956422, 100, 4000000
+    text = workloads.repetitive_copies_torch(k, L, device="cuda:0")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert text.numel() == k * (L + 1)
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(text.data_ptr(), text.numel(), 1, keepalive=text)
+        ctx.build()
+        st = ctx.stats()
+        assert st["n_syms"] == text.numel() and st["n_strings"] == k
+        nb, nr = _assert_image_properties(ctx, text, 1)
+        assert nb == 16 + nr * (st["sb"] + st["fb"])
+        out = torch.zeros(k * tail, dtype=torch.uint8, device="cuda:0")
+        ks, n = ctx.invert_image_tails(ctx.result_device_ptr(), nb, 1, tail, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    assert ks == k and n == k * tail
+    assert torch.equal(out.view(k, tail), text.view(k, L + 1)[:, L + 1 - tail:])
+    del text, out
+    torch.cuda.empty_cache()
+
+
 def test_result_pointer_is_complete_when_build_returns(hip, oracle_mod):
     """include/grlbwt_hip.h: "results are complete when a call returns" -- the image is read from ANOTHER stream (torch's
     default stream) right after build(), with no synchronisation of the engine's stream by the caller."""
