@@ -1647,12 +1647,18 @@ static constexpr int kRsKeys = kRsTile / kBlock;
 struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays are read or written
 // (DB = digit bits, 8-10: thread t owns the BPT = 2^DB / 256 neighbouring bins [t * BPT, (t + 1) * BPT) in the offset phase)
 // (second launch bound: 4 waves per SIMD = 4 / 2 / 1 workgroups of 256 / 512 / 1024 threads per CU, what the LDS tile leaves room for)
-template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock>
+// (DIRECT: the values are not staged in LDS -- every lane moves its value straight from where it was to where it goes, once the
+// keys' ranking has told it where.  For wide values (the 16-byte phrase records of the partition sort) the LDS tile is what limits
+// the tile size: 4096 records of 16 bytes already take 64 KB, and with 512-1024 bins such a tile leaves runs of 4-8 records = 64-128
+// bytes of values and 16-32 bytes of keys at the write front.  Keys only in LDS: 16384 records per tile, runs four times as long;
+// the value stores of a run come from different lanes and rows but reach the same lines of one L2 within the tile's lifetime.)
+template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock, bool DIRECT = false>
 __global__ void __launch_bounds__(TB)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
                         const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles) {
     constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
-    constexpr int EB = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
+    constexpr bool STAGED = !std::is_same<V, NoVal>::value && !DIRECT;
+    constexpr int EB = (STAGED && sizeof(V) > sizeof(K)) ? sizeof(V) : sizeof(K);
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[TILE * EB];
     __shared__ u32 s_cnt[NW][NB];      // per wave: running count, then exclusive base, of each digit
     __shared__ u64 s_gbase[NB];       // global position of tile-local index 0 of the digit's run (may wrap; mod 2^64)
@@ -1664,7 +1670,7 @@ __global__ void __launch_bounds__(TB)
     const u32 tile_n = left < (u64)TILE ? (u32)left : (u32)TILE;
     const u32 wbase = (u32)w * (64 * kRsKeys);
     K key[kRsKeys];
-    V val[std::is_same<V, NoVal>::value ? 1 : kRsKeys];
+    V val[STAGED ? kRsKeys : 1];
     u32 idx[kRsKeys];
 #pragma unroll
     for (int q = 0; q < kRsKeys; q++) {
@@ -1721,11 +1727,18 @@ __global__ void __launch_bounds__(TB)
             kb[idx[q]] = key[q];
         }
     }
-    if constexpr (!std::is_same<V, NoVal>::value) {
+    if constexpr (STAGED) {
 #pragma unroll
         for (int q = 0; q < kRsKeys; q++) {
             u32 t = wbase + q * 64 + lane;
             val[q] = t < tile_n ? vals_in[base + t] : V(0);
+        }
+    }
+    if constexpr (DIRECT && !std::is_same<V, NoVal>::value) {
+#pragma unroll
+        for (int q = 0; q < kRsKeys; q++) {
+            u32 t = wbase + q * 64 + lane;
+            if (t < tile_n) vals_out[s_gbase[dig[q]] + idx[q]] = vals_in[base + t];
         }
     }
     __syncthreads();
@@ -1742,7 +1755,7 @@ __global__ void __launch_bounds__(TB)
             keys_out[s_gbase[d] + t] = k;
         }
     }
-    if constexpr (!std::is_same<V, NoVal>::value) {
+    if constexpr (STAGED) {
         __syncthreads();
         V *vb = (V *)s_buf;
 #pragma unroll
@@ -2095,7 +2108,7 @@ inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *na
     return sort_keys_fwd(buf_a, buf_b, plan.E, plan.db, plan.bits, name);
 }
 
-template <class K, class V, int SITE, int DB, int TB = kBlock>
+template <class K, class V, int SITE, int DB, int TB = kBlock, bool DIRECT = false>
 inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shift, u32 dmask, u32 tiles, u32 *counts, u64 *offsets,
                     u32 *chunk_sums, u64 *chunk_off, const char *name) {
     prof_begin(std::string(name) + ".hist", n * sizeof(K));
@@ -2104,7 +2117,7 @@ inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shi
     after_launch(name);
     rs_offsets<(1 << DB)>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
     prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
-    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles);
+    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB, DIRECT>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles);
     prof_end();
     after_launch(name);
 }
@@ -2212,18 +2225,18 @@ static constexpr u32 kNoId = 0xFFFFFFFFu;
 // (The other form -- the forward pass stores where every element went, the way back is a plain gather -- was measured slower on
 // the 964 M records of level 1 of the 10 GB build: forward 36 + back 22.8 ms against 32.4 + 19.2 ms; the 4 bytes per element per
 // pass of destinations cost more than the ballot ranking they save.)
-template <class K, class W, int DB = 8>
-__global__ void __launch_bounds__(kBlock)
+template <class K, class W, int DB = 8, int TB = kBlock>
+__global__ void __launch_bounds__(TB)
     k_rs_unscatter(const K *keys_in, const W *src, W *dst, u64 n, int shift, u32 dmask, const u64 *offsets /*[tiles][NB]*/) {
-    constexpr int NB = 1 << DB, BPT = NB / kBlock;
-    __shared__ u32 s_cnt[4][NB];
+    constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
+    __shared__ u32 s_cnt[NW][NB];
     __shared__ u64 s_gbase[NB];
-    __shared__ u32 s_wsum[4];
+    __shared__ u32 s_wsum[NW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * NB; i += kBlock) (&s_cnt[0][0])[i] = 0;
-    const u64 base = (u64)blockIdx.x * kRsTile;
+    for (int i = threadIdx.x; i < NW * NB; i += TB) (&s_cnt[0][0])[i] = 0;
+    const u64 base = (u64)blockIdx.x * TILE;
     const u64 left = n - base;
-    const u32 tile_n = left < (u64)kRsTile ? (u32)left : (u32)kRsTile;
+    const u32 tile_n = left < (u64)TILE ? (u32)left : (u32)TILE;
     const u32 wbase = (u32)w * (64 * kRsKeys);
     u32 dig[kRsKeys], idx[kRsKeys];
 #pragma unroll
@@ -2235,13 +2248,14 @@ __global__ void __launch_bounds__(kBlock)
     wave_rank<DB, kRsKeys>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
     __syncthreads();
     {
-        u32 cw[BPT][4], tt[BPT], sum = 0;
+        u32 cw[BPT][NW], tt[BPT], sum = 0;
+        const bool has = (int)threadIdx.x * BPT < NB;
 #pragma unroll
         for (int e = 0; e < BPT; e++) {
             const int d = threadIdx.x * BPT + e;
             tt[e] = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { cw[e][k] = s_cnt[k][d]; tt[e] += cw[e][k]; }
+            for (int k = 0; k < NW; k++) { cw[e][k] = has ? s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
             sum += tt[e];
         }
         u32 incl = sum;
@@ -2254,15 +2268,16 @@ __global__ void __launch_bounds__(kBlock)
         __syncthreads();
         u32 start = incl - sum;
         for (int k = 0; k < w; k++) start += s_wsum[k];
+        if (has) {
 #pragma unroll
-        for (int e = 0; e < BPT; e++) {
-            const int d = threadIdx.x * BPT + e;
-            s_cnt[0][d] = start;
-            s_cnt[1][d] = start + cw[e][0];
-            s_cnt[2][d] = start + cw[e][0] + cw[e][1];
-            s_cnt[3][d] = start + cw[e][0] + cw[e][1] + cw[e][2];
-            s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
-            start += tt[e];
+            for (int e = 0; e < BPT; e++) {
+                const int d = threadIdx.x * BPT + e;
+                u32 run = start;
+#pragma unroll
+                for (int k = 0; k < NW; k++) { s_cnt[k][d] = run; run += cw[e][k]; }
+                s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
+                start += tt[e];
+            }
         }
     }
     __syncthreads();
@@ -2281,6 +2296,7 @@ struct PartSort {
     u64 n = 0;
     int passes = 0, shifts[8], widths[8];
     u32 tiles = 0;
+    int tb = kBlock;                  // threads per workgroup of the passes (forward and backward agree): 1024 = tiles of 16384 records, values moved directly
     K *kbuf[9] = {nullptr};          // kbuf[0] = the caller's keys (kept), kbuf[p + 1] = keys after pass p (owned)
     u64 *offs[8] = {nullptr};
     const K *sorted_keys() const { return kbuf[passes]; }
@@ -2300,7 +2316,13 @@ struct PartSort {
             shifts[p] = sh;
             sh += widths[p];
         }
-        tiles = (u32)((n + kRsTile - 1) / kRsTile);
+        // (GRLBWT_PART_THREADS=1024: tiles of 16384 records with the values moved directly instead of staged in LDS.  Measured on
+        // the 10 GB build and left off: the 16-byte stores of a wave then go to 64 different lines -- phrase_part.scatter 39.6 -> 55.4
+        // ms, the way back 23.3 -> 27.9 ms; the longer runs at the write front do not make up for the request rate)
+        static const int tb_env = getenv("GRLBWT_PART_THREADS") ? atoi(getenv("GRLBWT_PART_THREADS")) : 0;
+        tb = tb_env >= 1024 ? 1024 : kBlock;
+        const u64 tile = (u64)tb * kRsItems;
+        tiles = (u32)((n + tile - 1) / tile);
         u32 *counts = (u32 *)dev_alloc((u64)1024 * tiles * sizeof(u32));
         u32 chunks = (tiles + kRsChunk - 1) / kRsChunk;
         u32 *chunk_sums = (u32 *)dev_alloc((u64)1024 * chunks * sizeof(u32));
@@ -2312,7 +2334,11 @@ struct PartSort {
             offs[p] = (u64 *)dev_alloc(((u64)1 << db) * tiles * sizeof(u64));
             const u32 dmask = (1u << widths[p]) - 1u;
             V *vin = cur ? vals_b : vals_a, *vout = cur ? vals_a : vals_b;
-            if (db == 8) rs_pass<K, V, 2, 8>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+            if (tb == 1024) {
+                if (db == 8) rs_pass<K, V, 2, 8, 1024, true>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+                else if (db == 9) rs_pass<K, V, 2, 9, 1024, true>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+                else rs_pass<K, V, 2, 10, 1024, true>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+            } else if (db == 8) rs_pass<K, V, 2, 8>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
             else if (db == 9) rs_pass<K, V, 2, 9>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
             else rs_pass<K, V, 2, 10>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
             cur ^= 1;
@@ -2331,7 +2357,11 @@ struct PartSort {
             W *dst = (p == 0) ? out : ((src == tmp) ? in : tmp);
             const u32 dmask = (1u << widths[p]) - 1u;
             prof_begin(name, n * (sizeof(K) + 2 * sizeof(W)));
-            if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            if (tb == 1024) {
+                if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8, 1024>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+                else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9, 1024>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+                else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10, 1024>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            } else if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
             else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
             else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
             prof_end();

@@ -101,11 +101,15 @@ def test_one_word_cells_in_64_bits(hip, oracle_mod, monkeypatch):
     parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
-def test_partitioned_phrase_naming(hip, oracle_mod, monkeypatch, capfd):
+@pytest.mark.parametrize("part_threads", ["256", "1024"])
+def test_partitioned_phrase_naming(hip, oracle_mod, monkeypatch, capfd, part_threads):
     """prim::PartSort (forward passes + the re-ranking passes back) and prim::k_part_dedupe on the device: partitioned phrase
     naming forced on for small inputs (by default it starts at 2^20 phrase occurrences per level), stage by stage against the
-    oracle; then with partitions that cannot fit their LDS table (one partition for 3 M distinct phrases)."""
+    oracle; then with partitions that cannot fit their LDS table (one partition for 3 M distinct phrases).  Both tile forms of
+    the partition sort: 4096 records with the values staged in LDS (the default), and 16384 records with the values moved directly
+    (GRLBWT_PART_THREADS=1024: measured slower, kept behind the switch)."""
     monkeypatch.setenv("GRLBWT_PART_MIN_OCC", "0")
+    monkeypatch.setenv("GRLBWT_PART_THREADS", part_threads)
     parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
     parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1)
     parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
