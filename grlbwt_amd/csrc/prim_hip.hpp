@@ -2225,10 +2225,15 @@ static constexpr u32 kNoId = 0xFFFFFFFFu;
 // (The other form -- the forward pass stores where every element went, the way back is a plain gather -- was measured slower on
 // the 964 M records of level 1 of the 10 GB build: forward 36 + back 22.8 ms against 32.4 + 19.2 ms; the 4 bytes per element per
 // pass of destinations cost more than the ballot ranking they save.)
-template <class K, class W, int DB = 8, int TB = kBlock>
+// (STAGED, round 5: the elements are READ in the output order of the forward pass -- neighbouring lanes take neighbouring elements of
+// a digit's run, as the forward write-out stores them -- and brought to input order through LDS, instead of one gather per element
+// whose 64 lanes hit 64 different runs: a wave instruction then touches ~8 lines instead of 64.)
+template <class K, class W, int DB = 8, int TB = kBlock, bool STAGED = true>
 __global__ void __launch_bounds__(TB)
     k_rs_unscatter(const K *keys_in, const W *src, W *dst, u64 n, int shift, u32 dmask, const u64 *offsets /*[tiles][NB]*/) {
     constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
+    __shared__ u32 s_e[STAGED ? TILE : 1];       // by output position of the tile: input position << 10 | digit
+    __shared__ W s_v[STAGED ? TILE : 1];         // by input position: the element
     __shared__ u32 s_cnt[NW][NB];
     __shared__ u64 s_gbase[NB];
     __shared__ u32 s_wsum[NW];
@@ -2281,10 +2286,30 @@ __global__ void __launch_bounds__(TB)
         }
     }
     __syncthreads();
+    if constexpr (STAGED) {
+#pragma unroll
+        for (int q = 0; q < kRsKeys; q++) {
+            const u32 t = wbase + q * 64 + lane;
+            if (t < tile_n) s_e[idx[q] + s_cnt[w][dig[q]]] = (t << 10) | dig[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kRsKeys; j++) {
+            const u32 t = (u32)j * TB + threadIdx.x;
+            if (t < tile_n) { const u32 e = s_e[t]; s_v[e >> 10] = src[s_gbase[e & 1023u] + t]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kRsKeys; j++) {
+            const u32 t = (u32)j * TB + threadIdx.x;
+            if (t < tile_n) dst[base + t] = s_v[t];
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < kRsKeys; q++) {
         u32 t = wbase + q * 64 + lane;
         if (t < tile_n) dst[base + t] = src[s_gbase[dig[q]] + (u64)(idx[q] + s_cnt[w][dig[q]])];
+    }
     }
 }
 
@@ -2357,10 +2382,15 @@ struct PartSort {
             W *dst = (p == 0) ? out : ((src == tmp) ? in : tmp);
             const u32 dmask = (1u << widths[p]) - 1u;
             prof_begin(name, n * (sizeof(K) + 2 * sizeof(W)));
-            if (tb == 1024) {
-                if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8, 1024>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-                else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9, 1024>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-                else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10, 1024>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            static const bool gather = getenv("GRLBWT_UNSCATTER_GATHER") != nullptr;      // (the form of rounds 3-4: one gather per element)
+            if (gather && tb != 1024) {
+                if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8, kBlock, false>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+                else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9, kBlock, false>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+                else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10, kBlock, false>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            } else if (tb == 1024) {
+                if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8, 1024, false>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+                else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9, 1024, false>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+                else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10, 1024, false>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
             } else if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
             else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
             else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
