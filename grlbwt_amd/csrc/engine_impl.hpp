@@ -980,9 +980,9 @@ struct KeepRangeIn {      // 1 for the kept suffixes (SufKeep) among the positio
     SufKeep keep; u64 q0;
     GRL_DEV u32 operator()(u64 i) const { return keep(q0 + i) ? 1u : 0u; }
 };
-struct KeyRangeFn {       // (key, position, owner of the key's range) of those, compacted
+struct KeyRangeFn {       // (key, position, owner of the key's range) of those, compacted  (pos_base: the arrays describe MY part of the dictionary, positions travel as global ones)
     SufKeep keep; const u32 *ex; u64 q0; const u32 *dict_sym; int K, b; const u64 *spl; int N;
-    u64 *lk; u32 *lp; u32 *own; u32 *idx; RunKeys rk;
+    u64 *lk; u32 *lp; u32 *own; u32 *idx; RunKeys rk; u32 pos_base = 0;
     GRL_DEV void operator()(u64 i) const {
         const u64 q = q0 + i;
         if (keep(q)) {
@@ -990,7 +990,7 @@ struct KeyRangeFn {       // (key, position, owner of the key's range) of those,
             const u64 key = suffix_key0(dict_sym, q, keep.ph_off[keep.dict_phr[q] + 1], K, b, rk);
             u32 d = 0;
             for (int r = 1; r < N; r++) if (key >= spl[r]) d = (u32)r;      // the LAST rank whose range starts at or below the key
-            lk[o] = key; lp[o] = (u32)q; own[o] = d; idx[o] = o;
+            lk[o] = key; lp[o] = (u32)q + pos_base; own[o] = d; idx[o] = o;
         }
     }
 };
@@ -1227,16 +1227,21 @@ static constexpr u32 kRecSym = 0x3FFFFFFFu, kRecFinal = 0x40000000u, kRecLastT =
 // records of 8-16 bytes: 9.9 GB at level 2 of the 10 GB collection)
 struct RecArray {
     const SufRec *rec;
-    GRL_DEV SufRec operator()(u32 q) const { return rec[q]; }
+    GRL_DEV SufRec operator()(u32, u32 q) const { return rec[q]; }
+};
+struct RecSlot {           // by sorted slot: what the owners of the positions answered (dictionary sharded by owner; the phrase number travels in the record in both index widths)
+    const SufRecT<8> *rec;
+    GRL_DEV SufRecT<8> operator()(u32 j, u32) const { return rec[j]; }
 };
 struct RecCompute {
     const u32 *dict_sym; const u32 *dict_phr; const u32 *ph_off; const idx_t *ph_freq; const u8 *ph_lastT; u32 bwt_code;
-    GRL_DEV SufRec operator()(u32 q) const {
+    u32 phr_base = 0;             // (my part of a dictionary sharded by owner: phrase numbers travel as global ones)
+    GRL_DEV SufRec operator()(u32, u32 q) const {
         const u32 k = dict_phr[q];
         SufRec r;
         r.freq = ph_freq[k];
         r.left = (((u64)q == (u64)ph_off[k]) ? bwt_code : dict_sym[q - 1]) | (((u64)q + 1 == (u64)ph_off[k + 1]) ? kRecFinal : 0u) | (ph_lastT[k] ? kRecLastT : 0u);
-        r.set_phr(k);
+        r.set_phr(k + phr_base);
         return r;
     }
 };
@@ -1274,11 +1279,11 @@ struct GroupAccumSmallFn {
         const u32 te = large ? t0 : t1;
         for (u32 j = t0; j < te; j++) {
             const u32 q = perm[j];
-            SufRec r = rec(q);
+            const auto r = rec(j, q);
             if (j == t0) first = r.left;
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
-            acc += r.freq;
+            acc += (idx_t)r.freq;
             if (left == bwt_code) {                 // a whole phrase: the group its metasymbol will be read from
                 fl = 1;
                 const u32 k = r.phr(dict_phr, q);
@@ -1310,10 +1315,10 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
         u32 mn = 0xFFFFFFFFu, mx = 0; idx_t acc = 0; u8 fl = 0;
         for (u32 j = t; j < te; j++) {
             const u32 q = perm[j];
-            SufRec r = rec(q);
+            const auto r = rec(j, q);
             u32 left = r.left & kRecSym;
             mn = left < mn ? left : mn; mx = left > mx ? left : mx;
-            acc += r.freq;
+            acc += (idx_t)r.freq;
             if (left == bwt_code) {
                 fl = 1;
                 const u32 k = r.phr(dict_phr, q);
@@ -1327,17 +1332,17 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
     }
 };
 enum : u8 { GF_VALID = 1, GF_RANKED = 2, GF_MULTI = 4 };
+template <class REC>
 struct GroupDecideFn {
-    const u32 *perm; const u32 *gstart; const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
+    const u32 *perm; const u32 *gstart; REC rec;
     const u32 *gmin; const u32 *gmax; const u8 *gfull;
     u8 *gflag;
     GRL_DEV void operator()(u64 g) const {
         u32 t0 = gstart[g], size = gstart[g + 1] - t0;
         if (size <= kGroupChunk) return;                            // decided by GroupAccumSmallFn
-        u64 q = perm[t0];
-        u32 k = dict_phr[q];
-        bool pfinal = (q + 1 == ph_off[k + 1]);
-        bool valid = !pfinal || ph_lastT[k];                        // exact_par_phase.cpp:162
+        const u32 first = rec(t0, perm[t0]).left;                   // (the flags of the group's first member, as the small fold reads them)
+        bool pfinal = (first & kRecFinal) != 0;
+        bool valid = !pfinal || (first & kRecLastT);                // exact_par_phase.cpp:162
         bool ranked = valid && (gmin[g] != gmax[g] || gfull[g]);    // :187
         gflag[g] = (valid ? GF_VALID : 0) | (ranked ? GF_RANKED : 0) | (size > 1 ? GF_MULTI : 0);
     }
@@ -1447,6 +1452,60 @@ struct PosOwnerFn {        // own[i] = that rank, for record i
         for (int r = 1; r < N; r++) if (q >= sbase[r]) d = (u32)r;      // the LAST rank whose part starts at or below q (empty parts in front of it share the start)
         own[i] = d;
     }
+};
+struct ExtCompactFn {      // ExtKeyFn without the key: the unresolved slots compacted, and the request for each one's next K symbols (position << 32 | item)
+    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag;
+    u32 *uslot; u32 *uq; u8 *uhead; u64 *req;
+    GRL_DEV void operator()(u64 i) const {
+        if (uflag[i]) {
+            const u64 t = act ? (u64)act[i] : i;
+            const u32 q = perm[t], o = uex[i];
+            uslot[o] = (u32)t; uq[o] = q; uhead[o] = hflag[t]; req[o] = ((u64)q << 32) | o;
+        }
+    }
+};
+struct ExtKeyOwnerFn {     // on the owner: symbols [x, x + K) of the suffix at MY position (req >> 32) - s0, x = that + Lres (ExtKeyFn's key, no run field)
+    const u64 *req; const u32 *dict_sym; const u64 *pw; u64 S, s0, Lres; int K, b; u64 *ans;
+    GRL_DEV void operator()(u64 i) const {
+        const u64 x = (req[i] >> 32) - s0 + Lres;
+        u64 w = 0;
+        if (x < S) {
+            w = pw[x >> 6] >> (x & 63);
+            if ((x & 63) + (u64)K > 64) w |= pw[(x >> 6) + 1] << (64 - (x & 63));
+        }
+        u32 valid = x >= S ? 0u : (u32)K;
+        const u32 starts = (u32)(w & ((1ull << K) - 1ull));
+        if (x < S && starts) valid = (u32)__builtin_ctz(starts);
+        if (x < S && x + valid > S) valid = (u32)(S - x);
+        const u64 sent = (1ull << b) - 1;
+        u64 key = 0;
+        for (int j = 0; j < K; j++) key = (key << b) | (((u32)j < valid) ? (u64)dict_sym[x + (u64)j] : sent);
+        ans[i] = key;
+    }
+};
+struct ExtAnswerFn {       // ukey[item] = the owner's answer
+    const u64 *req; const u64 *ans; u64 *ukey;
+    GRL_DEV void operator()(u64 i) const { ukey[(u32)req[i]] = ans[i]; }
+};
+struct RecRequestFn {      // (position << 32 | slot) of every sorted suffix of my key range
+    const u32 *perm; u64 *req;
+    GRL_DEV void operator()(u64 t) const { req[t] = ((u64)perm[t] << 32) | t; }
+};
+struct RecOwnerFn {        // on the owner: what the group fold wants to know about the suffix at my position (req >> 32) - s0
+    const u64 *req; RecCompute rc; u64 s0; SufRecT<8> *ans;
+    GRL_DEV void operator()(u64 i) const {
+        const u32 q = (u32)((req[i] >> 32) - s0);
+        const u32 k = rc.dict_phr[q];
+        SufRecT<8> r;
+        r.freq = (u64)rc.ph_freq[k];
+        r.left = (((u64)q == (u64)rc.ph_off[k]) ? rc.bwt_code : rc.dict_sym[q - 1]) | (((u64)q + 1 == (u64)rc.ph_off[k + 1]) ? kRecFinal : 0u) | (rc.ph_lastT[k] ? kRecLastT : 0u);
+        r.k = k + rc.phr_base;
+        ans[i] = r;
+    }
+};
+struct RecAnswerFn {       // recs[slot] = the owner's answer
+    const u64 *req; const SufRecT<8> *ans; SufRecT<8> *recs;
+    GRL_DEV void operator()(u64 i) const { recs[(u32)req[i]] = ans[i]; }
 };
 struct WalkRequestFn {     // (position of the representative << 32 | my metasymbol) for every metasymbol of my key range
     const u32 *repq; u64 *req;
@@ -2206,9 +2265,9 @@ struct ListValFn {        // value of the i-th phrase of the lists I merged: thr
 // equal keys, so a group never spans two ranks and rank order = sorted order).  Positional ranks are
 // global slots (base of the rank + local slot); after every pass the ranks of the (re)sorted suffixes
 // are exchanged as (position, rank) pairs.
-struct ApplyPairsFn {     // value[pair >> 32] = low 32 bits
-    const u64 *pairs; u32 *value;
-    GRL_DEV void operator()(u64 i) const { u64 p = pairs[i]; value[p >> 32] = (u32)p; }
+struct ApplyPairsFn {     // value[(pair >> 32) - base] = low 32 bits
+    const u64 *pairs; u32 *value; u64 base = 0;
+    GRL_DEV void operator()(u64 i) const { u64 p = pairs[i]; value[(p >> 32) - base] = (u32)p; }
 };
 struct OwnPhraseIn {      // 1 if the whole-phrase suffix of phrase k sorted into my slots
     const u32 *pslot;
@@ -3276,6 +3335,48 @@ class Engine {
         }
     };
 
+    // ---- collection-level mode: records addressed to the OWNER of a dictionary position -------------------------------------
+    // rec[i] = position << 32 | payload.  Sorted (stable) by the rank whose part of the merged dictionary holds the position
+    // (dsb = sbase[0..N] on the device); cnt[d] = records for rank d.
+    void bucket_by_owner(const Comm &C, const u64 *dsb, DBuf<u64> &rec, u64 n, std::vector<u64> &cnt, const char *name) {
+        const int N = C.size;
+        int obits = (int)bitlen64((u64)N - 1);
+        if (obits < 1) obits = 1;
+        DBuf<u32> own(n), own2(n);
+        DBuf<u64> rec2(n), bound(2 * ((u64)N + 1));
+        prim::for_each(n, PosOwnerFn{rec.p, dsb, N, own.p}, name);
+        const int res = prim::sort_pairs<u32, u64>(own.p, rec.p, own2.p, rec2.p, n, 0, obits, name);
+        prim::for_each((u64)N + 1, KeyBoundFn{res ? own2.p : own.p, n, nullptr, bound.p}, name);
+        std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
+        cnt.assign(N, 0);
+        for (int d = 0; d < N; d++) cnt[d] = bh[2 * (d + 1)] - bh[2 * d];
+        if (res) rec = std::move(rec2);
+    }
+    // Ask the owners: the requests req[0..n) travel to the owners of their positions, `answer(requests, count, out)` fills one A
+    // per request there, the answers come back.  Afterwards req[] is in owner order and back[i] answers req[i].  A failure only
+    // this rank can have (memory, an internal check) is agreed on at the counter exchanges: every rank raises.
+    template <class A, class F>
+    void owner_round_trip(const Comm &C, const u64 *dsb, DBuf<u64> &req, u64 n, DBuf<A> &back, F answer, const char *name, const char *xname) {
+        const int N = C.size, me = C.rank;
+        std::vector<u64> scnt(N, 0), rcnt(N, 0);
+        try { bucket_by_owner(C, dsb, req, n, scnt, name); }
+        catch (const prim::Error &e) { C.fail(e); std::fill(scnt.begin(), scnt.end(), 0); }
+        std::vector<u64> mat = C.allgather_u64(scnt);            // (raises on every rank if one of them failed above)
+        u64 nr = 0, maxb = 0;
+        for (int g = 0; g < N; g++) {
+            rcnt[g] = mat[(u64)g * N + me]; nr += rcnt[g];
+            for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]);
+        }
+        DBuf<u64> mine;
+        DBuf<A> ans;
+        try { mine.alloc(nr); ans.alloc(nr); back.alloc(n); } catch (const prim::Error &e) { C.fail(e); }
+        C.allgather_u64({});                                     // (the bulk exchanges below have no way back)
+        C.named(xname).alltoall(req.p, scnt, mine.p, rcnt, 8, maxb);
+        try { answer(mine.p, nr, ans.p); } catch (const prim::Error &e) { C.fail(e); }
+        C.allgather_u64({});
+        C.named(xname).alltoall(ans.p, rcnt, back.p, scnt, sizeof(A), maxb);
+    }
+
     // a5-a8 on D distinct phrases given as (position in t, length, frequency, ends-with-terminator);
     // fills L (grammar, has_hocc, pre-BWT, M) and phrase_val[k] = rank<<2 | (freq>1)<<1 | lastT.
     // With a communicator (collection-level mode: t, ph_* are the MERGED dictionary, identical on every rank) the suffix
@@ -3289,16 +3390,28 @@ class Engine {
                     const u32 *fused_ph_slot = nullptr, u32 *fused_slot_val = nullptr,        // (both set: the values go straight to the slots)
                     const prim::U128 *pkeys = nullptr, u64 pDs = 0, int pkb = 0,              // (phrases [0, pDs) given by their records)
                     const std::vector<u64> *dbase = nullptr,          // (collection-level mode: rank g merged the phrases [dbase[g], dbase[g + 1])
-                    const std::vector<u64> *sbase = nullptr) {        //  = the dictionary positions [sbase[g], sbase[g + 1]))
+                    const std::vector<u64> *sbase = nullptr,          //  = the dictionary positions [sbase[g], sbase[g + 1]))
+                    bool sharded_dict = false) {                      // (t, ph_* describe MY part of the dictionary only: see below)
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
-        DBuf<u32> dict_sym(S), dict_phr(S);
+        // DICTIONARY SHARDED BY OWNER (collection-level mode, round 5): every rank holds the phrases it merged and nothing of the
+        // others' -- t, ph_pos, ph_freq, ph_off, ph_lastT are LOCAL arrays of Dl phrases / Sl symbols, a dictionary position
+        // travels as the global number s0 + local offset, a phrase as d0 + local number.  What a rank needs to know about a position
+        // it does not own it ASKS of the owner (owner_round_trip): the next K symbols of an unresolved suffix in every refinement
+        // round, and what the group fold reads per member (frequency, left symbol, flags, phrase).  No replicated dictionary, no
+        // all-gather of the merged phrases, no O(S) or O(D) pass that every rank repeats.
+        const bool sharded = C && sharded_dict && dbase && sbase;
+        const u64 d0 = sharded ? (*dbase)[C->rank] : 0, s0 = sharded ? (*sbase)[C->rank] : 0;
+        const u64 Dl = sharded ? (*dbase)[C->rank + 1] - d0 : D, Sl = sharded ? (*sbase)[C->rank + 1] - s0 : S;
+        DBuf<u64> dsb;                           // sbase[] on the device (owner of a position)
+        if (C && sbase) { dsb.alloc((u64)C->size + 1); prim::h2d(dsb.p, sbase->data(), ((u64)C->size + 1) * 8); }
+        DBuf<u32> dict_sym(Sl), dict_phr(Sl);
         RankBits pbits;                          // phrase starts over the dictionary positions (dictionary build, suffix refinement)
         {
             StageTimer st(&tm.dict_sort, "dict_sort");
-            build_rankbits32(pbits, ph_off, D, S + 1, "dict_build");
+            build_rankbits32(pbits, ph_off, Dl, Sl + 1, "dict_build");
             // (4 positions per lane: 16 per lane, four phrases walked one after the other, was latency-bound -- 42 ms at 10 GB)
-            prim::for_each((S + 3) / 4, DictBuildFn<cell_t, FIRST, 4>{t, ops, ph_off, D, S, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p,
-                                                                      pkeys, pDs, pkb}, "dict_build");
+            prim::for_each((Sl + 3) / 4, DictBuildFn<cell_t, FIRST, 4>{t, ops, ph_off, Dl, Sl, ph_pos, dict_sym.p, dict_phr.p, pbits.words.p, pbits.base.p,
+                                                                       pkeys, pDs, pkb}, "dict_build");
         }
         // ---- a6: sort all phrase suffixes (radix on the first K symbols + refinement by symbol extension) ----------
         u64 Sg = S;                              // my slots of the sorted order (all of them without a communicator)
@@ -3525,7 +3638,151 @@ class Engine {
             prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
             L.info.sort_iters = iters;
         };
+        // The same with the dictionary sharded by owner.  Every rank runs the same sequence of collectives (the refinement goes on
+        // until NO rank has an unresolved suffix left); a failure only this rank can have is recorded and raised by every rank at
+        // the next counter exchange, and the rank-local sections in between are skipped once one is pending.
+        auto sort_sharded = [&] {
+            StageTimer st(&tm.dict_sort, "dict_sort");
+            const int N = C->size, me = C->rank;
+            auto local = [&](auto &&fn) { if (!C->pending) { try { fn(); } catch (const prim::Error &e) { C->fail(e); } } };
+            int b = (int)bitlen64(sigma);
+            if (b < 1) b = 1;
+            int K = 64 / b;
+            if (K < 1) K = 1;
+            if (K > 16) K = 16;
+            static const int kmax = getenv("GRLBWT_SORT_KMAX") ? atoi(getenv("GRLBWT_SORT_KMAX")) : 16;
+            if (kmax >= 1 && K > kmax) K = kmax;
+            if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
+            const int kbits = K * b;
+            const u64 sent = (1ull << b) - 1ull;
+            static const u32 cap = getenv("GRLBWT_SEG_CAP") ? (u32)atoi(getenv("GRLBWT_SEG_CAP")) : kSegCap;
+            const SufKeep keep{dict_phr.p, ph_off, ph_lastT, false};
+            // splitters from a sample every rank takes of its own part
+            u64 nsl = 0;
+            DBuf<u64> samp;
+            local([&] {
+                // (GRLBWT_TEST_FAIL_RANK_SORT=<rank>: the tests make one rank fail here)
+                if (test_fail_rank("GRLBWT_TEST_FAIL_RANK_SORT", me)) throw prim::Error(-71, "suffix refinement does not terminate (injected by the test)");
+                nsl = Sl < 64 ? Sl : std::max<u64>(64, 8192 / (u64)N);
+                if (nsl > Sl) nsl = Sl;
+                samp.alloc(nsl);
+                if (nsl) prim::for_each(nsl, SampleKey0Fn{dict_sym.p, dict_phr.p, ph_off, K, b, Sl / nsl, samp.p, RunKeys()}, "dist.sample_keys");
+            });
+            if (C->pending) nsl = 0;
+            std::vector<u64> sbb;
+            DBuf<u64> alls = C->named("sort.splitter_sample").template allgather_v<u64>(samp.p, nsl, sbb);
+            std::vector<u64> hs = alls.to_host(sbb[N]), spl(N, 0);
+            std::sort(hs.begin(), hs.end());
+            if (!hs.empty()) for (int d = 1; d < N; d++) spl[d] = hs[(u64)d * hs.size() / N];
+            std::vector<u64> scnt(N, 0), rcnt(N, 0);
+            DBuf<u64> sk, ka;
+            DBuf<u32> sp;
+            local([&] {
+                DBuf<u64> dspl(N);
+                prim::h2d(dspl.p, spl.data(), (u64)N * 8);
+                DBuf<u32> kex(Sl + 1);
+                const u64 nk = prim::exclusive_scan<u32>(Sl, KeepRangeIn{keep, 0}, kex.p, false, "suffix_keep");
+                DBuf<u64> lk(nk), bound(2 * ((u64)N + 1));
+                DBuf<u32> lp(nk), own(nk), own2(nk), idx(nk), idx2(nk);
+                prim::for_each(Sl, KeyRangeFn{keep, kex.p, 0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p, RunKeys(), (u32)s0}, "suffix_keys0");
+                int obits = (int)bitlen64((u64)N - 1);
+                if (obits < 1) obits = 1;
+                const int res = prim::sort_pairs<u32, u32>(own.p, idx.p, own2.p, idx2.p, nk, 0, obits, "dist.key_owner_sort");
+                sk.alloc(nk); sp.alloc(nk);
+                prim::for_each(nk, GatherKeyPosFn{res ? idx2.p : idx.p, lk.p, lp.p, sk.p, sp.p}, "dist.key_owner_sort");
+                prim::for_each((u64)N + 1, KeyBoundFn{res ? own2.p : own.p, nk, nullptr, bound.p}, "dist.owner_bounds");
+                std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
+                for (int d = 0; d < N; d++) scnt[d] = bh[2 * (d + 1)] - bh[2 * d];
+            });
+            if (C->pending) std::fill(scnt.begin(), scnt.end(), 0);
+            std::vector<u64> mat = C->allgather_u64(scnt);           // (raises on every rank if one of them failed above)
+            u64 maxb = 0;
+            Sg = 0;
+            for (int g = 0; g < N; g++) {
+                rcnt[g] = mat[(u64)g * N + me];
+                Sg += rcnt[g];
+                for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]);
+            }
+            local([&] { ka.alloc(Sg); perm.alloc(Sg); });
+            C->allgather_u64({});                                // (the bulk exchanges below have no way back)
+            C->named("sort.sample_keys").alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
+            C->named("sort.sample_pos").alltoall(sp.p, scnt, perm.p, rcnt, 4, maxb);
+            sk.release(); sp.release();
+            DBuf<u8> hflag, uflag;
+            DBuf<u32> ex;
+            local([&] {
+                gid.alloc(Sg); gstart.alloc(Sg + 1); hflag.alloc(Sg); uflag.alloc(Sg); ex.alloc(Sg + 1);
+                DBuf<u64> kb(Sg);
+                DBuf<u32> vb(Sg);
+                const u64 *ks = ka.p;
+                if (prim::sort_pairs<u64, u32>(ka.p, perm.p, kb.p, vb.p, Sg, 0, kbits, "suffix_sort0")) { std::swap(perm, vb); ks = kb.p; }
+                prim::for_each(Sg, HeadFlagFn{ks, hflag.p}, "suffix_heads");
+                prim::for_each(Sg, FirstUnresolvedFn{ks, hflag.p, Sg, sent, uflag.p}, "suffix_unresolved");
+            });
+            ka.release();
+            u64 Lres = (u64)K, iters = 1, A = Sg;
+            DBuf<u32> act;
+            bool refined = false;
+            for (;;) {
+                u64 U = 0;
+                DBuf<u32> uex;
+                local([&] { uex.alloc(A + 1); U = A ? prim::exclusive_scan<u32>(A, ByteIn{uflag.p}, uex.p, false, "suffix_unresolved_scan") : 0; });
+                if (C->pending) U = 0;
+                std::vector<u64> us = C->allgather_u64({U});     // (every rank goes on while ANY rank has unresolved suffixes: the owners answer)
+                u64 Uany = 0;
+                for (u64 v : us) Uany = std::max(Uany, v);
+                if (Uany == 0) break;
+                if (Lres > (u64)maxlen + (u64)K) throw prim::Error(-71, "suffix refinement does not terminate");      // (the same on every rank)
+                DBuf<u32> uslot, uq, hex;
+                DBuf<u64> ukey, req, back;
+                DBuf<u8> uhead, unext;
+                local([&] {
+                    uslot.alloc(U); uq.alloc(U); hex.alloc(U + 1); ukey.alloc(U); req.alloc(U); uhead.alloc(U); unext.alloc(U);
+                    prim::for_each(A, ExtCompactFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, uslot.p, uq.p, uhead.p, req.p}, "suffix_keys");
+                });
+                if (C->pending) U = 0;
+                owner_round_trip<u64>(*C, dsb.p, req, U, back, [&](const u64 *rq, u64 nrq, u64 *out) {
+                    prim::for_each(nrq, ExtKeyOwnerFn{rq, dict_sym.p, pbits.words.p, Sl, s0, Lres, K, b, out}, "suffix_keys");
+                }, "dist.ext_owner_sort", "sort.ext_keys");
+                local([&] {
+                    if (U == 0) { act = std::move(uslot); uflag = std::move(unext); A = 0; refined = true; return; }      // (nothing of mine left: I only answer)
+                    prim::for_each(U, ExtAnswerFn{req.p, back.p, ukey.p}, "suffix_keys");
+                    const u64 nseg = prim::exclusive_scan<u32>(U, ByteIn{uhead.p}, hex.p, false, "suffix_heads");
+                    DBuf<u32> seg_start(nseg + 1), bex(U + 1);
+                    prim::for_each(U, SegStartFn{uhead.p, hex.p, U, seg_start.p}, "suffix_gstart");
+                    prim::for_each(U, SegSortSmallFn{uhead.p, hex.p, seg_start.p, uslot.p, uq.p, ukey.p, sent, cap, perm.p, hflag.p, unext.p}, "suffix_sort.small");
+                    const u64 NB = prim::exclusive_scan<u32>(U, SegBigIn{uhead.p, hex.p, seg_start.p, cap}, bex.p, false, "suffix_sort.big_scan");
+                    if (NB) {                        // groups above kSegCap: by key, then (stable) by group
+                        DBuf<u32> bitem(NB), bidx(NB), bidx2(NB), key2(NB), key2b(NB);
+                        DBuf<u64> bkey(NB), bkey2(NB);
+                        prim::for_each(U, SegBigGatherFn{uhead.p, hex.p, seg_start.p, bex.p, ukey.p, cap, bitem.p, bkey.p, bidx.p}, "suffix_sort.big_gather");
+                        const u32 *i1 = prim::sort_pairs<u64, u32>(bkey.p, bidx.p, bkey2.p, bidx2.p, NB, 0, kbits, "suffix_sort") ? bidx2.p : bidx.p;
+                        u32 *i1o = (i1 == bidx.p) ? bidx2.p : bidx.p;
+                        prim::for_each(NB, SegBigSegKeyFn{i1, bitem.p, uhead.p, hex.p, key2.p}, "suffix_sort.big_groups");
+                        int sbits = (int)bitlen64(nseg);
+                        if (sbits < 1) sbits = 1;
+                        const int res = prim::sort_pairs<u32, u32>(key2.p, (u32 *)i1, key2b.p, i1o, NB, 0, sbits, "suffix_sort");
+                        prim::for_each(NB, SegBigWriteFn{res ? key2b.p : key2.p, res ? i1o : i1, bitem.p, ukey.p, uq.p, uslot.p, NB, sent,
+                                                         perm.p, hflag.p, unext.p}, "suffix_refine");
+                    }
+                    act = std::move(uslot);
+                    uflag = std::move(unext);
+                    A = U;
+                    refined = true;
+                });
+                Lres += (u64)K;
+                iters++;
+            }
+            pbits.base.release();
+            local([&] {
+                G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
+                prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
+                prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
+            });
+            L.info.sort_iters = iters;
+        };
         if (!C) sort_local();
+        else if (sharded) sort_sharded();
         else { try { sort_local(); } catch (const prim::Error &e) { C->fail(e); } }
 
         // ---- a7: equal-suffix groups -> pre-BWT, ranks -----------------------
@@ -3540,6 +3797,19 @@ class Engine {
         {
             StageTimer st(&tm.dict_groups, "dict_groups");
             u64 Ml = 0, P0l = 0;
+            // (dictionary sharded by owner: what the fold reads per member comes from the owners of the members' positions, by slot)
+            DBuf<SufRecT<8>> recs;
+            if (sharded) {
+                DBuf<u64> rq;
+                DBuf<SufRecT<8>> back;
+                u64 nrq = 0;
+                if (!C->pending) { try { rq.alloc(Sg); prim::for_each(Sg, RecRequestFn{perm.p, rq.p}, "suffix_records"); nrq = Sg; } catch (const prim::Error &e) { C->fail(e); nrq = 0; } }
+                const RecCompute rcl{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, sigma + 1, (u32)d0};
+                owner_round_trip<SufRecT<8>>(*C, dsb.p, rq, nrq, back, [&](const u64 *r, u64 nr, SufRecT<8> *out) {
+                    prim::for_each(nr, RecOwnerFn{r, rcl, s0, out}, "suffix_records");
+                }, "dist.rec_owner_sort", "group.records");
+                if (!C->pending) { try { recs.alloc(Sg); prim::for_each(nrq, RecAnswerFn{rq.p, back.p, recs.p}, "suffix_records"); } catch (const prim::Error &e) { C->fail(e); } }
+            }
             auto groups_local = [&] {
             grank.alloc(G + 1); pidx.alloc(G + 1); gmin.alloc(G); gmax.alloc(G); gacc.alloc(G); gfull.alloc(G); gflag.alloc(G);
             if (fused_vals) gphr.alloc(G); else pslot.alloc(D);
@@ -3549,7 +3819,10 @@ class Engine {
                 const bool fly = C && C->size >= fly_min;
                 DBuf<SufRec> rec;
                 DBuf<u32> coff(G + 1);
-                if (!fly) {
+                if (sharded) {
+                    prim::for_each(G, GroupAccumSmallFn<RecSlot>{perm.p, gstart.p, RecSlot{recs.p}, nullptr, bwt_code,
+                                                                 gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
+                } else if (!fly) {
                     rec.alloc(S);
                     prim::for_each(S, SuffixRecFn{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code, rec.p}, "suffix_records");
                     prim::for_each(G, GroupAccumSmallFn<RecArray>{perm.p, gstart.p, RecArray{rec.p}, dict_phr.p, bwt_code,
@@ -3560,13 +3833,18 @@ class Engine {
                                                                     gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
                 }
                 const u64 NC = prim::exclusive_scan<u32>(G, GroupChunksIn{gstart.p}, coff.p, true, "group_accum_large");
+                if (sharded) {
+                    prim::for_each(NC, GroupAccumLargeFn<RecSlot>{perm.p, coff.p, G, gstart.p, RecSlot{recs.p}, nullptr, bwt_code,
+                                                                  gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
+                    prim::for_each(G, GroupDecideFn<RecSlot>{perm.p, gstart.p, RecSlot{recs.p}, gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
+                } else
                 if (!fly) prim::for_each(NC, GroupAccumLargeFn<RecArray>{perm.p, coff.p, G, gstart.p, RecArray{rec.p}, dict_phr.p, bwt_code,
                                                                          gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
                 else prim::for_each(NC, GroupAccumLargeFn<RecCompute>{perm.p, coff.p, G, gstart.p, RecCompute{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code},
                                                                       dict_phr.p, bwt_code, gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
             }
-            prim::for_each(G, GroupDecideFn{perm.p, gstart.p, dict_phr.p, ph_off, ph_lastT, gmin.p, gmax.p, gfull.p,
-                                            gflag.p}, "group_decide");
+            if (!sharded) prim::for_each(G, GroupDecideFn<RecCompute>{perm.p, gstart.p, RecCompute{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, bwt_code},
+                                                                       gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
             {   // ranks of the ranked groups and pre-BWT index of the valid ones: one scan of pairs (one host synchronisation)
                 const prim::Pair<u32, u32> tot = prim::exclusive_scan_emit<prim::Pair<u32, u32>>(G, RankedValidIn{gflag.p}, SplitPairEmitFn{grank.p, pidx.p}, "group_ranks");
                 Ml = tot.a; P0l = tot.b;
@@ -3626,7 +3904,7 @@ class Engine {
                 DBuf<u32> ginfo(G);
                 prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, (u32)Moff, ginfo.p}, "grammar_ginfo");
                 static const bool replicated_grammar = getenv("GRLBWT_DIST_REPLICATED_GRAMMAR") != nullptr;
-                if (C && sbase && !replicated_grammar) {
+                if (C && sbase && (!replicated_grammar || sharded)) {      // (a dictionary sharded by owner has no other form)
                     // Sharded by the owner of the dictionary position (round 5): I hold dm[] of MY part of the dictionary only.  The marks
                     // of my groups go to the owners of their positions, the walks of my metasymbols are done by the owners of their
                     // representatives and the answers come back.  (Rounds 1-4: dm[] of the WHOLE dictionary on every rank, every rank's
@@ -3653,7 +3931,7 @@ class Engine {
                     try {
                         prim::h2d(dsb.p, sbase->data(), ((u64)N + 1) * 8);
                         dm.alloc(Sme);
-                        prim::for_each(Sme, DictMetaInitFn{dict_sym.p, dict_phr.p, ph_off, ph_lastT, dm.p, s0}, "grammar_init");
+                        prim::for_each(Sme, DictMetaInitFn{dict_sym.p, dict_phr.p, ph_off, ph_lastT, dm.p, sharded ? 0 : s0}, "grammar_init");      // (sharded dictionary: the arrays are my part already)
                         DBuf<u32> mex(Sg + 1);
                         const u64 nm = prim::exclusive_scan<u32>(Sg, MarkedIn{gid.p, ginfo.p}, mex.p, false, "dist.mark_scan");
                         mp.alloc(nm);
@@ -3726,11 +4004,11 @@ class Engine {
                 DBuf<u64> pinfo(D);
                 prim::for_each(D, PackPhraseInfoFn{fused_ph_slot, ph_freq, ph_lastT, pinfo.p}, "phrase_values");
                 prim::for_each(G, GroupPhraseValFn{gfull.p, gphr.p, grank.p, pinfo.p, fused_slot_val}, "slot_values");
-            } else phrase_val.alloc(D);
+            } else phrase_val.alloc(sharded ? Dl : D);
             if (fused_vals) {}
             else if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, grank.p, phrase_val.p}, "phrase_values");
             else {                               // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
-                DBuf<u32> phrase_rank(D), fex(D + 1);
+                DBuf<u32> phrase_rank(sharded ? Dl : D), fex(D + 1);
                 const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{pslot.p}, fex.p, true, "dist.full_scan");
                 DBuf<u64> fp(nf);
                 prim::for_each(D, OwnPhrasePairFn{pslot.p, fex.p, grank.p, (u32)Moff, fp.p}, "dist.full_pairs");
@@ -3751,9 +4029,14 @@ class Engine {
                     if (got != (*dbase)[me + 1] - (*dbase)[me]) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
                     DBuf<u64> mine(got);
                     C->named("phrase.rank_pairs").alltoall(fp.p, scnt, mine.p, rcnt, 8, maxb);
+                    if (sharded) {               // (my phrases' arrays are local: ranks, frequencies and values by local phrase number)
+                        prim::for_each(got, ApplyPairsFn{mine.p, phrase_rank.p, d0}, "dist.apply_phrase_ranks");
+                        prim::for_each(got, PhraseValDistFn{phrase_rank.p, ph_freq, ph_lastT, phrase_val.p}, "phrase_values");
+                    } else {
                     prim::for_each(got, ApplyPairsFn{mine.p, phrase_rank.p}, "dist.apply_phrase_ranks");
                     // (only my own range of phrase_val is filled and read)
                     prim::for_each(got, PhraseValDistFn{phrase_rank.p + (*dbase)[me], ph_freq + (*dbase)[me], ph_lastT + (*dbase)[me], phrase_val.p + (*dbase)[me]}, "phrase_values");
+                    }
                 } else {
                 std::vector<u64> bb;
                 DBuf<u64> allf = C->named("phrase.rank_pairs").template allgather_v<u64>(fp.p, nf, bb);
@@ -4294,6 +4577,7 @@ class Engine {
         std::vector<u64> dbase(N + 1, 0), sbase(N + 1, 0);
         u64 D, S;
         u32 maxlen;
+        bool sharded_dict = false;               // the merged dictionary stays sharded by owner through the dictionary stage
         {
             StageTimer st(&tm.hash, "hash");
             // (rank-local, sized by what THIS rank received: a failure here -- memory, table overflow -- is recorded and
@@ -4339,6 +4623,35 @@ class Engine {
                 prim::for_each((So64 + 15) / 16, ListCellsFn{o_pos.p, o_off.p, Do, So64, rcells.p, ocells.p, obits.words.p, obits.base.p}, "dist.owner_cells");
             }
             rcells.release(); rlen.release(); rfreq.release();
+            // DICTIONARY SHARDED BY OWNER (round 5; dict_stage): every rank keeps the phrases it merged and nobody gets anybody
+            // else's -- no all-gather of cells, lengths, frequencies and flags, no O(D) pass over the whole dictionary on every rank.
+            // Levels with very long phrases (run-aware suffix keys, >= GRLBWT_RUN_KEYS_MIN cells) take the gathered form below, as
+            // does GRLBWT_DIST_GATHERED_DICT=1 (rounds 1-4).
+            {
+                u64 ml = 0, fl = 0;
+                if (!C.pending) { try {
+                    ml = Do ? (u64)prim::reduce_max<u32>(Do, LenIn{o_len.p}, "dist.maxlen") : 0;
+                    fl = prim::reduce_sum<u64>(Do, IdxIn<idx_t>{o_freq.p}, "dist.freq_check");
+                } catch (const prim::Error &e) { C.fail(e); } }
+                std::vector<u64> mf = C.allgather_u64({ml, fl});
+                u64 mx = 0, fs = 0;
+                for (int g = 0; g < N; g++) { mx = std::max(mx, mf[2 * g]); fs += mf[2 * g + 1]; }
+                if (fs != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
+                static const u64 run_min = getenv("GRLBWT_RUN_KEYS_MIN") ? (u64)atoll(getenv("GRLBWT_RUN_KEYS_MIN")) : 512;
+                static const bool gathered = getenv("GRLBWT_DIST_GATHERED_DICT") != nullptr || getenv("GRLBWT_DIST_REPLICATED_DICT") != nullptr;
+                if (!gathered && mx < run_min) {
+                    sharded_dict = true;
+                    maxlen = (u32)mx;
+                    S = sbase[N];
+                    gcells = std::move(ocells);              // MY cells, phrases, frequencies, flags
+                    ph_off = std::move(o_off);
+                    ph_freq = std::move(o_freq);
+                    ph_lastT = std::move(o_lastT);
+                    ph_pos.alloc(Do);
+                    prim::for_each(Do, OffToPosFn{ph_off.p, ph_pos.p}, "dist.dict_offsets");
+                }
+            }
+            if (!sharded_dict) {
             gcells = C.named("dict.merged_cells").allgather_v<u32>(ocells.p, So64, sbase, true);
             ph_len = C.named("dict.merged_len").allgather_v<u32>(o_len.p, Do, dbase, true);
             if (sizeof(idx_t) == 8 && occ_total < 0xFFFFFFFFull) {      // (every merged frequency fits u32: 4 instead of 8 bytes per phrase on the wire)
@@ -4356,17 +4669,18 @@ class Engine {
             S = prim::exclusive_scan<u32>(D, LenIn{ph_len.p}, ph_off.p, true, "dist.dict_offsets");
             if (S != sbase[N]) throw prim::Error(-71, "dictionary exchange: cell count mismatch");
             prim::for_each(D, OffToPosFn{ph_off.p, ph_pos.p}, "dist.dict_offsets");
+            }
         }
-        // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar replicated ----
+        // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar passes and dictionary by owner ----
         DBuf<u32> gval;
         dict_stage<u32, false>(getenv("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
-                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase);
+                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase, sharded_dict);
         // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
         {
             StageTimer st(&tm.emit, "emit");
             DBuf<u32> rval(Dr), sval(P.D);
-            prim::for_each(Dr, ListValFn{list_slot.p, slot_min.p, rep_ex.p, gval.p, dbase[me], rval.p}, "dist.list_values");
+            prim::for_each(Dr, ListValFn{list_slot.p, slot_min.p, rep_ex.p, gval.p, sharded_dict ? 0 : dbase[me], rval.p}, "dist.list_values");      // (sharded dictionary: gval holds my phrases only)
             C.named("emit.phrase_values").alltoall(rval.p, rpc, sval.p, pc, 4, maxp);
             prim::for_each(P.D, ScatterU32Fn{order.p, sval.p, lval.p}, "dist.local_values");
         }

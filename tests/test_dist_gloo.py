@@ -135,6 +135,7 @@ def test_replicated_grammar_fallback_agrees(sim, oracle_mod, tmp_path, monkeypat
     """Since round 5 the grammar passes run where a dictionary position lives (marks and walk requests go to the owner of the
     position); the older form -- every rank applies every mark to a walk array of the whole dictionary -- stays behind a switch."""
     monkeypatch.setenv("GRLBWT_DIST_REPLICATED_GRAMMAR", "1")
+    monkeypatch.setenv("GRLBWT_DIST_GATHERED_DICT", "1")        # (a dictionary sharded by owner has no replicated walk array)
     _run(3, sim, "reads", tmp_path, 29597)
     data = open(tmp_path / "reads.input", "rb").read()
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
@@ -153,6 +154,7 @@ def test_group_fold_with_computed_suffix_records(sim, oracle_mod, tmp_path, monk
     """From 8 ranks on the group fold computes what it needs of a suffix where it needs it (no record array over the whole
     dictionary); forced here at 2 and 3 ranks, with the large-group path taken by every group."""
     monkeypatch.setenv("GRLBWT_DIST_REC_FLY_MIN", "2")
+    monkeypatch.setenv("GRLBWT_DIST_GATHERED_DICT", "1")        # (the gathered dictionary's fold; with the dictionary sharded by owner the records come from the owners)
     _run(2, sim, "reads", tmp_path, 29600)
     data = open(tmp_path / "reads.input", "rb").read()
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
@@ -160,6 +162,27 @@ def test_group_fold_with_computed_suffix_records(sim, oracle_mod, tmp_path, monk
     _run(3, sim, "tokens", tmp_path, 29601)
     data = open(tmp_path / "tokens.input", "rb").read()
     assert open(tmp_path / "tokens.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 2)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gathered_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch, world):
+    """Since round 5 the merged dictionary stays sharded by owner through the dictionary stage (symbols of positions a rank does not
+    own are asked of their owners, round by round of the refinement); rounds 1-4 all-gathered it to every rank.  That form stays
+    behind a switch -- it is also what levels with very long phrases take -- and gives the same image."""
+    monkeypatch.setenv("GRLBWT_DIST_GATHERED_DICT", "1")
+    for kind, w, port in (("reads", 1, 29602), ("tokens", 2, 29603)):
+        _run(world, sim, kind, tmp_path, port + 2 * world)
+        data = open(tmp_path / ("%s.input" % kind), "rb").read()
+        assert open(tmp_path / ("%s.rl_bwt" % kind), "rb").read() == oracle_mod.rl_bwt(data, w)
+
+
+def test_long_phrase_levels_take_the_gathered_dictionary(sim, oracle_mod, tmp_path, monkeypatch):
+    """Levels whose longest phrase reaches GRLBWT_RUN_KEYS_MIN cells (run-aware suffix keys) gather the dictionary; the others of
+    the same build keep it sharded: both forms in one build (limit lowered to 6 cells)."""
+    monkeypatch.setenv("GRLBWT_RUN_KEYS_MIN", "6")
+    _run(3, sim, "reads", tmp_path, 29612)
+    data = open(tmp_path / "reads.input", "rb").read()
+    assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
 
 
 def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
