@@ -1491,17 +1491,20 @@ struct RecRequestFn {      // (position << 32 | slot) of every sorted suffix of 
     const u32 *perm; u64 *req;
     GRL_DEV void operator()(u64 t) const { req[t] = ((u64)perm[t] << 32) | t; }
 };
-struct RecOwnerFn {        // on the owner: what the group fold wants to know about the suffix at my position (req >> 32) - s0
-    const u64 *req; RecCompute rc; u64 s0; SufRecT<8> *ans;
-    GRL_DEV void operator()(u64 i) const {
-        const u32 q = (u32)((req[i] >> 32) - s0);
+struct RecLocalFn {        // on the owner, streaming: what the group fold wants to know about the suffix at each of MY positions
+    RecCompute rc; SufRecT<8> *out;
+    GRL_DEV void operator()(u64 q) const {
         const u32 k = rc.dict_phr[q];
         SufRecT<8> r;
         r.freq = (u64)rc.ph_freq[k];
-        r.left = (((u64)q == (u64)rc.ph_off[k]) ? rc.bwt_code : rc.dict_sym[q - 1]) | (((u64)q + 1 == (u64)rc.ph_off[k + 1]) ? kRecFinal : 0u) | (rc.ph_lastT[k] ? kRecLastT : 0u);
+        r.left = ((q == (u64)rc.ph_off[k]) ? rc.bwt_code : rc.dict_sym[q - 1]) | ((q + 1 == (u64)rc.ph_off[k + 1]) ? kRecFinal : 0u) | (rc.ph_lastT[k] ? kRecLastT : 0u);
         r.k = k + rc.phr_base;
-        ans[i] = r;
+        out[q] = r;
     }
+};
+struct RecOwnerFn {        // ... and the answer to a request: ONE gather (computed per request it was five dependent ones: 83 ms per rank at N = 2 of the 10 GB collection)
+    const u64 *req; const SufRecT<8> *local; u64 s0; SufRecT<8> *ans;
+    GRL_DEV void operator()(u64 i) const { ans[i] = local[(req[i] >> 32) - s0]; }
 };
 struct RecAnswerFn {       // recs[slot] = the owner's answer
     const u64 *req; const SufRecT<8> *ans; SufRecT<8> *recs;
@@ -3806,7 +3809,9 @@ class Engine {
                 if (!C->pending) { try { rq.alloc(Sg); prim::for_each(Sg, RecRequestFn{perm.p, rq.p}, "suffix_records"); nrq = Sg; } catch (const prim::Error &e) { C->fail(e); nrq = 0; } }
                 const RecCompute rcl{dict_sym.p, dict_phr.p, ph_off, ph_freq, ph_lastT, sigma + 1, (u32)d0};
                 owner_round_trip<SufRecT<8>>(*C, dsb.p, rq, nrq, back, [&](const u64 *r, u64 nr, SufRecT<8> *out) {
-                    prim::for_each(nr, RecOwnerFn{r, rcl, s0, out}, "suffix_records");
+                    DBuf<SufRecT<8>> mine(Sl);
+                    prim::for_each(Sl, RecLocalFn{rcl, mine.p}, "suffix_records");
+                    prim::for_each(nr, RecOwnerFn{r, mine.p, s0, out}, "suffix_records.answers");
                 }, "dist.rec_owner_sort", "group.records");
                 if (!C->pending) { try { recs.alloc(Sg); prim::for_each(nrq, RecAnswerFn{rq.p, back.p, recs.p}, "suffix_records"); } catch (const prim::Error &e) { C->fail(e); } }
             }
@@ -4639,7 +4644,9 @@ class Engine {
                 if (fs != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
                 static const u64 run_min = getenv("GRLBWT_RUN_KEYS_MIN") ? (u64)atoll(getenv("GRLBWT_RUN_KEYS_MIN")) : 512;
                 static const bool gathered = getenv("GRLBWT_DIST_GATHERED_DICT") != nullptr || getenv("GRLBWT_DIST_REPLICATED_DICT") != nullptr;
-                if (!gathered && mx < run_min) {
+                // (GRLBWT_DIST_SHARDED_DICT_MIN=<ranks>: from how many ranks on -- see the figures in DESIGN.md section 6)
+                static const int sd_min = getenv("GRLBWT_DIST_SHARDED_DICT_MIN") ? atoi(getenv("GRLBWT_DIST_SHARDED_DICT_MIN")) : 4;
+                if (!gathered && mx < run_min && N >= sd_min) {
                     sharded_dict = true;
                     maxlen = (u32)mx;
                     S = sbase[N];

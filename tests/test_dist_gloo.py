@@ -185,6 +185,25 @@ def test_long_phrase_levels_take_the_gathered_dictionary(sim, oracle_mod, tmp_pa
     assert open(tmp_path / "reads.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 1)
 
 
+def test_sharded_dictionary_at_two_and_three_ranks(sim, oracle_mod, tmp_path, monkeypatch):
+    """By default the merged dictionary stays sharded by owner from 4 ranks on (below, the gathered form is faster: DESIGN.md
+    section 6); forced here at 2 and 3 ranks, with every group of the refinement on the large-group path in one of the runs, and
+    with a failure injected into one rank's part of the sharded sort (every rank raises the same error, nobody waits)."""
+    monkeypatch.setenv("GRLBWT_DIST_SHARDED_DICT_MIN", "1")
+    for world, kind, w, port in ((2, "reads", 1, 29620), (3, "tokens", 2, 29622), (3, "uniform", 1, 29624)):
+        _run(world, sim, kind, tmp_path, port)
+        data = open(tmp_path / ("%s.input" % kind), "rb").read()
+        assert open(tmp_path / ("%s.rl_bwt" % kind), "rb").read() == oracle_mod.rl_bwt(data, w)
+    monkeypatch.setenv("GRLBWT_SEG_CAP", "1")
+    _run(2, sim, "tokens", tmp_path, 29626)
+    data = open(tmp_path / "tokens.input", "rb").read()
+    assert open(tmp_path / "tokens.rl_bwt", "rb").read() == oracle_mod.rl_bwt(data, 2)
+    monkeypatch.delenv("GRLBWT_SEG_CAP")
+    monkeypatch.setenv("GRLBWT_TEST_FAIL_RANK_SORT", "1")
+    _run(3, sim, "injected", tmp_path, 29628)
+    assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -71"] * 3
+
+
 def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
     monkeypatch.setenv("GRLBWT_DIST_REPLICATED_DICT", "1")
     _run(2, sim, "uniform", tmp_path, 29591)
