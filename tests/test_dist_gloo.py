@@ -24,7 +24,12 @@ def _run(world, lib, case, out_dir, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(HERE, "dist_worker.py"), lib, "gloo", case, str(out_dir)]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    # (the dictionaries of these inputs have a few thousand symbols: the size from which the dictionary stays sharded by owner --
+    # 2^27 symbols by default -- is lowered to zero, so that from 4 ranks on, or wherever a test lowers that limit too, the
+    # sharded form is what runs)
+    env = dict(os.environ)
+    env.setdefault("GRLBWT_DIST_SHARDED_DICT_MIN_SYMS", "0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
 
 

@@ -431,7 +431,10 @@ def test_dist_kernels_multi_rank_on_one_gpu(hip, oracle_mod, tmp_path, world, ca
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(29650 + world),
            os.path.join(here, "dist_worker.py"), hip, "gloo-cuda", case, str(tmp_path)]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    # (the dictionary sharded by owner -- by default from 4 ranks and 2^27 dictionary symbols on -- is forced: its owner round
+    # trips, the owner-side kernels and the sharded sort run on the GPU here; the gathered form runs in the 1 GB test below)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here),
+                       env=dict(os.environ, GRLBWT_DIST_SHARDED_DICT_MIN="1", GRLBWT_DIST_SHARDED_DICT_MIN_SYMS="0"))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     data = open(tmp_path / (case + ".input"), "rb").read()
     w = 2 if case == "tokens" else 1
@@ -702,6 +705,6 @@ def test_sharded_equals_single_gpu_image(hip, tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", "29672",
            os.path.join(here, "dist_worker.py"), hip, "nccl", "illumina_dev:%d:%d" % (reads, genome), str(tmp_path)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here),
-                       env=dict(os.environ, GRLBWT_A2A_SELF_VIA_COMM="1"))
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+                       env=dict(os.environ, GRLBWT_A2A_SELF_VIA_COMM="1", GRLBWT_DIST_SHARDED_DICT_MIN="1", GRLBWT_DIST_SHARDED_DICT_MIN_SYMS="0"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]      # (this leg with the dictionary sharded by owner: its round trips through RCCL)
     assert open(tmp_path / "illumina_dev.rank0.md5").read() == want
