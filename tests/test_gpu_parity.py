@@ -474,9 +474,12 @@ def test_configs2_at_chromosome_scale_order_checked(hip):
     4 M cells of every string decoded by the per-run LF walk (grlbwt_invert_image_tails) and compared with the text** -- a BWT with
     the right symbol counts in a wrong order does not survive 400 M LF steps."""
     import torch
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    if free < 230 << 30:
-        pytest.skip("needs ~230 GB of free device memory")
+    with engine.Context(0, 0, hip) as probe:        # (the arena earlier tests of this process grew is reused by this build: it counts as free)
+        held = probe.memory_usage()["reserved_bytes"]
+    if free + held < 215 << 30:
+        pytest.skip("needs ~215 GB of device memory (free + what the engine's arena already holds): %d GB" % ((free + held) >> 30))
     L, k, tail = 248956422, 100, 4000000
     text = workloads.repetitive_copies_torch(k, L, device="cuda:0")
     torch.cuda.synchronize()
