@@ -895,6 +895,8 @@ struct DictBuildFn {      // one lane per PER consecutive dictionary positions: 
 // never valid (exact_par_phase.cpp:162: no pre-BWT entry, no rank) -- unless it is a whole one-cell phrase, whose value
 // is read from its group.  A quarter of all dictionary suffixes are of that kind (one per phrase): they are left out of
 // the sort, and so of the group stage, altogether.
+// (flags above the left symbol of a suffix record, see SufRecT below: the suffix is the last cell of its phrase / that phrase ends a string)
+static constexpr u32 kRecSym = 0x3FFFFFFFu, kRecFinal = 0x40000000u, kRecLastT = 0x80000000u;
 struct SufKeep {
     const u32 *dict_phr; const u32 *ph_off; const u8 *ph_lastT;
     bool all = false;     // levels with long phrases keep every suffix: the doubling rounds (DoubleKeyFn) want a slot for every position
@@ -983,6 +985,7 @@ struct KeepRangeIn {      // 1 for the kept suffixes (SufKeep) among the positio
 struct KeyRangeFn {       // (key, position, owner of the key's range) of those, compacted  (pos_base: the arrays describe MY part of the dictionary, positions travel as global ones)
     SufKeep keep; const u32 *ex; u64 q0; const u32 *dict_sym; int K, b; const u64 *spl; int N;
     u64 *lk; u32 *lp; u32 *own; u32 *idx; RunKeys rk; u32 pos_base = 0;
+    u64 *lrec = nullptr; const idx_t *ph_freq = nullptr; u32 bwt_code = 0;      // (dictionary sharded by owner: what the group fold reads about the suffix travels with it)
     GRL_DEV void operator()(u64 i) const {
         const u64 q = q0 + i;
         if (keep(q)) {
@@ -991,6 +994,11 @@ struct KeyRangeFn {       // (key, position, owner of the key's range) of those,
             u32 d = 0;
             for (int r = 1; r < N; r++) if (key >= spl[r]) d = (u32)r;      // the LAST rank whose range starts at or below the key
             lk[o] = key; lp[o] = (u32)q + pos_base; own[o] = d; idx[o] = o;
+            if (lrec) {
+                const u32 k = keep.dict_phr[q];
+                const u32 left = ((q == (u64)keep.ph_off[k]) ? bwt_code : dict_sym[q - 1]) | ((q + 1 == (u64)keep.ph_off[k + 1]) ? kRecFinal : 0u) | (keep.ph_lastT[k] ? kRecLastT : 0u);
+                lrec[o] = ((u64)ph_freq[k] << 32) | (u64)left;
+            }
         }
     }
 };
@@ -1220,7 +1228,6 @@ template <> struct alignas(16) SufRecT<8> { u64 freq; u32 left; u32 k; GRL_HD vo
 typedef SufRecT<sizeof(idx_t)> SufRec;      // one 8/16-byte gather per sorted suffix
 // left carries two flags above the symbol (symbols are < 2^30): the suffix is the last cell of its phrase, and that
 // phrase ends a string -- what the group decision needs from the group's first member.
-static constexpr u32 kRecSym = 0x3FFFFFFFu, kRecFinal = 0x40000000u, kRecLastT = 0x80000000u;
 // What the group fold reads per sorted suffix: from the array SuffixRecFn streamed out (RecArray), or computed where it is
 // needed (RecCompute: five gathers per member instead of one, no array over the whole dictionary -- the collection-level mode
 // from GRLBWT_DIST_REC_FLY_MIN ranks on (default 8), where a rank folds 1/N of the suffixes and the array would still be S
@@ -1228,6 +1235,10 @@ static constexpr u32 kRecSym = 0x3FFFFFFFu, kRecFinal = 0x40000000u, kRecLastT =
 struct RecArray {
     const SufRec *rec;
     GRL_DEV SufRec operator()(u32, u32 q) const { return rec[q]; }
+};
+struct RecWire {           // by arrival index: the 8-byte record that came with the suffix's (key, position) from the owner of the position (frequency << 32 | left symbol and flags)
+    const u64 *rec;
+    GRL_DEV SufRecT<8> operator()(u32, u32 a) const { const u64 x = rec[a]; SufRecT<8> r; r.freq = x >> 32; r.left = (u32)x; r.k = 0; return r; }
 };
 struct RecSlot {           // by sorted slot: what the owners of the positions answered (dictionary sharded by owner; the phrase number travels in the record in both index widths)
     const SufRecT<8> *rec;
@@ -1269,6 +1280,7 @@ struct GroupAccumSmallFn {
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag; u32 *pslot;
     u32 *gphr;            // non-null: the whole phrase of a group is recorded BY GROUP (sequential store) instead of pslot[phrase] = group
+    const u32 *pos_of = nullptr;      // non-null: ... as the dictionary POSITION of that member (by slot), not its phrase number (dictionary sharded by owner)
     GRL_DEV void operator()(u64 g) const {
         const u32 t0 = gstart[g], t1 = gstart[g + 1];
         const bool large = t1 - t0 > kGroupChunk;   // folded by GroupAccumLargeFn with atomics: start from the identities
@@ -1286,7 +1298,7 @@ struct GroupAccumSmallFn {
             acc += (idx_t)r.freq;
             if (left == bwt_code) {                 // a whole phrase: the group its metasymbol will be read from
                 fl = 1;
-                const u32 k = r.phr(dict_phr, q);
+                const u32 k = pos_of ? pos_of[j] : r.phr(dict_phr, q);
                 if (gphr) gphr[g] = k; else pslot[k] = (u32)g;
             }
         }
@@ -1308,6 +1320,7 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
     const u32 *perm; const u32 *coff; u64 G; const u32 *gstart; REC rec; const u32 *dict_phr;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u32 *pslot; u32 *gphr;
+    const u32 *pos_of = nullptr;
     GRL_DEV void operator()(u64 c) const {
         const u32 g = (u32)upper_bound<u32>(coff, G, (u32)c) - 1;     // the group with coff[g] <= c < coff[g + 1]
         const u32 t1 = gstart[g + 1], t = gstart[g] + ((u32)c - coff[g]) * kGroupChunk;
@@ -1321,7 +1334,7 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
             acc += (idx_t)r.freq;
             if (left == bwt_code) {
                 fl = 1;
-                const u32 k = r.phr(dict_phr, q);
+                const u32 k = pos_of ? pos_of[j] : r.phr(dict_phr, q);
                 if (gphr) gphr[g] = k; else pslot[k] = g;
             }
         }
@@ -1463,6 +1476,37 @@ struct ExtCompactFn {      // ExtKeyFn without the key: the unresolved slots com
             uslot[o] = (u32)t; uq[o] = q; uhead[o] = hflag[t]; req[o] = ((u64)q << 32) | o;
         }
     }
+};
+struct ExtCompactAiFn {    // the same when the sorted values are ARRIVAL INDICES (records travelled with the suffixes): the position for the request comes from pos_of[]
+    const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag; const u32 *pos_of;
+    u32 *uslot; u32 *uq; u8 *uhead; u64 *req;
+    GRL_DEV void operator()(u64 i) const {
+        if (uflag[i]) {
+            const u64 t = act ? (u64)act[i] : i;
+            const u32 a = perm[t], o = uex[i];
+            uslot[o] = (u32)t; uq[o] = a; uhead[o] = hflag[t]; req[o] = ((u64)pos_of[a] << 32) | o;
+        }
+    }
+};
+struct GatherU32Fn {       // out[t] = table[index[t]]
+    const u32 *index; const u32 *table; u32 *out;
+    GRL_DEV void operator()(u64 t) const { out[t] = table[index[t]]; }
+};
+struct GatherU64Fn {       // out[t] = table[index[t]]
+    const u32 *index; const u64 *table; u64 *out;
+    GRL_DEV void operator()(u64 t) const { out[t] = table[index[t]]; }
+};
+struct IotaU32Fn {
+    u32 *out;
+    GRL_DEV void operator()(u64 i) const { out[i] = (u32)i; }
+};
+struct GroupPosPairFn {    // (position of the group's whole-phrase member << 32 | metasymbol rank) of the groups that hold one, compacted
+    const u8 *gfull; const u32 *gpos; const u32 *grank; u32 m_off; const u32 *ex; u64 *pairs;
+    GRL_DEV void operator()(u64 g) const { if (gfull[g]) pairs[ex[g]] = ((u64)gpos[g] << 32) | (u64)(m_off + grank[g]); }
+};
+struct ApplyPosPairsFn {   // on the owner: rank of the phrase whose first cell sits at my position (pair >> 32) - s0
+    const u64 *pairs; const u32 *dict_phr; u64 s0; u32 *phrase_rank;
+    GRL_DEV void operator()(u64 i) const { const u64 p = pairs[i]; phrase_rank[dict_phr[(p >> 32) - s0]] = (u32)p; }
 };
 struct ExtKeyOwnerFn {     // on the owner: symbols [x, x + K) of the suffix at MY position (req >> 32) - s0, x = that + Lres (ExtKeyFn's key, no run field)
     const u64 *req; const u32 *dict_sym; const u64 *pw; u64 S, s0, Lres; int K, b; u64 *ans;
@@ -3394,7 +3438,8 @@ class Engine {
                     const prim::U128 *pkeys = nullptr, u64 pDs = 0, int pkb = 0,              // (phrases [0, pDs) given by their records)
                     const std::vector<u64> *dbase = nullptr,          // (collection-level mode: rank g merged the phrases [dbase[g], dbase[g + 1])
                     const std::vector<u64> *sbase = nullptr,          //  = the dictionary positions [sbase[g], sbase[g + 1]))
-                    bool sharded_dict = false) {                      // (t, ph_* describe MY part of the dictionary only: see below)
+                    bool sharded_dict = false,                        // (t, ph_* describe MY part of the dictionary only: see below)
+                    u64 maxfreq = ~0ull) {                            // (the largest phrase frequency of the round, where the caller knows it)
         L.info.D = D; L.info.S = S; L.info.max_phrase_len = maxlen;
         // DICTIONARY SHARDED BY OWNER (collection-level mode, round 5): every rank holds the phrases it merged and nothing of the
         // others' -- t, ph_pos, ph_freq, ph_off, ph_lastT are LOCAL arrays of Dl phrases / Sl symbols, a dictionary position
@@ -3405,6 +3450,14 @@ class Engine {
         const bool sharded = C && sharded_dict && dbase && sbase;
         const u64 d0 = sharded ? (*dbase)[C->rank] : 0, s0 = sharded ? (*sbase)[C->rank] : 0;
         const u64 Dl = sharded ? (*dbase)[C->rank + 1] - d0 : D, Sl = sharded ? (*sbase)[C->rank + 1] - s0 : S;
+        // With every frequency below 2^32 the 8 bytes the group fold reads about a suffix (frequency, left symbol, flags) travel WITH
+        // its (key, position) record in the sample-sort exchange: no round trip for them afterwards (24 bytes per suffix over the
+        // fabric and a gather pass on the owner -- 3.3 GB and ~14 ms per rank at N = 8 of the 10 GB collection).  The values a rank
+        // sorts are then ARRIVAL INDICES; pos_arr[] / rec_arr[] give the position and the record of an arrival.
+        static const bool rec_round_trip = getenv("GRLBWT_DIST_REC_ROUND_TRIP") != nullptr;
+        const bool carry = sharded && maxfreq < 0xFFFFFFFFull && !rec_round_trip;
+        DBuf<u32> pos_arr, perm_ai;              // (carry) position of every arrival; the sorted arrival indices once perm holds positions again
+        DBuf<u64> rec_arr;                       // (carry) record of every arrival
         DBuf<u64> dsb;                           // sbase[] on the device (owner of a position)
         if (C && sbase) { dsb.alloc((u64)C->size + 1); prim::h2d(dsb.p, sbase->data(), ((u64)C->size + 1) * 8); }
         DBuf<u32> dict_sym(Sl), dict_phr(Sl);
@@ -3678,7 +3731,7 @@ class Engine {
             std::sort(hs.begin(), hs.end());
             if (!hs.empty()) for (int d = 1; d < N; d++) spl[d] = hs[(u64)d * hs.size() / N];
             std::vector<u64> scnt(N, 0), rcnt(N, 0);
-            DBuf<u64> sk, ka;
+            DBuf<u64> sk, ka, sr;
             DBuf<u32> sp;
             local([&] {
                 DBuf<u64> dspl(N);
@@ -3687,12 +3740,15 @@ class Engine {
                 const u64 nk = prim::exclusive_scan<u32>(Sl, KeepRangeIn{keep, 0}, kex.p, false, "suffix_keep");
                 DBuf<u64> lk(nk), bound(2 * ((u64)N + 1));
                 DBuf<u32> lp(nk), own(nk), own2(nk), idx(nk), idx2(nk);
-                prim::for_each(Sl, KeyRangeFn{keep, kex.p, 0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p, RunKeys(), (u32)s0}, "suffix_keys0");
+                DBuf<u64> lr(carry ? nk : 0);
+                prim::for_each(Sl, KeyRangeFn{keep, kex.p, 0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p, RunKeys(), (u32)s0,
+                                              carry ? lr.p : nullptr, ph_freq, sigma + 1}, "suffix_keys0");
                 int obits = (int)bitlen64((u64)N - 1);
                 if (obits < 1) obits = 1;
                 const int res = prim::sort_pairs<u32, u32>(own.p, idx.p, own2.p, idx2.p, nk, 0, obits, "dist.key_owner_sort");
                 sk.alloc(nk); sp.alloc(nk);
                 prim::for_each(nk, GatherKeyPosFn{res ? idx2.p : idx.p, lk.p, lp.p, sk.p, sp.p}, "dist.key_owner_sort");
+                if (carry) { sr.alloc(nk); prim::for_each(nk, GatherU64Fn{res ? idx2.p : idx.p, lr.p, sr.p}, "dist.key_owner_sort"); }
                 prim::for_each((u64)N + 1, KeyBoundFn{res ? own2.p : own.p, nk, nullptr, bound.p}, "dist.owner_bounds");
                 std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
                 for (int d = 0; d < N; d++) scnt[d] = bh[2 * (d + 1)] - bh[2 * d];
@@ -3706,11 +3762,13 @@ class Engine {
                 Sg += rcnt[g];
                 for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]);
             }
-            local([&] { ka.alloc(Sg); perm.alloc(Sg); });
+            local([&] { ka.alloc(Sg); perm.alloc(Sg); if (carry) { pos_arr.alloc(Sg); rec_arr.alloc(Sg); } });
             C->allgather_u64({});                                // (the bulk exchanges below have no way back)
             C->named("sort.sample_keys").alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
-            C->named("sort.sample_pos").alltoall(sp.p, scnt, perm.p, rcnt, 4, maxb);
-            sk.release(); sp.release();
+            C->named("sort.sample_pos").alltoall(sp.p, scnt, carry ? pos_arr.p : perm.p, rcnt, 4, maxb);
+            if (carry) C->named("sort.sample_rec").alltoall(sr.p, scnt, rec_arr.p, rcnt, 8, maxb);
+            sk.release(); sp.release(); sr.release();
+            if (carry) local([&] { prim::for_each(Sg, IotaU32Fn{perm.p}, "suffix_keys0"); });      // the values of the sort: arrival indices
             DBuf<u8> hflag, uflag;
             DBuf<u32> ex;
             local([&] {
@@ -3741,7 +3799,8 @@ class Engine {
                 DBuf<u8> uhead, unext;
                 local([&] {
                     uslot.alloc(U); uq.alloc(U); hex.alloc(U + 1); ukey.alloc(U); req.alloc(U); uhead.alloc(U); unext.alloc(U);
-                    prim::for_each(A, ExtCompactFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, uslot.p, uq.p, uhead.p, req.p}, "suffix_keys");
+                    if (carry) prim::for_each(A, ExtCompactAiFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, pos_arr.p, uslot.p, uq.p, uhead.p, req.p}, "suffix_keys");
+                    else prim::for_each(A, ExtCompactFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, uslot.p, uq.p, uhead.p, req.p}, "suffix_keys");
                 });
                 if (C->pending) U = 0;
                 owner_round_trip<u64>(*C, dsb.p, req, U, back, [&](const u64 *rq, u64 nrq, u64 *out) {
@@ -3781,6 +3840,13 @@ class Engine {
                 G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
                 prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
                 prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
+                if (carry) {                     // from here on perm[] holds positions again; the arrival indices stay for the fold's records
+                    DBuf<u32> pp(Sg);
+                    prim::for_each(Sg, GatherU32Fn{perm.p, pos_arr.p, pp.p}, "suffix_gid");
+                    perm_ai = std::move(perm);
+                    perm = std::move(pp);
+                    pos_arr.release();
+                }
             });
             L.info.sort_iters = iters;
         };
@@ -3802,7 +3868,7 @@ class Engine {
             u64 Ml = 0, P0l = 0;
             // (dictionary sharded by owner: what the fold reads per member comes from the owners of the members' positions, by slot)
             DBuf<SufRecT<8>> recs;
-            if (sharded) {
+            if (sharded && !carry) {
                 DBuf<u64> rq;
                 DBuf<SufRecT<8>> back;
                 u64 nrq = 0;
@@ -3817,14 +3883,17 @@ class Engine {
             }
             auto groups_local = [&] {
             grank.alloc(G + 1); pidx.alloc(G + 1); gmin.alloc(G); gmax.alloc(G); gacc.alloc(G); gfull.alloc(G); gflag.alloc(G);
-            if (fused_vals) gphr.alloc(G); else pslot.alloc(D);
-            if (C) pslot.fill_ff();              // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
+            if (fused_vals || carry) gphr.alloc(G); else pslot.alloc(D);      // (carry: gphr[g] = dictionary position of the group's whole-phrase member)
+            if (C && !carry) pslot.fill_ff();    // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
             {
                 static const int fly_min = getenv("GRLBWT_DIST_REC_FLY_MIN") ? atoi(getenv("GRLBWT_DIST_REC_FLY_MIN")) : 8;
                 const bool fly = C && C->size >= fly_min;
                 DBuf<SufRec> rec;
                 DBuf<u32> coff(G + 1);
-                if (sharded) {
+                if (carry) {
+                    prim::for_each(G, GroupAccumSmallFn<RecWire>{perm_ai.p, gstart.p, RecWire{rec_arr.p}, nullptr, bwt_code,
+                                                                 gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, nullptr, gphr.p, perm.p}, "group_accum");
+                } else if (sharded) {
                     prim::for_each(G, GroupAccumSmallFn<RecSlot>{perm.p, gstart.p, RecSlot{recs.p}, nullptr, bwt_code,
                                                                  gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
                 } else if (!fly) {
@@ -3838,7 +3907,11 @@ class Engine {
                                                                     gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
                 }
                 const u64 NC = prim::exclusive_scan<u32>(G, GroupChunksIn{gstart.p}, coff.p, true, "group_accum_large");
-                if (sharded) {
+                if (carry) {
+                    prim::for_each(NC, GroupAccumLargeFn<RecWire>{perm_ai.p, coff.p, G, gstart.p, RecWire{rec_arr.p}, nullptr, bwt_code,
+                                                                  gmin.p, gmax.p, gacc.p, gfull.p, nullptr, gphr.p, perm.p}, "group_accum_large");
+                    prim::for_each(G, GroupDecideFn<RecWire>{perm_ai.p, gstart.p, RecWire{rec_arr.p}, gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
+                } else if (sharded) {
                     prim::for_each(NC, GroupAccumLargeFn<RecSlot>{perm.p, coff.p, G, gstart.p, RecSlot{recs.p}, nullptr, bwt_code,
                                                                   gmin.p, gmax.p, gacc.p, gfull.p, pslot.p, gphr.p}, "group_accum_large");
                     prim::for_each(G, GroupDecideFn<RecSlot>{perm.p, gstart.p, RecSlot{recs.p}, gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
@@ -4012,7 +4085,29 @@ class Engine {
             } else phrase_val.alloc(sharded ? Dl : D);
             if (fused_vals) {}
             else if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, grank.p, phrase_val.p}, "phrase_values");
-            else {                               // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
+            else if (carry) {
+                // the groups that hold a whole phrase know the POSITION of that member: (position, metasymbol) pairs go to the owner of the
+                // position, which knows the phrase that starts there -- no array over all D phrases on any rank
+                const int N = C->size, me = C->rank;
+                std::vector<u64> scnt(N, 0), rcnt(N, 0);
+                DBuf<u64> fp;
+                if (!C->pending) { try {
+                    DBuf<u32> gex(G + 1);
+                    const u64 nf = prim::exclusive_scan<u32>(G, ByteIn{gfull.p}, gex.p, false, "dist.full_scan");
+                    fp.alloc(nf);
+                    prim::for_each(G, GroupPosPairFn{gfull.p, gphr.p, grank.p, (u32)Moff, gex.p, fp.p}, "dist.full_pairs");
+                    bucket_by_owner(*C, dsb.p, fp, nf, scnt, "dist.full_pairs");
+                } catch (const prim::Error &e) { C->fail(e); std::fill(scnt.begin(), scnt.end(), 0); } }
+                std::vector<u64> mat = C->allgather_u64(scnt);
+                u64 got = 0, maxb = 0;
+                for (int g = 0; g < N; g++) { rcnt[g] = mat[(u64)g * N + me]; got += rcnt[g]; for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]); }
+                if (got != Dl) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+                DBuf<u64> mine(got);
+                DBuf<u32> phrase_rank(Dl);
+                C->named("phrase.rank_pairs").alltoall(fp.p, scnt, mine.p, rcnt, 8, maxb);
+                prim::for_each(got, ApplyPosPairsFn{mine.p, dict_phr.p, s0, phrase_rank.p}, "dist.apply_phrase_ranks");
+                prim::for_each(Dl, PhraseValDistFn{phrase_rank.p, ph_freq, ph_lastT, phrase_val.p}, "phrase_values");
+            } else {                             // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
                 DBuf<u32> phrase_rank(sharded ? Dl : D), fex(D + 1);
                 const u64 nf = prim::exclusive_scan<u32>(D, OwnPhraseIn{pslot.p}, fex.p, true, "dist.full_scan");
                 DBuf<u64> fp(nf);
@@ -4684,7 +4779,7 @@ class Engine {
         // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar passes and dictionary by owner ----
         DBuf<u32> gval;
         dict_stage<u32, false>(getenv("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
-                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase, sharded_dict);
+                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase, sharded_dict, occ_total);      // (no phrase occurs more often than there are phrase occurrences)
         // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
         {

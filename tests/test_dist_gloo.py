@@ -209,6 +209,17 @@ def test_sharded_dictionary_at_two_and_three_ranks(sim, oracle_mod, tmp_path, mo
     assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -71"] * 3
 
 
+def test_sharded_dictionary_records_by_round_trip(sim, oracle_mod, tmp_path, monkeypatch):
+    """With the dictionary sharded by owner, what the group fold reads about a suffix travels with its (key, position) record
+    while every frequency fits 32 bits; collections beyond that (and this switch) ask the owners in a round trip of their own."""
+    monkeypatch.setenv("GRLBWT_DIST_REC_ROUND_TRIP", "1")
+    monkeypatch.setenv("GRLBWT_DIST_SHARDED_DICT_MIN", "1")
+    for world, kind, w, port in ((2, "reads", 1, 29630), (4, "tokens", 2, 29632)):
+        _run(world, sim, kind, tmp_path, port)
+        data = open(tmp_path / ("%s.input" % kind), "rb").read()
+        assert open(tmp_path / ("%s.rl_bwt" % kind), "rb").read() == oracle_mod.rl_bwt(data, w)
+
+
 def test_replicated_dictionary_fallback_agrees(sim, oracle_mod, tmp_path, monkeypatch):
     monkeypatch.setenv("GRLBWT_DIST_REPLICATED_DICT", "1")
     _run(2, sim, "uniform", tmp_path, 29591)
