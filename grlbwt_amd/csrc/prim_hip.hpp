@@ -2882,7 +2882,8 @@ inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *na
     plan = SmPlan<IDX>();
     plan.G = G;
     if (G == 0) return;
-    plan.spt = mostly_plain ? 4 : 8;
+    static const int spt_env = getenv("GRLBWT_SM_SPT") ? atoi(getenv("GRLBWT_SM_SPT")) : 0;      // (experiments: 4 or 8 segments per thread at every level)
+    plan.spt = spt_env == 4 || spt_env == 8 ? spt_env : (mostly_plain ? 4 : 8);
     const u64 kSmTile = (u64)kBlock * plan.spt;
     plan.tiles = (G + kSmTile - 1) / kSmTile;
     const u64 T = plan.tiles;
