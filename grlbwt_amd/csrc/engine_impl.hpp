@@ -1280,7 +1280,7 @@ struct GroupAccumSmallFn {
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u8 *gflag; u32 *pslot;
     u32 *gphr;            // non-null: the whole phrase of a group is recorded BY GROUP (sequential store) instead of pslot[phrase] = group
-    const u32 *pos_of = nullptr;      // non-null: ... as the dictionary POSITION of that member (by slot), not its phrase number (dictionary sharded by owner)
+    bool slot_mode = false;           // ... as the SLOT of that member, not its phrase number (dictionary sharded by owner: the slot gives its position and owner)
     GRL_DEV void operator()(u64 g) const {
         const u32 t0 = gstart[g], t1 = gstart[g + 1];
         const bool large = t1 - t0 > kGroupChunk;   // folded by GroupAccumLargeFn with atomics: start from the identities
@@ -1298,7 +1298,7 @@ struct GroupAccumSmallFn {
             acc += (idx_t)r.freq;
             if (left == bwt_code) {                 // a whole phrase: the group its metasymbol will be read from
                 fl = 1;
-                const u32 k = pos_of ? pos_of[j] : r.phr(dict_phr, q);
+                const u32 k = slot_mode ? (u32)j : r.phr(dict_phr, q);
                 if (gphr) gphr[g] = k; else pslot[k] = (u32)g;
             }
         }
@@ -1320,7 +1320,7 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
     const u32 *perm; const u32 *coff; u64 G; const u32 *gstart; REC rec; const u32 *dict_phr;
     u32 bwt_code;
     u32 *gmin; u32 *gmax; idx_t *gacc; u8 *gfull; u32 *pslot; u32 *gphr;
-    const u32 *pos_of = nullptr;
+    bool slot_mode = false;
     GRL_DEV void operator()(u64 c) const {
         const u32 g = (u32)upper_bound<u32>(coff, G, (u32)c) - 1;     // the group with coff[g] <= c < coff[g + 1]
         const u32 t1 = gstart[g + 1], t = gstart[g] + ((u32)c - coff[g]) * kGroupChunk;
@@ -1334,7 +1334,7 @@ struct GroupAccumLargeFn {   // one lane per chunk of a large group (a lane per 
             acc += (idx_t)r.freq;
             if (left == bwt_code) {
                 fl = 1;
-                const u32 k = pos_of ? pos_of[j] : r.phr(dict_phr, q);
+                const u32 k = slot_mode ? (u32)j : r.phr(dict_phr, q);
                 if (gphr) gphr[g] = k; else pslot[k] = g;
             }
         }
@@ -1387,7 +1387,7 @@ struct GroupEmitFn {      // (m_off, p_off: metasymbols / pre-BWT entries of the
                 s = (f & GF_MULTI) ? hocc_code : bwt_code;
                 u32 u = grank[g];
                 has_hocc[u] = (f & GF_MULTI) ? 1 : 0;
-                repq[u] = perm[gstart[g]];
+                repq[u] = perm ? perm[gstart[g]] : gstart[g];      // (perm null: the representative's SLOT, for positions kept as (owner, offset))
                 u_to_p0[u] = p_off + j;
             }
             psym[j] = s;
@@ -1424,9 +1424,10 @@ struct MarkedIn {          // 1 for the slots MetaPosFn would write (members of 
 };
 struct MetaPairFn {        // (position << 32 | metasymbol) of the marked slots, compacted: what a rank tells the others
     const u32 *perm; const u32 *gid; const u32 *ginfo; const u32 *ex; u32 sigma3; u64 *pairs;
+    const u32 *pown = nullptr; u32 *own = nullptr;      // (positions as (owner, offset): the owner of slot t, copied beside the pair)
     GRL_DEV void operator()(u64 t) const {
         u32 gi = ginfo[gid[t]];
-        if (gi & 1u) pairs[ex[t]] = ((u64)perm[t] << 32) | (u64)((gi >> 1) + sigma3);
+        if (gi & 1u) { pairs[ex[t]] = ((u64)perm[t] << 32) | (u64)((gi >> 1) + sigma3); if (own) own[ex[t]] = pown[t]; }
     }
 };
 // The grammar walk reads ONE array: dm[q] = meta << 32 | last-cell-of-its-phrase << 31 | that-phrase-ends-a-string << 30 | symbol
@@ -1480,12 +1481,23 @@ struct ExtCompactFn {      // ExtKeyFn without the key: the unresolved slots com
 struct ExtCompactAiFn {    // the same when the sorted values are ARRIVAL INDICES (records travelled with the suffixes): the position for the request comes from pos_of[]
     const u32 *act; const u8 *uflag; const u32 *uex; const u32 *perm; const u8 *hflag; const u32 *pos_of;
     u32 *uslot; u32 *uq; u8 *uhead; u64 *req;
+    const u64 *bounds = nullptr; int N = 0; u32 *own = nullptr;      // (positions as (owner, offset): the owner of an arrival is the rank it came from)
     GRL_DEV void operator()(u64 i) const {
         if (uflag[i]) {
             const u64 t = act ? (u64)act[i] : i;
             const u32 a = perm[t], o = uex[i];
             uslot[o] = (u32)t; uq[o] = a; uhead[o] = hflag[t]; req[o] = ((u64)pos_of[a] << 32) | o;
+            if (own) { u32 d = 0; for (int r = 1; r < N; r++) if ((u64)a >= bounds[r]) d = (u32)r; own[o] = d; }
         }
+    }
+};
+struct ArrivalOwnerFn {    // own[t] = the rank the arrival index[t] came from (arrivals sit in sender order: bounds[g] <= a < bounds[g + 1])
+    const u32 *index; const u64 *bounds; int N; u32 *own;
+    GRL_DEV void operator()(u64 t) const {
+        const u64 a = index[t];
+        u32 d = 0;
+        for (int r = 1; r < N; r++) if (a >= bounds[r]) d = (u32)r;
+        own[t] = d;
     }
 };
 struct GatherU32Fn {       // out[t] = table[index[t]]
@@ -1500,9 +1512,12 @@ struct IotaU32Fn {
     u32 *out;
     GRL_DEV void operator()(u64 i) const { out[i] = (u32)i; }
 };
-struct GroupPosPairFn {    // (position of the group's whole-phrase member << 32 | metasymbol rank) of the groups that hold one, compacted
-    const u8 *gfull; const u32 *gpos; const u32 *grank; u32 m_off; const u32 *ex; u64 *pairs;
-    GRL_DEV void operator()(u64 g) const { if (gfull[g]) pairs[ex[g]] = ((u64)gpos[g] << 32) | (u64)(m_off + grank[g]); }
+struct GroupPosPairFn {    // (position of the group's whole-phrase member << 32 | metasymbol rank) of the groups that hold one, compacted; gslot[g] = that member's slot
+    const u8 *gfull; const u32 *gslot; const u32 *grank; u32 m_off; const u32 *ex; u64 *pairs;
+    const u32 *perm; const u32 *pown; u32 *own;
+    GRL_DEV void operator()(u64 g) const {
+        if (gfull[g]) { const u32 t = gslot[g]; pairs[ex[g]] = ((u64)perm[t] << 32) | (u64)(m_off + grank[g]); own[ex[g]] = pown[t]; }
+    }
 };
 struct ApplyPosPairsFn {   // on the owner: rank of the phrase whose first cell sits at my position (pair >> 32) - s0
     const u64 *pairs; const u32 *dict_phr; u64 s0; u32 *phrase_rank;
@@ -1556,7 +1571,11 @@ struct RecAnswerFn {       // recs[slot] = the owner's answer
 };
 struct WalkRequestFn {     // (position of the representative << 32 | my metasymbol) for every metasymbol of my key range
     const u32 *repq; u64 *req;
-    GRL_DEV void operator()(u64 u) const { req[u] = ((u64)repq[u] << 32) | u; }
+    const u32 *perm = nullptr; const u32 *pown = nullptr; u32 *own = nullptr;      // (positions as (owner, offset): repq[] holds the representative's SLOT)
+    GRL_DEV void operator()(u64 u) const {
+        if (own) { const u32 t = repq[u]; req[u] = ((u64)perm[t] << 32) | u; own[u] = pown[t]; }
+        else req[u] = ((u64)repq[u] << 32) | u;
+    }
 };
 struct WalkAnswerFn {      // answers come back in the order the requests left: g1 << 32 | g0 of the metasymbol in the request's low half
     const u64 *req; const u64 *ans; u32 *g0; u32 *g1;
@@ -3385,13 +3404,20 @@ class Engine {
     // ---- collection-level mode: records addressed to the OWNER of a dictionary position -------------------------------------
     // rec[i] = position << 32 | payload.  Sorted (stable) by the rank whose part of the merged dictionary holds the position
     // (dsb = sbase[0..N] on the device); cnt[d] = records for rank d.
-    void bucket_by_owner(const Comm &C, const u64 *dsb, DBuf<u64> &rec, u64 n, std::vector<u64> &cnt, const char *name) {
+    // (own_of given: positions travel as (owner, offset in the owner's part) -- own_of[i] is record i's owner, the position field its
+    // offset; that is how a dictionary of 2^32 symbols and more is addressed with 32-bit fields)
+    static u64 test_dict_part_pad() {
+        static const u64 pad = getenv("GRLBWT_TEST_DICT_PART_PAD") ? (u64)atoll(getenv("GRLBWT_TEST_DICT_PART_PAD")) : 0;
+        return pad;
+    }
+    void bucket_by_owner(const Comm &C, const u64 *dsb, DBuf<u64> &rec, u64 n, std::vector<u64> &cnt, const char *name, DBuf<u32> *own_of = nullptr) {
         const int N = C.size;
         int obits = (int)bitlen64((u64)N - 1);
         if (obits < 1) obits = 1;
-        DBuf<u32> own(n), own2(n);
+        DBuf<u32> own, own2(n);
         DBuf<u64> rec2(n), bound(2 * ((u64)N + 1));
-        prim::for_each(n, PosOwnerFn{rec.p, dsb, N, own.p}, name);
+        if (own_of) own = std::move(*own_of);
+        else { own.alloc(n); prim::for_each(n, PosOwnerFn{rec.p, dsb, N, own.p}, name); }
         const int res = prim::sort_pairs<u32, u64>(own.p, rec.p, own2.p, rec2.p, n, 0, obits, name);
         prim::for_each((u64)N + 1, KeyBoundFn{res ? own2.p : own.p, n, nullptr, bound.p}, name);
         std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
@@ -3403,10 +3429,10 @@ class Engine {
     // per request there, the answers come back.  Afterwards req[] is in owner order and back[i] answers req[i].  A failure only
     // this rank can have (memory, an internal check) is agreed on at the counter exchanges: every rank raises.
     template <class A, class F>
-    void owner_round_trip(const Comm &C, const u64 *dsb, DBuf<u64> &req, u64 n, DBuf<A> &back, F answer, const char *name, const char *xname) {
+    void owner_round_trip(const Comm &C, const u64 *dsb, DBuf<u64> &req, u64 n, DBuf<A> &back, F answer, const char *name, const char *xname, DBuf<u32> *own_of = nullptr) {
         const int N = C.size, me = C.rank;
         std::vector<u64> scnt(N, 0), rcnt(N, 0);
-        try { bucket_by_owner(C, dsb, req, n, scnt, name); }
+        try { bucket_by_owner(C, dsb, req, n, scnt, name, own_of); }
         catch (const prim::Error &e) { C.fail(e); std::fill(scnt.begin(), scnt.end(), 0); }
         std::vector<u64> mat = C.allgather_u64(scnt);            // (raises on every rank if one of them failed above)
         u64 nr = 0, maxb = 0;
@@ -3449,14 +3475,19 @@ class Engine {
         // all-gather of the merged phrases, no O(S) or O(D) pass that every rank repeats.
         const bool sharded = C && sharded_dict && dbase && sbase;
         const u64 d0 = sharded ? (*dbase)[C->rank] : 0, s0 = sharded ? (*sbase)[C->rank] : 0;
-        const u64 Dl = sharded ? (*dbase)[C->rank + 1] - d0 : D, Sl = sharded ? (*sbase)[C->rank + 1] - s0 : S;
+        const u64 Dl = sharded ? (*dbase)[C->rank + 1] - d0 : D, Sl = sharded ? (*sbase)[C->rank + 1] - s0 - test_dict_part_pad() : S;
         // With every frequency below 2^32 the 8 bytes the group fold reads about a suffix (frequency, left symbol, flags) travel WITH
         // its (key, position) record in the sample-sort exchange: no round trip for them afterwards (24 bytes per suffix over the
         // fabric and a gather pass on the owner -- 3.3 GB and ~14 ms per rank at N = 8 of the 10 GB collection).  The values a rank
         // sorts are then ARRIVAL INDICES; pos_arr[] / rec_arr[] give the position and the record of an arrival.
         static const bool rec_round_trip = getenv("GRLBWT_DIST_REC_ROUND_TRIP") != nullptr;
         const bool carry = sharded && maxfreq < 0xFFFFFFFFull && !rec_round_trip;
-        DBuf<u32> pos_arr, perm_ai;              // (carry) position of every arrival; the sorted arrival indices once perm holds positions again
+        // In this form a position is (owner, OFFSET in the owner's part): the owner of an arrival is the rank it came from (arrivals
+        // sit in sender order), so 32-bit fields address a dictionary whose parts are each below 2^32 symbols, whatever their sum.
+        if (sharded && !carry && S >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols and a phrase frequency >= 2^32, or GRLBWT_DIST_REC_ROUND_TRIP)");
+        const u64 sq = carry ? 0 : s0;           // what the owner subtracts from a position it is asked about
+        DBuf<u32> pos_arr, perm_ai, pown;        // (carry) offset of every arrival; the sorted arrival indices once perm holds offsets again; owner by slot
+        DBuf<u64> abounds;                       // (carry) arrivals [abounds[g], abounds[g + 1]) came from rank g
         DBuf<u64> rec_arr;                       // (carry) record of every arrival
         DBuf<u64> dsb;                           // sbase[] on the device (owner of a position)
         if (C && sbase) { dsb.alloc((u64)C->size + 1); prim::h2d(dsb.p, sbase->data(), ((u64)C->size + 1) * 8); }
@@ -3741,7 +3772,7 @@ class Engine {
                 DBuf<u64> lk(nk), bound(2 * ((u64)N + 1));
                 DBuf<u32> lp(nk), own(nk), own2(nk), idx(nk), idx2(nk);
                 DBuf<u64> lr(carry ? nk : 0);
-                prim::for_each(Sl, KeyRangeFn{keep, kex.p, 0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p, RunKeys(), (u32)s0,
+                prim::for_each(Sl, KeyRangeFn{keep, kex.p, 0, dict_sym.p, K, b, dspl.p, N, lk.p, lp.p, own.p, idx.p, RunKeys(), (u32)sq,
                                               carry ? lr.p : nullptr, ph_freq, sigma + 1}, "suffix_keys0");
                 int obits = (int)bitlen64((u64)N - 1);
                 if (obits < 1) obits = 1;
@@ -3762,7 +3793,17 @@ class Engine {
                 Sg += rcnt[g];
                 for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]);
             }
-            local([&] { ka.alloc(Sg); perm.alloc(Sg); if (carry) { pos_arr.alloc(Sg); rec_arr.alloc(Sg); } });
+            // (known to every rank alike: slots are 32-bit)
+            for (int d = 0; d < N; d++) { u64 sd = 0; for (int g = 0; g < N; g++) sd += mat[(u64)g * N + d]; if (sd >= 0xFFFFFFF0ull) throw prim::Error(-75, "a key range of the dictionary's suffixes has >= 2^32 of them: use more ranks"); }
+            local([&] {
+                ka.alloc(Sg); perm.alloc(Sg);
+                if (carry) {
+                    pos_arr.alloc(Sg); rec_arr.alloc(Sg); abounds.alloc((u64)N + 1);
+                    std::vector<u64> ab((u64)N + 1, 0);
+                    for (int g = 0; g < N; g++) ab[g + 1] = ab[g] + rcnt[g];
+                    prim::h2d(abounds.p, ab.data(), ((u64)N + 1) * 8);
+                }
+            });
             C->allgather_u64({});                                // (the bulk exchanges below have no way back)
             C->named("sort.sample_keys").alltoall(sk.p, scnt, ka.p, rcnt, 8, maxb);
             C->named("sort.sample_pos").alltoall(sp.p, scnt, carry ? pos_arr.p : perm.p, rcnt, 4, maxb);
@@ -3794,18 +3835,20 @@ class Engine {
                 for (u64 v : us) Uany = std::max(Uany, v);
                 if (Uany == 0) break;
                 if (Lres > (u64)maxlen + (u64)K) throw prim::Error(-71, "suffix refinement does not terminate");      // (the same on every rank)
-                DBuf<u32> uslot, uq, hex;
+                DBuf<u32> uslot, uq, hex, uown;
                 DBuf<u64> ukey, req, back;
                 DBuf<u8> uhead, unext;
                 local([&] {
                     uslot.alloc(U); uq.alloc(U); hex.alloc(U + 1); ukey.alloc(U); req.alloc(U); uhead.alloc(U); unext.alloc(U);
-                    if (carry) prim::for_each(A, ExtCompactAiFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, pos_arr.p, uslot.p, uq.p, uhead.p, req.p}, "suffix_keys");
+                    if (carry) uown.alloc(U);
+                    if (carry) prim::for_each(A, ExtCompactAiFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, pos_arr.p, uslot.p, uq.p, uhead.p, req.p,
+                                                                abounds.p, N, uown.p}, "suffix_keys");
                     else prim::for_each(A, ExtCompactFn{refined ? act.p : nullptr, uflag.p, uex.p, perm.p, hflag.p, uslot.p, uq.p, uhead.p, req.p}, "suffix_keys");
                 });
                 if (C->pending) U = 0;
                 owner_round_trip<u64>(*C, dsb.p, req, U, back, [&](const u64 *rq, u64 nrq, u64 *out) {
-                    prim::for_each(nrq, ExtKeyOwnerFn{rq, dict_sym.p, pbits.words.p, Sl, s0, Lres, K, b, out}, "suffix_keys");
-                }, "dist.ext_owner_sort", "sort.ext_keys");
+                    prim::for_each(nrq, ExtKeyOwnerFn{rq, dict_sym.p, pbits.words.p, Sl, sq, Lres, K, b, out}, "suffix_keys");
+                }, "dist.ext_owner_sort", "sort.ext_keys", carry && !C->pending && uown.p ? &uown : nullptr);
                 local([&] {
                     if (U == 0) { act = std::move(uslot); uflag = std::move(unext); A = 0; refined = true; return; }      // (nothing of mine left: I only answer)
                     prim::for_each(U, ExtAnswerFn{req.p, back.p, ukey.p}, "suffix_keys");
@@ -3840,9 +3883,11 @@ class Engine {
                 G = prim::exclusive_scan<u32>(Sg, ByteIn{hflag.p}, ex.p, false, "suffix_heads");
                 prim::for_each(Sg, GroupStartsFn{hflag.p, ex.p, Sg, gstart.p}, "suffix_gstart");
                 prim::for_each(Sg, DenseGidFn{hflag.p, ex.p, gid.p}, "suffix_gid");
-                if (carry) {                     // from here on perm[] holds positions again; the arrival indices stay for the fold's records
+                if (carry) {                     // from here on perm[] holds positions (offsets, owner in pown[]) again; the arrival indices stay for the fold's records
                     DBuf<u32> pp(Sg);
+                    pown.alloc(Sg);
                     prim::for_each(Sg, GatherU32Fn{perm.p, pos_arr.p, pp.p}, "suffix_gid");
+                    prim::for_each(Sg, ArrivalOwnerFn{perm.p, abounds.p, N, pown.p}, "suffix_gid");
                     perm_ai = std::move(perm);
                     perm = std::move(pp);
                     pos_arr.release();
@@ -3883,7 +3928,7 @@ class Engine {
             }
             auto groups_local = [&] {
             grank.alloc(G + 1); pidx.alloc(G + 1); gmin.alloc(G); gmax.alloc(G); gacc.alloc(G); gfull.alloc(G); gflag.alloc(G);
-            if (fused_vals || carry) gphr.alloc(G); else pslot.alloc(D);      // (carry: gphr[g] = dictionary position of the group's whole-phrase member)
+            if (fused_vals || carry) gphr.alloc(G); else pslot.alloc(D);      // (carry: gphr[g] = slot of the group's whole-phrase member)
             if (C && !carry) pslot.fill_ff();    // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
             {
                 static const int fly_min = getenv("GRLBWT_DIST_REC_FLY_MIN") ? atoi(getenv("GRLBWT_DIST_REC_FLY_MIN")) : 8;
@@ -3892,7 +3937,7 @@ class Engine {
                 DBuf<u32> coff(G + 1);
                 if (carry) {
                     prim::for_each(G, GroupAccumSmallFn<RecWire>{perm_ai.p, gstart.p, RecWire{rec_arr.p}, nullptr, bwt_code,
-                                                                 gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, nullptr, gphr.p, perm.p}, "group_accum");
+                                                                 gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, nullptr, gphr.p, true}, "group_accum");
                 } else if (sharded) {
                     prim::for_each(G, GroupAccumSmallFn<RecSlot>{perm.p, gstart.p, RecSlot{recs.p}, nullptr, bwt_code,
                                                                  gmin.p, gmax.p, gacc.p, gfull.p, gflag.p, pslot.p, gphr.p}, "group_accum");
@@ -3909,7 +3954,7 @@ class Engine {
                 const u64 NC = prim::exclusive_scan<u32>(G, GroupChunksIn{gstart.p}, coff.p, true, "group_accum_large");
                 if (carry) {
                     prim::for_each(NC, GroupAccumLargeFn<RecWire>{perm_ai.p, coff.p, G, gstart.p, RecWire{rec_arr.p}, nullptr, bwt_code,
-                                                                  gmin.p, gmax.p, gacc.p, gfull.p, nullptr, gphr.p, perm.p}, "group_accum_large");
+                                                                  gmin.p, gmax.p, gacc.p, gfull.p, nullptr, gphr.p, true}, "group_accum_large");
                     prim::for_each(G, GroupDecideFn<RecWire>{perm_ai.p, gstart.p, RecWire{rec_arr.p}, gmin.p, gmax.p, gfull.p, gflag.p}, "group_decide");
                 } else if (sharded) {
                     prim::for_each(NC, GroupAccumLargeFn<RecSlot>{perm.p, coff.p, G, gstart.p, RecSlot{recs.p}, nullptr, bwt_code,
@@ -3955,7 +4000,7 @@ class Engine {
             // only: a run cut by a piece boundary stays two runs, which describe the same symbols.
             static const bool replicated_pre = getenv("GRLBWT_DIST_REPLICATED_PREBWT") != nullptr || getenv("GRLBWT_DIST_REPLICATED_INDUCTION") != nullptr;      // (the replicated induction wants the whole pre-BWT)
             const bool pre_local = C && !replicated_pre;
-            prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, perm.p, bwt_code, hocc_code, pre_local ? 0u : (u32)Moff,
+            prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, carry ? nullptr : perm.p, bwt_code, hocc_code, pre_local ? 0u : (u32)Moff,
                                           pre_local ? 0u : (u32)P0off, psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p, pu0.p}, "prebwt_emit");
             if (C) {                             // every rank's (Ml, P0l) is known: one exchange per array
                 if (!pre_local) {
@@ -3989,35 +4034,27 @@ class Engine {
                     // marks all-gathered to everybody and applied by everybody -- at every N: 24 + 8 ms and 10 GB per rank at N = 8 of the
                     // 10 GB collection, 4.8 GB of pairs sent per rank.)
                     const int N = C->size, me = C->rank;
-                    const u64 s0 = (*sbase)[me], Sme = (*sbase)[me + 1] - s0;
-                    DBuf<u64> dm, dsb((u64)N + 1);
-                    int obits = (int)bitlen64((u64)N - 1);
-                    if (obits < 1) obits = 1;
+                    const u64 s0 = carry ? 0 : (*sbase)[me], Sme = (*sbase)[me + 1] - (*sbase)[me] - test_dict_part_pad();      // (carry: positions are offsets in the owner's part)
+                    DBuf<u64> dm;
                     // records (position << 32 | payload) -> sorted by the owner of the position, counts per owner
-                    auto by_owner = [&](DBuf<u64> &rec, u64 n, std::vector<u64> &cnt, const char *name) {
-                        DBuf<u32> own(n), own2(n);
-                        DBuf<u64> rec2(n), bound(2 * ((u64)N + 1));
-                        prim::for_each(n, PosOwnerFn{rec.p, dsb.p, N, own.p}, name);
-                        const int res = prim::sort_pairs<u32, u64>(own.p, rec.p, own2.p, rec2.p, n, 0, obits, name);
-                        prim::for_each((u64)N + 1, KeyBoundFn{res ? own2.p : own.p, n, nullptr, bound.p}, name);
-                        std::vector<u64> bh = bound.to_host(2 * ((u64)N + 1));
-                        for (int d = 0; d < N; d++) cnt[d] = bh[2 * (d + 1)] - bh[2 * d];
-                        if (res) rec = std::move(rec2);
+                    auto by_owner = [&](DBuf<u64> &rec, u64 n, std::vector<u64> &cnt, const char *name, DBuf<u32> *own_of) {
+                        bucket_by_owner(*C, dsb.p, rec, n, cnt, name, own_of);
                     };
                     std::vector<u64> mcnt(N, 0), wcnt(N, 0), mrc(N, 0), wrc(N, 0);
                     DBuf<u64> mp, wq;
                     try {
-                        prim::h2d(dsb.p, sbase->data(), ((u64)N + 1) * 8);
+                        DBuf<u32> mown, wown;
                         dm.alloc(Sme);
                         prim::for_each(Sme, DictMetaInitFn{dict_sym.p, dict_phr.p, ph_off, ph_lastT, dm.p, sharded ? 0 : s0}, "grammar_init");      // (sharded dictionary: the arrays are my part already)
                         DBuf<u32> mex(Sg + 1);
                         const u64 nm = prim::exclusive_scan<u32>(Sg, MarkedIn{gid.p, ginfo.p}, mex.p, false, "dist.mark_scan");
                         mp.alloc(nm);
-                        prim::for_each(Sg, MetaPairFn{perm.p, gid.p, ginfo.p, mex.p, sigma3, mp.p}, "dist.mark_pairs");
-                        by_owner(mp, nm, mcnt, "dist.mark_owner_sort");
+                        if (carry) { mown.alloc(nm); wown.alloc(Ml); }
+                        prim::for_each(Sg, MetaPairFn{perm.p, gid.p, ginfo.p, mex.p, sigma3, mp.p, pown.p, mown.p}, "dist.mark_pairs");
+                        by_owner(mp, nm, mcnt, "dist.mark_owner_sort", carry ? &mown : nullptr);
                         wq.alloc(Ml);
-                        prim::for_each(Ml, WalkRequestFn{repq.p, wq.p}, "dist.walk_requests");
-                        by_owner(wq, Ml, wcnt, "dist.walk_owner_sort");
+                        prim::for_each(Ml, WalkRequestFn{repq.p, wq.p, perm.p, pown.p, wown.p}, "dist.walk_requests");
+                        by_owner(wq, Ml, wcnt, "dist.walk_owner_sort", carry ? &wown : nullptr);
                     } catch (const prim::Error &e) { C->fail(e); std::fill(mcnt.begin(), mcnt.end(), 0); std::fill(wcnt.begin(), wcnt.end(), 0); }
                     std::vector<u64> both(mcnt);
                     both.insert(both.end(), wcnt.begin(), wcnt.end());
@@ -4095,8 +4132,9 @@ class Engine {
                     DBuf<u32> gex(G + 1);
                     const u64 nf = prim::exclusive_scan<u32>(G, ByteIn{gfull.p}, gex.p, false, "dist.full_scan");
                     fp.alloc(nf);
-                    prim::for_each(G, GroupPosPairFn{gfull.p, gphr.p, grank.p, (u32)Moff, gex.p, fp.p}, "dist.full_pairs");
-                    bucket_by_owner(*C, dsb.p, fp, nf, scnt, "dist.full_pairs");
+                    DBuf<u32> fown(nf);
+                    prim::for_each(G, GroupPosPairFn{gfull.p, gphr.p, grank.p, (u32)Moff, gex.p, fp.p, perm.p, pown.p, fown.p}, "dist.full_pairs");
+                    bucket_by_owner(*C, dsb.p, fp, nf, scnt, "dist.full_pairs", &fown);
                 } catch (const prim::Error &e) { C->fail(e); std::fill(scnt.begin(), scnt.end(), 0); } }
                 std::vector<u64> mat = C->allgather_u64(scnt);
                 u64 got = 0, maxb = 0;
@@ -4105,7 +4143,7 @@ class Engine {
                 DBuf<u64> mine(got);
                 DBuf<u32> phrase_rank(Dl);
                 C->named("phrase.rank_pairs").alltoall(fp.p, scnt, mine.p, rcnt, 8, maxb);
-                prim::for_each(got, ApplyPosPairsFn{mine.p, dict_phr.p, s0, phrase_rank.p}, "dist.apply_phrase_ranks");
+                prim::for_each(got, ApplyPosPairsFn{mine.p, dict_phr.p, 0, phrase_rank.p}, "dist.apply_phrase_ranks");      // (offsets in my part)
                 prim::for_each(Dl, PhraseValDistFn{phrase_rank.p, ph_freq, ph_lastT, phrase_val.p}, "phrase_values");
             } else {                             // a whole-phrase suffix sits on the rank that owns its key: (phrase, metasymbol) pairs
                 DBuf<u32> phrase_rank(sharded ? Dl : D), fex(D + 1);
@@ -4678,6 +4716,7 @@ class Engine {
         u64 D, S;
         u32 maxlen;
         bool sharded_dict = false;               // the merged dictionary stays sharded by owner through the dictionary stage
+        u64 maxfreq = 0;                         // the largest merged phrase frequency
         {
             StageTimer st(&tm.hash, "hash");
             // (rank-local, sized by what THIS rank received: a failure here -- memory, table overflow -- is recorded and
@@ -4712,9 +4751,16 @@ class Engine {
             } catch (const prim::Error &e) { C.fail(e); Do = 0; So64 = 0; }
             // ---- the merged dictionary, replicated: owner parts in rank order -----------------------------------
             std::vector<u64> cnt = C.allgather_u64({Do, So64});
-            for (int g = 0; g < N; g++) { dbase[g + 1] = dbase[g] + cnt[2 * g]; sbase[g + 1] = sbase[g] + cnt[2 * g + 1]; }
+            // (GRLBWT_TEST_DICT_PART_PAD=<symbols>: the tests put that many unused positions behind every rank's part, so that the
+            // global numbering passes 2^32 on a small dictionary -- a form that still used it would wrap)
+            const u64 part_pad = test_dict_part_pad();
+            for (int g = 0; g < N; g++) {
+                dbase[g + 1] = dbase[g] + cnt[2 * g]; sbase[g + 1] = sbase[g] + cnt[2 * g + 1] + part_pad;
+                if (cnt[2 * g + 1] >= 0xFFFFFFF0ull) throw prim::Error(-75, "a rank's part of the dictionary has >= 2^32 symbols: use more ranks");
+            }
             D = dbase[N];
-            if (sbase[N] >= 0xFFFFFFF0ull) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols)");
+            // (a dictionary of 2^32 symbols and more in all is taken in the sharded form, where positions are (owner, offset): below)
+            const bool wide_dict = sbase[N] >= 0xFFFFFFF0ull;
             prim::exclusive_scan_nosync<u32>(Do, LenIn{o_len.p}, o_off.p, true, "dist.dict_offsets");
             DBuf<u32> ocells(So64);
             {
@@ -4728,14 +4774,15 @@ class Engine {
             // Levels with very long phrases (run-aware suffix keys, >= GRLBWT_RUN_KEYS_MIN cells) take the gathered form below, as
             // does GRLBWT_DIST_GATHERED_DICT=1 (rounds 1-4).
             {
-                u64 ml = 0, fl = 0;
+                u64 ml = 0, fl = 0, fm = 0;
                 if (!C.pending) { try {
                     ml = Do ? (u64)prim::reduce_max<u32>(Do, LenIn{o_len.p}, "dist.maxlen") : 0;
                     fl = prim::reduce_sum<u64>(Do, IdxIn<idx_t>{o_freq.p}, "dist.freq_check");
+                    fm = Do ? (u64)prim::reduce_max<u64>(Do, IdxIn<idx_t>{o_freq.p}, "dist.freq_check") : 0;
                 } catch (const prim::Error &e) { C.fail(e); } }
-                std::vector<u64> mf = C.allgather_u64({ml, fl});
+                std::vector<u64> mf = C.allgather_u64({ml, fl, fm});
                 u64 mx = 0, fs = 0;
-                for (int g = 0; g < N; g++) { mx = std::max(mx, mf[2 * g]); fs += mf[2 * g + 1]; }
+                for (int g = 0; g < N; g++) { mx = std::max(mx, mf[3 * g]); fs += mf[3 * g + 1]; maxfreq = std::max(maxfreq, mf[3 * g + 2]); }
                 if (fs != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
                 static const u64 run_min = getenv("GRLBWT_RUN_KEYS_MIN") ? (u64)atoll(getenv("GRLBWT_RUN_KEYS_MIN")) : 512;
                 static const bool gathered = getenv("GRLBWT_DIST_GATHERED_DICT") != nullptr || getenv("GRLBWT_DIST_REPLICATED_DICT") != nullptr;
@@ -4744,7 +4791,7 @@ class Engine {
                 // (... and from how many dictionary symbols on: a small dictionary's all-gather costs less than the collectives of the
                 // refinement rounds -- the 1 GB collection at N = 8: 35.7 ms gathered, 40.3 ms sharded, 216 vs 349 collectives)
                 static const u64 sd_syms = getenv("GRLBWT_DIST_SHARDED_DICT_MIN_SYMS") ? (u64)atoll(getenv("GRLBWT_DIST_SHARDED_DICT_MIN_SYMS")) : ((u64)1 << 27);
-                if (!gathered && mx < run_min && N >= sd_min && sbase[N] >= sd_syms) {
+                if (!gathered && mx < run_min && ((N >= sd_min && sbase[N] >= sd_syms) || wide_dict)) {
                     sharded_dict = true;
                     maxlen = (u32)mx;
                     S = sbase[N];
@@ -4756,6 +4803,7 @@ class Engine {
                     prim::for_each(Do, OffToPosFn{ph_off.p, ph_pos.p}, "dist.dict_offsets");
                 }
             }
+            if (!sharded_dict && wide_dict) throw prim::Error(-75, "dictionary too large (>= 2^32 symbols with phrases of >= GRLBWT_RUN_KEYS_MIN cells, or GRLBWT_DIST_GATHERED_DICT)");
             if (!sharded_dict) {
             gcells = C.named("dict.merged_cells").allgather_v<u32>(ocells.p, So64, sbase, true);
             ph_len = C.named("dict.merged_len").allgather_v<u32>(o_len.p, Do, dbase, true);
@@ -4779,7 +4827,7 @@ class Engine {
         // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar passes and dictionary by owner ----
         DBuf<u32> gval;
         dict_stage<u32, false>(getenv("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
-                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase, sharded_dict, occ_total);      // (no phrase occurs more often than there are phrase occurrences)
+                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase, sharded_dict, maxfreq);
         // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
         {

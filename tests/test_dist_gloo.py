@@ -261,3 +261,21 @@ def test_fewer_strings_than_ranks_is_rejected():
     from grlbwt_amd import dist as gdist
     with pytest.raises(ValueError):
         gdist.shard_records(np.frombuffer(b"AC\nGT\n", dtype=np.uint8), 0, 3)
+
+
+def test_sharded_dictionary_beyond_32_bit_positions(sim, oracle_mod, tmp_path, monkeypatch):
+    """A dictionary position travels as (owner, offset in the owner's part) when the dictionary is sharded by owner and the records
+    ride with the sort exchange: the parts must each be below 2^32 symbols, their sum need not.  GRLBWT_TEST_DICT_PART_PAD puts
+    2^31 unused positions behind every rank's part, so the global numbering of these small dictionaries passes 2^32 from the third
+    rank on -- a step that still used a global 32-bit position would wrap and lose parity.  The forms that do use global positions
+    (records by round trip) refuse such a dictionary on every rank."""
+    monkeypatch.setenv("GRLBWT_TEST_DICT_PART_PAD", str(1 << 31))
+    monkeypatch.setenv("GRLBWT_RUN_KEYS_MIN", str(1 << 30))      # (levels with very long phrases take the gathered form, which has global positions)
+    for world, kind, w, port in ((3, "reads", 1, 29640), (4, "tokens", 2, 29642), (3, "longruns", 1, 29644)):
+        _run(world, sim, kind, tmp_path, port)
+        data = open(tmp_path / ("%s.input" % kind), "rb").read()
+        assert open(tmp_path / ("%s.rl_bwt" % kind), "rb").read() == oracle_mod.rl_bwt(data, w)
+    monkeypatch.setenv("GRLBWT_DIST_REC_ROUND_TRIP", "1")
+    _run(3, sim, "injected", tmp_path, 29646)
+    assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -75"] * 3
+

@@ -30,5 +30,7 @@ run 3 tiny $S
 run 2 repetitive $S GRLBWT_SEG_CAP=1
 run 3 reads $S GRLBWT_RUN_KEYS_MIN=6
 run 3 reads GRLBWT_DIST_REPLICATED_PREBWT=1 GRLBWT_DIST_GATHERED_DICT=1
+# (positions as (owner, offset): every rank's part padded by 2^31 positions, the global numbering passes 2^32)
+run 4 tokens $S GRLBWT_TEST_DICT_PART_PAD=2147483648 GRLBWT_RUN_KEYS_MIN=1073741824
 # (no failure-injection case here: with libasan preloaded into python the first C++ throw of the library trips ASAN's own
 # __cxa_throw interceptor check -- the failure paths are covered by tests/test_dist_gloo.py without the sanitizer)
