@@ -43,7 +43,9 @@ extern "C" {
 #define GRLBWT_ERANGE (-75)     /* input beyond what this build supports -- the limits, all checked:
                                  *   collection            < 2^40 cells (64-bit positions from 2^32 - 256 cells on);
                                  *   symbols, and the alphabet of every level (metasymbols of a round)       < 2^30;
-                                 *   distinct phrases of one round < 2^32, their symbols (the round's dictionary) < 2^32;
+                                 *   distinct phrases of one round < 2^32, their symbols (the round's dictionary) < 2^32
+                                 *   (collection-level mode: per rank's part of the merged dictionary and per key range of its
+                                 *   suffixes, while every phrase frequency is < 2^32 and no phrase has >= 512 cells);
                                  *   phrase-table slots of one round <= 2^31 (2^30 with the hot table of level 0);
                                  *   phrase OCCURRENCES of one round: no bound of their own in the 64-bit build (level 0 of a
                                  *   24.9 GB collection has 7.3 G); a shard of the collection-level mode < 2^32 per round.
