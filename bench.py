@@ -268,12 +268,18 @@ def main():
         flags |= gdist.pool_flags(comm)
     ctx = engine.Context(local_rank, flags, lib)
 
-    def step(c=ctx, t=text):
+    # N > 1: the image of the timed steps stays in parts on the ranks that induced them (GRLBWT_COMM_KEEP_PARTS: what the grlbwt
+    # executable's --gpus does -- N ranks write one file at N offsets); GRLBWT_BENCH_GATHER_IMAGE=1 times the all-gather to every
+    # rank as well.  The steps after the timed region gather it, for the md5 and the comparison with a single-GPU build.
+    keep_parts = comm is not None and world > 1 and os.environ.get("GRLBWT_BENCH_GATHER_IMAGE") != "1"
+
+    def step(c=ctx, t=text, parts=None):
         c.attach_device(t.data_ptr(), t.numel(), 1, keepalive=t)
         if comm is None:
             c.build()
         else:
-            gdist.dist_build(c, comm)      # BWT of the whole collection (all shards), identical on every rank
+            # BWT of the whole collection (all shards): the same image for every N
+            gdist.dist_build(c, comm, keep_parts if parts is None else parts)
 
     def barrier():
         torch.cuda.synchronize()
@@ -317,6 +323,11 @@ def main():
 
     # the image the timed steps produced (outside the timed region): size, runs, md5 -- so that a driver run and a lease run
     # can be compared, and tests/test_gpu_parity.py::test_headline_10GB_round_trip decodes exactly this image
+    parts_span = None
+    if keep_parts:
+        parts_span = ctx.result_part()
+        step(parts=False)                 # (untimed, every rank: the whole image on every rank from here on)
+        barrier()
     image = None
     if rank == 0 and os.environ.get("GRLBWT_BENCH_MD5", "1") != "0":
         from grlbwt_amd import dist as _gd
@@ -397,7 +408,7 @@ def main():
         ctx.profile_enable(True)
         if comm is not None and os.environ.get("GRLBWT_BENCH_DETAIL"):
             comm.log = []
-    step()
+    step(parts=False)
     barrier()
     out = None
     if rank == 0:
@@ -548,7 +559,10 @@ def main():
             # value = the build with the input resident in HBM (the contract of this bench); value_cli = the same bytes through the
             # grlbwt executable, file in the page cache -> .rl_bwt file closed (SURVEY 8(d)'s wording of the metric; median run)
             "value_cli": (cli_e2e or {}).get("MBps_wall"),
-            "config": {"workload": wl, "input_resident": "HBM", "output": ".rl_bwt image in HBM",
+            "config": {"workload": wl, "input_resident": "HBM",
+                       "output": (".rl_bwt image in HBM" if not keep_parts else
+                                  ".rl_bwt image in HBM, in %d parts on the ranks that induced them (rank 0: bytes [%d, %d)); gathered after the "
+                                  "timed region for the md5 / single-GPU comparison" % (world, parts_span[0], parts_span[0] + parts_span[1])),
                        "value_is": "HBM-resident build (value); value_cli = wall time of the CLI, file in -> .rl_bwt file closed, median of the timed runs",
                        "parallelism": ("1 GPU" if world == 1 else
                                        "the ONE collection sharded by record over %d GPUs (%d reads each): local LMS parsing/hashing/emission, "
@@ -573,7 +587,7 @@ def main():
         out["devices"] = devices
         out["distinct_devices"] = len({d.get("uuid") or d.get("pci_bus_id") or (d["local_rank"], d["hip_device"]) for d in devices})
         if comm is not None:     # totals over warmup + timed + profile steps on rank 0
-            nsteps = args.warmup + args.steps + 1
+            nsteps = args.warmup + args.steps + 1 + (1 if keep_parts else 0)
             out["collectives_per_step"] = {"allgather": comm.n_allgather // nsteps, "alltoallv": comm.n_alltoall // nsteps,
                                            "bytes": comm.bytes_moved // nsteps, "ms_in_callbacks": round(comm.seconds / nsteps * 1e3, 3)}
             # the sharded result against a single-GPU build of the WHOLE collection on this rank (outside the timed region;

@@ -88,8 +88,11 @@ static void report_time(std::chrono::steady_clock::time_point a, std::chrono::st
 // ---- --gpus N: the collection-level mode from the command line -------------------------------------------------------
 // The parent cuts the file into N record shards (byte ranges ending on a separator) and starts one process per GPU BEFORE
 // anything touches the HIP runtime; rank 0 makes the RCCL id and publishes it through a shared page; every rank loads its
-// shard, joins the communicator (grlbwt_rccl_comm_create) and runs grlbwt_dist_build; rank 0 reports and writes the file.
+// shard, joins the communicator (grlbwt_rccl_comm_create) and runs grlbwt_dist_build; rank 0 reports.  The image stays in parts
+// on the ranks that induced them (GRLBWT_COMM_KEEP_PARTS): every rank writes its part at its offset of <output>.tmp~<parent pid>
+// (grlbwt_result_write_part), the parent renames the file over the output once every rank has ended well, and removes it otherwise.
 struct SharedPage {
+    std::atomic<int> written[64];           // 1 = this rank's part is in the file, < 0 = it failed
     std::atomic<int> id_ready;
     char id[GRLBWT_RCCL_ID_BYTES];
     std::atomic<int> loaded[64];            // 0 = not yet, 1 = shard loaded, < 0 = the error code of the load
@@ -120,7 +123,7 @@ static uint64_t next_record_start(int fd, uint64_t from, uint64_t n, int w, uint
     }
     return n;
 }
-static int rank_main(const arguments &args, int rank, int size, uint64_t off_bytes, uint64_t n_bytes, bool idx64, SharedPage *sh) {
+static int rank_main(const arguments &args, int rank, int size, uint64_t off_bytes, uint64_t n_bytes, bool idx64, SharedPage *sh, const std::string &tmp_out) {
     const bool root = rank == 0;
     const auto t_start = std::chrono::steady_clock::now();
     grlbwt_ctx *ctx = nullptr;
@@ -162,6 +165,7 @@ static int rank_main(const arguments &args, int rank, int size, uint64_t off_byt
     rc = grlbwt_rccl_comm_create(ctx, sh->id, rank, size, &comm);
     if (rc != GRLBWT_OK) return die(rc, "joining the communicator");
     if (root) std::cout << "Parsing the text and inferring the BWT on " << size << " GPUs (record shards, RCCL)" << std::endl;
+    comm.flags |= GRLBWT_COMM_KEEP_PARTS;
     rc = grlbwt_dist_build(ctx, &comm);
     if (rc != GRLBWT_OK) {
         if (rc == GRLBWT_EILLFORMED && root) std::cout << "Error: the file is ill formed" << std::endl;
@@ -169,6 +173,9 @@ static int rank_main(const arguments &args, int rank, int size, uint64_t off_byt
     }
     const auto t_built = std::chrono::steady_clock::now();
     int code = 0;
+    rc = grlbwt_result_write_part(ctx, tmp_out.c_str());
+    sh->written[rank].store(rc == GRLBWT_OK ? 1 : -1);
+    if (rc != GRLBWT_OK) code = die(rc, "writing the output");
     if (root) {
         // the reference's per-round / per-level statistics (exact_par_phase.cpp:484-488, exact_ind_phase.cpp:372-378)
         grlbwt_stats st;
@@ -195,8 +202,13 @@ static int rank_main(const arguments &args, int rank, int size, uint64_t off_byt
         std::cout << "  Stage seconds of rank 0: dictionary of LMS phrases " << c.t_classify + c.t_hash << ", sorting + preliminary BWT " << c.t_dict_sort
                   << ", compressing " << c.t_dict_groups << ", parse " << c.t_emit << ", induced symbols " << c.t_ind_expand << ", induction "
                   << c.t_ind_split << ", assembling " << c.t_ind_assemble << std::endl;
-        rc = grlbwt_result_write_file(ctx, args.output_file.c_str());
-        if (rc != GRLBWT_OK) code = die(rc, "writing the output");
+        bool all_written = true;
+        for (int g = 0; g < size && all_written; g++) {
+            int v;
+            while ((v = sh->written[g].load()) == 0) { if (sh->aborted.load()) { v = -1; break; } usleep(200); }
+            if (v < 0) all_written = false;
+        }
+        if (!all_written) { if (code == 0) code = 2; }
         else {
             const auto t_written = std::chrono::steady_clock::now();
             std::cout << "The resulting BCR BWT was stored in " << args.output_file << std::endl;
@@ -232,7 +244,9 @@ static int run_multi_gpu(const arguments &args) {
     new (sh) SharedPage();
     sh->id_ready.store(0);
     sh->aborted.store(0);
-    for (int g = 0; g < 64; g++) sh->loaded[g].store(0);
+    for (int g = 0; g < 64; g++) { sh->loaded[g].store(0); sh->written[g].store(0); }
+    const std::string tmp_out = args.output_file + ".tmp~" + std::to_string((long)getpid());
+    unlink(tmp_out.c_str());
     const bool idx64 = n >= 0xFFFFFF00ull;       // (include/grlbwt_hip.h: 64-bit positions from 2^32 - 256 cells on)
     std::cout << std::flush;
     std::vector<pid_t> kids;
@@ -240,7 +254,7 @@ static int run_multi_gpu(const arguments &args) {
         pid_t pid = fork();                  // (this process has not touched the GPU: the children initialise HIP themselves)
         if (pid < 0) fail(2, "grlbwt: fork failed");
         if (pid == 0) {
-            int rc = rank_main(args, g, N, cut[g] * (uint64_t)w, (cut[g + 1] - cut[g]) * (uint64_t)w, idx64, sh);
+            int rc = rank_main(args, g, N, cut[g] * (uint64_t)w, (cut[g + 1] - cut[g]) * (uint64_t)w, idx64, sh, tmp_out);
             std::cout << std::flush;
             _exit(rc);
         }
@@ -283,7 +297,13 @@ static int run_multi_gpu(const arguments &args) {
             killed = true;
         }
     }
-    const int worst = first_bad;
+    int worst = first_bad;
+    // the ranks wrote their parts into the temporary: it becomes the output only when every one of them ended well
+    if (worst == 0 && rename(tmp_out.c_str(), args.output_file.c_str()) != 0) {
+        std::cerr << "grlbwt: cannot move the output into place: " << args.output_file << std::endl;
+        worst = 2;
+    }
+    if (worst != 0) unlink(tmp_out.c_str());
     return worst;
 }
 

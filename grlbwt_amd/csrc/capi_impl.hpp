@@ -469,14 +469,16 @@ void load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fx_flags, uint64_t *
 // thread lives for the whole image and writes the chunks in order as their copies land in a ring of pinned buffers; the device
 // copies (50+ GB/s) stay ahead of it.  (Before: a writer thread per 64 MiB chunk that started eight more: 0.97-1.17 s for the
 // 8.3 GB image of the 10 GB build.)
-void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
+// (part = true: the nb bytes go to offset file_off of `path` itself, created if needed and never truncated -- one of N ranks
+// writing one file, grlbwt_result_write_part; publishing the complete file is the caller's business)
+void write_image(const uint8_t *dev_image, uint64_t nb, const char *path, bool part = false, uint64_t file_off = 0) {
     // The image goes to <path>.tmp~<pid> and is renamed over the target once it is complete and closed (the reference renames
     // bwt_lev_0 to the output name, grl_bwt.hpp:77): an existing output stays intact until then, and a run that is killed or fails
     // leaves at most the temporary behind -- removed on every error path here.  What replacing an existing output costs is the
     // release of its cached pages inside rename() (~0.6 s for 8.3 GB).
     const double t_a = io_now();
-    const std::string tmp = std::string(path) + ".tmp~" + std::to_string((long)getpid());
-    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const std::string tmp = part ? std::string(path) : std::string(path) + ".tmp~" + std::to_string((long)getpid());
+    int fd = open(tmp.c_str(), part ? (O_WRONLY | O_CREAT) : (O_WRONLY | O_CREAT | O_TRUNC), 0644);
     if (fd < 0) throw prim::Error(GRLBWT_EINVAL, std::string("cannot open ") + tmp);
     constexpr int NBUF = 4;
     char *bufs[NBUF] = {nullptr, nullptr, nullptr, nullptr};
@@ -497,7 +499,7 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
     };
     try {
         const uint64_t chunk = nb < kIoChunk ? nb : kIoChunk;
-        if (nb && posix_fallocate(fd, 0, (off_t)nb) != 0 && ftruncate(fd, (off_t)nb) != 0) ok = false;
+        if (!part && nb && posix_fallocate(fd, 0, (off_t)nb) != 0 && ftruncate(fd, (off_t)nb) != 0) ok = false;
         const double t_b = io_now();
         auto body = [&] {
             prim::thread_attach();
@@ -514,7 +516,7 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
                 const double t0 = io_now();
                 try { prim::fence_wait(fences[k]); } catch (...) { ok = false; }
                 const double t1 = io_now();
-                if (ok && !par_io(fd, bufs[k], j.off, j.len, true, 1)) ok = false;
+                if (ok && !par_io(fd, bufs[k], file_off + j.off, j.len, true, 1)) ok = false;
                 t_wait_copy += t1 - t0; t_pwrite += io_now() - t1;
                 { std::lock_guard<std::mutex> g(mu); written++; }
                 cv.notify_all();
@@ -537,7 +539,7 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
                 cv.notify_all();
             } else {                                                          // (no writer thread: in line)
                 prim::fence_wait(fences[k]);
-                if (!par_io(fd, bufs[k], off, len, true, 1)) ok = false;
+                if (!par_io(fd, bufs[k], file_off + off, len, true, 1)) ok = false;
             }
         }
         {   // everything handed over: wait for the writer to drain
@@ -552,13 +554,13 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path) {
         try { prim::sync(); } catch (...) {}
         for (int k = 0; k < NBUF; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
         close(fd);
-        unlink(tmp.c_str());
+        if (!part) unlink(tmp.c_str());
         throw;
     }
     for (int k = 0; k < NBUF; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
     if (close(fd) != 0) ok = false;
-    if (ok && rename(tmp.c_str(), path) != 0) ok = false;
-    if (!ok) { unlink(tmp.c_str()); throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path); }
+    if (ok && !part && rename(tmp.c_str(), path) != 0) ok = false;
+    if (!ok) { if (!part) unlink(tmp.c_str()); throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path); }
 }
 
 // ---- primitive self-test (device vs host loops) -----------------------------
@@ -982,12 +984,23 @@ int grlbwt_result_device_ptr(const grlbwt_ctx *ctx, const void **dev_ptr) {
     return GRLBWT_OK;
 }
 int grlbwt_result_download(const grlbwt_ctx *ctx, void *host_out, uint64_t capacity) {
-    if (!HAS_ENG(ctx) || !host_out || ENG(ctx, image_bytes) == 0 || capacity < ENG(ctx, image_bytes)) return GRLBWT_EINVAL;
-    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { prim::d2h(host_out, ENG(ctx, image.p), ENG(ctx, image_bytes)); });
+    if (!HAS_ENG(ctx) || !host_out || ENG(ctx, image_bytes) == 0 || capacity < ENG(ctx, image_part_bytes)) return GRLBWT_EINVAL;
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { if (ENG(ctx, image_part_bytes)) prim::d2h(host_out, ENG(ctx, image.p), ENG(ctx, image_part_bytes)); });
 }
 int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path) {
     if (!HAS_ENG(ctx) || !path || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
+    if (ENG(ctx, image_part_bytes) != ENG(ctx, image_bytes)) return GRLBWT_EINVAL;      // (this context holds a part: grlbwt_result_write_part)
     return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { write_image(ENG(ctx, image.p), ENG(ctx, image_bytes), path); });
+}
+int grlbwt_result_part(const grlbwt_ctx *ctx, uint64_t *offset, uint64_t *bytes) {
+    if (!HAS_ENG(ctx) || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
+    if (offset) *offset = ENG(ctx, image_part_off);
+    if (bytes) *bytes = ENG(ctx, image_part_bytes);
+    return GRLBWT_OK;
+}
+int grlbwt_result_write_part(const grlbwt_ctx *ctx, const char *path) {
+    if (!HAS_ENG(ctx) || !path || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { write_image(ENG(ctx, image.p), ENG(ctx, image_part_bytes), path, true, ENG(ctx, image_part_off)); });
 }
 
 int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells) {
@@ -1135,11 +1148,13 @@ int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm) {
             grl32::Engine::Comm C;
             C.rank = comm->rank; C.size = comm->size; C.user = comm->user; C.ag = comm->allgather; C.a2a = comm->alltoallv;
             C.stream_ordered = (comm->flags & GRLBWT_COMM_STREAM_ORDERED) != 0;
+            C.keep_parts = (comm->flags & GRLBWT_COMM_KEEP_PARTS) != 0;
             ctx->e32->dist_build(C);
         } else {
             grl64::Engine::Comm C;
             C.rank = comm->rank; C.size = comm->size; C.user = comm->user; C.ag = comm->allgather; C.a2a = comm->alltoallv;
             C.stream_ordered = (comm->flags & GRLBWT_COMM_STREAM_ORDERED) != 0;
+            C.keep_parts = (comm->flags & GRLBWT_COMM_KEEP_PARTS) != 0;
             ctx->e64->dist_build(C);
         }
     });

@@ -2917,8 +2917,10 @@ class Engine {
     Runs bwt;                         // BWT of level `bwt_level`
     int bwt_level = -1;
     DBuf<u8> image;                   // .rl_bwt bytes (device)
-    u64 image_bytes = 0;
+    u64 image_bytes = 0;              // of the WHOLE image
     u64 image_runs = 0;
+    // what `image` holds: all of it, or (collection-level mode with Comm::keep_parts) the bytes [image_part_off, + image_part_bytes)
+    u64 image_part_off = 0, image_part_bytes = 0;
     bool keep_texts = false;          // debug/parity: keep every level's text
     std::vector<DBuf<u32>> kept_texts;
     std::vector<Runs> kept_bwts;      // debug/parity: BWT of every level (index = level)
@@ -3292,6 +3294,7 @@ class Engine {
         int (*ag)(void *, const void *, void *, u64) = nullptr;
         int (*a2a)(void *, const void *, const u64 *, const u64 *, void *, const u64 *, const u64 *) = nullptr;
         bool stream_ordered = false;      // callbacks enqueue on the engine's stream: no host synchronisation around them
+        bool keep_parts = false;          // the image stays where its runs were induced: no all-gather at the end (dist_finish)
         // bytes this rank sends to OTHER ranks, by exchange site (profiling builds: "@xfer:<site>" entries of the launch profile,
         // what tools/gpu_scale_projection.py prices the fabric with); named("...") tags the next exchange
         mutable const char *what = "unnamed";
@@ -4581,6 +4584,7 @@ class Engine {
         if (sb + fb <= 8 && fb < 8) prim::pack_records(bwt.R, RunRecordFn{bwt.sym.p, run_len(), sb}, sb + fb, image.p + 16, "pack_rl_bwt");
         else prim::for_each(bwt.R, PackRunsFn{bwt.sym.p, run_len(), sb, fb, image.p, 16u}, "pack_rl_bwt");
         image_runs = bwt.R;
+        image_part_off = 0; image_part_bytes = image_bytes;
         // "results are complete when a call returns" (include/grlbwt_hip.h): the image pointer may be handed to another
         // stream (torch, a copy engine) right after the build, so the engine's stream is drained here
         prim::sync();
@@ -5170,17 +5174,30 @@ class Engine {
         const u64 first = drop[me], Rm = R - first;
         if (extra[me]) prim::for_each(1, AddLenFn{bwt.len.p + (R - 1), extra[me]}, "pack_rl_bwt");
         const u32 sb = (u32)stats.sb, fb = (u32)stats.fb, rec = sb + fb;
-        DBuf<u8> part(Rm * rec);
-        prim::for_each(Rm, PackRunsFn{bwt.sym.p + first, RunLen{bwt.len.p + first, nullptr}, sb, fb, part.p, 0u}, "pack_rl_bwt");
+        u8 hdr[16] = {0};
+        for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
         std::vector<u64> cnt = C.allgather_u64({Rm * rec}), base(N + 1, 0);
         for (int g = 0; g < N; g++) base[g + 1] = base[g] + cnt[g];
         image_bytes = 16 + base[N];
         image_runs = base[N] / rec;
-        image.alloc(image_bytes);
-        u8 hdr[16] = {0};
-        for (int i = 0; i < 8; i++) { hdr[i] = (u8)((u64)sb >> (8 * i)); hdr[8 + i] = (u8)((u64)fb >> (8 * i)); }
-        prim::h2d(image.p, hdr, 16);
-        C.named("image.parts").allgather_v<u8>(part.p, Rm * rec, base, true, image.p + 16);
+        if (C.keep_parts) {
+            // The image stays in parts (Comm::keep_parts): my runs are bytes [16 + base[me], 16 + base[me + 1]) of it, rank 0's part
+            // starts with the header.  Nothing crosses the fabric -- every rank sends its part to N - 1 peers otherwise, 13 GB per
+            // rank of the 10 GB collection's 8.3 GB image at N = 8 -- and N ranks write one file at N offsets (grlbwt_result_write_part).
+            const u64 h = me == 0 ? 16 : 0;
+            image_part_off = me == 0 ? 0 : 16 + base[me];
+            image_part_bytes = h + Rm * rec;
+            image.alloc(image_part_bytes);
+            if (h) prim::h2d(image.p, hdr, 16);
+            prim::for_each(Rm, PackRunsFn{bwt.sym.p + first, RunLen{bwt.len.p + first, nullptr}, sb, fb, image.p + h, 0u}, "pack_rl_bwt");
+        } else {
+            DBuf<u8> part(Rm * rec);
+            prim::for_each(Rm, PackRunsFn{bwt.sym.p + first, RunLen{bwt.len.p + first, nullptr}, sb, fb, part.p, 0u}, "pack_rl_bwt");
+            image.alloc(image_bytes);
+            prim::h2d(image.p, hdr, 16);
+            C.named("image.parts").allgather_v<u8>(part.p, Rm * rec, base, true, image.p + 16);
+            image_part_off = 0; image_part_bytes = image_bytes;
+        }
         stats.n_strings = g_n_strings;
         stats.n_syms = g_n_syms;
         linfo[0].R = image_runs;

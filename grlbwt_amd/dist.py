@@ -26,6 +26,7 @@ class CommStruct(C.Structure):
 
 
 COMM_STREAM_ORDERED = 1
+COMM_KEEP_PARTS = 2          # the image stays in parts on the ranks that induced them (include/grlbwt_hip.h)
 
 
 class _DevView:
@@ -178,17 +179,22 @@ def agree_or_raise(err, device, group=None):
         raise engine.GrlbwtError(-22, "another rank rejected its shard")
 
 
-def dist_build(ctx, comm):
-    """Run the collection-level build on a context that already holds this rank's shard."""
+def dist_build(ctx, comm, keep_parts=False):
+    """Run the collection-level build on a context that already holds this rank's shard.  keep_parts: the image is not
+    gathered; every rank keeps its part (ctx.result_part(), ctx.write_part(path))."""
     L = ctx.L
     comm.attach(ctx)
+    comm.struct.flags = (comm.struct.flags & ~COMM_KEEP_PARTS) | (COMM_KEEP_PARTS if keep_parts else 0)
     L.grlbwt_dist_build.argtypes = [C.c_void_p, C.POINTER(CommStruct)]
     ctx._ck(L.grlbwt_dist_build(ctx._h, C.byref(comm.struct)))
 
 
-def grl_bwt_algo_sharded(shard, cell_bytes=1, device="cpu", lib=None, flags=0, group=None, comm_out=None):
+def grl_bwt_algo_sharded(shard, cell_bytes=1, device="cpu", lib=None, flags=0, group=None, comm_out=None, keep_parts=False,
+                         part_file=None):
     """BCR BWT (.rl_bwt bytes) of the whole collection whose rank-th record shard is `shard`.
-    Every rank returns the same bytes."""
+    Every rank returns the same bytes -- or, with keep_parts, (offset, part bytes, image bytes): its part of the image, which
+    it also writes at that offset of `part_file` if one is named (the caller removes a stale file first; the file is complete
+    once every rank has returned)."""
     dev = torch.device(device)
     comm = Communicator(dev, group)
     if comm_out is not None:
@@ -209,5 +215,9 @@ def grl_bwt_algo_sharded(shard, cell_bytes=1, device="cpu", lib=None, flags=0, g
         except engine.GrlbwtError as e:
             err = e
         agree_or_raise(err, dev, group)
-        dist_build(ctx, comm)
+        dist_build(ctx, comm, keep_parts)
+        if keep_parts:
+            if part_file is not None:
+                ctx.write_part(part_file)
+            return ctx.result_part()[0], ctx.result_bytes(), ctx.result_size()[0]
         return ctx.result_bytes()

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "grlbwt_rccl_comm_destroy", "grlbwt_fastx_probe", "grlbwt_text_load_fastx", "grlbwt_fastx_convert_device", "grlbwt_text_attach_device", "grlbwt_get_stats",
     "grlbwt_parse_round", "grlbwt_parse_phase", "grlbwt_round_info_get", "grlbwt_induce_first",
     "grlbwt_induce_level", "grlbwt_induce_phase", "grlbwt_level_info_get", "grlbwt_build", "grlbwt_result_size",
-    "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_level_text_size",
+    "grlbwt_result_device_ptr", "grlbwt_result_download", "grlbwt_result_write_file", "grlbwt_result_part", "grlbwt_result_write_part", "grlbwt_level_text_size",
     "grlbwt_level_text_download", "grlbwt_level_bwt_size", "grlbwt_level_bwt_download", "grlbwt_get_counters",
     "grlbwt_selftest", "grlbwt_profile_enable", "grlbwt_profile_dump", "grlbwt_dist_build", "grlbwt_memory_usage", "grlbwt_invert_image", "grlbwt_invert_image_tails",
     "grlbwt_image_plain", "grlbwt_image_rle", "grlbwt_image_stats_get", "grlbwt_image_split_runs",
@@ -157,6 +157,8 @@ def load_library(path=None, allow_test_standin=False):
     L.grlbwt_result_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.grlbwt_result_download.argtypes = [vp, vp, u64]
     L.grlbwt_result_write_file.argtypes = [vp, C.c_char_p]
+    L.grlbwt_result_part.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.grlbwt_result_write_part.argtypes = [vp, C.c_char_p]
     L.grlbwt_level_text_size.argtypes = [vp, i32, C.POINTER(u64)]
     L.grlbwt_level_text_download.argtypes = [vp, i32, vp]
     L.grlbwt_level_bwt_size.argtypes = [vp, i32, C.POINTER(u64)]
@@ -305,14 +307,26 @@ class Context:
         self._ck(self.L.grlbwt_result_device_ptr(self._h, C.byref(p)))
         return p.value
 
+    def result_part(self):
+        """(offset, bytes) of what this context holds of the image: all of it, or this rank's part (collection-level build
+        with dist.COMM_KEEP_PARTS)."""
+        off, nb = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.grlbwt_result_part(self._h, C.byref(off), C.byref(nb)))
+        return off.value, nb.value
+
     def result_bytes(self):
-        nb, _ = self.result_size()
-        out = (C.c_uint8 * nb)()
+        """The image bytes this context holds (result_part)."""
+        _, nb = self.result_part()
+        out = (C.c_uint8 * max(nb, 1))()
         self._ck(self.L.grlbwt_result_download(self._h, out, nb))
-        return bytes(out)
+        return bytes(out)[:nb]
 
     def write_file(self, path):
         self._ck(self.L.grlbwt_result_write_file(self._h, os.fsencode(path)))
+
+    def write_part(self, path):
+        """This context's part at its offset of `path` (created if missing, never truncated)."""
+        self._ck(self.L.grlbwt_result_write_part(self._h, os.fsencode(path)))
 
     # ---- inspection --------------------------------------------------------
     def level_text(self, lvl):

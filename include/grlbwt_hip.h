@@ -179,6 +179,13 @@ int grlbwt_result_device_ptr(const grlbwt_ctx *ctx, const void **dev_ptr);
 int grlbwt_result_download(const grlbwt_ctx *ctx, void *host_out, uint64_t capacity);
 /* (pinned double-buffered download, the file is written while the next chunk comes down) */
 int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path);
+/* What this context holds of the image: all of it -- (0, image_bytes) -- after grlbwt_build and grlbwt_dist_build, or this
+ * rank's part after a grlbwt_dist_build with GRLBWT_COMM_KEEP_PARTS (bytes may be 0 on a rank whose slice merged into a
+ * neighbour's run). */
+int grlbwt_result_part(const grlbwt_ctx *ctx, uint64_t *offset, uint64_t *bytes);
+/* The part at its offset of `path` (created if missing, never truncated: the caller removes a stale file first and publishes
+ * the complete one -- a barrier and a rename -- once every rank has returned; the grlbwt executable's --gpus does). */
+int grlbwt_result_write_part(const grlbwt_ctx *ctx, const char *path);
 
 /* ---- .rl_bwt consumers: scripts/grl2plain.cpp (expand the runs) + scripts/reverse_bwt.cpp with
  * scripts/fm_index.h:79-83 (LF walk), on the device.  Rebuilds the collection (strings in input order,
@@ -276,6 +283,13 @@ typedef struct grlbwt_comm {
     uint32_t flags;
 } grlbwt_comm;
 #define GRLBWT_COMM_STREAM_ORDERED 1u
+/* GRLBWT_COMM_KEEP_PARTS: the image is NOT gathered at the end of the build; every rank keeps the part whose runs it induced --
+ * bytes [offset, offset + bytes) of the image (grlbwt_result_part; rank 0's part starts with the 16-byte header), the parts in
+ * rank order make up the file.  grlbwt_result_size still reports the whole image, grlbwt_result_device_ptr /
+ * grlbwt_result_download give the part, grlbwt_result_write_part puts it at its offset of the output file: N ranks write one
+ * file, nothing of the image crosses the fabric.  (The reference's writer is one stream: exact_ind_phase.cpp:287-361 fills
+ * bwt_lev_0 front to back; the counterpart of its N threads here is N writers.) */
+#define GRLBWT_COMM_KEEP_PARTS 2u
 /* grl_bwt_algo over the sharded collection: par_phase with a dictionary merge per round, ind_phase, image */
 int grlbwt_dist_build(grlbwt_ctx *ctx, const grlbwt_comm *comm);
 

@@ -148,6 +148,29 @@ def main():
     shard = gdist.shard_records(data, rank, world)
     flags = engine.FLAG_FORCE_IDX64 if case == "repetitive" else 0
     comms = []
+    if os.environ.get("GRLBWT_TEST_KEEP_PARTS"):
+        # the image stays in parts: every rank writes its part at its offset of ONE file (grlbwt_result_write_part); the parts
+        # must tile the image
+        path = os.path.join(out_dir, case + ".rl_bwt")
+        if rank == 0 and os.path.exists(path):
+            os.remove(path)
+        dist.barrier()
+        off, part, total = gdist.grl_bwt_algo_sharded(shard.tobytes(), w, device, lib, flags, comm_out=comms, keep_parts=True, part_file=path)
+        spans = [None] * world
+        dist.all_gather_object(spans, (off, len(part)))
+        if rank == 0:
+            pos = 0
+            for o, n in spans:
+                assert o == pos or n == 0, spans
+                pos += n
+            assert pos == total and os.path.getsize(path) == total, (spans, total)
+            with open(os.path.join(out_dir, case + ".input"), "wb") as f:
+                f.write(data.tobytes())
+            with open(os.path.join(out_dir, case + ".a2a"), "w") as f:
+                f.write("%d %d" % (comms[0].n_allgather, comms[0].bytes_moved))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     out = gdist.grl_bwt_algo_sharded(shard.tobytes(), w, device, lib, flags, comm_out=comms)
     with open(os.path.join(out_dir, "%s.rank%d.md5" % (case, rank)), "w") as f:
         f.write(hashlib.md5(out).hexdigest())

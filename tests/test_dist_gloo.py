@@ -279,3 +279,14 @@ def test_sharded_dictionary_beyond_32_bit_positions(sim, oracle_mod, tmp_path, m
     _run(3, sim, "injected", tmp_path, 29646)
     assert [open(tmp_path / ("injected.rank%d" % r)).read() for r in range(3)] == ["raised -75"] * 3
 
+
+def test_image_kept_in_parts(sim, oracle_mod, tmp_path, monkeypatch):
+    """GRLBWT_COMM_KEEP_PARTS: no all-gather of the image; every rank holds the part whose runs it induced and writes it at its
+    offset of one file (grlbwt_result_part / grlbwt_result_write_part).  The parts tile the image (checked in the worker) and
+    the file equals the oracle's -- also where slices are single runs that merge into a neighbour's (parts of zero bytes)."""
+    monkeypatch.setenv("GRLBWT_TEST_KEEP_PARTS", "1")
+    for world, kind, w, port in ((3, "reads", 1, 29660), (4, "tokens", 2, 29662), (4, "samechar", 1, 29664), (3, "tiny", 1, 29666)):
+        _run(world, sim, kind, tmp_path, port)
+        data = open(tmp_path / ("%s.input" % kind), "rb").read()
+        assert open(tmp_path / ("%s.rl_bwt" % kind), "rb").read() == oracle_mod.rl_bwt(data, w)
+
