@@ -268,6 +268,26 @@ struct HashInsertFn {
     const u64 *hot_keys = nullptr;
     u64 hot_mask = 0;
     u32 slot_base = 0;
+    // DIRECT INDEX (byte texts with at most 8 distinct cell values -- DNA reads: A C G T N and the separator): three bits of a cell
+    // tell the values apart (dir_b0 < dir_b1 < dir_b2, found on the host from the byte histogram), so a phrase of <= 7 cells IS a
+    // number below 2^22 -- its cells' 3-bit codes, a 1 above them for the length -- and that number is its slot: no hash, no
+    // probe, no key compare, no claim.  Slots [0, kDirectSlots) in front of the table (slot_base), like the hot table this
+    // replaces.  The representative position of a slot is whatever occurrence wrote dir_rep[] last (first_seen: once per
+    // workgroup and slot, from the LDS count cache); DirectFixFn makes key, claim bit and so the dictionary entry afterwards.
+    // (parsing_strategies.h:82-145 hashes every phrase.)
+    static constexpr u32 kDirectSlots = 1u << 22;
+    u32 dir_on = 0, dir_b0 = 0, dir_b1 = 0, dir_b2 = 0;
+    u64 *dir_rep = nullptr;
+    GRL_DEV u32 direct_index(u64 chunk, u32 len) const {      // chunk = the phrase's cells in its low bytes, len <= 7
+        const u64 ones = 0x0101010101010101ull;
+        const u64 c = ((chunk >> dir_b0) & ones) | (((chunk >> dir_b1) & ones) << 1) | (((chunk >> dir_b2) & ones) << 2);
+        const u32 lo = (u32)c, hi = (u32)(c >> 32);
+        const u32 plo = (lo & 7u) | ((lo >> 5) & 0x38u) | ((lo >> 10) & 0x1C0u) | ((lo >> 15) & 0xE00u);
+        const u32 phi = (hi & 7u) | ((hi >> 5) & 0x38u) | ((hi >> 10) & 0x1C0u) | ((hi >> 15) & 0xE00u);
+        const u32 top = 1u << (3u * len);
+        return ((plo | (phi << 12)) & (top - 1u)) | top;
+    }
+    GRL_DEV void first_seen(u32 slot, u64 item) const { if (dir_on && slot < kDirectSlots) dir_rep[slot] = item; }
     // partitioned naming (see "phrase records"): with rec_h set, a phrase of <= rec_cmax cells leaves a record at its ordinal and
     // does NOT touch the table; longer ones take the table as before and mark their slot entry with kLongMark
     u32 *rec_h = nullptr; prim::U128 *rec_v = nullptr; int rec_b = 0; u32 rec_cmax = 0;
@@ -477,6 +497,8 @@ struct HashInsertFn {
                 u64 content = 0;
                 for (u64 j = 0; j < len; j++) content |= (u64)t[p + j] << (8 * j);
                 const u64 mine = kExactKey | (len << 60) | content;
+                if (dir_on) found = direct_index(content, (u32)len);
+                else
                 found = insert_exact(mine, p, exact_hash(mine) & (hot_keys ? hot_mask : mask), 0, false);
             } else found = find_or_insert(p, len, use_giant ? PhraseHash{(u32)(*giant_acc >> 32), (u32)*giant_acc}.finish(len) : ph.finish(len), ops.isT(t[e]));
             if (found != prim::kNoBucket) out_slot[ord] = (found & ~prim::kClaimBit) | (pack ? kLongMark : 0u);
@@ -518,18 +540,25 @@ struct HashInsertFn {
             const u32 len = e + 1;
             fast[j] = fast[j] && len <= 7;
             const u64 content = chunk[j] & ((1ull << (8 * len)) - 1ull);
+            if (dir_on) {                                                // (uniform) the phrase's number is its slot
+                mine[j] = 0; cur[j] = 0;
+                idx[j] = (u64)direct_index(chunk[j], len <= 7 ? len : 0u);
+            } else {
             mine[j] = kExactKey | ((u64)len << 60) | content;
             idx[j] = exact_hash(mine[j]) & (hot_keys ? hot_mask : mask);
+            }
         }
+        if (!dir_on) {
 #pragma unroll
         for (int j = 0; j < B; j++) cur[j] = hot_keys ? hot_keys[fast[j] ? idx[j] : 0] : prim::load_relaxed(&keys[(fast[j] ? idx[j] : 0) << ks]);
+        }
 #pragma unroll
         for (int j = 0; j < B; j++) {
             // (no continue/break/return inside divergent code here: see the note in find_or_insert)
             const u64 p = item[j];
             const bool ex = valid[j] && fast[j];
             u32 found = prim::kNoBucket;
-            if (ex) found = insert_exact(mine[j], p, idx[j], cur[j], true);
+            if (ex) found = dir_on ? (u32)idx[j] : insert_exact(mine[j], p, idx[j], cur[j], true);
             if (ex && found != prim::kNoBucket) {
                 const u64 ord = (u64)wb[j] + (u64)__builtin_popcountll(wp[j] & ((1ull << (p & 63)) - 1ull));
                 if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; found = prim::kNoBucket; }
@@ -624,6 +653,22 @@ struct HashInsertFn {
 struct SlotCountAdd {
     idx_t *counts; u64 cs;     // count of slot s at counts[s * cs]
     GRL_DEV void operator()(u32 slot, u32 c) const { prim::atomic_add(&counts[(u64)slot * cs], (idx_t)c); }
+};
+// Direct index, afterwards: one lane per slot of the direct region; a slot that counted occurrences becomes a table entry like
+// the claimed ones -- the exact key rebuilt from the slot number (sym_of_code: the cell value of every 3-bit code), the claim bit
+// at its representative's position -- so that the dictionary is compacted from the claim bits as for every other phrase.
+struct DirectFixFn {
+    const idx_t *counts; u64 *keys; const u64 *rep; u64 *claim_bits; u64 sym_of_code;      // (byte c of sym_of_code = cell value of code c)
+    GRL_DEV void operator()(u64 s) const {
+        if (s >= 8 && counts[s] != 0) {
+            const u32 len = (u32)((63 - __builtin_clzll(s)) / 3);
+            u64 content = 0;
+            for (u32 j = 0; j < len; j++) content |= ((sym_of_code >> (8 * ((s >> (3 * j)) & 7ull))) & 0xFFull) << (8 * j);
+            keys[s] = kExactKey | ((u64)len << 60) | content;
+            const u64 p = rep[s];
+            prim::atomic_or(&claim_bits[p >> 6], 1ull << (p & 63));
+        }
+    }
 };
 struct NoCountAdd {            // (experiments: the hashing pass without its count atomics)
     GRL_DEV void operator()(u32, u32) const {}
@@ -2917,6 +2962,8 @@ class Engine {
     Runs bwt;                         // BWT of level `bwt_level`
     int bwt_level = -1;
     DBuf<u8> image;                   // .rl_bwt bytes (device)
+    u64 sym_present[4] = {0, 0, 0, 0};  // byte texts: the cell values that occur in MY text (stats_t)
+    bool sym_present_known = false;
     u64 image_bytes = 0;              // of the WHOLE image
     u64 image_runs = 0;
     // what `image` holds: all of it, or (collection-level mode with Comm::keep_parts) the bytes [image_part_off, + image_part_bytes)
@@ -2940,6 +2987,9 @@ class Engine {
             mx = 255; while (h[mx] == 0) mx--;
             F = 0; for (int i = 0; i < 256; i++) if (h[i] > F) F = h[i];      // utils.cpp:161-175
             stats.n_strings = h[(u64)sep];
+            for (int i = 0; i < 4; i++) sym_present[i] = 0;
+            for (int i = 0; i < 256; i++) if (h[i]) sym_present[i >> 6] |= 1ull << (i & 63);
+            sym_present_known = true;
         } else {
             mn = prim::reduce_min<u64>(n, CellIn<cell_t>{t}, "stats.min");
             mx = prim::reduce_max<u64>(n, CellIn<cell_t>{t}, "stats.max");
@@ -3122,7 +3172,9 @@ class Engine {
         DBuf<idx_t> counts;
         // LDS pre-aggregation of the counts pays when few distinct phrases take most occurrences (level 0 of
         // DNA: 20 k phrases, 30 M occurrences); with mostly-distinct phrases the cache only thrashes.
-        const bool aggregate = frac < 0.25;
+        // (GRLBWT_FORCE_DIRECT_INDEX=1: the tests take the direct index -- below -- on texts too small for a sample)
+        const bool force_direct = HashInsertFn<cell_t, FIRST>::kExact && !part && getenv("GRLBWT_FORCE_DIRECT_INDEX") != nullptr;
+        const bool aggregate = frac < 0.25 || force_direct;
         // Table layout.  With few hot phrases the keys stay on lines of their own (the atomics on a hot count would keep
         // invalidating the key every probe reads: measured 4x slower interleaved).  With mostly-distinct phrases every
         // occurrence fetches a random key AND a random count: 16-byte (key, count) slots make that one line.
@@ -3136,6 +3188,32 @@ class Engine {
         u64 cap_hot = 0;
         DBuf<prim::U128> rec_v, rec_v2;
         if (part) { P.rec_h.alloc(n_occ); rec_v.alloc(n_occ); }
+        // Direct index instead (HashInsertFn::direct_index): byte texts with at most 8 distinct cell values, told apart by three of
+        // their bits.  GRLBWT_NO_DIRECT_INDEX=1 keeps the hot table.
+        bool direct = false;
+        u32 dir_b[3] = {0, 0, 0};
+        u64 sym_of_code = 0;
+        if (HashInsertFn<cell_t, FIRST>::kExact && aggregate && (s_n || force_direct) && !part && sym_present_known && !getenv("GRLBWT_NO_DIRECT_INDEX")) {
+            int syms[256], ns = 0;
+            for (int i = 0; i < 256; i++) if ((sym_present[i >> 6] >> (i & 63)) & 1ull) syms[ns++] = i;
+            for (u32 a = 0; a < 8 && !direct && ns <= 8; a++) for (u32 b = a + 1; b < 8 && !direct; b++) for (u32 c = b + 1; c < 8 && !direct; c++) {
+                u32 seen = 0; bool ok = true; u64 soc = 0;
+                for (int k = 0; k < ns && ok; k++) {
+                    const u32 code = ((syms[k] >> a) & 1u) | (((syms[k] >> b) & 1u) << 1) | (((syms[k] >> c) & 1u) << 2);
+                    if (seen & (1u << code)) ok = false;
+                    seen |= 1u << code;
+                    soc |= (u64)syms[k] << (8 * code);
+                }
+                if (ok) { direct = true; dir_b[0] = a; dir_b[1] = b; dir_b[2] = c; sym_of_code = soc; }
+            }
+        }
+        if (direct) {
+            cap_hot = HashInsertFn<cell_t, FIRST>::kDirectSlots;
+            if (cap_max > (1ull << 30)) cap_max = 1ull << 30;             // slot ids of both regions stay below 2^31
+            if (cap > cap_max) cap = cap_max;
+            if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: direct index on bits %u, %u, %u of a cell (%llu slots in front of the table)\n", prim::rt().tag,
+                                                      dir_b[0], dir_b[1], dir_b[2], (unsigned long long)cap_hot);
+        } else
         if (aggregate && s_n && !part && !getenv("GRLBWT_NO_HOT_TABLE")) {
             cap_hot = 1024;
             while (cap_hot < 4 * s_distinct) cap_hot <<= 1;               // load <= 0.25: short probe chains
@@ -3166,7 +3244,8 @@ class Engine {
                      P.next_text.p, scal.p, n, n_occ, rep_pos.p ? rep_pos.p + cap_hot : nullptr, claim.p};
                 if (part) { f.rec_h = P.rec_h.p; f.rec_v = rec_v.p; f.rec_b = rec_b; f.rec_cmax = rec_cmax; }
                 f.giant_list = giant_list.p; f.giant_n = scal.p + 4; f.giant_cap = (u32)std::min<u64>(giant_cap, 0xFFFFFFFFull);
-                if (cap_hot) {
+                if (direct) { f.dir_on = 1; f.dir_b0 = dir_b[0]; f.dir_b1 = dir_b[1]; f.dir_b2 = dir_b[2]; f.dir_rep = rep_pos.p; f.slot_base = (u32)cap_hot; }
+                else if (cap_hot) {
                     HF fh{t, ops, startbits.p, wordbase.p, keys.p, cap_hot - 1, cap_hot, 0, P.next_text.p, scal.p, n, n_occ, rep_pos.p, claim.p};
                     fh.walk_cap = HF::kLongWalk;            // (a phrase of thousands of cells has no business in the hot table: the pass over the text
                                                             // would find it there and compare it cell by cell with itself)
@@ -3212,6 +3291,7 @@ class Engine {
                 }
                 if (sc[1]) throw prim::Error(-71, "phrase hashing: consistency check " + std::to_string(sc[1]) + " failed (" +
                                                        std::to_string(sc[2]) + ", " + std::to_string(sc[3]) + ")");
+                if (direct) prim::for_each(cap_hot, DirectFixFn{counts_p, keys.p, rep_pos.p, claim.p, sym_of_code}, "hash_direct_fix");
                 break;
             }
         }

@@ -862,6 +862,12 @@ GRL_DEV u32 agg_take_claim(const F &f, u32 s, u64 item, bool valid) {
     }
     return s;
 }
+// f.first_seen(bucket, item), for functors that have one: called for (at least) one item of every bucket a workgroup counts --
+// when the bucket enters the workgroup's LDS count cache, or for every item that goes past the cache
+template <class F>
+GRL_DEV auto agg_first_seen(const F &f, u32 s, u64 item, int) -> decltype(f.first_seen(s, item), void()) { f.first_seen(s, item); }
+template <class F>
+GRL_DEV void agg_first_seen(const F &, u32, u64, long) {}
 template <int SLOTS, bool AGG, class F, class A>
 __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F f, A add) {
     __shared__ u32 c_key[AGG ? SLOTS : 1];
@@ -889,18 +895,18 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
     volatile u32 *defer = s_defer[w];
     u64 start = (u64)blockIdx.x * per_block;
     u64 end = start + per_block < n ? start + per_block : n;
-    auto count = [&](u32 s) {
+    auto count = [&](u32 s, u64 item) {
         if (s != kNoBucket) {                 // (nested, no early return: see the compiler note in engine_impl.hpp)
             if (AGG) {
                 u32 h = (s * 2654435761u) >> (32 - __builtin_ctz(SLOTS));
                 bool done = false;
                 for (int p = 0; p < 4 && !done; p++) {
                     u32 old = atomicCAS(&c_key[h], kNoBucket, s);
-                    if (old == kNoBucket || old == s) { atomicAdd(&c_cnt[h], 1u); done = true; }
+                    if (old == kNoBucket || old == s) { atomicAdd(&c_cnt[h], 1u); done = true; if (old == kNoBucket) agg_first_seen(f, s, item, 0); }
                     else h = (h + 1) & (SLOTS - 1);
                 }
-                if (!done) add(s, 1u);
-            } else add(s, 1u);
+                if (!done) { add(s, 1u); agg_first_seen(f, s, item, 0); }
+            } else { add(s, 1u); agg_first_seen(f, s, item, 0); }
         }
     };
     if constexpr (BATCH) {
@@ -913,7 +919,7 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 const u64 it = start + (v ? defer[k & (DCAP - 1)] : 0u);
                 if (v) s = f.process(it);
                 s = agg_take_claim(f, s, it, v);
-                if (v) count(s);
+                if (v) count(s, it);
                 dh = dt - dh >= 64u ? dh + 64u : dt;
             }
         };
@@ -936,7 +942,7 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                     const unsigned long long m = __ballot(df);
                     if (df) defer[(dt + (u32)__popcll(m & ((1ull << lane) - 1ull))) & (DCAP - 1)] = (u32)(item[j] - start);
                     dt += (u32)__popcll(m);
-                    if (valid[j] && !df) count(slot[j]);
+                    if (valid[j] && !df) count(slot[j], item[j]);
                 }
                 qh = qt - qh >= 64u * F::kBatch ? qh + 64u * F::kBatch : qt;
                 run_deferred(false);
@@ -979,7 +985,7 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                 u32 s = kNoBucket;
                 if (v) s = f.process(it);
                 s = agg_take_claim(f, s, it, v);
-                if (v) count(s);
+                if (v) count(s, it);
             }
         }
     }
@@ -1005,6 +1011,7 @@ struct NoAggFn {
                 }
             }
             add(s, 1u);
+            agg_first_seen(f, s, i, 0);
         }
     }
 };

@@ -140,6 +140,10 @@ inline void for_each_giant(u64 n_items, const u64 *items, F f, A add, const char
         }
     }
 }
+template <class F>
+inline auto agg_first_seen(const F &f, u32 s, u64 item, int) -> decltype(f.first_seen(s, item), void()) { f.first_seen(s, item); }
+template <class F>
+inline void agg_first_seen(const F &, u32, u64, long) {}
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
     if constexpr (F::kBatch > 1) {       // the functor's batched form (what the HIP kernel calls), kBatch work items at a time
@@ -153,7 +157,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             for (int j = 0; j < k; j++) {
                 slot[j] = agg_take_claim(f, slot[j], item[j]);
                 if (slot[j] == kDeferBucket) slot[j] = agg_take_claim(f, f.process(item[j]), item[j]);       // (the HIP kernel queues these up)
-                if (slot[j] != kNoBucket) add(slot[j], 1u);
+                if (slot[j] != kNoBucket) { add(slot[j], 1u); agg_first_seen(f, slot[j], item[j], 0); }
             }
             k = 0;
         };
@@ -161,7 +165,7 @@ inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
             if (f.is_start(i)) { item[k] = i; valid[k] = true; if (++k == F::kBatch) flush(); }
         if (k) flush();
     } else {
-        for (u64 i = 0; i < n; i++) { u32 s = agg_take_claim(f, f(i), i); if (s != kNoBucket) add(s, 1u); }
+        for (u64 i = 0; i < n; i++) { u32 s = agg_take_claim(f, f(i), i); if (s != kNoBucket) { add(s, 1u); agg_first_seen(f, s, i, 0); } }
     }
 }
 // stage clocks: host wall time here (the HIP runtime uses event pairs on its stream)

@@ -318,10 +318,15 @@ def test_table_sizing_from_a_sample(sim, oracle_mod, capfd, monkeypatch):
     assert len(data) > (1 << 20)
     parity.check_final(sim, data, 1)
     err = capfd.readouterr().err
-    assert "table" in err and "hot table of" in err              # few phrases dominate: they get the small dense table in front
+    assert "table" in err and "direct index on bits" in err      # at most 8 distinct cell values: phrases of <= 7 cells are their own slot number
+    monkeypatch.setenv("GRLBWT_NO_DIRECT_INDEX", "1")
+    parity.check_final(sim, data, 1)
+    err = capfd.readouterr().err
+    assert "hot table of" in err                                 # ... otherwise, few phrases dominate: they get the small dense table in front
     monkeypatch.setenv("GRLBWT_NO_HOT_TABLE", "1")
     parity.check_final(sim, data, 1)
     monkeypatch.delenv("GRLBWT_NO_HOT_TABLE")
+    monkeypatch.delenv("GRLBWT_NO_DIRECT_INDEX")
     rep = (b"ACGTTGCA" * 16 + b"\n") * 6000
     parity.check_final(sim, rep + workloads.uniform_reads(6000, 100, seed=77).tobytes(), 1)
 
@@ -364,3 +369,28 @@ def test_partitioned_phrase_naming(sim, oracle_mod, monkeypatch, capfd):
     monkeypatch.setenv("GRLBWT_TABLE_TRACE", "1")
     parity.check_stagewise(sim, workloads.sampled_reads(3000, 100, 20000, seed=12).tobytes(), 1)
     assert "falling back to the hash table" in capfd.readouterr().err
+
+
+def test_direct_index_of_short_phrases(sim, oracle_mod, monkeypatch):
+    """Byte texts with at most 8 distinct cell values: a phrase of <= 7 cells is named by its own number (three bits per cell,
+    HashInsertFn::direct_index) -- no table.  Forced on texts too small for a sample, stage by stage against the oracle: DNA with
+    N, an alphabet whose codes need non-adjacent bits, exactly 8 values, phrases of every length around 7 and at the very end of the
+    text (the walk path must give the same slot as the batch path); 9 values fall back to the table."""
+    monkeypatch.setenv("GRLBWT_FORCE_DIRECT_INDEX", "1")
+    rng = np.random.default_rng(5)
+    dna = workloads.sampled_reads(3000, 100, 20000, seed=11).copy()
+    dna[rng.integers(0, dna.size, size=300)] = ord("N")
+    dna[dna.size - 1] = 10
+    dna[np.flatnonzero(workloads.sampled_reads(3000, 100, 20000, seed=11) == 10)] = 10
+    parity.check_stagewise(sim, dna.tobytes(), 1)
+    # (values told apart by bits 0, 3, 6 -- all 8 codes in use; by bits 1, 4, 7; three values; 9 values: no direct index;
+    # 8 one-hot values: no three bits tell them apart, no direct index either)
+    for alphabet in (bytes([0, 1, 8, 9, 64, 65, 72, 73]), bytes([0x20, 0x22, 0x30, 0x32, 0xA0, 0xA2]), b"\x00ab", bytes(range(10, 19)),
+                     bytes([1, 2, 4, 8, 16, 32, 64, 128])):
+        vals = np.frombuffer(alphabet, dtype=np.uint8)
+        body = vals[1:][rng.integers(0, len(vals) - 1, size=40000)]
+        body[rng.integers(0, body.size, size=700)] = vals[0]
+        text = np.concatenate([body, vals[:1]])
+        parity.check_stagewise(sim, text.tobytes(), 1)
+    parity.check_final(sim, b"ACGTACG\nACGTACGT\nAC\nA\n\nACGTAC\nGATTACA\n", 1)
+
