@@ -505,8 +505,17 @@ struct HashInsertFn {
         }
         return found;
     }
-    GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const { process_batch_exact(item, valid, slot); }
-    GRL_DEV void process_batch_exact(const u64 *item, const bool *valid, u32 *slot) const {
+    GRL_DEV void process_batch(const u64 *item, const bool *valid, u32 *slot) const { process_batch_exact<false>(item, valid, slot, nullptr, nullptr); }
+    // the streaming form (prim::k_for_each_agg, STREAM): the kernel hands over the next phrase start and the ordinal of every
+    // item -- no start-bit window, no rank lookup: ONE load per phrase (its cells) where the form above has five
+    static constexpr bool kStream = kExact;
+    GRL_DEV u64 ordinal_base(u64 p) const { return (u64)wordbase[p >> 6]; }               // (p a multiple of 64)
+    GRL_DEV u64 next_item(u64 p) const { return next_set_bit(startbits, p + 1, n); }
+    GRL_DEV void process_batch_stream(const u64 *item, const bool *valid, u32 *slot, const u64 *next, const u64 *ord) const {
+        process_batch_exact<true>(item, valid, slot, next, ord);
+    }
+    template <bool STREAM>
+    GRL_DEV void process_batch_exact(const u64 *item, const bool *valid, u32 *slot, const u64 *next, const u64 *ordv) const {
         constexpr int B = kBatch;
         u64 chunk[B], wp[B], w0[B], w1[B], mine[B], idx[B], cur[B];
         idx_t wb[B];
@@ -518,24 +527,32 @@ struct HashInsertFn {
             fast[j] = valid[j] && can && p + 8 <= n;
             const u64 pp = fast[j] ? p : 0;
             chunk[j] = can ? load8(t + pp) : 0ull;
+            if constexpr (!STREAM) {
             wp[j] = startbits[pp >> 6];
             const u64 b1 = (pp + 1) >> 6;
             w0[j] = startbits[b1];
             w1[j] = startbits[b1 + 1];
             wb[j] = wordbase[pp >> 6];
+            } else { wp[j] = w0[j] = w1[j] = 0; wb[j] = 0; }
         }
         const u64 sepx = (u64)ops.sep * 0x0101010101010101ull;
 #pragma unroll
         for (int j = 0; j < B; j++) {
             const u64 p = item[j];
+            u32 spos;
+            if constexpr (STREAM) {
+                const u64 nx = next[j] - p;                             // (>= 1 for a valid item: the next phrase start behind p)
+                spos = nx < 8 ? (u32)nx : 8u;
+            } else {
             const u32 sh = (u32)((p + 1) & 63);
             u64 bits = w0[j] >> sh;
             if (sh) bits |= w1[j] << (64 - sh);
             bits &= 0x7Full;                                            // start bits of cells p+1 .. p+7
+            spos = bits ? (u32)__builtin_ctzll(bits) + 1u : 8u;
+            }
             const u64 x = chunk[j] ^ sepx;
             const u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;     // lowest set bit: first terminator byte
             const u32 tpos = z ? (u32)(__builtin_ctzll(z) >> 3) : 8u;  // cell index of the first terminator (8: none)
-            const u32 spos = bits ? (u32)__builtin_ctzll(bits) + 1u : 8u;
             const u32 e = tpos == 0 ? 0u : (tpos < spos ? tpos : spos);  // last cell of the phrase
             const u32 len = e + 1;
             fast[j] = fast[j] && len <= 7;
@@ -560,7 +577,7 @@ struct HashInsertFn {
             u32 found = prim::kNoBucket;
             if (ex) found = dir_on ? (u32)idx[j] : insert_exact(mine[j], p, idx[j], cur[j], true);
             if (ex && found != prim::kNoBucket) {
-                const u64 ord = (u64)wb[j] + (u64)__builtin_popcountll(wp[j] & ((1ull << (p & 63)) - 1ull));
+                const u64 ord = STREAM ? ordv[j] : (u64)wb[j] + (u64)__builtin_popcountll(wp[j] & ((1ull << (p & 63)) - 1ull));
                 if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; found = prim::kNoBucket; }
                 else out_slot[ord] = found & ~prim::kClaimBit;
             }

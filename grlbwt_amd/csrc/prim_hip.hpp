@@ -868,6 +868,10 @@ template <class F>
 GRL_DEV auto agg_first_seen(const F &f, u32 s, u64 item, int) -> decltype(f.first_seen(s, item), void()) { f.first_seen(s, item); }
 template <class F>
 GRL_DEV void agg_first_seen(const F &, u32, u64, long) {}
+template <class F>
+constexpr auto agg_is_stream(int) -> decltype(F::kStream) { return F::kStream; }
+template <class F>
+constexpr bool agg_is_stream(long) { return false; }
 template <int SLOTS, bool AGG, class F, class A>
 __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F f, A add) {
     __shared__ u32 c_key[AGG ? SLOTS : 1];
@@ -876,6 +880,11 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
     // waves drift apart freely and hide each other's gather latency
     constexpr int kWaveChunk = kAggChunk / (kBlock / 64);
     constexpr bool BATCH = F::kBatch > 1;
+    // STREAMING batched functors (F::kStream): a wave takes a CONTIGUOUS quarter of the block's positions, so the work items it
+    // queues are consecutive work items of the whole index space -- the k-th one has ordinal f.ordinal_base(first position) + k,
+    // and the item behind it in the queue is the next work item.  The functor gets both (process_batch_stream) and needs neither
+    // the rank structure nor a window of the flag bits per item: three of its five loads per item (level 0 of the 10 GB build).
+    constexpr bool STREAM = agg_is_stream<F>(0);
     // batched functors: the work items queue up ACROSS chunks in a ring until a full batch (64 * kBatch items) is there,
     // and the items the batch code hands back (kDeferBucket: the rare long cases) queue up in a second ring until 64 of
     // them can take the generic path together -- without this, almost every wave ran the divergent generic code for a few
@@ -911,6 +920,11 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
     };
     if constexpr (BATCH) {
         u32 qh = 0, qt = 0, dh = 0, dt = 0;            // ring heads / tails (items are offsets from `start`, < 2^32)
+        const u64 wspan = per_block / (kBlock / 64);   // (per_block is a multiple of kAggChunk: wave spans start on multiples of 64)
+        const u64 wstart = start + (u64)w * wspan < end ? start + (u64)w * wspan : end;
+        const u64 wend = wstart + wspan < end ? wstart + wspan : end;
+        u64 ord0 = 0;
+        if constexpr (STREAM) ord0 = wstart < wend ? f.ordinal_base(wstart) : 0;
         auto run_deferred = [&](bool all) {
             while (dt - dh >= 64u || (all && dt != dh)) {
                 const u32 k = dh + (u32)lane;
@@ -934,6 +948,18 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
                     valid[j] = k < qt;
                     item[j] = start + (valid[j] ? queue[k & (QCAP - 1)] : 0u);
                 }
+                if constexpr (STREAM) {
+                    u64 next[F::kBatch], ord[F::kBatch];
+#pragma unroll
+                    for (int j = 0; j < F::kBatch; j++) {
+                        const u32 k = qh + (u32)j * 64 + lane;
+                        const bool have = k + 1u < qt;                       // (the item behind mine is in the ring)
+                        next[j] = start + (have ? queue[(k + 1u) & (QCAP - 1)] : 0u);
+                        if (valid[j] && !have) next[j] = f.next_item(item[j]);   // (the last one queued so far: looked up)
+                        ord[j] = ord0 + (u64)k;
+                    }
+                    f.process_batch_stream(item, valid, slot, next, ord);
+                } else
                 f.process_batch(item, valid, slot);
 #pragma unroll
                 for (int j = 0; j < F::kBatch; j++) {
@@ -949,14 +975,15 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
             }
         };
         static_assert(!BATCH || 64 * F::kBatch + kWaveChunk / 2 <= (int)QCAP, "the item ring is too small for this batch width");
-        for (u64 cbase = start; cbase < end; cbase += kAggChunk) {
-            const u64 base = cbase + (u64)w * kWaveChunk;
+        for (u64 cbase = STREAM ? wstart : start; cbase < (STREAM ? wend : end); cbase += STREAM ? (u64)kWaveChunk : (u64)kAggChunk) {
+            const u64 base = STREAM ? cbase : cbase + (u64)w * kWaveChunk;
+            const u64 lim = STREAM ? wend : end;
 #pragma nounroll
             for (int half = 0; half < 2; half++) {      // (a loop, not two copies of the batch code: the kernel is large already)
 #pragma unroll
                 for (int k = half * (kWaveChunk / 128); k < (half + 1) * (kWaveChunk / 128); k++) {
                     u64 i = base + (u64)k * 64 + lane;
-                    bool st = (i < end) && f.is_start(i);
+                    bool st = (i < lim) && f.is_start(i);
                     unsigned long long m = __ballot(st);
                     if (st) queue[(qt + (u32)__popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (u32)(i - start);
                     qt += (u32)__popcll(m);

@@ -144,8 +144,37 @@ template <class F>
 inline auto agg_first_seen(const F &f, u32 s, u64 item, int) -> decltype(f.first_seen(s, item), void()) { f.first_seen(s, item); }
 template <class F>
 inline void agg_first_seen(const F &, u32, u64, long) {}
+template <class F>
+constexpr auto agg_is_stream(int) -> decltype(F::kStream) { return F::kStream; }
+template <class F>
+constexpr bool agg_is_stream(long) { return false; }
 template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool, const char * = "") {
+    if constexpr (F::kBatch > 1 && agg_is_stream<F>(0)) {
+        // the streaming batched form (prim_hip.hpp k_for_each_agg, STREAM): the k-th work item has ordinal ordinal_base(0) + k and
+        // knows the item behind it; the last one of a "ring" looks its successor up (every 100th item here, to take that path too)
+        std::vector<u64> items;
+        for (u64 i = 0; i < n; i++) if (f.is_start(i)) items.push_back(i);
+        const u64 ord0 = n ? (u64)f.ordinal_base(0) : 0;
+        for (u64 k0 = 0; k0 < items.size(); k0 += F::kBatch) {
+            u64 item[F::kBatch], next[F::kBatch], ord[F::kBatch];
+            bool valid[F::kBatch];
+            u32 slot[F::kBatch];
+            for (int j = 0; j < F::kBatch; j++) {
+                const u64 k = k0 + (u64)j;
+                valid[j] = k < items.size();
+                item[j] = valid[j] ? items[k] : 0;
+                next[j] = 0; ord[j] = ord0 + k;
+                if (valid[j]) next[j] = (k + 1 < items.size() && k % 100 != 99) ? items[k + 1] : f.next_item(item[j]);
+            }
+            f.process_batch_stream(item, valid, slot, next, ord);
+            for (int j = 0; j < F::kBatch && k0 + (u64)j < items.size(); j++) {
+                slot[j] = agg_take_claim(f, slot[j], item[j]);
+                if (slot[j] == kDeferBucket) slot[j] = agg_take_claim(f, f.process(item[j]), item[j]);
+                if (slot[j] != kNoBucket) { add(slot[j], 1u); agg_first_seen(f, slot[j], item[j], 0); }
+            }
+        }
+    } else
     if constexpr (F::kBatch > 1) {       // the functor's batched form (what the HIP kernel calls), kBatch work items at a time
         u64 item[F::kBatch];
         bool valid[F::kBatch];
