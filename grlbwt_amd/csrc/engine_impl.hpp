@@ -510,7 +510,15 @@ struct HashInsertFn {
     // item -- no start-bit window, no rank lookup: ONE load per phrase (its cells) where the form above has five
     static constexpr bool kStream = kExact;
     GRL_DEV u64 ordinal_base(u64 p) const { return (u64)wordbase[p >> 6]; }               // (p a multiple of 64)
-    GRL_DEV u64 next_item(u64 p) const { return next_set_bit(startbits, p + 1, n); }
+    // (the next phrase start behind p if it lies within 8 cells, any position further away otherwise: that is all the batch form
+    // asks -- following the bits to the end of a phrase of 10^8 cells with one lane cost one_symbol_100M 0.17 s)
+    GRL_DEV u64 next_item(u64 p) const {
+        const u64 b0 = p + 1;
+        u64 bits = startbits[b0 >> 6] >> (b0 & 63);
+        if ((b0 & 63) > 56) bits |= startbits[(b0 >> 6) + 1] << (64 - (b0 & 63));
+        bits &= 0xFFull;
+        return bits ? b0 + (u64)__builtin_ctzll(bits) : p + 9;
+    }
     GRL_DEV void process_batch_stream(const u64 *item, const bool *valid, u32 *slot, const u64 *next, const u64 *ord) const {
         process_batch_exact<true>(item, valid, slot, next, ord);
     }
