@@ -519,6 +519,22 @@ struct HashInsertFn {
         bits &= 0xFFull;
         return bits ? b0 + (u64)__builtin_ctzll(bits) : p + 9;
     }
+    // prim::name_stream's protocol (direct index only): a phrase named from its own cells, everything else deferred
+    GRL_DEV u64 stream_load(u64 p) const { return load8(t + p); }
+    GRL_DEV u32 stream_name(u64 p, u64 chunk, u64 next) const {
+        const u64 nx = next - p;
+        const u32 spos = nx < 8 ? (u32)nx : 8u;
+        const u64 x = chunk ^ ((u64)ops.sep * 0x0101010101010101ull);
+        const u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+        const u32 tpos = z ? (u32)(__builtin_ctzll(z) >> 3) : 8u;
+        const u32 e = tpos == 0 ? 0u : (tpos < spos ? tpos : spos);
+        const u32 len = e + 1;
+        return len <= 7 ? direct_index(chunk, len) : prim::kDeferBucket;
+    }
+    GRL_DEV void stream_store(u64 ord, u32 slot) const {
+        if (ord >= n_occ) { scal[1] = 5; scal[3] = (u32)ord; }
+        else out_slot[ord] = slot;
+    }
     GRL_DEV void process_batch_stream(const u64 *item, const bool *valid, u32 *slot, const u64 *next, const u64 *ord) const {
         process_batch_exact<true>(item, valid, slot, next, ord);
     }
@@ -820,6 +836,7 @@ struct ListedFn {
     GRL_DEV u32 process(u64 v) const { return f.process(pos[v]); }
     GRL_DEV u32 operator()(u64 v) const { return f.process(pos[v]); }
     GRL_DEV void process_batch(const u64 *, const bool *, u32 *) const {}
+    GRL_DEV void first_seen(u32 slot, u64 v) const { f.first_seen(slot, pos[v]); }
 };
 
 // ------------------------------------------------------ a5: dictionary view
@@ -3302,6 +3319,18 @@ class Engine {
                         lbits.release(); lbase.release();
                         if (nl) prim::for_each_agg(nl, ListedFn<HF>{f, lpos.p, claim.p}, SlotCountAdd{cnt, cs}, false, "hash_long_phrases");
                     } else launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
+                } else if (direct && n_occ < 0xFFFFFFF0ull && !getenv("GRLBWT_NO_NAME_STREAM")) {
+                    // the direct index in a kernel of its own (prim::name_stream): what it cannot name -- phrases of more than 7 cells,
+                    // the last cells of the text -- is marked and takes the general code from a list afterwards
+                    DBuf<u64> lbits(nwords + 1);
+                    lbits.zero();
+                    prim::name_stream(n, f, SlotCountAdd{cnt, cs}, lbits.p, "hash_phrases");
+                    DBuf<u32> lbase(nwords + 1);
+                    const u64 nl = (u64)prim::exclusive_scan<u32>(nwords, PopcIn32{lbits.p}, lbase.p, false, "hash_long_list");
+                    DBuf<u64> lpos(nl ? nl : 1);
+                    if (nl) prim::for_each(nwords, BitPositionsFn{lbits.p, lbase.p, lpos.p}, "hash_long_list");
+                    lbits.release(); lbase.release();
+                    if (nl) prim::for_each_agg(nl, ListedFn<HF>{f, lpos.p, claim.p}, SlotCountAdd{cnt, cs}, aggregate, "hash_long_phrases");
                 } else launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
                 std::vector<u32> sc = scal.to_host(8);
                 if (sc[4] && !sc[1]) {            // the phrases too long for one lane: one wave each

@@ -591,11 +591,28 @@ __global__ void __launch_bounds__(kBlock) k_for_each(u64 n, F f) {
     u64 stride = (u64)gridDim.x * kBlock;
     for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) f(i);
 }
+// (grid of a grid-stride launch: what the CUs hold at once, when that is less than the 8 workgroups per CU of grid_for -- a functor
+// that takes more than 64 vector registers runs 5 or fewer workgroups per CU, and with 8 per CU launched the last 3 start when the
+// first 5 are done and run at low occupancy.  GRLBWT_FOR_EACH_GRID=fixed keeps 8 per CU; =2x launches twice the resident number.)
+template <class F>
+inline unsigned grid_for_each(u64 n) {
+    static const int mode = getenv("GRLBWT_FOR_EACH_GRID") ? (getenv("GRLBWT_FOR_EACH_GRID")[0] == 'f' ? 0 : 2) : 1;
+    static const u64 per_cu = [] {
+        int occ = 0;
+        if (mode == 0 || hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_for_each<F>, kBlock, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); return (u64)8; }
+        return (u64)(occ >= 8 ? 8 : occ * mode);
+    }();
+    u64 blocks = (n + kBlock - 1) / kBlock;
+    const u64 cap = (u64)rt().num_cus * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
 template <class F>
 inline void for_each(u64 n, F f, const char *name = "for_each") {
     if (n == 0) return;
     prof_begin(name);
-    hipLaunchKernelGGL(k_for_each<F>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, rt().stream, n, f);
+    hipLaunchKernelGGL(k_for_each<F>, dim3(grid_for_each<F>(n)), dim3(kBlock), 0, rt().stream, n, f);
     prof_end();
     after_launch(name);
 }
@@ -1024,6 +1041,115 @@ __global__ void __launch_bounds__(kBlock) k_for_each_agg(u64 n, u64 per_block, F
         }
     }
 }
+// ------------------------------------------ name_stream: the streaming form alone, for functors that NAME most of their work
+// items by a computation on the item's own cells (level 0 of a byte text with a direct index: engine_impl.hpp, HashInsertFn).
+// The same queue as k_for_each_agg's STREAM form -- a wave takes a contiguous quarter of the block's positions, the k-th item it
+// queues has ordinal f.ordinal_base(first position) + k, the queue entry behind it is the next item -- and nothing else: an item
+// the functor cannot name (f.stream_name returns kDeferBucket) only leaves its bit in defer_bits[] and goes through the general
+// code in a launch of its own afterwards.  k_for_each_agg carries that general code inline (58 KB of instructions, 106 scalar
+// registers with uniforms spilled to vector lanes, 276 vector + 206 scalar instructions per 64 items); this kernel does not.
+//   f.is_start(i), f.ordinal_base(p), f.next_item(p), f.stream_load(p) -> u64 (p + 8 <= n), f.stream_name(p, cells, next) -> bucket,
+//   f.stream_store(ordinal, bucket), f.first_seen(bucket, p); add(bucket, count) as in for_each_agg.
+template <int SLOTS, class F, class A>
+__global__ void __launch_bounds__(kBlock) k_name_stream(u64 n, u64 per_block, F f, A add, u64 *defer_bits) {
+    __shared__ u32 c_key[SLOTS];
+    __shared__ u32 c_cnt[SLOTS];
+    constexpr int NW = kBlock / 64, B = 4;
+    constexpr u32 QCAP = 512;
+    __shared__ u32 s_queue[NW][QCAP];
+    for (int i = threadIdx.x; i < SLOTS; i += kBlock) { c_key[i] = kNoBucket; c_cnt[i] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    volatile u32 *queue = s_queue[w];
+    const u64 start = (u64)blockIdx.x * per_block;
+    const u64 end = start + per_block < n ? start + per_block : n;
+    const u64 wspan = per_block / NW;                // (per_block is a multiple of kAggChunk: wave spans start on multiples of 64)
+    const u64 wstart = start + (u64)w * wspan < end ? start + (u64)w * wspan : end;
+    const u64 wend = wstart + wspan < end ? wstart + wspan : end;
+    const u64 ord0 = wstart < wend ? f.ordinal_base(wstart) : 0;
+    u32 qh = 0, qt = 0;                              // (items are offsets from wstart: a wave's span is below 2^32 positions)
+    auto run = [&](bool all) {
+        while (qt - qh >= 64u * B || (all && qt != qh)) {
+            u32 off[B], nx[B];
+            u64 cells[B];
+            bool valid[B], can[B];
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+                const u32 k = qh + (u32)j * 64 + lane;
+                valid[j] = k < qt;
+                off[j] = valid[j] ? queue[k & (QCAP - 1)] : 0u;
+                const bool have = k + 1u < qt;
+                nx[j] = have ? queue[(k + 1u) & (QCAP - 1)] : 0xFFFFFFFFu;
+                can[j] = valid[j] && wstart + (u64)off[j] + 8 <= n;
+                cells[j] = can[j] ? f.stream_load(wstart + (u64)off[j]) : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+                const u32 k = qh + (u32)j * 64 + lane;
+                const u64 p = wstart + (u64)off[j];
+                u64 next = wstart + (u64)nx[j];
+                if (valid[j] && nx[j] == 0xFFFFFFFFu) next = f.next_item(p);      // (the last item queued so far)
+                u32 s = kDeferBucket;
+                if (can[j]) s = f.stream_name(p, cells[j], next);
+                if (valid[j] && s == kDeferBucket) atomicOr(reinterpret_cast<unsigned long long *>(&defer_bits[p >> 6]), 1ull << (p & 63));
+                if (valid[j] && s != kDeferBucket) {
+                    f.stream_store(ord0 + (u64)k, s);
+                    u32 h = (s * 2654435761u) >> (32 - __builtin_ctz(SLOTS));
+                    bool done = false;
+                    for (int q = 0; q < 4 && !done; q++) {
+                        const u32 old = atomicCAS(&c_key[h], kNoBucket, s);
+                        if (old == kNoBucket || old == s) { atomicAdd(&c_cnt[h], 1u); done = true; if (old == kNoBucket) f.first_seen(s, p); }
+                        else h = (h + 1) & (SLOTS - 1);
+                    }
+                    if (!done) { add(s, 1u); f.first_seen(s, p); }
+                }
+            }
+            qh = qt - qh >= 64u * B ? qh + 64u * B : qt;
+        }
+    };
+    for (u64 cbase = wstart; cbase < wend; cbase += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u64 i = cbase + (u64)k * 64 + lane;
+            const bool st = (i < wend) && f.is_start(i);
+            const unsigned long long m = __ballot(st);
+            if (st) queue[(qt + (u32)__popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (u32)(i - wstart);
+            qt += (u32)__popcll(m);
+        }
+        run(false);            // leaves fewer than 256 items: the next 256 positions' starts still fit the ring
+    }
+    run(true);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SLOTS; i += kBlock) {
+        const u32 c = c_cnt[i];
+        if (c) add(c_key[i], c);
+    }
+}
+// Workgroups per CU for the kernels that cut the index space into ONE contiguous span per workgroup (k_for_each_agg,
+// k_name_stream): a multiple of what a CU holds at once.  With 8 per CU -- the figure these launches had until round 5 -- and 5 or 6
+// resident, the second wave of workgroups ran at half occupancy: the level-0 naming kernel took 37.2 ms at 8 per CU, 29.6 at 6,
+// 29.3 at 12 (tools/_build sweep, 10 GB build).  (GRLBWT_SPAN_BLOCKS_PER_CU overrides.)
+template <class K>
+inline u64 span_blocks_per_cu(K kernel, int threads) {
+    static const u64 forced = getenv("GRLBWT_SPAN_BLOCKS_PER_CU") ? (u64)atoll(getenv("GRLBWT_SPAN_BLOCKS_PER_CU")) : 0;
+    if (forced) return forced;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); return 8; }
+    return (u64)occ * 2;
+}
+template <class F, class A>
+inline void name_stream(u64 n, F f, A add, u64 *defer_bits, const char *name = "name_stream") {
+    if (n == 0) return;
+    static const u64 per_cu = span_blocks_per_cu(k_name_stream<2048, F, A>, kBlock);
+    u64 blocks = (u64)rt().num_cus * per_cu;
+    u64 per_block = ((n + blocks - 1) / blocks + kAggChunk - 1) / kAggChunk * kAggChunk;
+    if (per_block / (kBlock / 64) >= 0xFFFFFF00ull) throw Error(-75, "name_stream: a wave's span has >= 2^32 positions");
+    blocks = (n + per_block - 1) / per_block;
+    prof_begin(name);
+    hipLaunchKernelGGL((k_name_stream<2048, F, A>), dim3((unsigned)blocks), dim3(kBlock), 0, rt().stream, n, per_block, f, add, defer_bits);
+    prof_end();
+    after_launch(name);
+}
 template <class F, class A>
 struct NoAggFn {
     F f; A add;
@@ -1046,7 +1172,10 @@ template <class F, class A>
 inline void for_each_agg(u64 n, F f, A add, bool aggregate, const char *name = "for_each_agg") {
     if (n == 0) return;
     if (getenv("GRLBWT_NOAGG")) { for_each(n, NoAggFn<F, A>{f, add}, name); return; }
-    u64 blocks = (u64)rt().num_cus * 8;
+    // (measured on the 10 GB build: the list passes of the levels above 0 -- no LDS count cache -- 11.0 -> 8.7 ms with twice the
+    // resident workgroups per CU instead of 8; the level-0 kernel with the cache 40.4 -> 43.2 ms: it keeps 8)
+    static const u64 per_cu_plain = span_blocks_per_cu(k_for_each_agg<2048, false, F, A>, kBlock);
+    u64 blocks = (u64)rt().num_cus * (aggregate ? (u64)8 : per_cu_plain);
     u64 per_block = ((n + blocks - 1) / blocks + kAggChunk - 1) / kAggChunk * kAggChunk;
     blocks = (n + per_block - 1) / per_block;
     prof_begin(name);

@@ -144,6 +144,21 @@ template <class F>
 inline auto agg_first_seen(const F &f, u32 s, u64 item, int) -> decltype(f.first_seen(s, item), void()) { f.first_seen(s, item); }
 template <class F>
 inline void agg_first_seen(const F &, u32, u64, long) {}
+// prim_hip.hpp name_stream, serially: every item named by the functor's streaming methods, the others marked in defer_bits
+template <class F, class A>
+inline void name_stream(u64 n, F f, A add, u64 *defer_bits, const char * = "") {
+    std::vector<u64> items;
+    for (u64 i = 0; i < n; i++) if (f.is_start(i)) items.push_back(i);
+    const u64 ord0 = n ? (u64)f.ordinal_base(0) : 0;
+    for (u64 k = 0; k < items.size(); k++) {
+        const u64 p = items[k];
+        const u64 next = (k + 1 < items.size() && k % 100 != 99) ? items[k + 1] : f.next_item(p);
+        u32 s = kDeferBucket;
+        if (p + 8 <= n) s = f.stream_name(p, f.stream_load(p), next);
+        if (s == kDeferBucket) defer_bits[p >> 6] |= 1ull << (p & 63);
+        else { f.stream_store(ord0 + k, s); add(s, 1u); f.first_seen(s, p); }
+    }
+}
 template <class F>
 constexpr auto agg_is_stream(int) -> decltype(F::kStream) { return F::kStream; }
 template <class F>
