@@ -58,6 +58,7 @@ struct DBuf {
     ~DBuf() { release(); }
     void alloc(u64 n_) { release(); p = (T *)prim::dev_alloc((n_ ? n_ : 1) * sizeof(T)); n = n_; }
     void release() { if (p) prim::dev_free(p); p = nullptr; n = 0; }
+    void shrink(u64 n_) { if (p && n_ < n) { prim::dev_shrink(p, (n_ ? n_ : 1) * sizeof(T)); n = n_; } }      // the first n_ elements stay
     void zero() { prim::dev_memset(p, 0, n * sizeof(T)); }
     void fill_ff() { prim::dev_memset(p, 0xFF, n * sizeof(T)); }
     std::vector<T> to_host(u64 cnt) const { std::vector<T> h(cnt); prim::d2h(h.data(), p, cnt * sizeof(T)); return h; }
@@ -4673,16 +4674,46 @@ class Engine {
         // ---- the stream merge: count (T positions, run heads), then emit
         const AsmSeg seg{kinds.p, nh_sym.p, nh_len.p, cells, take_code, tstarts.p, esym.p, epos.p};
         prim::SmPlan<idx_t> plan;
-        prim::stream_merge_count<AsmSeg, idx_t>(G, seg, plan, "asm", NH * 64 < G);      // (few pre-BWT runs among the segments: small tiles, see prim_hip.hpp)
-        if (plan.take_total != Tsum) { plan.release(); throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
-                                                                                       std::to_string(plan.take_total) + " vs " + std::to_string(Tsum) + ")"); }
-        if (plan.len_total != L.n_out) { plan.release(); throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(plan.len_total) +
-                                                                                       " symbols, the level has " + std::to_string(L.n_out)); }
-        I.A = plan.atoms;
-        const u64 Ro = plan.heads;
+        auto check_totals = [&] {
+            if (plan.take_total != Tsum) { plan.release(); throw prim::Error(-71, "induction: BWT_{r+1} consumption mismatch (level " + std::to_string(r) + ": " +
+                                                                                           std::to_string(plan.take_total) + " vs " + std::to_string(Tsum) + ")"); }
+            if (plan.len_total != L.n_out) { plan.release(); throw prim::Error(-71, "induction: BWT of level " + std::to_string(r) + " describes " + std::to_string(plan.len_total) +
+                                                                                           " symbols, the level has " + std::to_string(L.n_out)); }
+        };
         Runs out;
-        out.sym.alloc(Ro); out.pos.alloc(Ro + 1);
-        try { prim::stream_merge_emit<AsmSeg, idx_t>(seg, plan, out.sym.p, out.pos.p, "asm"); } catch (...) { plan.release(); throw; }
+        u64 Ro = 0;
+        // ONE WALK (round 6): the run heads are found and written by one pass over the segments, the run index at every tile's start
+        // comes from a look-back across the tiles (prim::stream_merge_onepass) -- the count pass (28 of 125 ms of pass C at 10 GB)
+        // re-derived exactly what the emit pass derives.  The runs are written into arrays sized for an upper bound (every segment
+        // a run + every run of T a run) and the arrays give their tails back.  GRLBWT_ASM_TWO_PASS=1 (the tests) and a walk that
+        // gave up take the two-pass form.
+        // Where the segments are almost all plain cells (level 0 of a read collection: 2.6 M tiles of 1024 segments, 100+ tiles per
+        // microsecond) the look-back costs more than the count pass it saves -- 37-44 ms against 30 -- and the two-pass form stays.
+        // (GRLBWT_ASM_ONE_WALK=1: the tests take the one-walk form at every level, plain or not)
+        const bool two_pass = getenv("GRLBWT_ASM_TWO_PASS") != nullptr;
+        const bool plain_too = getenv("GRLBWT_ASM_ONE_WALK") != nullptr;
+        const bool mostly_plain = NH * 64 < G;
+        bool done = false;
+        if (!two_pass && (!mostly_plain || plain_too)) {
+            const u64 cap = G + Re + 1;
+            // queued segments: a TAKE that spans more than kSmInline further runs of T -- at most Re / kSmInline of them
+            const u64 qcap = Re / prim::kSmInline + 1;
+            out.sym.alloc(cap); out.pos.alloc(cap + 1);
+            try { done = prim::stream_merge_onepass<AsmSeg, idx_t>(G, seg, plan, out.sym.p, out.pos.p, cap, qcap, "asm", mostly_plain); } catch (...) { plan.release(); throw; }
+            if (done) {
+                check_totals();
+                Ro = plan.heads;
+                out.sym.shrink(Ro); out.pos.shrink(Ro + 1);
+            } else { out.sym.release(); out.pos.release(); }
+        }
+        if (!done) {
+            prim::stream_merge_count<AsmSeg, idx_t>(G, seg, plan, "asm", mostly_plain);      // (few pre-BWT runs among the segments: small tiles, see prim_hip.hpp)
+            check_totals();
+            Ro = plan.heads;
+            out.sym.alloc(Ro); out.pos.alloc(Ro + 1);
+            try { prim::stream_merge_emit<AsmSeg, idx_t>(seg, plan, out.sym.p, out.pos.p, "asm"); } catch (...) { plan.release(); throw; }
+        }
+        I.A = plan.atoms;
         plan.release();
         const idx_t total = (idx_t)L.n_out;
         prim::h2d(out.pos.p + Ro, &total, sizeof(idx_t));

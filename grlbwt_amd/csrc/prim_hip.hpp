@@ -47,6 +47,18 @@ struct Error : std::runtime_error {
                                       " at " + __FILE__ + ":" + std::to_string(__LINE__));  \
     } while (0)
 
+// Experiment switches (tile shapes, alternative kernels measured against each other) exist in DEVELOPMENT builds only:
+// tools/build_dev.sh compiles the library with -DGRLBWT_DEV_SWITCHES into tools/_build/ (bench.py takes it through
+// GRLBWT_HIP_LIB).  The product library reads none of them -- dev_env() is a constant there and the names do not reach the binary.
+inline const char *dev_env(const char *name) {
+#ifdef GRLBWT_DEV_SWITCHES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // ---------------------------------------------------------------- runtime state
 struct Runtime {
     hipStream_t stream = nullptr;
@@ -488,6 +500,24 @@ inline void dev_free(void *p) {
         if (pv->first + pv->second == off) { pv->second += len; return; }
     }
     sl.free_list.emplace(off, len);
+}
+// Keep the first `bytes` of a block and give the rest back (an array allocated for an upper bound, once its size is known).
+// Stream-ordered like dev_free: the tail may go to a later launch of the same stream at once.
+inline void dev_shrink(void *p, size_t bytes) {
+    if (!p || pool_disabled()) return;
+    Pool &P = pool();
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return;
+    if (bytes == 0) bytes = 16;
+    const size_t need = (bytes + 255) & ~(size_t)255, len = it->second.second;
+    if (need >= len) return;
+    it->second.second = need;
+    P.live_bytes -= len - need;
+    Slab &sl = P.slabs[it->second.first];
+    size_t off = (size_t)((char *)p - sl.base) + need, tail = len - need;
+    auto nx = sl.free_list.lower_bound(off);
+    if (nx != sl.free_list.end() && off + tail == nx->first) { tail += nx->second; sl.free_list.erase(nx); }
+    sl.free_list.emplace(off, tail);
 }
 inline void h2d(void *d, const void *h, size_t n) {
     // small uploads (counts, offsets tables, headers) go through a ring of pinned staging slots and do NOT wait: the
@@ -1976,22 +2006,27 @@ inline int sort_keys_fwd(u32 *a, u32 *b, u64 n, int begin_bit, int end_bit, cons
 //   k_xs_count    walks every item once: per-tile digit histogram of the first digit (LDS atomics on per-wave copies),
 //                 the number of keys of every item (one byte), the largest such number
 //   rs_offsets    digit-major exclusive offsets per (tile, digit); their grand total is the number of keys E
-//   k_xs_scatter  per sub-batch of 1024 items (4 per thread, their 4 chains walked INTERLEAVED: the walk is a chain of
+//   k_xs_scatter  per walk of 1024 items (4 per thread, their 4 chains walked INTERLEAVED: the walk is a chain of
 //                 dependent gathers, and 4 independent chains per lane is what hides their latency at the occupancy
 //                 the LDS staging leaves): key counts -> block scan -> keys straight into an LDS window in sequence
-//                 order -> the in-tile stable ranking of k_rs_scatter (wave64 ballots, per-wave running counters,
-//                 in-place LDS permutation) -> linear write-out at the tile's running digit offsets
+//                 order; when the next walk no longer fits the window -> the in-tile stable ranking of k_rs_scatter
+//                 (wave64 ballots, per-wave running counters, in-place LDS permutation) -> linear write-out at the
+//                 tile's running digit offsets
 // Traffic per key: 8 B written by the fused pass (+ the items' own arrays), then 8 B hist + 16 B scatter per further
 // pass -- against 8 B expand + 24 B per pass for expand-then-sort.  The first digit takes 9 bits when that saves a pass.
-static constexpr int kXsIpt = 4;                          // items per thread and sub-batch
-static constexpr int kXsBatch = kBlock * kXsIpt;          // 1024 items per sub-batch
-static constexpr int kXsTileItems = 4096;                 // items per tile (4 sub-batches)
+// (IPT items per thread and walk, TI items per tile -- a multiple of 256 x IPT.  SEVERAL walks fill one ranking window (round 6): a walk
+// of 1024 runs drops ~1600 keys at level 0 of the 10 GB build, so ranking after every walk filled 40 % of the window and paid the five
+// barriers of a ranking round per 1600 keys.  Measured on the 10 GB build: levels 1-3 13.9 / 6.7 / 3.1 -> 11.9 / 5.7 / 2.6 ms, level 0
+// 18.8 -> 19.2-20 ms -- and 16.2 ms at four workgroups per CU, which the kernel's registers allow now that nothing spills (153-161 of
+// 170 for 8-byte cells, 137 -> 128 for 4-byte ones; rounds 3-5: 168 + ~100 bytes of scratch).  Walks of 768 items (IPT 3, six per
+// tile) fill the window better at levels 1-2 and were no faster: 19.4 / 13.1 / 5.6 ms.)
 static constexpr int kXsWin = 4096;                       // keys staged and ranked per round (16 rows of 64 per wave)
 struct XsPlan {
     bool ok = false;         // false: the fused path does not apply (an item with more than 32 keys); E is still valid
     u64 n = 0, E = 0;
     u32 maxc = 0, tiles = 0;
     int bits = 0, db = 8;    // sort bits, bits of the first digit
+    int ipt = 4, ti = 4096;  // items per thread and walk, items per tile (count and scatter agree)
     int md = 0;              // widest digit of the passes behind the fused one (0: the default)
     u8 *cnt8 = nullptr; u32 *counts = nullptr; u64 *offsets = nullptr;
     void release() {
@@ -2008,8 +2043,9 @@ GRL_DEV u32 xcd_tile(u32 b, u32 g) {
     const u32 per = g >> 3, rem = g & 7u, x = b & 7u, k = b >> 3;
     return x * per + (x < rem ? x : rem) + k;
 }
-template <class GEN, int DB>
+template <class GEN, int DB, int TI = 4096>
 __global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, u8 *cnt8, u32 *counts, u32 *scal /*[0] max keys per item*/) {
+    constexpr int kXsTileItems = TI;
     constexpr int NB = 1 << DB;
     __shared__ u32 s_h[kBlock / 64][NB];
     __shared__ u32 s_max;
@@ -2047,14 +2083,15 @@ __global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, 
     }
     if (threadIdx.x == 0 && s_max) atomicMax(&scal[0], s_max);
 }
-// (MINB = workgroups per CU the register budget is cut for: at 3 the kernel spills ~100 bytes per lane to scratch (168 VGPRs);
-// at 2 it keeps everything in registers at 8 instead of 12 waves per CU -- GRLBWT_XS_OCC=2|3 picks, see expand_sort)
+// (MINB = workgroups per CU the register budget is cut for: see expand_sort)
 // (K = u64, or u32 when a whole key fits 32 bits: half the bytes in LDS, in the write-out and in every later pass)
-template <class GEN, int DB, int MINB = 3, class K = u64>
+template <class GEN, int DB, int MINB = 3, class K = u64, int IPT = 4, int TI = 4096>
 __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32 dmask, const u8 *cnt8, const u64 *offsets /*[tiles][NB]*/, K *out,
                                                        int xcd_aware) {
     constexpr int NB = 1 << DB, BPT = NB / kBlock > 0 ? NB / kBlock : 1;     // bins per thread (contiguous)
     constexpr int ROWS = kXsWin / kBlock;                                   // 16 rows of 64 keys per wave and round
+    constexpr int kXsBatch = kBlock * IPT, kWalks = TI / kXsBatch;
+    static_assert(TI % kXsBatch == 0 && IPT <= 4, "tile = whole walks; the packed count scan holds four 16-bit fields");
     __shared__ __attribute__((aligned(16))) K s_cells[kXsWin];
     __shared__ u32 s_cnt[kBlock / 64][NB];
     __shared__ u64 s_goff[NB];       // running global offset of every digit for this tile
@@ -2064,140 +2101,163 @@ __global__ void __launch_bounds__(kBlock, MINB) k_xs_scatter(u64 n, GEN gen, u32
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u32 tile = xcd_aware ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     for (int d = threadIdx.x; d < NB; d += kBlock) s_goff[d] = offsets[(u64)tile * NB + d];
-    const u64 base = (u64)tile * kXsTileItems;
-    for (int b = 0; b < kXsTileItems / kXsBatch; b++) {
-        const u64 i0 = base + (u64)b * kXsBatch;
-        if (i0 >= n) break;                                          // uniform
-        // ---- key counts of my 4 items (slab j holds items i0 + j*256 ..): one packed scan gives every item its
-        // position in the sub-batch's key sequence (16 bits per slab: a slab has at most 256 * 32 keys)
-        u64 item[kXsIpt];
-        u32 c[kXsIpt];
-        u64 packed = 0;
+    const u64 base = (u64)tile * TI;
+    // A ROUND = walks until the window is full, then one ranking + write-out.  Walk b covers the items [i0, i0 + 256 IPT) of the tile;
+    // its keys, in sequence order, have the numbers [0, tot); a walk takes the keys [wlo, wlo + room) of them, room = what the window
+    // still holds -- the whole walk almost always; a walk of more than a window's keys (an item may drop 32) goes in pieces, its
+    // chains walked once per piece.  All of this is uniform over the workgroup.
+    int b = 0;                       // the walk to take keys from next
+    u32 wlo = 0;                     // keys of walk b already taken
+    u32 fill = 0;                    // keys in the window
+    bool have = false;               // counts and positions of walk b are in registers
+    u64 item[IPT];
+    u32 c[IPT], o[IPT], tot = 0;
+    for (;;) {
+        bool full = false;
+        while (!full) {
+            if (!have) {
+                const u64 i0 = base + (u64)b * kXsBatch;
+                if (b >= kWalks || i0 >= n) break;                             // uniform: the tile's items are used up
+                // ---- key counts of my items (slab j holds items i0 + j*256 ..): one packed scan gives every item its position
+                // in the walk's key sequence (16 bits per slab: a slab has at most 256 * 32 keys)
+                u64 packed = 0;
 #pragma unroll
-        for (int j = 0; j < kXsIpt; j++) {
-            item[j] = i0 + (u64)j * kBlock + threadIdx.x;
-            c[j] = item[j] < n ? (u32)cnt8[item[j]] : 0u;
-            packed |= (u64)c[j] << (16 * j);
-        }
-        u64 ptot;
-        const u64 pex = block_excl_scan<u64>(packed, s_w, &ptot);     // (barriers inside: also fences the previous sub-batch)
-        u32 o[kXsIpt], tot = 0;
-#pragma unroll
-        for (int j = 0; j < kXsIpt; j++) {
-            o[j] = tot + (u32)((pex >> (16 * j)) & 0xFFFFu);
-            tot += (u32)((ptot >> (16 * j)) & 0xFFFFu);
-        }
-        for (u32 win = 0; win == 0 || win < tot; win += kXsWin) {     // windows of the key sequence (almost always one)
-            // ---- walk: the 4 chains of a lane advance together; every step is 4 independent gathers
-            bool act[kXsIpt];
-            u32 cur[kXsIpt], pos[kXsIpt];
-            u64 rec[kXsIpt], ib[kXsIpt];
-#pragma unroll
-            for (int j = 0; j < kXsIpt; j++) {
-                act[j] = item[j] < n && (c[j] ? (o[j] < win + kXsWin && o[j] + c[j] > win) : win == 0);
-                cur[j] = gen.start(act[j] ? item[j] : 0);
-            }
-#pragma unroll
-            for (int j = 0; j < kXsIpt; j++) rec[j] = gen.node(cur[j]);
-#pragma unroll
-            for (int j = 0; j < kXsIpt; j++) {
-                pos[j] = o[j] - win;                                   // may wrap below zero: the window test below is unsigned
-                ib[j] = act[j] ? gen.item_bits(item[j]) : 0;
-                if (act[j] && gen.owns(rec[j])) {
-                    if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = (K)gen.key_own(cur[j], ib[j]);
-                    pos[j]++;
+                for (int j = 0; j < IPT; j++) {
+                    item[j] = i0 + (u64)j * kBlock + threadIdx.x;
+                    c[j] = item[j] < n ? (u32)cnt8[item[j]] : 0u;
+                    packed |= (u64)c[j] << (16 * j);
                 }
+                u64 ptot;
+                const u64 pex = block_excl_scan<u64>(packed, s_w, &ptot);
+                tot = 0;
+#pragma unroll
+                for (int j = 0; j < IPT; j++) {
+                    o[j] = tot + (u32)((pex >> (16 * j)) & 0xFFFFu);
+                    tot += (u32)((ptot >> (16 * j)) & 0xFFFFu);
+                }
+                have = true;
+                wlo = 0;
             }
-            for (;;) {
-                bool m[kXsIpt], any = false;
-                u32 nx[kXsIpt];
+            const u32 rest = tot - wlo, room = (u32)kXsWin - fill;
+            if (rest > room && fill > 0) full = true;                         // (rank what is there first: the walk then starts an empty window)
+            else {
+                // ---- walk: the chains of a lane advance together; every step is IPT independent gathers.  Key number q of the
+                // walk goes to window slot fill + q - wlo when that lies in [fill, kXsWin).
+                bool act[IPT];
+                u32 cur[IPT], pos[IPT];
+                u64 rec[IPT], ib[IPT];
 #pragma unroll
-                for (int j = 0; j < kXsIpt; j++) { m[j] = act[j] && gen.more(rec[j]); any = any || m[j]; nx[j] = m[j] ? gen.next(rec[j]) : 0u; }
-                if (!any) break;
-                u64 nrec[kXsIpt];
+                for (int j = 0; j < IPT; j++) {
+                    act[j] = item[j] < n && (c[j] ? (o[j] < wlo + room && o[j] + c[j] > wlo) : wlo == 0);
+                    cur[j] = gen.start(act[j] ? item[j] : 0);
+                }
 #pragma unroll
-                for (int j = 0; j < kXsIpt; j++) nrec[j] = gen.node(nx[j]);       // unconditional: 4 loads in flight per lane
+                for (int j = 0; j < IPT; j++) rec[j] = gen.node(cur[j]);
 #pragma unroll
-                for (int j = 0; j < kXsIpt; j++) {
-                    if (m[j]) {
-                        if (pos[j] < (u32)kXsWin) s_cells[pos[j]] = (K)gen.key_step(rec[j], nx[j], ib[j]);
+                for (int j = 0; j < IPT; j++) {
+                    pos[j] = o[j] - wlo;                                   // may wrap below zero: the window test below is unsigned
+                    ib[j] = act[j] ? gen.item_bits(item[j]) : 0;
+                    if (act[j] && gen.owns(rec[j])) {
+                        if (pos[j] < room) s_cells[fill + pos[j]] = (K)gen.key_own(cur[j], ib[j]);
                         pos[j]++;
-                        rec[j] = nrec[j];
                     }
                 }
-            }
+                for (;;) {
+                    bool m[IPT], any = false;
+                    u32 nx[IPT];
 #pragma unroll
-            for (int j = 0; j < kXsIpt; j++) if (act[j]) gen.finish(item[j], rec[j]);
-            __syncthreads();
-            // ---- rank the window's keys by the digit and write them out (the body of k_rs_scatter)
-            const u32 hn = tot - win < (u32)kXsWin ? tot - win : (u32)kXsWin;
-            if (hn == 0) continue;                                    // uniform (tot == 0)
-            const u32 rpw = (u32)__builtin_amdgcn_readfirstlane((int)(((hn + 63) / 64 + 3) / 4));   // rows per wave (uniform, in an SGPR): every wave takes a contiguous share
-            for (int d = threadIdx.x; d < (kBlock / 64) * NB; d += kBlock) (&s_cnt[0][0])[d] = 0;
-            K key[ROWS];
-            u32 idx[ROWS];
+                    for (int j = 0; j < IPT; j++) { m[j] = act[j] && gen.more(rec[j]); any = any || m[j]; nx[j] = m[j] ? gen.next(rec[j]) : 0u; }
+                    if (!any) break;
+                    u64 nrec[IPT];
 #pragma unroll
-            for (int q = 0; q < ROWS; q++) {
-                const u32 t = ((u32)w * rpw + q) * 64 + lane;
-                key[q] = ((u32)q < rpw && t < hn) ? s_cells[t] : K(0);
-            }
-            __syncthreads();
-            // (rows behind rpw hold nothing: skipped by a workgroup-uniform branch -- a sub-batch of 1024 runs drops about
-            // 1600 keys at level 0, 7 of the 16 rows)
-            wave_rank<DB, ROWS, false>([&](int q) { return (u32)key[q] & dmask; }, (u32)w * rpw * 64u + (u32)lane, hn, rpw, &s_cnt[w][0], idx);
-            __syncthreads();
-            {   // thread t owns bins [t*BPT, (t+1)*BPT): wave bases, round-local digit starts, global bases
-                u32 cw[BPT][4], tt[BPT], sum = 0;
+                    for (int j = 0; j < IPT; j++) nrec[j] = gen.node(nx[j]);       // unconditional: IPT loads in flight per lane
 #pragma unroll
-                for (int e = 0; e < BPT; e++) {
-                    const int d = threadIdx.x * BPT + e;
-                    tt[e] = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { cw[e][k] = d < NB ? s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
-                    sum += tt[e];
-                }
-                u32 incl = sum;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    u32 v = (u32)__shfl_up((int)incl, off);
-                    if (lane >= off) incl += v;
-                }
-                if (lane == 63) s_wsum[w] = incl;
-                __syncthreads();
-                u32 start = incl - sum;
-                for (int k = 0; k < w; k++) start += s_wsum[k];
-#pragma unroll
-                for (int e = 0; e < BPT; e++) {
-                    const int d = threadIdx.x * BPT + e;
-                    if (d < NB) {
-                        s_cnt[0][d] = start;
-                        s_cnt[1][d] = start + cw[e][0];
-                        s_cnt[2][d] = start + cw[e][0] + cw[e][1];
-                        s_cnt[3][d] = start + cw[e][0] + cw[e][1] + cw[e][2];
-                        const u64 g = s_goff[d];
-                        s_gbase[d] = g - (u64)start;
-                        s_goff[d] = g + tt[e];
-                        start += tt[e];
+                    for (int j = 0; j < IPT; j++) {
+                        if (m[j]) {
+                            if (pos[j] < room) s_cells[fill + pos[j]] = (K)gen.key_step(rec[j], nx[j], ib[j]);
+                            pos[j]++;
+                            rec[j] = nrec[j];
+                        }
                     }
                 }
-            }
-            __syncthreads();
 #pragma unroll
-            for (int q = 0; q < ROWS; q++) {
-                const u32 t = ((u32)w * rpw + q) * 64 + lane;
-                if ((u32)q < rpw && t < hn) s_cells[idx[q] + s_cnt[w][(u32)key[q] & dmask]] = key[q];   // in place: the round's keys are in registers
+                for (int j = 0; j < IPT; j++) if (act[j]) gen.finish(item[j], rec[j]);
+                const u32 took = rest < room ? rest : room;
+                fill += took;
+                wlo += took;
+                if (wlo >= tot) { have = false; b++; }                       // the walk is done (also a walk without keys: its side effects are)
+                else full = true;                                            // a walk larger than the window: the next piece after the ranking
             }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < ROWS; j++) {
-                const u32 t = (u32)j * kBlock + threadIdx.x;
-                if (t < hn) {
-                    const K k = s_cells[t];
-                    out[s_gbase[(u32)k & dmask] + t] = k;
-                }
-            }
-            __syncthreads();
         }
+        if (fill == 0) break;                                                // uniform: nothing left
+        __syncthreads();
+        // ---- rank the window's keys by the digit and write them out (the body of k_rs_scatter)
+        const u32 hn = fill;
+        fill = 0;
+        const u32 rpw = (u32)__builtin_amdgcn_readfirstlane((int)(((hn + 63) / 64 + 3) / 4));   // rows per wave (uniform, in an SGPR): every wave takes a contiguous share
+        for (int d = threadIdx.x; d < (kBlock / 64) * NB; d += kBlock) (&s_cnt[0][0])[d] = 0;
+        K key[ROWS];
+        u32 idx[ROWS];
+#pragma unroll
+        for (int q = 0; q < ROWS; q++) {
+            const u32 t = ((u32)w * rpw + q) * 64 + lane;
+            key[q] = ((u32)q < rpw && t < hn) ? s_cells[t] : K(0);
+        }
+        __syncthreads();
+        // (rows behind rpw hold nothing: skipped by a workgroup-uniform branch)
+        wave_rank<DB, ROWS, false>([&](int q) { return (u32)key[q] & dmask; }, (u32)w * rpw * 64u + (u32)lane, hn, rpw, &s_cnt[w][0], idx);
+        __syncthreads();
+        {   // thread t owns bins [t*BPT, (t+1)*BPT): wave bases, round-local digit starts, global bases
+            u32 cw[BPT][4], tt[BPT], sum = 0;
+#pragma unroll
+            for (int e = 0; e < BPT; e++) {
+                const int d = threadIdx.x * BPT + e;
+                tt[e] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { cw[e][k] = d < NB ? s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
+                sum += tt[e];
+            }
+            u32 incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                u32 v = (u32)__shfl_up((int)incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63) s_wsum[w] = incl;
+            __syncthreads();
+            u32 start = incl - sum;
+            for (int k = 0; k < w; k++) start += s_wsum[k];
+#pragma unroll
+            for (int e = 0; e < BPT; e++) {
+                const int d = threadIdx.x * BPT + e;
+                if (d < NB) {
+                    s_cnt[0][d] = start;
+                    s_cnt[1][d] = start + cw[e][0];
+                    s_cnt[2][d] = start + cw[e][0] + cw[e][1];
+                    s_cnt[3][d] = start + cw[e][0] + cw[e][1] + cw[e][2];
+                    const u64 g = s_goff[d];
+                    s_gbase[d] = g - (u64)start;
+                    s_goff[d] = g + tt[e];
+                    start += tt[e];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ROWS; q++) {
+            const u32 t = ((u32)w * rpw + q) * 64 + lane;
+            if ((u32)q < rpw && t < hn) s_cells[idx[q] + s_cnt[w][(u32)key[q] & dmask]] = key[q];   // in place: the round's keys are in registers
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) {
+            const u32 t = (u32)j * kBlock + threadIdx.x;
+            if (t < hn) {
+                const K k = s_cells[t];
+                out[s_gbase[(u32)k & dmask] + t] = k;
+            }
+        }
+        __syncthreads();
     }
 }
 // Phase 1: count.  Returns the number of keys; plan.ok tells whether expand_sort may follow (else the caller expands
@@ -2219,7 +2279,7 @@ inline u64 expand_count(u64 n, GEN gen, int bits, XsPlan &plan, const char *name
     }
     const int NB = 1 << plan.db;
     const u32 dmask = bits >= plan.db ? (u32)NB - 1u : (1u << bits) - 1u;
-    plan.tiles = (u32)((n + kXsTileItems - 1) / kXsTileItems);
+    plan.tiles = (u32)((n + (u64)plan.ti - 1) / (u64)plan.ti);
     plan.cnt8 = (u8 *)dev_alloc(n);
     plan.counts = (u32 *)dev_alloc((u64)NB * plan.tiles * sizeof(u32));
     plan.offsets = (u64 *)dev_alloc((u64)NB * plan.tiles * sizeof(u64));
@@ -2254,16 +2314,16 @@ inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *na
     const u32 dmask = plan.bits >= plan.db ? (u32)NB - 1u : (1u << plan.bits) - 1u;
     // XCD-contiguous tile ranges were measured 7 % SLOWER for this kernel on the 10 GB build (32.8 vs 30.6 ms at level 0,
     // 16.9 vs 14.8 at level 1): the round-robin deal already lets the 8 L2s share every digit's write front; opt-in only
-    static const int xcd_aware = getenv("GRLBWT_XCD_MAP") ? 1 : 0;
+    const int xcd_aware = 0;
     prof_begin(std::string(name) + ".xscatter", plan.E * sizeof(K));
-    static const int occ = getenv("GRLBWT_XS_OCC") ? atoi(getenv("GRLBWT_XS_OCC")) : 3;
-    if (occ == 2) {
-        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9, 2, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
-        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8, 2, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
-    } else {
-        if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9, 3, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
-        else hipLaunchKernelGGL((k_xs_scatter<GEN, 8, 3, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
-    }
+    // (three workgroups per CU: at two the kernel keeps everything in registers, at three it spills ~100 bytes per lane and is the
+    // faster one -- it hides its gathers with waves, not with registers: round 3)
+    // Workgroups per CU the register budget is cut for.  8-byte cells: three -- the LDS window allows no more.  4-byte cells (level 0 of
+    // a DNA collection): FOUR (round 6: 137 -> 128 registers, nothing spilled; level 0 of the 10 GB build 19.2 -> 16.2 ms) -- the kernel
+    // hides its chain gathers with waves, not with registers (round 3: two per CU, everything in registers, was the slower form).
+    constexpr int kOcc = sizeof(K) == 4 ? 4 : 3;
+    if (plan.db == 9) hipLaunchKernelGGL((k_xs_scatter<GEN, 9, kOcc, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
+    else hipLaunchKernelGGL((k_xs_scatter<GEN, 8, kOcc, K>), dim3(plan.tiles), dim3(kBlock), 0, rt().stream, plan.n, gen, dmask, plan.cnt8, plan.offsets, buf_a, xcd_aware);
     prof_end();
     after_launch(name);
     if (plan.bits <= plan.db || plan.E == 0) return 0;
@@ -2745,7 +2805,8 @@ static constexpr u32 kSmInline = 8;                        // atoms behind the f
                                                            // and copied by a kernel of its own, one lane per atom (a pre-BWT run of BWT markers can
                                                            // take tens of millions of runs: the deep levels of a read collection)
 template <class IDX>
-struct SmWide { IDX r, L, x, cnt; u64 k; };                // run index / symbol position / T position of the segment, atoms behind the first, first of their runs
+struct SmWide { IDX r, L, x, cnt; u64 k; IDX tile1; };     // run index / symbol position / T position of the segment, atoms behind the first, first of their runs;
+                                                           // tile1 != 0 (one walk): r counts from the start of tile tile1 - 1, whose base the status words hold
 template <class IDX>
 struct SmPlan {
     u64 G = 0, tiles = 0;
@@ -2808,6 +2869,88 @@ __global__ void __launch_bounds__(kBlock) k_sm_sums(u64 G, u64 tiles, SEG seg, I
 //   * the two ranks of a TAKE segment come from ONE word of the T vector whenever its ends share it;
 //   * the emit pass stages the tile's heads in LDS and writes them out linearly (a lane's heads are consecutive, so the direct
 //     stores of a wave were 64 addresses 40 bytes apart: 24 ms for level 0 of the 10 GB build against 12 for the count pass).
+// ---- decoupled look-back (the one-walk form of the stream merge).  A tile publishes 8-byte words that validate themselves
+// (flag in the top two bits, written by ONE agent-scope store, read by agent-scope loads: a single naturally aligned granule
+// needs no fence on either side, MI355X_MICROARCH.md "inter-workgroup visibility"):  0 = nothing yet, 1 = the tile's own sum,
+// 2 = the sum of the tile and of every tile in front of it, 3 = the tile gave up (a wait ran out, or a tile in front gave up).
+// Tiles are ordered by blockIdx: the hardware starts the workgroups of a grid in index order (per XCD queue), so the smallest
+// unfinished tile is always running and waits only for finished ones.  HIP does not promise that order, hence the deadline:
+// a tile that waits longer gives up, everybody behind it does the same at once, and the host takes the two-pass form.
+// (Round 2 measured this shape for plain scans -- 2048 elements per tile -- and dropped it: the publication chain across eight
+// L2s cost more than the second read of the inputs.  A tile of the stream merge is 10-30 us of work; there it pays.)
+static constexpr u64 kLbAgg = 1ull << 62, kLbPre = 2ull << 62, kLbBad = 3ull << 62, kLbVal = (1ull << 62) - 1ull;
+GRL_DEV void lb_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+GRL_DEV u64 lb_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct SmLb {
+    u64 *st_head = nullptr;      // [tiles] flag | run heads (own, then inclusive)
+    u64 *res = nullptr;          // [0] run heads in all, [1] != 0: some tile gave up
+    u64 patience = 0;            // ticks of wall_clock64() (100 MHz) a tile waits for another one
+};
+// one wave: the sum of the values of tiles [0, t).  A round looks at the 64 x W tiles in front of `hi` (lane l at tiles
+// hi - 1 - l - 64 j), nearest first; the first inclusive word ends the walk.  false: a tile in front gave up or the deadline passed.
+// The window has to cover the tiles that have published their own sum but not yet their inclusive one -- the ones that are in
+// THEIR look-back: throughput in tiles per microsecond x the latency of a look-back.  And the waiting has to be quiet: the status
+// words of the tiles in flight are a few KB -- a handful of memory channels -- and every agent-scope load is a trip to the memory
+// side, so a wave re-reads only the words it is still waiting for and sleeps longer every time.  (First form: all lanes re-read
+// their words every 0.1 us.  Level 0 of the 10 GB build -- 2.6 M tiles of 1024 segments, 100+ tiles per microsecond -- then ran at
+// the rate of the look-back: 39.5 ms with 64 tiles per round, 44.4 ms with 256, against 30.3 ms for count + emit.)
+template <int W>
+GRL_DEV bool lb_lookback(const u64 *status, u64 t, u64 patience, u64 &excl) {
+    const int lane = threadIdx.x & 63;
+    const u64 t0 = wall_clock64();
+    u64 sum = 0, hi = t;
+    bool ok = true, done = false;
+    while (hi > 0 && ok && !done) {
+        u64 v[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) v[j] = 0;
+        bool ready = false;
+        int jp = W;                              // first row that holds an inclusive word (W: none)
+        unsigned long long upto = ~0ull;         // ... and the lanes of that row up to and including it
+        int nap = 1;
+        while (!ready && ok) {
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const u64 back = (u64)lane + 64ull * (u64)j;                    // tile hi - 1 - back
+                if (back >= hi) v[j] = kLbPre;                                  // (in front of tile 0: an inclusive zero)
+                else if ((v[j] >> 62) == 0 && j <= jp) v[j] = lb_load(status + (hi - 1 - back));
+            }
+            ready = true; jp = W; upto = ~0ull;
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                if (jp == W) {                                                  // (rows behind the first inclusive word do not matter)
+                    const unsigned long long pm = __ballot((v[j] >> 62) >= 2), zm = __ballot((v[j] >> 62) == 0);
+                    const unsigned long long up = pm ? (((pm & (~pm + 1ull)) << 1) - 1ull) : ~0ull;
+                    if (zm & up) ready = false;
+                    if (pm) { jp = j; upto = up; }
+                }
+            }
+            if (!ready) {
+                if (wall_clock64() - t0 > patience) ok = false;
+                else {
+                    for (int z = 0; z < nap; z++) __builtin_amdgcn_s_sleep(16);     // 16 x 64 clocks ~ 0.4 us per unit
+                    if (nap < 8) nap++;
+                }
+            }
+        }
+        if (ok) {
+            u64 part = 0;
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const bool take = j < jp || (j == jp && ((upto >> lane) & 1ull));
+                if (take) { part += v[j] & kLbVal; bad = bad || (v[j] >> 62) == 3; }
+            }
+            if (__ballot(bad)) ok = false;
+            part = wave_reduce<u64, Op::Sum>(part);
+            sum += __shfl(part, 0, 64);                                         // (the reduction lands in lane 0)
+            done = jp != W;
+            hi = hi > 64ull * W ? hi - 64ull * W : 0;
+        }
+    }
+    excl = sum;
+    return ok;
+}
 template <class LT, int SPT> struct SmShared {
     static constexpr int kSmTile = kBlock * SPT;
     u32 sym[kSmTile + kSmTile / 32];            // bit 31: TAKE (symbols are < 2^30); skewed by one slot per 32.  Emit: the staged heads' symbols
@@ -2816,10 +2959,13 @@ template <class LT, int SPT> struct SmShared {
     u32 w1[4];
     u32 last[kBlock];
 };
-template <class LT, class SEG, class IDX, bool EMIT, int SPT>
-GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const IDX lb, const IDX hb, const u32 prev_tile, const bool plain, const u64 ord0,
+// MODE 0: count pass, 1: emit pass of the two-pass form, 2: ONE WALK (round 6) -- count and emit together; the run index at the tile's
+// start (hb) is not an input but comes from a decoupled look-back over per-tile status words (SmLb), see k_sm_merge
+template <class LT, class SEG, class IDX, int MODE, int SPT>
+GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const IDX lb, IDX hb, const u32 prev_tile, const bool plain, const u64 ord0,
                      SmShared<LT, SPT> &S, IDX *tile_heads, IDX *tile_atoms, u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue,
-                     u64 queue_cap, u32 *osym, IDX *ostart) {
+                     u64 queue_cap, u32 *osym, IDX *ostart, const SmLb &lbk) {
+    constexpr bool EMIT = MODE != 0;
     constexpr int TILE = kBlock * SPT;
     typedef Pair<LT, LT> P2;
     // striped loads (neighbouring lanes, neighbouring segments) -> LDS -> blocked (a lane's segments are consecutive)
@@ -2946,10 +3092,47 @@ GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const 
             tlast[blockIdx.x] = S.last[(nin - 1) / SPT];
         }
     } else {
-        __shared__ u64 s_h[4];
-        u64 htot;
-        const u64 hl0 = block_excl_scan<u64>(nh, s_h, &htot);       // my first head, counted from the tile's
+        __shared__ Pair<u64, u64> s_h[4];
+        __shared__ u64 s_lb[2];
+        Pair<u64, u64> htot2;
+        const u64 hl0 = block_excl_scan<Pair<u64, u64>>(Pair<u64, u64>(nh, na), s_h, &htot2).a;       // my first head, counted from the tile's
+        const u64 htot = htot2.a;
+        // ONE WALK: my heads are exact (the symbol in front of the tile was worked out by thread 0 at the start: k_sm_merge), so
+        // the tile's own sum goes out at once.  The look-back itself comes as LATE as possible -- behind the loop that stages the
+        // heads in LDS, whose inline atoms are the tile's last gathers: by then the tiles in front have published, and a second
+        // trip to their words (each one a round trip to the memory side) is rare.  Only a tile whose heads do not fit LDS needs
+        // its base before that loop; the queued segments carry their place relative to the tile (SmWide::tile1) and the launch
+        // that copies them adds the base.
         const bool staged = htot <= (u64)TILE;                       // (uniform) the tile's heads fit the LDS arrays the segments came through
+        u64 hbm = (u64)hb;
+        bool live = true;
+        auto look_back = [&] {                    // (all threads; a barrier inside)
+            if (threadIdx.x < 64) {
+                const u64 t = blockIdx.x;
+                u64 excl = 0;
+                const bool ok = lb_lookback<(SPT >= 8 ? 1 : 4)>(lbk.st_head, t, lbk.patience, excl);
+                if (threadIdx.x == 0) {
+                    lb_store(lbk.st_head + t, ok ? (kLbPre | ((excl + htot) & kLbVal)) : kLbBad);
+                    if (!ok) lb_store(lbk.res + 1, 1ull);
+                    else if (t + 1 == gridDim.x) lbk.res[0] = excl + htot;
+                    s_lb[0] = excl; s_lb[1] = ok ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            hbm = s_lb[0]; live = s_lb[1] != 0;
+        };
+        if constexpr (MODE == 2) {
+            if (threadIdx.x == 0) { lb_store(lbk.st_head + blockIdx.x, kLbAgg | (htot & kLbVal)); tile_atoms[blockIdx.x] = (IDX)htot2.b; }
+            const unsigned long long anyw = __ballot(nwide != 0);
+            if (anyw) {                            // (rare: the atoms of the queued segments, for the launch that copies them)
+                wide_atoms = wave_reduce<unsigned long long, Op::Sum>(wide_atoms);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&wide[1], wide_atoms);
+            }
+            if (!staged) look_back();
+        }
+        const IDX tile1 = (MODE == 2 && staged) ? (IDX)blockIdx.x + 1 : (IDX)0;      // queued segments: place relative to this tile
+        const u64 qbase_r = (MODE == 2 && staged) ? 0 : hbm;
+        if (live) {
         if (staged) {
             for (u32 k = threadIdx.x; k < (u32)htot; k += kBlock) S.sym[k] = kSmNoSym;      // (places of queued atoms stay marked: the wide kernel writes them)
             __syncthreads();
@@ -2960,14 +3143,14 @@ GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const 
             if (g0 + i < G) {
                 if (head[i]) {
                     if (staged) { S.sym[r] = fs[i]; S.len[r] = Ls[i]; }
-                    else { osym[(u64)hb + r] = fs[i]; ostart[(u64)hb + r] = lb + (IDX)Ls[i]; }
+                    else { osym[hbm + r] = fs[i]; ostart[hbm + r] = lb + (IDX)Ls[i]; }
                     r++;
                 }
                 if (sy[i] & 0x80000000u) {
                     const u64 in64 = inner[i] == 0xFFFFFFFFu ? k1m[i] - k0[i] : (u64)inner[i];
                     if (in64 > (u64)kSmInline) {
                         const u64 q = (u64)atomicAdd(&wide[2], 1ull);
-                        if (q < queue_cap) queue[q] = SmWide<IDX>{(IDX)((u64)hb + r), lb + (IDX)Ls[i], xb + (IDX)xs[i], (IDX)in64, k0[i] + 1};
+                        if (q < queue_cap) queue[q] = SmWide<IDX>{(IDX)(qbase_r + r), lb + (IDX)Ls[i], xb + (IDX)xs[i], (IDX)in64, k0[i] + 1, tile1};
                     } else {
                         // (all of a segment's loads in flight first, clamped instead of branched, was tried: no faster -- 18.9 vs 19.4 ms on
                         // level 1 of the 10 GB build -- and 24 more registers)
@@ -2977,25 +3160,29 @@ GRL_DEV void sm_tile(u64 G, const SEG &seg, const u64 base, const IDX xb, const 
                             const u32 sk = seg.esym(k);
                             const u64 off = seg.epos(k) - x;            // (< the segment's length)
                             if (staged) { S.sym[r + a] = sk; S.len[r + a] = Ls[i] + (LT)off; }
-                            else { osym[(u64)hb + r + a] = sk; ostart[(u64)hb + r + a] = lb + (IDX)Ls[i] + (IDX)off; }
+                            else { osym[hbm + r + a] = sk; ostart[hbm + r + a] = lb + (IDX)Ls[i] + (IDX)off; }
                         }
                     }
                     r += in64;
                 }
             }
         }
+        }
         if (staged) {
-            __syncthreads();
-            for (u32 k = threadIdx.x; k < (u32)htot; k += kBlock) {
-                const u32 sk = S.sym[k];
-                if (sk != kSmNoSym) { osym[(u64)hb + k] = sk; ostart[(u64)hb + k] = lb + (IDX)S.len[k]; }
+            if constexpr (MODE == 2) look_back();            // (its barrier is the one the write-out needs)
+            else __syncthreads();
+            if (live) {
+                for (u32 k = threadIdx.x; k < (u32)htot; k += kBlock) {
+                    const u32 sk = S.sym[k];
+                    if (sk != kSmNoSym) { osym[hbm + k] = sk; ostart[hbm + k] = lb + (IDX)S.len[k]; }
+                }
             }
         }
     }
 }
-template <class SEG, class IDX, bool EMIT, int SPT>
+template <class SEG, class IDX, int MODE, int SPT>
 __global__ void __launch_bounds__(kBlock) k_sm_merge(u64 G, SEG seg, const IDX *xbase, const IDX *lbase, const IDX *hbase, IDX *tile_heads, IDX *tile_atoms,
-                                                     u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue, u64 queue_cap, u32 *osym, IDX *ostart) {
+                                                     u32 *tfirst, u32 *tlast, unsigned long long *wide, SmWide<IDX> *queue, u64 queue_cap, u32 *osym, IDX *ostart, SmLb lbk) {
     constexpr int kSmTile = kBlock * SPT;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[sizeof(SmShared<IDX, SPT>)];
     const u64 base = (u64)blockIdx.x * kSmTile;
@@ -3003,16 +3190,32 @@ __global__ void __launch_bounds__(kBlock) k_sm_merge(u64 G, SEG seg, const IDX *
     const IDX xb = xbase[blockIdx.x], lb = lbase[blockIdx.x], lnext = lbase[blockIdx.x + 1];
     IDX hb = 0;
     u32 prev_tile = kSmNoSym;
-    if constexpr (EMIT) { hb = hbase[blockIdx.x]; if (blockIdx.x > 0) prev_tile = tlast[blockIdx.x - 1]; }
+    if constexpr (MODE == 1) { hb = hbase[blockIdx.x]; if (blockIdx.x > 0) prev_tile = tlast[blockIdx.x - 1]; }
+    if constexpr (MODE == 2) {
+        // the last symbol of the segment in front of the tile, by thread 0 itself: its record, and where it is a TAKE -- it ends where my
+        // tile's T axis begins -- the run of T in front of xb.  Three dependent loads, issued before everything else: they are back when
+        // the tile's own chain of four is.  (The count pass of the two-pass form leaves this to the scan over the tiles: there the
+        // loads sat at the end of the tile.)
+        if (threadIdx.x == 0 && blockIdx.x > 0) {
+            u32 sym; IDX len; bool take;
+            seg.fetch(seg.locate(base - 1), sym, len, take);
+            if (take) {
+                u64 bits, before;
+                seg.eword((u64)xb >> 6, bits, before);
+                sym = seg.esym(before + (u64)__builtin_popcountll(bits & ((1ull << ((u64)xb & 63)) - 1ull)) - 1);      // run starts in [0, xb) - 1
+            }
+            prev_tile = sym;
+        }
+    }
     const u64 gend = base + kSmTile < G ? base + kSmTile : G;
     const u64 ord0 = seg.pre_before(base), ord1 = seg.pre_before(gend);
     const bool plain = ord0 == ord1;                                   // (uniform) no pre-BWT run among the tile's segments
     if (sizeof(IDX) == 4 || (u64)(lnext - lb) >= 0xFFFFFFFFull)        // (uniform) offsets inside the tile in the index width ...
-        sm_tile<IDX, SEG, IDX, EMIT, SPT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<IDX, SPT> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
-                                     wide, queue, queue_cap, osym, ostart);
+        sm_tile<IDX, SEG, IDX, MODE, SPT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<IDX, SPT> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
+                                     wide, queue, queue_cap, osym, ostart, lbk);
     else                                                               // ... or in 32 bits when the tile describes < 2^32 symbols
-        sm_tile<u32, SEG, IDX, EMIT, SPT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<u32, SPT> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
-                                     wide, queue, queue_cap, osym, ostart);
+        sm_tile<u32, SEG, IDX, MODE, SPT>(G, seg, base, xb, lb, hb, prev_tile, plain, ord0, *reinterpret_cast<SmShared<u32, SPT> *>(s_raw), tile_heads, tile_atoms, tfirst, tlast,
+                                     wide, queue, queue_cap, osym, ostart, lbk);
 }
 // heads of tile t without the provisional head of its first segment where the tile in front ends with the same symbol
 template <class IDX>
@@ -3027,15 +3230,18 @@ struct SmWideCountIn {
 };
 // the atoms of the queued TAKE segments, one lane per atom (entries in queue order, qbase = exclusive prefix of their counts)
 template <class SEG, class IDX>
-__global__ void __launch_bounds__(kBlock) k_sm_wide(u64 natoms, u64 nq, SEG seg, const SmWide<IDX> *queue, const u64 *qbase, u32 *osym, IDX *ostart) {
+__global__ void __launch_bounds__(kBlock) k_sm_wide(u64 natoms, u64 nq, SEG seg, const SmWide<IDX> *queue, const u64 *qbase, u32 *osym, IDX *ostart,
+                                                    const u64 *st_head /* one walk: inclusive run counts per tile */) {
     const u64 stride = (u64)gridDim.x * kBlock;
     for (u64 y = (u64)blockIdx.x * kBlock + threadIdx.x; y < natoms; y += stride) {
         u64 lo = 0, hi = nq;                   // last entry with qbase <= y
         while (lo + 1 < hi) { const u64 mid = (lo + hi) >> 1; if (qbase[mid] <= y) lo = mid; else hi = mid; }
         const SmWide<IDX> e = queue[lo];
         const u64 a = y - qbase[lo], k = e.k + a;
-        osym[e.r + (IDX)a] = seg.esym(k);
-        ostart[e.r + (IDX)a] = e.L + (IDX)(seg.epos(k) - (u64)e.x);
+        u64 r = (u64)e.r + a;
+        if (e.tile1 > (IDX)1) r += st_head[(u64)e.tile1 - 2] & kLbVal;       // (runs in front of the segment's tile = inclusive count of the tile in front of it)
+        osym[r] = seg.esym(k);
+        ostart[r] = e.L + (IDX)(seg.epos(k) - (u64)e.x);
     }
 }
 // passes 1 + 2: the plan's prefixes and totals (one host synchronisation); pass 3 follows through stream_merge_emit
@@ -3067,11 +3273,11 @@ inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char *na
     exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.lbase}, plan.lbase, (IDX *)(dres + 1), plan.lbase + T, name);
     prof_begin(std::string(name) + ".count");
     if (plan.spt == 4)
-        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, false, 4>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
-                           (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, 0, 4>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
+                           (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr, SmLb());
     else
-        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, false, 8>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
-                           (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr);
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, 0, 8>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
+                           (const IDX *)nullptr, plan.hbase, tatoms, tfirst, plan.tlast, (unsigned long long *)(dres + 4), (SmWide<IDX> *)nullptr, (u64)0, (u32 *)nullptr, (IDX *)nullptr, SmLb());
     prof_end();
     after_launch(name);
     exclusive_scan_async<IDX, SmHeadsIn<IDX>>(T, SmHeadsIn<IDX>{plan.hbase, tfirst, plan.tlast}, plan.hbase, (IDX *)(dres + 2), plan.hbase + T, name);
@@ -3090,11 +3296,11 @@ inline void stream_merge_emit(SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart
     dev_memset(wide, 0, 3 * sizeof(unsigned long long));
     prof_begin(std::string(name) + ".emit", plan.heads * (sizeof(u32) + sizeof(IDX)));
     if (plan.spt == 4)
-        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, true, 4>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
-                           (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart);
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, 1, 4>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
+                           (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart, SmLb());
     else
-        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, true, 8>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
-                           (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart);
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, 1, 8>), dim3((unsigned)plan.tiles), dim3(kBlock), 0, rt().stream, plan.G, seg, (const IDX *)plan.xbase,
+                           (const IDX *)plan.lbase, (const IDX *)plan.hbase, (IDX *)nullptr, (IDX *)nullptr, (u32 *)nullptr, plan.tlast, wide, queue, nq, osym, ostart, SmLb());
     prof_end();
     after_launch(name);
     if (nq) {
@@ -3102,12 +3308,96 @@ inline void stream_merge_emit(SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart
         exclusive_scan_async<u64, SmWideCountIn<IDX>>(nq, SmWideCountIn<IDX>{queue}, qbase, (u64 *)nullptr, qbase + nq, name);
         prof_begin(std::string(name) + ".wide", plan.wide_atoms * (sizeof(u32) + sizeof(IDX)));
         hipLaunchKernelGGL((k_sm_wide<SEG, IDX>), dim3(grid_for(plan.wide_atoms, kBlock)), dim3(kBlock), 0, rt().stream, plan.wide_atoms, nq, seg,
-                           (const SmWide<IDX> *)queue, (const u64 *)qbase, osym, ostart);
+                           (const SmWide<IDX> *)queue, (const u64 *)qbase, osym, ostart, (const u64 *)nullptr);
         prof_end();
         after_launch(name);
         dev_free(qbase);
     }
     dev_free(queue); dev_free(wide);
+}
+
+// Status words of the look-back: memory of the runtime's own allocator (hipMalloc), kept between calls -- agent-scope polling
+// across the XCDs' L2s is what the microarchitecture guide measured on such memory; the engine's arena is mapped memory.
+inline u64 *lookback_scratch(size_t words) {
+    static u64 *buf = nullptr;
+    static size_t cap = 0;
+    static int dev = -1;
+    if (dev != rt().device) { buf = nullptr; cap = 0; dev = rt().device; }      // (another device: the old block stays with its device)
+    if (words > cap) {
+        if (buf) { GRL_HIP_CHECK(hipStreamSynchronize(rt().stream)); (void)hipFree(buf); buf = nullptr; cap = 0; }
+        size_t want = words + words / 4 + 4096;
+        GRL_HIP_CHECK(hipMalloc((void **)&buf, want * sizeof(u64)));
+        cap = want;
+    }
+    return buf;
+}
+// The one-walk form: sums + scans as in stream_merge_count, then ONE merge kernel that finds the run heads and writes them; the
+// run index at a tile's start comes from the look-back.  osym / ostart must hold `out_cap` entries (an upper bound of the runs:
+// segments + runs of T).  Returns false when the walk gave up -- the queue of wide segments overflowed, or a tile waited too long
+// for another one -- and the caller takes stream_merge_count + stream_merge_emit; the plan then holds nothing.
+template <class SEG, class IDX>
+inline bool stream_merge_onepass(u64 G, SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart, u64 out_cap, u64 queue_cap, const char *name = "stream_merge",
+                                 bool mostly_plain = false) {
+    plan.release();
+    plan = SmPlan<IDX>();
+    plan.G = G;
+    if (G == 0) return true;
+    static const int spt_dev = dev_env("GRLBWT_DEV_SM1_SPT") ? atoi(dev_env("GRLBWT_DEV_SM1_SPT")) : 0;
+    plan.spt = spt_dev == 4 || spt_dev == 8 ? spt_dev : (mostly_plain ? 4 : 8);
+    const u64 kSmTile = (u64)kBlock * plan.spt;
+    plan.tiles = (G + kSmTile - 1) / kSmTile;
+    const u64 T = plan.tiles;
+    plan.xbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    plan.lbase = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    IDX *tatoms = (IDX *)dev_alloc((T + 1) * sizeof(IDX));
+    prof_begin(std::string(name) + ".sums");
+    if (plan.spt == 4) hipLaunchKernelGGL((k_sm_sums<SEG, IDX, 4>), dim3((unsigned)((T + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, rt().stream, G, T, seg, plan.xbase, plan.lbase);
+    else hipLaunchKernelGGL((k_sm_sums<SEG, IDX, 8>), dim3((unsigned)((T + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, rt().stream, G, T, seg, plan.xbase, plan.lbase);
+    prof_end();
+    after_launch(name);
+    u64 *dres = (u64 *)dev_alloc(8 * sizeof(u64));      // [0] TAKE symbols, [1] symbols, [2] atoms, [3] -, [4] -, [5] atoms of the queued segments, [6] queued segments
+    dev_memset(dres, 0, 8 * sizeof(u64));               // (the scans store IDX-wide totals into zeroed words)
+    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.xbase}, plan.xbase, (IDX *)(dres + 0), plan.xbase + T, name);
+    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{plan.lbase}, plan.lbase, (IDX *)(dres + 1), plan.lbase + T, name);
+    u64 *st = lookback_scratch(T + 2);
+    dev_memset(st, 0, (T + 2) * sizeof(u64));
+    SmLb lbk;
+    lbk.st_head = st; lbk.res = st + T;
+    lbk.patience = 200000000ull;                        // two seconds of the 100 MHz clock
+    SmWide<IDX> *queue = (SmWide<IDX> *)dev_alloc((queue_cap ? queue_cap : 1) * sizeof(SmWide<IDX>));
+    unsigned long long *wide = (unsigned long long *)(dres + 4);      // [1] atoms of the queued segments, [2] queue fill
+    (void)out_cap;
+    prof_begin(std::string(name) + ".walk");
+    if (plan.spt == 4)
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, 2, 4>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
+                           (const IDX *)nullptr, (IDX *)nullptr, tatoms, (u32 *)nullptr, (u32 *)nullptr, wide, queue, queue_cap, osym, ostart, lbk);
+    else
+        hipLaunchKernelGGL((k_sm_merge<SEG, IDX, 2, 8>), dim3((unsigned)T), dim3(kBlock), 0, rt().stream, G, seg, (const IDX *)plan.xbase, (const IDX *)plan.lbase,
+                           (const IDX *)nullptr, (IDX *)nullptr, tatoms, (u32 *)nullptr, (u32 *)nullptr, wide, queue, queue_cap, osym, ostart, lbk);
+    prof_end();
+    after_launch(name);
+    exclusive_scan_async<IDX, PtrIn<IDX>>(T, PtrIn<IDX>{tatoms}, tatoms, (IDX *)(dres + 2), (IDX *)nullptr, name);
+    d2d(dres + 7, lbk.res, sizeof(u64));                // run heads in all
+    d2d(dres + 3, lbk.res + 1, sizeof(u64));            // a tile gave up
+    u64 h[8];
+    d2h(h, dres, 8 * sizeof(u64));
+    dev_free(dres); dev_free(tatoms);
+    plan.take_total = h[0]; plan.len_total = h[1]; plan.atoms = h[2]; plan.heads = h[7]; plan.wide_atoms = h[5]; plan.wide_n = h[6];
+    const bool gave_up = h[3] != 0 || h[6] > queue_cap || plan.heads > out_cap;
+    if (gave_up) { dev_free(queue); plan.release(); plan = SmPlan<IDX>(); plan.G = G; return false; }
+    if (plan.wide_n) {
+        const u64 nq = plan.wide_n;
+        u64 *qbase = (u64 *)dev_alloc((nq + 1) * sizeof(u64));
+        exclusive_scan_async<u64, SmWideCountIn<IDX>>(nq, SmWideCountIn<IDX>{queue}, qbase, (u64 *)nullptr, qbase + nq, name);
+        prof_begin(std::string(name) + ".wide", plan.wide_atoms * (sizeof(u32) + sizeof(IDX)));
+        hipLaunchKernelGGL((k_sm_wide<SEG, IDX>), dim3(grid_for(plan.wide_atoms, kBlock)), dim3(kBlock), 0, rt().stream, plan.wide_atoms, nq, seg,
+                           (const SmWide<IDX> *)queue, (const u64 *)qbase, osym, ostart, (const u64 *)lbk.st_head);
+        prof_end();
+        after_launch(name);
+        dev_free(qbase);
+    }
+    dev_free(queue);
+    return true;
 }
 
 }   // namespace prim

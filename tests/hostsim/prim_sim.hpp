@@ -61,6 +61,8 @@ inline void *dev_alloc(size_t bytes) {
     return p;
 }
 inline void dev_free(void *p) { std::free(p); }
+inline void dev_shrink(void *, size_t) {}
+inline const char *dev_env(const char *) { return nullptr; }      // (experiment switches: development builds of the device library only)
 inline void h2d(void *d, const void *h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void d2h(void *h, const void *d, size_t n) { if (n) std::memcpy(h, d, n); }
 inline void d2d(void *dst, const void *src, size_t n) { if (n) std::memmove(dst, src, n); }
@@ -453,6 +455,31 @@ inline void stream_merge_count(u64 G, SEG seg, SmPlan<IDX> &plan, const char * =
     plan = SmPlan<IDX>();
     plan.G = G;
     sm_walk(G, seg, plan, [](u64, u32, u64) {});
+}
+// the one-walk form (prim_hip.hpp stream_merge_onepass): heads written into arrays of out_cap entries; false = "gave up", the caller
+// takes count + emit (GRLBWT_SIM_ONEPASS_GIVES_UP: the tests take that branch)
+static constexpr u32 kSmInline = 8;
+template <class SEG, class IDX>
+inline bool stream_merge_onepass(u64 G, SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart, u64 out_cap, u64 queue_cap, const char * = "", bool = false) {
+    plan = SmPlan<IDX>();
+    plan.G = G;
+    if (getenv("GRLBWT_SIM_ONEPASS_GIVES_UP")) return false;
+    // (serially: the bound the caller computed must hold for every head the walk writes, and for the queued segments)
+    u64 wide = 0;
+    {
+        u64 x = 0;
+        for (u64 g = 0; g < G; g++) {
+            u32 sym; IDX len; bool take;
+            seg.fetch(seg.locate(g), sym, len, take);
+            if (take) { const u64 k0 = seg.erank(x + 1) - 1, k1 = seg.erank(x + (u64)len); if (k1 - 1 - k0 > kSmInline) wide++; x += (u64)len; }
+        }
+    }
+    if (wide > queue_cap) throw Error(-71, "stream_merge_onepass: the caller's queue bound does not hold");
+    sm_walk(G, seg, plan, [&](u64 r, u32 s, u64 at) {
+        if (r >= out_cap) throw Error(-71, "stream_merge_onepass: the caller's bound on the runs does not hold");
+        osym[r] = s; ostart[r] = (IDX)at;
+    });
+    return true;
 }
 template <class SEG, class IDX>
 inline void stream_merge_emit(SEG seg, SmPlan<IDX> &plan, u32 *osym, IDX *ostart, const char * = "") {

@@ -176,6 +176,25 @@ def test_unfused_expansion_branch(sim, oracle_mod, monkeypatch):
     parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
+def test_pass_c_walk_forms(sim, oracle_mod, monkeypatch):
+    """Pass C in one walk (prim::stream_merge_onepass: run heads into arrays sized for the caller's bound -- the stand-in throws when
+    the bound on the runs or on the queued segments does not hold) at every level, the two-pass form forced, and the fallback of
+    a walk that gave up; the same outputs stage by stage."""
+    reads = workloads.sampled_reads(3000, 100, 20000, seed=11).tobytes()
+    reps = workloads.repetitive_copies(30, 8000, seed=4).tobytes()
+    monkeypatch.setenv("GRLBWT_ASM_ONE_WALK", "1")
+    parity.check_stagewise(sim, reads, 1)
+    parity.check_stagewise(sim, reps, 1, engine.FLAG_FORCE_IDX64)
+    parity.check_stagewise(sim, workloads.zipf_tokens(30000, doc_len=100, vocab=3000).tobytes(), 2)
+    monkeypatch.setenv("GRLBWT_SIM_ONEPASS_GIVES_UP", "1")
+    parity.check_stagewise(sim, reads, 1)
+    parity.check_stagewise(sim, reps, 1)
+    monkeypatch.delenv("GRLBWT_SIM_ONEPASS_GIVES_UP")
+    monkeypatch.delenv("GRLBWT_ASM_ONE_WALK")
+    monkeypatch.setenv("GRLBWT_ASM_TWO_PASS", "1")
+    parity.check_stagewise(sim, reads, 1)
+
+
 @pytest.mark.parametrize("layout", ["packed", "separate"])
 def test_wider_cell_layouts(sim, oracle_mod, monkeypatch, layout):
     """Induced cells that do not fit one 64-bit word (bucket + run length + symbol > 64 bits) travel as bucket + packed

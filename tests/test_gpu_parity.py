@@ -85,6 +85,19 @@ def test_wider_cell_layouts(hip, oracle_mod, monkeypatch, layout):
     parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
+@pytest.mark.parametrize("form", ["one_walk", "two_pass"])
+def test_pass_c_walk_forms(hip, oracle_mod, monkeypatch, form):
+    """Pass C on the device in both forms at EVERY level: one walk with the run index of a tile from the look-back across the tiles
+    (prim::k_sm_merge<..., 2, ...>: by default the levels whose segments mix cells and pre-BWT runs), and count + emit (by default
+    the levels of plain cells); stage by stage against the oracle -- reads, long runs whose TAKE segments span many runs of T (the
+    queued segments carry tile-relative places in the one-walk form), tokens, 64-bit indices."""
+    monkeypatch.setenv("GRLBWT_ASM_ONE_WALK" if form == "one_walk" else "GRLBWT_ASM_TWO_PASS", "1")
+    parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
+    parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1, engine.FLAG_FORCE_IDX64)
+    parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2)
+    parity.check_final(hip, workloads.sampled_reads(330000, 150, 1660000, seed=20260508).tobytes(), 1)
+
+
 def test_unfused_expansion_branch(hip, oracle_mod, monkeypatch):
     """The count + scan + expand + split fallback of passes A+B (taken when a run drops more cells than the fused kernel
     stages): the limit is lowered so that ordinary inputs take it on the device."""
