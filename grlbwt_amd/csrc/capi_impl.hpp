@@ -645,66 +645,63 @@ int test_sort(uint64_t n, uint64_t seed, int bits) {
 }
 
 struct SelfValid {
-    GRL_DEV bool operator()(const prim::U128 &v) const { return (v.hi >> 61) != 0; }
+    GRL_DEV bool operator()(uint64_t hi) const { return (hi >> 61) != 0; }
 };
-struct SelfBoundsFn {
-    const uint32_t *sk; uint64_t n; int shift; uint64_t nparts; uint64_t *pstart;
-    GRL_DEV void operator()(uint64_t p) const { pstart[p] = p == nparts ? n : grl32::lower_bound<uint32_t>(sk, n, (uint32_t)(p << shift)); }
-};
-// PartSort (forward, backward) + part_dedupe against host containers
+// RecSort (forward, backward) + rec_dedupe against host containers
 int test_part(uint64_t n, uint64_t seed, int pbits) {
     while (pbits < 20 && (n >> pbits) > 3000) pbits++;          // partitions that fit the LDS table (as the engine sizes them)
-    std::vector<uint32_t> hk(n);
-    std::vector<prim::U128> hv(n);
+    std::vector<uint64_t> hk(n), hh(n);
     uint64_t s = seed;
     for (uint64_t i = 0; i < n; i++) {
         const uint64_t r = sm64(s);
         const uint64_t id = r % (n / 3 + 1);                                          // ~3 records per distinct value
-        if (r % 11 == 0) hv[i] = prim::U128(i, 0);                                    // invalid record
-        else hv[i] = prim::U128(id * 0x9E3779B97F4A7C15ull, (id % 5) | (3ull << 61));
-        hk[i] = (uint32_t)((hv[i].lo ^ hv[i].hi) * 0x85EBCA6Bull >> 7);
+        if (r % 11 == 0) { hk[i] = i; hh[i] = 0; }                                    // invalid record
+        else { hh[i] = (id % 5) | (3ull << 61); hk[i] = (id * 0x9E3779B97F4A7C15ull) ^ (hh[i] * 0xD6E8FEB86659FD93ull); }
     }
-    grl32::DBuf<uint32_t> dk(n), wa(n), wb(n), wc(n), lid(n), dcnt(n);
-    grl32::DBuf<prim::U128> va(n), vb(n), dval(n);
-    prim::h2d(dk.p, hk.data(), n * 4);
-    prim::h2d(va.p, hv.data(), n * sizeof(prim::U128));
-    prim::PartSort<uint32_t, prim::U128> ps;
-    const int res = ps.forward(dk.p, va.p, vb.p, n, 32 - pbits, 32, "selftest.part");
-    std::vector<prim::U128> sv = (res ? vb : va).to_host(n);
-    std::vector<uint32_t> sk(n);
-    prim::d2h(sk.data(), ps.sorted_keys(), n * 4);
-    for (uint64_t j = 0; j < n; j++) {
-        if (j && (sk[j - 1] >> (32 - pbits)) > (sk[j] >> (32 - pbits))) return 1;
-        if (sk[j] != (uint32_t)((sv[j].lo ^ sv[j].hi) * 0x85EBCA6Bull >> 7)) return 2;   // keys and values moved together
+    grl32::DBuf<uint64_t> ka(n), ha(n), kb(n), hb(n), dkey(n), dhi(n);
+    grl32::DBuf<uint32_t> wa(n), wb(n), wc(n), lid(n), dcnt(n);
+    prim::h2d(ka.p, hk.data(), n * 8);
+    prim::h2d(ha.p, hh.data(), n * 8);
+    prim::RecSort ps;
+    const int res = ps.forward(ka.p, ha.p, kb.p, hb.p, n, pbits, "selftest.part");
+    std::vector<uint64_t> sk = (res ? kb : ka).to_host(n), sh = (res ? hb : ha).to_host(n);
+    {   // a permutation of the input pairs, grouped by partition, stable inside a partition
+        std::map<std::pair<uint64_t, uint64_t>, int64_t> bal;
+        for (uint64_t i = 0; i < n; i++) bal[{hk[i], hh[i]}]++;
+        for (uint64_t j = 0; j < n; j++) {
+            if (j && prim::RecSort::part_of(sk[j - 1], pbits) > prim::RecSort::part_of(sk[j], pbits)) return 1;
+            if (--bal[{sk[j], sh[j]}] < 0) return 2;                                  // keys and values moved together
+        }
     }
     // backward: an element per sorted record returns to the record's original place
     std::vector<uint32_t> hw(n);
-    for (uint64_t j = 0; j < n; j++) hw[j] = (uint32_t)(sv[j].lo * 31 + sv[j].hi);
+    for (uint64_t j = 0; j < n; j++) hw[j] = (uint32_t)(sk[j] * 31 + sh[j]);
     prim::h2d(wa.p, hw.data(), n * 4);
     ps.backward(wa.p, wb.p, wc.p, "selftest.part_back");
     std::vector<uint32_t> ho = wc.to_host(n);
-    for (uint64_t i = 0; i < n; i++) if (ho[i] != (uint32_t)(hv[i].lo * 31 + hv[i].hi)) return 3;
+    for (uint64_t i = 0; i < n; i++) if (ho[i] != (uint32_t)(hk[i] * 31 + hh[i])) return 3;
     // per-partition de-duplication
     const uint64_t nparts = (uint64_t)1 << pbits;
     grl32::DBuf<uint64_t> pstart(nparts + 1);
     grl32::DBuf<uint32_t> pcount(nparts), ovf(1);
     ovf.zero();
-    prim::for_each(nparts + 1, SelfBoundsFn{ps.sorted_keys(), n, 32 - pbits, nparts, pstart.p}, "selftest.bounds");
-    prim::part_dedupe(nparts, pstart.p, res ? vb.p : va.p, SelfValid{}, lid.p, pcount.p, dval.p, dcnt.p, ovf.p, "selftest.dedupe");
+    prim::for_each(nparts + 1, prim::RecBoundsFn{res ? kb.p : ka.p, n, pbits, nparts, pstart.p}, "selftest.bounds");
+    prim::rec_dedupe(nparts, pstart.p, res ? kb.p : ka.p, res ? hb.p : ha.p, SelfValid{}, lid.p, pcount.p, dkey.p, dhi.p, dcnt.p, ovf.p, "selftest.dedupe");
     if (ovf.get(0)) return 4;
-    std::vector<uint64_t> hp = pstart.to_host(nparts + 1);
+    std::vector<uint64_t> hp = pstart.to_host(nparts + 1), hdk = dkey.to_host(n), hdh = dhi.to_host(n);
     std::vector<uint32_t> hl = lid.to_host(n), hc = pcount.to_host(nparts), hdc = dcnt.to_host(n);
-    std::vector<prim::U128> hd = dval.to_host(n);
+    if (hp[0] != 0 || hp[nparts] != n) return 10;
     for (uint64_t p = 0; p < nparts; p++) {
         std::map<std::pair<uint64_t, uint64_t>, uint32_t> seen;
         for (uint64_t i = hp[p]; i < hp[p + 1]; i++) {
-            if ((sv[i].hi >> 61) == 0) { if (hl[i] != prim::kNoId) return 5; continue; }
-            seen[{sv[i].lo, sv[i].hi}]++;
+            if (prim::RecSort::part_of(sk[i], pbits) != p) return 11;
+            if ((sh[i] >> 61) == 0) { if (hl[i] != prim::kNoId) return 5; continue; }
+            seen[{sk[i], sh[i]}]++;
             if (hl[i] >= hc[p]) return 6;
-            if (!(hd[hp[p] + hl[i]] == sv[i])) return 7;                               // the local id names the record's value
+            if (hdk[hp[p] + hl[i]] != sk[i] || hdh[hp[p] + hl[i]] != sh[i]) return 7;    // the local id names the record's value
         }
         if (seen.size() != hc[p]) return 8;
-        for (uint32_t j = 0; j < hc[p]; j++) if (seen[{hd[hp[p] + j].lo, hd[hp[p] + j].hi}] != hdc[hp[p] + j]) return 9;
+        for (uint32_t j = 0; j < hc[p]; j++) if (seen[{hdk[hp[p] + j], hdh[hp[p] + j]}] != hdc[hp[p] + j]) return 9;
     }
     return 0;
 }

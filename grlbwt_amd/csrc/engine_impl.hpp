@@ -215,7 +215,7 @@ struct PhraseHash {
     }
 };
 
-// ---- phrase records of the partitioned naming (levels above 0, single-GPU rounds; prim::PartSort / prim::part_dedupe) ----
+// ---- phrase records of the partitioned naming (levels above 0, single-GPU rounds; prim::RecSort / prim::rec_dedupe) ----
 // A phrase of at most cmax = min(7, 124 / b) cells (b = bits per symbol) IS a 128-bit record: symbol j at bits [j b, (j+1) b) of
 // (lo, hi), hi bit 60 = the phrase ends a string, hi bits 61..63 = its length (0 = no record: the phrase is longer and goes
 // through the hash table as before).  Equal records <=> equal phrases: no hashing, no look at the text to tell them apart.
@@ -233,8 +233,15 @@ GRL_HD u32 rec_sym(const prim::U128 &r, u32 j, int b) {
     return (u32)(v & ((1ull << b) - 1ull));
 }
 GRL_HD u32 rec_len(const prim::U128 &r) { return (u32)(r.hi >> 61); }
-struct RecValid {
-    GRL_DEV bool operator()(const prim::U128 &r) const { return (r.hi >> 61) != 0; }
+// A record travels through the partition sort (prim::RecSort) as two words: `hi` as it is (symbols above bit 64, flags, length) and
+// key = lo ^ rec_g(hi).  The sort groups the records by a hash of the KEY alone (its passes read 8 bytes per record, no hash array);
+// folding hi into the key keeps records that differ only above bit 64 -- long phrases with a common start -- out of one partition,
+// and (key, hi) pairs are equal exactly when the records are.  rec_lo() undoes it.
+GRL_HD u64 rec_g(u64 hi) { return hi * 0xD6E8FEB86659FD93ull; }
+GRL_HD u64 rec_key(u64 lo, u64 hi) { return lo ^ rec_g(hi); }
+GRL_HD u64 rec_lo(u64 key, u64 hi) { return key ^ rec_g(hi); }
+struct RecValid {         // (by the hi word: the length field; the long phrases, which take the hash table, leave invalid records)
+    GRL_DEV bool operator()(u64 hi) const { return (hi >> 61) != 0; }
 };
 static constexpr u32 kLongMark = 0x80000000u;      // in the per-occurrence slot array: the occurrence went through the hash table (slot in the low bits)
 
@@ -289,9 +296,9 @@ struct HashInsertFn {
         return ((plo | (phi << 12)) & (top - 1u)) | top;
     }
     GRL_DEV void first_seen(u32 slot, u64 item) const { if (dir_on && slot < kDirectSlots) dir_rep[slot] = item; }
-    // partitioned naming (see "phrase records"): with rec_h set, a phrase of <= rec_cmax cells leaves a record at its ordinal and
+    // partitioned naming (see "phrase records"): with rec_k set, a phrase of <= rec_cmax cells leaves a record at its ordinal and
     // does NOT touch the table; longer ones take the table as before and mark their slot entry with kLongMark
-    u32 *rec_h = nullptr; prim::U128 *rec_v = nullptr; int rec_b = 0; u32 rec_cmax = 0;
+    u64 *rec_k = nullptr; u64 *rec_hi = nullptr; int rec_b = 0; u32 rec_cmax = 0;      // (record of the occurrence with ordinal o: rec_k[o], rec_hi[o])
     u32 *long_count = nullptr;     // (sample pass: how many phrases are longer than rec_cmax)
     u64 walk_cap = ~0ull;          // (sample pass: a phrase longer than this is left out -- one lane walking a 10^8-cell phrase a second time: 6 s)
     // Byte cells: 4 phrases per lane at once through the exact-key path (process_batch).  A phrase of <= 7 cells is cut
@@ -367,9 +374,10 @@ struct HashInsertFn {
                 for (u32 j = 0; j < 7; j++) if (j <= eo) rec_put(klo, khi, ops.sym(cs[j]), j, rec_b);
                 const u64 len = (u64)eo + 1;
                 if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; }
-                else if (rec_h) {
-                    rec_h[ord] = (u32)((((klo ^ (khi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) ^ (len * 0x85EBCA6Bull)) >> 32);
-                    rec_v[ord] = prim::U128(klo, khi | (((tm >> eo) & 1u) ? kPhrLastT : 0ull) | (len << 61));
+                else if (rec_k) {
+                    const u64 hi = khi | (((tm >> eo) & 1u) ? kPhrLastT : 0ull) | (len << 61);
+                    rec_k[ord] = rec_key(klo, hi);
+                    rec_hi[ord] = hi;
                     out_slot[ord] = 0;
                 }
                 fast = true;
@@ -481,15 +489,16 @@ struct HashInsertFn {
         if (ok && pack) {
             const u64 len = e - p + 1;
             if (len <= (u64)rec_cmax) {
-                if (rec_h) {                       // the phrase is its record: nothing to look up
-                    rec_h[ord] = (u32)((((klo ^ (khi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) ^ (len * 0x85EBCA6Bull)) >> 32);
-                    rec_v[ord] = prim::U128(klo, khi | (ops.isT(t[e]) ? kPhrLastT : 0ull) | (len << 61));
+                if (rec_k) {                       // the phrase is its record: nothing to look up
+                    const u64 hi = khi | (ops.isT(t[e]) ? kPhrLastT : 0ull) | (len << 61);
+                    rec_k[ord] = rec_key(klo, hi);
+                    rec_hi[ord] = hi;
                     out_slot[ord] = 0;
                 }
                 ok = false;                        // (not an error: no table work for this phrase)
             } else {
                 if (long_count) prim::atomic_add(long_count, 1u);
-                if (rec_h) { rec_h[ord] = (u32)ord * 2654435761u; rec_v[ord] = prim::U128(ord, 0ull); }
+                if (rec_k) { rec_k[ord] = ord; rec_hi[ord] = 0ull; }      // (an invalid record; the sort's hash of the ordinal spreads them over the partitions)
             }
         }
         if (ok) {
@@ -769,7 +778,7 @@ struct PhraseRecordFn {
     static constexpr int CMAX = B ? (124 / B < 7 ? 124 / B : 7) : 7;
     const cell_t *t; CellOps<cell_t, false> ops; const u64 *startbits; const idx_t *wordbase;
     u64 n, n_occ;
-    u32 *rec_h; prim::U128 *rec_v; int rec_b; u32 rec_cmax;      // (B == 0 reads these two)
+    u64 *rec_k; u64 *rec_hi; int rec_b; u32 rec_cmax;            // (B == 0 reads the last two)
     u64 *long_bits;       // bit p: the phrase starting at p is left to the walk (a counter for a list of them serialised the pass:
                           // 38 M same-address atomics at level 2 of the 10 GB build, 171 ms)
     u32 *scal;
@@ -807,8 +816,9 @@ struct PhraseRecordFn {
                     const u64 len = (u64)eo + 1;
                     if (ord >= n_occ) { scal[1] = 5; scal[2] = (u32)p; scal[3] = (u32)ord; }
                     else {
-                        rec_h[ord] = (u32)((((klo ^ (khi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) ^ (len * 0x85EBCA6Bull)) >> 32);
-                        rec_v[ord] = prim::U128(klo, khi | (((tm >> eo) & 1u) ? kPhrLastT : 0ull) | (len << 61));
+                        const u64 hi = khi | (((tm >> eo) & 1u) ? kPhrLastT : 0ull) | (len << 61);
+                        rec_k[ord] = rec_key(klo, hi);
+                        rec_hi[ord] = hi;
                     }
                     listed = false;
                 }
@@ -902,26 +912,23 @@ struct ClaimCompactFn {     // step 2, one lane per phrase: its table entry (a r
     CompactTableFn<cell_t, FIRST> c;
     GRL_DEV void operator()(u64 k) const { c.emit((u64)c.ph_slot[k], k); }
 };
-struct PartBoundsFn {      // lane p in [0, 2^P]: first record of partition p in the sorted key array
-    const u32 *skeys; u64 n; int shift; u64 nparts; u64 *pstart;
-    GRL_DEV void operator()(u64 p) const { pstart[p] = p == nparts ? n : lower_bound<u32>(skeys, n, (u32)(p << shift)); }
-};
 struct PartPhraseFn {      // distinct phrase k of the partitioned naming: from the staging area of its partition
-    const u32 *pbase; u64 nparts; const u64 *pstart; const prim::U128 *dval; const u32 *dcnt; u32 slot0;
+    const u32 *pbase; u64 nparts; const u64 *pstart; const u64 *dkey; const u64 *dhi; const u32 *dcnt; u32 slot0;
     prim::U128 *ph_key; u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
     GRL_DEV void operator()(u64 k) const {
         const u64 p = upper_bound<u32>(pbase, nparts, (u32)k) - 1;
         const u64 src = pstart[p] + (k - (u64)pbase[p]);
-        const prim::U128 r = dval[src];
+        const u64 hi = dhi[src];
+        const prim::U128 r(rec_lo(dkey[src], hi), hi);
         ph_key[k] = r; ph_pos[k] = 0; ph_freq[k] = (idx_t)dcnt[src]; ph_len[k] = rec_len(r); ph_slot[k] = slot0 + (u32)k;
         ph_lastT[k] = (r.hi & kPhrLastT) ? 1 : 0;
     }
 };
 struct PartValFn {         // record at sorted position i -> the value of its phrase (read where GroupPhraseValFn put it)
-    const u32 *skeys; int shift; const u32 *pbase; const u32 *lid; const u32 *slot_val; u32 slot0; u32 *out;
+    const u64 *skey; int bits; const u32 *pbase; const u32 *lid; const u32 *slot_val; u32 slot0; u32 *out;
     GRL_DEV void operator()(u64 i) const {
         const u32 l = lid[i];
-        out[i] = l == prim::kNoId ? 0u : slot_val[(u64)slot0 + (u64)pbase[skeys[i] >> shift] + (u64)l];
+        out[i] = l == prim::kNoId ? 0u : slot_val[(u64)slot0 + (u64)pbase[prim::RecSort::part_of(skey[i], bits)] + (u64)l];
     }
 };
 struct PartCombineFn {     // the parse: occurrences that went through the table read their slot's value, the others take the value that came back
@@ -3085,12 +3092,13 @@ class Engine {
         // phrases' values back to text order
         u64 Ds = 0; int part_bits = 0, rec_b = 0; u32 slot0 = 0;
         DBuf<prim::U128> ph_key;
-        DBuf<u32> rec_h, lid, pbase;
-        prim::PartSort<u32, prim::U128> psort;
+        DBuf<u32> lid, pbase;
+        DBuf<u64> skey;            // the records' keys in partition order (the emission reads every record's partition from them)
+        prim::RecSort psort;
         void clear() {
             n_occ = D = S = cap = Ds = 0; maxlen = 0; part_bits = rec_b = 0; slot0 = 0;
             next_text.release(); ph_pos.release(); ph_freq.release(); ph_len.release(); ph_slot.release(); ph_off.release(); ph_lastT.release();
-            ph_key.release(); rec_h.release(); lid.release(); pbase.release(); psort.release();
+            ph_key.release(); skey.release(); lid.release(); pbase.release(); psort.release();
         }
     };
 
@@ -3120,8 +3128,8 @@ class Engine {
         if (sizeof(idx_t) == 4 && n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "parse too large for u32 phrase ordinals");
 
         // ---- partitioned naming (levels above 0, single-GPU rounds): a phrase of <= cmax cells is a 128-bit record; the records
-        // are grouped by a hash prefix into partitions that fit an LDS table (prim::PartSort), de-duplicated and counted there
-        // (prim::part_dedupe), and the phrases' values travel back through the sort's passes in reverse (emit_local).  Only the
+        // are grouped by a hash prefix into partitions that fit an LDS table (prim::RecSort), de-duplicated and counted there
+        // (prim::rec_dedupe), and the phrases' values travel back through the sort's passes in reverse (emit_local).  Only the
         // longer phrases (1 % at level 1, ~12 % at levels 2-3 of the 10 GB build) still go through the hash table below.
         // Round 2's table took 3 random HBM accesses per occurrence (probe, verification, count atomic: 51 / 51 / 18 G/s) and the
         // emission a fourth; this path streams.  GRLBWT_NO_PART=1 switches it off; GRLBWT_PART_MIN_OCC sets the smallest level.
@@ -3229,8 +3237,8 @@ class Engine {
         // their own in front of the big one -- slots [0, cap_hot) -- filled by hashing the sample once more (claims on: they
         // are dictionary phrases like the others) and read-only in the pass over the text.  GRLBWT_NO_HOT_TABLE=1 switches it off.
         u64 cap_hot = 0;
-        DBuf<prim::U128> rec_v, rec_v2;
-        if (part) { P.rec_h.alloc(n_occ); rec_v.alloc(n_occ); }
+        DBuf<u64> rec_k, rec_hi;
+        if (part) { rec_k.alloc(n_occ); rec_hi.alloc(n_occ); }
         // Direct index instead (HashInsertFn::direct_index): byte texts with at most 8 distinct cell values, told apart by three of
         // their bits.  GRLBWT_NO_DIRECT_INDEX=1 keeps the hot table.
         bool direct = false;
@@ -3285,7 +3293,7 @@ class Engine {
                 u64 probe_limit = (cap == cap_max) ? cap : 96;
                 HF f{t, ops, startbits.p, wordbase.p, keys.p + cap_hot, cap - 1, probe_limit, ks,
                      P.next_text.p, scal.p, n, n_occ, rep_pos.p ? rep_pos.p + cap_hot : nullptr, claim.p};
-                if (part) { f.rec_h = P.rec_h.p; f.rec_v = rec_v.p; f.rec_b = rec_b; f.rec_cmax = rec_cmax; }
+                if (part) { f.rec_k = rec_k.p; f.rec_hi = rec_hi.p; f.rec_b = rec_b; f.rec_cmax = rec_cmax; }
                 f.giant_list = giant_list.p; f.giant_n = scal.p + 4; f.giant_cap = (u32)std::min<u64>(giant_cap, 0xFFFFFFFFull);
                 if (direct) { f.dir_on = 1; f.dir_b0 = dir_b[0]; f.dir_b1 = dir_b[1]; f.dir_b2 = dir_b[2]; f.dir_rep = rep_pos.p; f.slot_base = (u32)cap_hot; }
                 else if (cap_hot) {
@@ -3302,7 +3310,7 @@ class Engine {
                         DBuf<u64> lbits(nwords + 1);
                         lbits.zero();
                         auto records = [&](auto bw) {
-                            prim::for_each(n, PhraseRecordFn<cell_t, decltype(bw)::value>{t, ops, startbits.p, wordbase.p, n, n_occ, P.rec_h.p, rec_v.p, rec_b,
+                            prim::for_each(n, PhraseRecordFn<cell_t, decltype(bw)::value>{t, ops, startbits.p, wordbase.p, n, n_occ, rec_k.p, rec_hi.p, rec_b,
                                                                                           rec_cmax, lbits.p, scal.p}, "hash_phrases");
                         };
                         switch (rec_b) {
@@ -3356,34 +3364,34 @@ class Engine {
         u64 Ds = 0;
         DBuf<u64> pstart;
         DBuf<u32> dcnt;
-        const prim::U128 *dval = nullptr;
+        DBuf<u64> dkey, dhi;                      // the partitions' distinct records (staging: partition p's at pstart[p] ..)
         if (part) {
             StageTimer st(&tm.hash, "hash");
-            rec_v2.alloc(n_occ);
-            const int res = P.psort.forward(P.rec_h.p, rec_v.p, rec_v2.p, n_occ, 32 - part_bits, 32, "phrase_part");
-            const prim::U128 *svals = res ? rec_v2.p : rec_v.p;
-            prim::U128 *stage = res ? rec_v.p : rec_v2.p;
+            DBuf<u64> rec_k2(n_occ), rec_hi2(n_occ);
+            const int res = P.psort.forward(rec_k.p, rec_hi.p, rec_k2.p, rec_hi2.p, n_occ, part_bits, "phrase_part");
+            DBuf<u64> shi;
+            if (res) { P.skey = std::move(rec_k2); shi = std::move(rec_hi2); dkey = std::move(rec_k); dhi = std::move(rec_hi); }
+            else { P.skey = std::move(rec_k); shi = std::move(rec_hi); dkey = std::move(rec_k2); dhi = std::move(rec_hi2); }
             const u64 nparts = (u64)1 << part_bits;
             pstart.alloc(nparts + 1);
-            prim::for_each(nparts + 1, PartBoundsFn{P.psort.sorted_keys(), n_occ, 32 - part_bits, nparts, pstart.p}, "phrase_part.bounds");
+            prim::for_each(nparts + 1, prim::RecBoundsFn{P.skey.p, n_occ, part_bits, nparts, pstart.p}, "phrase_part.bounds");
             P.lid.alloc(n_occ); P.pbase.alloc(nparts + 1); dcnt.alloc(n_occ);
             DBuf<u32> pcount(nparts), ovf(1);
             ovf.zero();
-            prim::part_dedupe(nparts, pstart.p, svals, RecValid{}, P.lid.p, pcount.p, stage, dcnt.p, ovf.p, "phrase_dedupe");
+            prim::rec_dedupe(nparts, pstart.p, P.skey.p, shi.p, RecValid{}, P.lid.p, pcount.p, dkey.p, dhi.p, dcnt.p, ovf.p, "phrase_dedupe");
             if (ovf.get(0)) {
                 // a partition with more distinct phrases than its LDS table takes (or an injected limit in the tests): this level
                 // goes through the hash table after all
                 if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: a phrase partition overflowed, falling back to the hash table\n", prim::rt().tag);
                 L.info.table_retries++;
-                rec_v.release(); rec_v2.release(); keys.release(); counts.release(); rep_pos.release(); claim.release();
+                shi.release(); dkey.release(); dhi.release(); keys.release(); counts.release(); rep_pos.release(); claim.release();
                 startbits.release(); wordbase.release(); pstart.release(); dcnt.release();
                 P.clear();
                 hash_local<cell_t, FIRST>(t, n, ops, P, L, false);
                 return;
             }
             Ds = (u64)prim::exclusive_scan<u32>(nparts, PtrU32In{pcount.p}, P.pbase.p, true, "phrase_dedupe.scan");
-            dval = stage;
-            (res ? rec_v2 : rec_v).release();            // the sorted records are no longer needed (the staging buffer is)
+            shi.release();                                // the sorted hi words are no longer needed (the keys are: the emission's partitions)
             P.Ds = Ds; P.part_bits = part_bits; P.rec_b = rec_b; P.slot0 = (u32)P.cap;
             if (P.cap + Ds >= (1ull << 32)) throw prim::Error(-75, "phrase tables beyond 2^32 entries");
             P.cap += Ds;                                  // values of the record phrases live behind the table's slots
@@ -3400,9 +3408,9 @@ class Engine {
             P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
             if (part) {                                   // phrases [0, Ds): from the partitions' staging areas
                 P.ph_key.alloc(Ds);
-                prim::for_each(Ds, PartPhraseFn{P.pbase.p, (u64)1 << part_bits, pstart.p, dval, dcnt.p, P.slot0, P.ph_key.p, P.ph_pos.p, P.ph_freq.p,
+                prim::for_each(Ds, PartPhraseFn{P.pbase.p, (u64)1 << part_bits, pstart.p, dkey.p, dhi.p, dcnt.p, P.slot0, P.ph_key.p, P.ph_pos.p, P.ph_freq.p,
                                                 P.ph_len.p, P.ph_slot.p, P.ph_lastT.p}, "phrase_dedupe.phrases");
-                rec_v.release(); rec_v2.release(); dcnt.release(); pstart.release();
+                dkey.release(); dhi.release(); dcnt.release(); pstart.release();
             }
             // ... and the phrases of the table behind them
             prim::for_each(nwords, ClaimSlotsFn{claim.p, cbase.p, startbits.p, wordbase.p, P.next_text.p, P.ph_slot.p + Ds}, "table_compact");
@@ -4340,10 +4348,11 @@ class Engine {
             // neighbours in the value array), the values go back to text order through the sort's passes in reverse, and the
             // occurrences that went through the table read theirs from their slot
             DBuf<u32> va(P.n_occ), vb(P.n_occ), vc(P.n_occ);
-            prim::for_each(P.n_occ, PartValFn{P.psort.sorted_keys(), 32 - P.part_bits, P.pbase.p, P.lid.p, sv, P.slot0, va.p}, "emit_part.values");
+            prim::for_each(P.n_occ, PartValFn{P.skey.p, P.part_bits, P.pbase.p, P.lid.p, sv, P.slot0, va.p}, "emit_part.values");
+            P.skey.release();
             P.psort.backward(va.p, vb.p, vc.p, "emit_part.back");
             prim::for_each(P.n_occ, PartCombineFn{sv, vc.p, P.next_text.p}, "emit_parse");
-            P.psort.release(); P.lid.release(); P.pbase.release(); P.rec_h.release(); P.ph_key.release();
+            P.psort.release(); P.lid.release(); P.pbase.release(); P.ph_key.release();
         } else prim::for_each((P.n_occ + 3) / 4, MapFn{sv, P.next_text.p, P.n_occ}, "emit_parse");
     }
 

@@ -1610,7 +1610,7 @@ inline void byte_histogram(const u8 *p, u64 n, u64 *hist_host) {
 // store requests; the LDS-staged form below 3.8 ms.  One wave per 1024-key tile without workgroup barriers was
 // 1.3x slower than the first of those.)
 static constexpr int kRsItems = 16;                 // keys per lane (24 and 32 measured slower: registers, LDS)
-static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup of 256 threads (PartSort, k_rs_unscatter; the plain sorts: sort_pairs)
+static constexpr int kRsTile = kBlock * kRsItems;   // 4096 keys per workgroup of 256 threads (the plain sorts below 2^22 keys: sort_pairs)
 
 // The lanes of the wave whose digit equals mine (valid lanes only): how many of them sit below me, and how many there are.
 // The mismatch mask is the OR over the digit bits of ballot ^ (my bit ? ~0 : 0): two vector instructions per bit and half.
@@ -1657,7 +1657,15 @@ GRL_DEV void wave_match(u32 d, bool valid, u32 &below, u32 &count) {
 // (SITE: a tag that only names the instantiation -- the induction's bucket split gets kernels of its own in profiler
 // output, apart from the other keys-only 64-bit sorts; TB = threads per workgroup: the tile is TB x kRsItems keys, 4096 at
 // 256 threads, 8192 at 512; hist and scatter of a pass agree)
-template <class K, int SITE = 0, int DB = 8, int TB = kBlock>
+// (MIX: the digit is taken from key x kMixMul instead of the key -- a record sort that groups by a hash of the key without
+// a hash array of its own: RecSort)
+static constexpr u64 kMixMul = 0x9E3779B97F4A7C15ull;
+template <bool MIX, class K>
+GRL_DEV u32 rs_digit(K k, int shift, u32 dmask) {
+    if constexpr (MIX) return (u32)(((u64)k * kMixMul) >> shift) & dmask;
+    else return (u32)(k >> shift) & dmask;
+}
+template <class K, int SITE = 0, int DB = 8, int TB = kBlock, bool MIX = false>
 __global__ void __launch_bounds__(TB) k_rs_hist(const K *keys, u64 n, int shift, u32 dmask, u32 *counts, u32 tiles) {
     constexpr int TILE = TB * kRsItems, NB = 1 << DB;
     __shared__ u32 s_h[TB / 64][NB];
@@ -1687,7 +1695,7 @@ __global__ void __launch_bounds__(TB) k_rs_hist(const K *keys, u64 n, int shift,
 #pragma unroll
     for (int r = 0; r < kRsItems; r++) {
         const u64 i = base + (u64)r * TB + threadIdx.x;      // only meaningful on the guarded path
-        const u32 d = (u32)(k[r] >> shift) & dmask;
+        const u32 d = rs_digit<MIX>(k[r], shift, dmask);
         const bool valid = vec || i < n;
         u32 below, count;
         wave_match<DB, true>(d, valid, below, count);
@@ -1715,8 +1723,21 @@ __global__ void __launch_bounds__(TB) k_rs_hist(const K *keys, u64 n, int shift,
 // (PHASED = false: row by row -- match, LDS read, LDS add, sum -- with nothing kept per row but idx: for k_xs_scatter, whose
 // four interleaved chain walks leave no registers for a second per-row array (phased there: 22.3 -> 26.1 ms at level 0 of the
 // 10 GB build, spills in the ranking loop); one LDS round trip per row instead of the three of rounds 1-4)
-template <int DB, int ROWS, bool PHASED = true, class DIG>
-GRL_DEV void wave_rank(DIG dig, u32 t0, u32 limit, u32 nrows, u32 *cnt, u32 (&idx)[ROWS]) {
+// (CT = u16: the counters of a wide digit at 16 waves per workgroup -- 16 x 512 words do not fit beside a 16384-key tile, halves do:
+// a wave holds at most 1024 keys.  The halves are read and added to through the 32-bit word that holds them -- one address for the
+// load and the add, so their order is the program's.)
+template <class CT>
+GRL_DEV u32 rank_cnt_load(CT *cnt, u32 d) {
+    if constexpr (sizeof(CT) == 4) return __hip_atomic_load(&cnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else return (__hip_atomic_load(reinterpret_cast<u32 *>(cnt) + (d >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (16u * (d & 1u))) & 0xFFFFu;
+}
+template <class CT>
+GRL_DEV void rank_cnt_add(CT *cnt, u32 d, u32 v) {
+    if constexpr (sizeof(CT) == 4) (void)__hip_atomic_fetch_add(&cnt[d], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else (void)__hip_atomic_fetch_add(reinterpret_cast<u32 *>(cnt) + (d >> 1), v << (16u * (d & 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+template <int DB, int ROWS, bool PHASED = true, class CT = u32, class DIG>
+GRL_DEV void wave_rank(DIG dig, u32 t0, u32 limit, u32 nrows, CT *cnt, u32 (&idx)[ROWS]) {
     if constexpr (!PHASED) {
 #pragma unroll
         for (int q = 0; q < ROWS; q++) {
@@ -1737,9 +1758,8 @@ GRL_DEV void wave_rank(DIG dig, u32 t0, u32 limit, u32 nrows, u32 *cnt, u32 (&id
                 const u32 plo = (u32)vm & ~mlo, phi = (u32)(vm >> 32) & ~mhi;
                 const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
                 if (valid) {
-                    u32 *c = &cnt[d];
-                    const u32 old = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    if (below == 0u) (void)__hip_atomic_fetch_add(c, (u32)__popc(plo) + (u32)__popc(phi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const u32 old = rank_cnt_load<CT>(cnt, d);
+                    if (below == 0u) rank_cnt_add<CT>(cnt, d, (u32)__popc(plo) + (u32)__popc(phi));
                     idx[q] = old + below;
                 }
             }
@@ -1777,9 +1797,9 @@ GRL_DEV void wave_rank(DIG dig, u32 t0, u32 limit, u32 nrows, u32 *cnt, u32 (&id
         idx[q] = 0;
         if ((u32)q < nrows) {
             if (info[q] >> 16) {
-                u32 *c = &cnt[dig(q)];
-                idx[q] = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if ((info[q] & 0xFFu) == 0u) (void)__hip_atomic_fetch_add(c, (info[q] >> 8) & 0xFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const u32 d = dig(q);
+                idx[q] = rank_cnt_load<CT>(cnt, d);
+                if ((info[q] & 0xFFu) == 0u) rank_cnt_add<CT>(cnt, d, (info[q] >> 8) & 0xFFu);
             }
         }
     }
@@ -1845,15 +1865,17 @@ struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays 
 // the tile size: 4096 records of 16 bytes already take 64 KB, and with 512-1024 bins such a tile leaves runs of 4-8 records = 64-128
 // bytes of values and 16-32 bytes of keys at the write front.  Keys only in LDS: 16384 records per tile, runs four times as long;
 // the value stores of a run come from different lanes and rows but reach the same lines of one L2 within the tile's lifetime.)
-template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock, bool DIRECT = false>
+// (dig_out: the digit of every key, in input order -- what the way back of a RecSort pass re-ranks from: 2 bytes instead of the key)
+template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock, bool DIRECT = false, bool MIX = false>
 __global__ void __launch_bounds__(TB)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
-                        const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles) {
+                        const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles, u16 *dig_out = nullptr) {
     constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
     constexpr bool STAGED = !std::is_same<V, NoVal>::value && !DIRECT;
     constexpr int EB = (STAGED && sizeof(V) > sizeof(K)) ? sizeof(V) : sizeof(K);
+    typedef typename std::conditional<(NW * NB > 4096), u16, u32>::type CT;      // (per-wave counters: halves when the words would not fit, see wave_rank)
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[TILE * EB];
-    __shared__ u32 s_cnt[NW][NB];      // per wave: running count, then exclusive base, of each digit
+    __shared__ __attribute__((aligned(4))) CT s_cnt[NW][NB];      // per wave: running count, then exclusive base, of each digit
     __shared__ u64 s_gbase[NB];       // global position of tile-local index 0 of the digit's run (may wrap; mod 2^64)
     __shared__ u32 s_wsum[NW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1874,8 +1896,12 @@ __global__ void __launch_bounds__(TB)
     __syncthreads();
     u32 dig[kRsKeys];
 #pragma unroll
-    for (int q = 0; q < kRsKeys; q++) dig[q] = (u32)(key[q] >> shift) & dmask;
-    wave_rank<DB, kRsKeys>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
+    for (int q = 0; q < kRsKeys; q++) dig[q] = rs_digit<MIX>(key[q], shift, dmask);
+    if (dig_out) {
+#pragma unroll
+        for (int q = 0; q < kRsKeys; q++) { const u32 t = wbase + q * 64 + lane; if (t < tile_n) dig_out[base + t] = (u16)dig[q]; }
+    }
+    wave_rank<DB, kRsKeys, true, CT>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
     __syncthreads();
     {   // thread t, bins [t*BPT, (t+1)*BPT): wave bases, tile-local digit starts, global bases (threads behind the last bin idle)
         u32 cw[BPT][NW], tt[BPT], sum = 0;
@@ -1885,7 +1911,7 @@ __global__ void __launch_bounds__(TB)
             const int d = threadIdx.x * BPT + e;
             tt[e] = 0;
 #pragma unroll
-            for (int k = 0; k < NW; k++) { cw[e][k] = has ? s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
+            for (int k = 0; k < NW; k++) { cw[e][k] = has ? (u32)s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
             sum += tt[e];
         }
         u32 incl = sum;
@@ -1904,7 +1930,7 @@ __global__ void __launch_bounds__(TB)
                 const int d = threadIdx.x * BPT + e;
                 u32 run = start;
 #pragma unroll
-                for (int k = 0; k < NW; k++) { s_cnt[k][d] = run; run += cw[e][k]; }
+                for (int k = 0; k < NW; k++) { s_cnt[k][d] = (CT)run; run += cw[e][k]; }
                 s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
                 start += tt[e];
             }
@@ -1916,7 +1942,7 @@ __global__ void __launch_bounds__(TB)
     for (int q = 0; q < kRsKeys; q++) {
         u32 t = wbase + q * 64 + lane;
         if (t < tile_n) {
-            idx[q] += s_cnt[w][dig[q]];
+            idx[q] += (u32)s_cnt[w][dig[q]];
             kb[idx[q]] = key[q];
         }
     }
@@ -1943,7 +1969,7 @@ __global__ void __launch_bounds__(TB)
         u32 t = (u32)j * TB + threadIdx.x;
         if (t < tile_n) {
             K k = kb[t];
-            u32 d = (u32)(k >> shift) & dmask;
+            u32 d = rs_digit<MIX>(k, shift, dmask);
             dpack[j >> 1] |= d << (16 * (j & 1));
             keys_out[s_gbase[d] + t] = k;
         }
@@ -2331,16 +2357,16 @@ inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *na
     return sort_keys_fwd(buf_a, buf_b, plan.E, plan.db, plan.bits, name);
 }
 
-template <class K, class V, int SITE, int DB, int TB = kBlock, bool DIRECT = false>
+template <class K, class V, int SITE, int DB, int TB = kBlock, bool DIRECT = false, bool MIX = false>
 inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shift, u32 dmask, u32 tiles, u32 *counts, u64 *offsets,
-                    u32 *chunk_sums, u64 *chunk_off, const char *name) {
+                    u32 *chunk_sums, u64 *chunk_off, const char *name, u16 *dig_out = nullptr) {
     prof_begin(std::string(name) + ".hist", n * sizeof(K));
-    hipLaunchKernelGGL((k_rs_hist<K, SITE, DB, TB>), dim3(tiles), dim3(TB), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
+    hipLaunchKernelGGL((k_rs_hist<K, SITE, DB, TB, MIX>), dim3(tiles), dim3(TB), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
     prof_end();
     after_launch(name);
     rs_offsets<(1 << DB)>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
     prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
-    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB, DIRECT>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles);
+    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB, DIRECT, MIX>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles, dig_out);
     prof_end();
     after_launch(name);
 }
@@ -2442,7 +2468,7 @@ struct alignas(16) U128 {
 };
 static constexpr u32 kNoId = 0xFFFFFFFFu;
 
-// One pass of PartSort::backward: src holds one element per record in the OUTPUT order of the forward pass, dst gets them in its
+// One pass of RecSort::backward: src holds one element per record in the OUTPUT order of the forward pass, dst gets them in its
 // INPUT order.  The ranking of k_rs_scatter is recomputed from the pass's input keys; the elements are gathered (runs of
 // equal digits are neighbours in src) and written linearly.
 // (The other form -- the forward pass stores where every element went, the way back is a plain gather -- was measured slower on
@@ -2451,13 +2477,14 @@ static constexpr u32 kNoId = 0xFFFFFFFFu;
 // (STAGED, round 5: the elements are READ in the output order of the forward pass -- neighbouring lanes take neighbouring elements of
 // a digit's run, as the forward write-out stores them -- and brought to input order through LDS, instead of one gather per element
 // whose 64 lanes hit 64 different runs: a wave instruction then touches ~8 lines instead of 64.)
-template <class K, class W, int DB = 8, int TB = kBlock, bool STAGED = true>
+template <class K, class W, int DB = 8, int TB = kBlock>
 __global__ void __launch_bounds__(TB)
     k_rs_unscatter(const K *keys_in, const W *src, W *dst, u64 n, int shift, u32 dmask, const u64 *offsets /*[tiles][NB]*/) {
     constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
-    __shared__ u32 s_e[STAGED ? TILE : 1];       // by output position of the tile: input position << 10 | digit
-    __shared__ W s_v[STAGED ? TILE : 1];         // by input position: the element
-    __shared__ u32 s_cnt[NW][NB];
+    typedef typename std::conditional<(NW * NB > 4096), u16, u32>::type CT;      // (as in k_rs_scatter)
+    __shared__ u32 s_e[TILE];                    // by output position of the tile: input position << 10 | digit
+    __shared__ W s_v[TILE];                      // by input position: the element
+    __shared__ __attribute__((aligned(4))) CT s_cnt[NW][NB];
     __shared__ u64 s_gbase[NB];
     __shared__ u32 s_wsum[NW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2473,7 +2500,7 @@ __global__ void __launch_bounds__(TB)
         dig[q] = t < tile_n ? ((u32)(keys_in[base + t] >> shift) & dmask) : 0u;
     }
     __syncthreads();
-    wave_rank<DB, kRsKeys>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
+    wave_rank<DB, kRsKeys, true, CT>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
     __syncthreads();
     {
         u32 cw[BPT][NW], tt[BPT], sum = 0;
@@ -2483,7 +2510,7 @@ __global__ void __launch_bounds__(TB)
             const int d = threadIdx.x * BPT + e;
             tt[e] = 0;
 #pragma unroll
-            for (int k = 0; k < NW; k++) { cw[e][k] = has ? s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
+            for (int k = 0; k < NW; k++) { cw[e][k] = has ? (u32)s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
             sum += tt[e];
         }
         u32 incl = sum;
@@ -2502,93 +2529,77 @@ __global__ void __launch_bounds__(TB)
                 const int d = threadIdx.x * BPT + e;
                 u32 run = start;
 #pragma unroll
-                for (int k = 0; k < NW; k++) { s_cnt[k][d] = run; run += cw[e][k]; }
+                for (int k = 0; k < NW; k++) { s_cnt[k][d] = (CT)run; run += cw[e][k]; }
                 s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
                 start += tt[e];
             }
         }
     }
     __syncthreads();
-    if constexpr (STAGED) {
-#pragma unroll
-        for (int q = 0; q < kRsKeys; q++) {
-            const u32 t = wbase + q * 64 + lane;
-            if (t < tile_n) s_e[idx[q] + s_cnt[w][dig[q]]] = (t << 10) | dig[q];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kRsKeys; j++) {
-            const u32 t = (u32)j * TB + threadIdx.x;
-            if (t < tile_n) { const u32 e = s_e[t]; s_v[e >> 10] = src[s_gbase[e & 1023u] + t]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kRsKeys; j++) {
-            const u32 t = (u32)j * TB + threadIdx.x;
-            if (t < tile_n) dst[base + t] = s_v[t];
-        }
-    } else {
 #pragma unroll
     for (int q = 0; q < kRsKeys; q++) {
-        u32 t = wbase + q * 64 + lane;
-        if (t < tile_n) dst[base + t] = src[s_gbase[dig[q]] + (u64)(idx[q] + s_cnt[w][dig[q]])];
+        const u32 t = wbase + q * 64 + lane;
+        if (t < tile_n) s_e[idx[q] + (u32)s_cnt[w][dig[q]]] = (t << 10) | dig[q];
     }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRsKeys; j++) {
+        const u32 t = (u32)j * TB + threadIdx.x;
+        if (t < tile_n) { const u32 e = s_e[t]; s_v[e >> 10] = src[s_gbase[e & 1023u] + t]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRsKeys; j++) {
+        const u32 t = (u32)j * TB + threadIdx.x;
+        if (t < tile_n) dst[base + t] = s_v[t];
     }
 }
 
-// Stable sort of n (key, value) records by key bits [begin_bit, end_bit) that remembers what it takes to send one element per
-// record back from sorted order to the original order (the passes' input keys and tile offsets).  `keys` must stay alive and
-// unchanged until the last backward() call.
-template <class K, class V>
-struct PartSort {
+// Records of two 64-bit words (key, hi) grouped into 2^bits partitions by the top bits of key x kMixMul -- a hash of the key that
+// needs no array of its own -- and the way back: one element per record from sorted order to the original order.
+// (Phrase naming of the levels above 0.  Rounds 3-5 sorted (32-bit hash, 128-bit record) pairs on tiles of 4096 records, the 16-byte
+// values being what limited the tile: 20 bytes per record and pass at 0.32-0.34 of the HBM peak, 30.8 ms for the two passes over the
+// 964 M records of level 1 of the 10 GB build.  A record split into two words sorts like the (key, position) pairs of the suffix
+// sort -- 16384-record tiles, both words staged through the same 128 KB of LDS one after the other -- and the way back reads the
+// 2-byte digits the forward pass left instead of the keys.)
+// The caller owns the four record buffers (forward tells which pair holds the result); the sort owns the digits and tile offsets of
+// its passes until release().
+struct RecSort {
     u64 n = 0;
-    int passes = 0, shifts[8], widths[8];
+    int bits = 0, passes = 0, shifts[4] = {0, 0, 0, 0}, widths[4] = {0, 0, 0, 0};
     u32 tiles = 0;
-    int tb = kBlock;                  // threads per workgroup of the passes (forward and backward agree): 1024 = tiles of 16384 records, values moved directly
-    K *kbuf[9] = {nullptr};          // kbuf[0] = the caller's keys (kept), kbuf[p + 1] = keys after pass p (owned)
-    u64 *offs[8] = {nullptr};
-    const K *sorted_keys() const { return kbuf[passes]; }
-    // vals_a holds the values; returns 0 if the sorted values end in vals_a, 1 if in vals_b
-    int forward(K *keys, V *vals_a, V *vals_b, u64 n_, int begin_bit, int end_bit, const char *name = "part_sort") {
+    u16 *dig[4] = {nullptr, nullptr, nullptr, nullptr};       // digit of every record at the input of pass p
+    u64 *offs[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kThreads = 1024;
+    GRL_HD static u64 part_of(u64 key, int bits_) { return bits_ ? (key * kMixMul) >> (64 - bits_) : 0; }
+    // returns 0 if the sorted records are in (key_a, hi_a), 1 if in (key_b, hi_b)
+    int forward(u64 *key_a, u64 *hi_a, u64 *key_b, u64 *hi_b, u64 n_, int bits_, const char *name = "rec_sort") {
         release();
-        n = n_;
-        passes = 0;
-        kbuf[0] = keys;
-        if (n == 0 || end_bit <= begin_bit) return 0;
-        // two passes up to 20 bits (digits of up to 10 bits: a pass fewer matters more here than the shorter runs at the write
-        // front -- the values are 16-byte records), three beyond
-        const int bits = end_bit - begin_bit;
-        passes = bits <= 8 ? 1 : (bits <= 20 ? 2 : (bits + 9) / 10);
-        for (int p = 0, sh = begin_bit; p < passes; p++) {
+        n = n_; bits = bits_;
+        if (n == 0 || bits <= 0) { bits = 0; return 0; }
+        if (bits > 27) throw Error(-22, "RecSort: more than 2^27 partitions");
+        // digits of at most 9 bits (the 16 waves' counters of a 10-bit digit do not fit beside the tile): two passes up to 18 bits
+        passes = (bits + 8) / 9;
+        for (int p = 0, sh = 64 - bits; p < passes; p++) {
             widths[p] = bits / passes + (p < bits % passes ? 1 : 0);
             shifts[p] = sh;
             sh += widths[p];
         }
-        // (GRLBWT_PART_THREADS=1024: tiles of 16384 records with the values moved directly instead of staged in LDS.  Measured on
-        // the 10 GB build and left off: the 16-byte stores of a wave then go to 64 different lines -- phrase_part.scatter 39.6 -> 55.4
-        // ms, the way back 23.3 -> 27.9 ms; the longer runs at the write front do not make up for the request rate)
-        static const int tb_env = getenv("GRLBWT_PART_THREADS") ? atoi(getenv("GRLBWT_PART_THREADS")) : 0;
-        tb = tb_env >= 1024 ? 1024 : kBlock;
-        const u64 tile = (u64)tb * kRsItems;
+        const u64 tile = (u64)kThreads * kRsItems;
         tiles = (u32)((n + tile - 1) / tile);
-        u32 *counts = (u32 *)dev_alloc((u64)1024 * tiles * sizeof(u32));
+        u32 *counts = (u32 *)dev_alloc((u64)512 * tiles * sizeof(u32));
         u32 chunks = (tiles + kRsChunk - 1) / kRsChunk;
-        u32 *chunk_sums = (u32 *)dev_alloc((u64)1024 * chunks * sizeof(u32));
-        u64 *chunk_off = (u64 *)dev_alloc((u64)1024 * chunks * sizeof(u64));
+        u32 *chunk_sums = (u32 *)dev_alloc((u64)512 * chunks * sizeof(u32));
+        u64 *chunk_off = (u64 *)dev_alloc((u64)512 * chunks * sizeof(u64));
         int cur = 0;
         for (int p = 0; p < passes; p++) {
-            const int db = widths[p] <= 8 ? 8 : widths[p];
-            kbuf[p + 1] = (K *)dev_alloc(n * sizeof(K));
+            const int db = widths[p] <= 8 ? 8 : 9;
+            dig[p] = (u16 *)dev_alloc(n * sizeof(u16));
             offs[p] = (u64 *)dev_alloc(((u64)1 << db) * tiles * sizeof(u64));
             const u32 dmask = (1u << widths[p]) - 1u;
-            V *vin = cur ? vals_b : vals_a, *vout = cur ? vals_a : vals_b;
-            if (tb == 1024) {
-                if (db == 8) rs_pass<K, V, 2, 8, 1024, true>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
-                else if (db == 9) rs_pass<K, V, 2, 9, 1024, true>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
-                else rs_pass<K, V, 2, 10, 1024, true>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
-            } else if (db == 8) rs_pass<K, V, 2, 8>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
-            else if (db == 9) rs_pass<K, V, 2, 9>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
-            else rs_pass<K, V, 2, 10>(kbuf[p], vin, kbuf[p + 1], vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name);
+            u64 *kin = cur ? key_b : key_a, *kout = cur ? key_a : key_b, *vin = cur ? hi_b : hi_a, *vout = cur ? hi_a : hi_b;
+            if (db == 8) rs_pass<u64, u64, 2, 8, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, dig[p]);
+            else rs_pass<u64, u64, 2, 9, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, dig[p]);
             cur ^= 1;
         }
         dev_free(counts); dev_free(chunk_sums); dev_free(chunk_off);
@@ -2597,87 +2608,101 @@ struct PartSort {
     // in[j] belongs to the record at sorted position j; out[i] = the element of the record that was at position i originally.
     // tmp: scratch of n elements (used with more than one pass); `in` is overwritten when passes > 2.
     template <class W>
-    void backward(W *in, W *tmp, W *out, const char *name = "part_sort.back") const {
+    void backward(W *in, W *tmp, W *out, const char *name = "rec_sort.back") const {
         if (n == 0) return;
         if (passes == 0) { d2d(out, in, n * sizeof(W)); return; }
         W *src = in;
         for (int p = passes - 1; p >= 0; p--) {
             W *dst = (p == 0) ? out : ((src == tmp) ? in : tmp);
             const u32 dmask = (1u << widths[p]) - 1u;
-            prof_begin(name, n * (sizeof(K) + 2 * sizeof(W)));
-            static const bool gather = getenv("GRLBWT_UNSCATTER_GATHER") != nullptr;      // (the form of rounds 3-4: one gather per element)
-            if (gather && tb != 1024) {
-                if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8, kBlock, false>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-                else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9, kBlock, false>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-                else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10, kBlock, false>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-            } else if (tb == 1024) {
-                if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8, 1024, false>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-                else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9, 1024, false>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-                else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10, 1024, false>), dim3(tiles), dim3(1024), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-            } else if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<K, W, 8>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-            else if (widths[p] == 9) hipLaunchKernelGGL((k_rs_unscatter<K, W, 9>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
-            else hipLaunchKernelGGL((k_rs_unscatter<K, W, 10>), dim3(tiles), dim3(kBlock), 0, rt().stream, kbuf[p], src, dst, n, shifts[p], dmask, offs[p]);
+            prof_begin(name, n * (sizeof(u16) + 2 * sizeof(W)));
+            if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<u16, W, 8, kThreads>), dim3(tiles), dim3(kThreads), 0, rt().stream, (const u16 *)dig[p], src, dst, n, 0, dmask, offs[p]);
+            else hipLaunchKernelGGL((k_rs_unscatter<u16, W, 9, kThreads>), dim3(tiles), dim3(kThreads), 0, rt().stream, (const u16 *)dig[p], src, dst, n, 0, dmask, offs[p]);
             prof_end();
             after_launch(name);
             src = dst;
         }
     }
     void release() {
-        for (int p = 0; p < 8; p++) {
-            if (kbuf[p + 1]) dev_free(kbuf[p + 1]);
+        for (int p = 0; p < 4; p++) {
+            if (dig[p]) dev_free(dig[p]);
             if (offs[p]) dev_free(offs[p]);
-            kbuf[p + 1] = nullptr; offs[p] = nullptr;
+            dig[p] = nullptr; offs[p] = nullptr;
         }
-        kbuf[0] = nullptr;
-        passes = 0; n = 0;
+        passes = 0; n = 0; bits = 0;
     }
-    PartSort() {}
-    PartSort(const PartSort &) = delete;
-    PartSort &operator=(const PartSort &) = delete;
-    ~PartSort() { release(); }
+    RecSort() {}
+    RecSort(const RecSort &) = delete;
+    RecSort &operator=(const RecSort &) = delete;
+    ~RecSort() { release(); }
+};
+// lane p in [0, 2^bits]: first record of partition p in the sorted key array
+struct RecBoundsFn {
+    const u64 *skey; u64 n; int bits; u64 nparts; u64 *pstart;
+    GRL_DEV void operator()(u64 p) const {
+        u64 lo = 0, hi = n;
+        if (p == nparts) lo = n;
+        else while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (RecSort::part_of(skey[mid], bits) < p) lo = mid + 1; else hi = mid; }
+        pstart[p] = lo;
+    }
 };
 
-// Per-partition de-duplication of 128-bit values in LDS.  Partition p = records [pstart[p], pstart[p + 1]).  One workgroup
-// of 1024 threads per partition: an open-addressing table of kPdSlots entries (hash tag | index of the representative
-// record) and a counter per entry; a match is confirmed against the representative's value (the partition was just read:
-// it sits in L2).  Records with valid(v) == false take no part (lid = kNoId).  Outputs: lid[i] = dense local id of record
-// i's value among the distinct values of its partition; pcount[p]; the j-th distinct value of p and its count at
-// dval[pstart[p] + j], dcnt[pstart[p] + j].  *overflow is set when a partition does not fit (more distinct values than the
-// table takes, or more than 2^26 records): the caller falls back to another method.
+// Per-partition de-duplication of (key, hi) records in LDS.  Partition p = records [pstart[p], pstart[p + 1]).  One workgroup
+// of 1024 threads per partition: an open-addressing table of kPdSlots entries -- five bits of hi | index of the entry's first
+// record, claimed by ONE compare-and-swap, with that record's KEY beside it and a counter.  A probe compares the key in LDS and
+// reads the representative's hi only when that word has more in it than the entry's five bits say (symbols above bit 64); while
+// the key of a fresh entry is not there yet -- its owner writes it right behind the swap -- the probe reads the representative's
+// key from memory instead: nobody waits for anybody.
+// (Rounds 3-5 kept a hash tag per entry and confirmed every tag match against the representative's 16 bytes: one random 16-byte
+// read per record -- two 8-byte ones with the record in two arrays: 15 and 19.4 ms for the 964 M records of level 1 of the 10 GB
+// build.)
+// Records with valid(hi) == false take no part (lid = kNoId).  Outputs: lid[i] = dense local id of record i's value among the
+// distinct values of its partition; pcount[p]; the j-th distinct value of p and its count at dkey / dhi / dcnt[pstart[p] + j].
+// *overflow is set when a partition does not fit (more distinct values than the table takes, or more than 2^26 records): the
+// caller falls back to another method.
 static constexpr int kPdSlots = 8192, kPdThreads = 1024;
+// what an entry keeps of hi: the top four bits (length, ends-a-string) and a flag "nothing else is set"
+GRL_DEV u32 pd_hi_bits(u64 hi) { return (u32)(hi >> 60) | (((hi << 4) == 0ull) ? 16u : 0u); }
 template <class VALID>
-__global__ void __launch_bounds__(kPdThreads) k_part_dedupe(const u64 *pstart, const U128 *vals, VALID valid, u32 *lid, u32 *pcount,
-                                                            U128 *dval, u32 *dcnt, u32 *overflow) {
-    __shared__ unsigned long long s_tab[kPdSlots];
+__global__ void __launch_bounds__(kPdThreads) k_rec_dedupe(const u64 *pstart, const u64 *skey, const u64 *shi, VALID valid, u32 *lid, u32 *pcount,
+                                                           u64 *dkey, u64 *dhi, u32 *dcnt, u32 *overflow) {
+    __shared__ u32 s_idx[kPdSlots];                     // hi bits << 27 | index of the representative + 1   (0: empty); later the entry's dense number
+    __shared__ unsigned long long s_key[kPdSlots];      // its key (0: not written yet; the keys 0 and 1 are never kept here)
     __shared__ u32 s_cnt[kPdSlots];
-    __shared__ u32 s_dense[kPdSlots];
     __shared__ u32 s_w[kPdThreads / 64];
     __shared__ u32 s_fail;
     const u64 a = pstart[blockIdx.x], b = pstart[blockIdx.x + 1];
-    for (int i = threadIdx.x; i < kPdSlots; i += kPdThreads) { s_tab[i] = 0ull; s_cnt[i] = 0u; }
+    for (int i = threadIdx.x; i < kPdSlots; i += kPdThreads) { s_idx[i] = 0u; s_key[i] = 0ull; s_cnt[i] = 0u; }
     if (threadIdx.x == 0) s_fail = (b - a >= (1ull << 26)) ? 1u : 0u;
     __syncthreads();
     const bool usable = s_fail == 0;
     for (u64 i = a + threadIdx.x; i < b && usable; i += kPdThreads) {
-        const U128 v = vals[i];
+        const u64 vk = skey[i], vh = shi[i];
         u32 res = kNoId;
-        if (valid(v)) {
-            u64 g = (v.lo ^ (v.hi * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+        if (valid(vh)) {
+            u64 g = (vk ^ (vh * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
             g ^= g >> 32; g *= 0xFF51AFD7ED558CCDull; g ^= g >> 29;
-            const unsigned long long tag = g >> 26;
-            const unsigned long long mine = (tag << 26) | (unsigned long long)(i - a + 1);
+            const u32 hb = pd_hi_bits(vh);
+            const u32 mine = (hb << 27) | (u32)(i - a + 1);
             u32 slot = (u32)g & (kPdSlots - 1);
             bool done = false;
             for (int probes = 0; probes < kPdSlots && !done; probes++) {
-                unsigned long long e = s_tab[slot];
-                if (e == 0ull) {
-                    const unsigned long long old = atomicCAS(&s_tab[slot], 0ull, mine);
-                    e = old == 0ull ? mine : old;
+                u32 e = s_idx[slot];
+                if (e == 0u) {
+                    const u32 old = atomicCAS(&s_idx[slot], 0u, mine);
+                    if (old == 0u) {
+                        if (vk > 1ull) __hip_atomic_store(&s_key[slot], (unsigned long long)vk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        done = true;
+                    }
+                    e = old == 0u ? mine : old;
                 }
-                if (e == mine) done = true;
-                else if ((e >> 26) == tag) {
-                    const U128 r = vals[a + ((e & ((1ull << 26) - 1ull)) - 1ull)];
-                    if (r.lo == v.lo && r.hi == v.hi) done = true;
+                if (!done && (e >> 27) == hb) {
+                    // same hi bits: the key -- from LDS when it is there -- and the rest of hi where there is a rest
+                    const u64 ri = a + (u64)((e & 0x7FFFFFFu) - 1u);
+                    const unsigned long long k = __hip_atomic_load(&s_key[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    bool same = k != 0ull ? k == (unsigned long long)vk : skey[ri] == vk;
+                    if (same && !(hb & 16u)) same = shi[ri] == vh;
+                    done = same;
                 }
                 if (!done) slot = (slot + 1) & (kPdSlots - 1);
             }
@@ -2691,7 +2716,7 @@ __global__ void __launch_bounds__(kPdThreads) k_part_dedupe(const u64 *pstart, c
     constexpr int PER = kPdSlots / kPdThreads;
     u32 occ = 0;
 #pragma unroll
-    for (int k = 0; k < PER; k++) occ += s_tab[threadIdx.x * PER + k] != 0ull ? 1u : 0u;
+    for (int k = 0; k < PER; k++) occ += s_idx[threadIdx.x * PER + k] != 0u ? 1u : 0u;
     u32 incl = occ;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -2707,10 +2732,12 @@ __global__ void __launch_bounds__(kPdThreads) k_part_dedupe(const u64 *pstart, c
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int sl = threadIdx.x * PER + k;
-        const unsigned long long e = s_tab[sl];
-        if (e != 0ull) {
-            s_dense[sl] = j;
-            dval[a + j] = vals[a + ((e & ((1ull << 26) - 1ull)) - 1ull)];
+        const u32 e = s_idx[sl];
+        if (e != 0u) {
+            const u64 ri = a + (u64)((e & 0x7FFFFFFu) - 1u);
+            s_idx[sl] = j;                          // (the slot's dense number from here on; only its own thread looks at it before the barrier)
+            dkey[a + j] = skey[ri];
+            dhi[a + j] = shi[ri];
             dcnt[a + j] = s_cnt[sl];
             j++;
         }
@@ -2719,16 +2746,16 @@ __global__ void __launch_bounds__(kPdThreads) k_part_dedupe(const u64 *pstart, c
     if (s_fail) { if (threadIdx.x == 0) { *overflow = 1u; pcount[blockIdx.x] = 0; } return; }
     for (u64 i = a + threadIdx.x; i < b; i += kPdThreads) {
         const u32 sl = lid[i];
-        if (sl != kNoId) lid[i] = s_dense[sl];
+        if (sl != kNoId) lid[i] = s_idx[sl];
     }
     if (threadIdx.x == 0) pcount[blockIdx.x] = total;
 }
 template <class VALID>
-inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID valid, u32 *lid, u32 *pcount, U128 *dval, u32 *dcnt, u32 *overflow,
-                        const char *name = "part_dedupe") {
+inline void rec_dedupe(u64 nparts, const u64 *pstart, const u64 *skey, const u64 *shi, VALID valid, u32 *lid, u32 *pcount, u64 *dkey, u64 *dhi, u32 *dcnt,
+                       u32 *overflow, const char *name = "rec_dedupe") {
     if (nparts == 0) return;
     prof_begin(name);
-    hipLaunchKernelGGL((k_part_dedupe<VALID>), dim3((unsigned)nparts), dim3(kPdThreads), 0, rt().stream, pstart, vals, valid, lid, pcount, dval, dcnt, overflow);
+    hipLaunchKernelGGL((k_rec_dedupe<VALID>), dim3((unsigned)nparts), dim3(kPdThreads), 0, rt().stream, pstart, skey, shi, valid, lid, pcount, dkey, dhi, dcnt, overflow);
     prof_end();
     after_launch(name);
 }

@@ -372,29 +372,37 @@ struct alignas(16) U128 {
     bool operator==(const U128 &o) const { return lo == o.lo && hi == o.hi; }
 };
 static constexpr u32 kNoId = 0xFFFFFFFFu;
-template <class K, class V>
-struct PartSort {
+// prim_hip.hpp RecSort, serially: records (key, hi) grouped by the top bits of key x kMixMul, stable; and the way back
+static constexpr u64 kMixMul = 0x9E3779B97F4A7C15ull;
+struct RecSort {
     u64 n = 0;
+    int bits = 0;
     std::vector<u64> order;          // order[j] = original position of the record at sorted position j
-    std::vector<K> skeys;
-    const K *sorted_keys() const { return skeys.data(); }
-    int forward(K *keys, V *vals_a, V *vals_b, u64 n_, int begin_bit, int end_bit, const char * = "") {
-        n = n_;
-        order.resize(n); skeys.resize(n);
+    static u64 part_of(u64 key, int bits_) { return bits_ ? (key * kMixMul) >> (64 - bits_) : 0; }
+    int forward(u64 *key_a, u64 *hi_a, u64 *key_b, u64 *hi_b, u64 n_, int bits_, const char * = "") {
+        n = n_; bits = bits_ > 0 ? bits_ : 0;
+        order.resize(n);
         std::iota(order.begin(), order.end(), 0);
-        const int bits = end_bit - begin_bit;
-        const K mask = bits >= (int)(8 * sizeof(K)) ? ~K(0) : (K)((K(1) << bits) - 1);
-        std::stable_sort(order.begin(), order.end(), [&](u64 a, u64 b) { return ((keys[a] >> begin_bit) & mask) < ((keys[b] >> begin_bit) & mask); });
-        for (u64 j = 0; j < n; j++) { skeys[j] = keys[order[j]]; vals_b[j] = vals_a[order[j]]; }
+        std::stable_sort(order.begin(), order.end(), [&](u64 a, u64 b) { return part_of(key_a[a], bits) < part_of(key_a[b], bits); });
+        for (u64 j = 0; j < n; j++) { key_b[j] = key_a[order[j]]; hi_b[j] = hi_a[order[j]]; }
         return 1;
     }
     template <class W>
     void backward(W *in, W *, W *out, const char * = "") const { for (u64 j = 0; j < n; j++) out[order[j]] = in[j]; }
-    void release() { order.clear(); skeys.clear(); n = 0; }
+    void release() { order.clear(); n = 0; bits = 0; }
+};
+struct RecBoundsFn {
+    const u64 *skey; u64 n; int bits; u64 nparts; u64 *pstart;
+    void operator()(u64 p) const {
+        u64 lo = 0, hi = n;
+        if (p == nparts) lo = n;
+        else while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (RecSort::part_of(skey[mid], bits) < p) lo = mid + 1; else hi = mid; }
+        pstart[p] = lo;
+    }
 };
 template <class VALID>
-inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID valid, u32 *lid, u32 *pcount, U128 *dval, u32 *dcnt, u32 *overflow,
-                        const char * = "") {
+inline void rec_dedupe(u64 nparts, const u64 *pstart, const u64 *skey, const u64 *shi, VALID valid, u32 *lid, u32 *pcount, u64 *dkey, u64 *dhi, u32 *dcnt,
+                       u32 *overflow, const char * = "") {
     // (GRLBWT_SIM_PD_LIMIT: the tests make partitions "overflow" so that the caller's fallback runs)
     const char *lim = getenv("GRLBWT_SIM_PD_LIMIT");
     const u32 limit = lim ? (u32)atoi(lim) : 6000u;
@@ -402,10 +410,10 @@ inline void part_dedupe(u64 nparts, const u64 *pstart, const U128 *vals, VALID v
         const u64 a = pstart[p], b = pstart[p + 1];
         u32 d = 0;
         for (u64 i = a; i < b; i++) {
-            if (!valid(vals[i])) { lid[i] = kNoId; continue; }
+            if (!valid(shi[i])) { lid[i] = kNoId; continue; }
             u32 j = 0;
-            while (j < d && !(dval[a + j] == vals[i])) j++;
-            if (j == d) { dval[a + d] = vals[i]; dcnt[a + d] = 0; d++; }
+            while (j < d && !(dkey[a + j] == skey[i] && dhi[a + j] == shi[i])) j++;
+            if (j == d) { dkey[a + d] = skey[i]; dhi[a + d] = shi[i]; dcnt[a + d] = 0; d++; }
             dcnt[a + j]++;
             lid[i] = j;
         }

@@ -364,7 +364,7 @@ def test_hot_table_with_generic_keys(sim, oracle_mod, capfd, monkeypatch):
 
 def test_partitioned_phrase_naming(sim, oracle_mod, monkeypatch, capfd):
     """Levels above 0 of single-GPU builds name their phrases through 128-bit records, a partition sort that can be undone and
-    per-partition de-duplication (prim::PartSort / prim::part_dedupe; by default from 2^20 occurrences per level on): forced
+    per-partition de-duplication (prim::RecSort / prim::rec_dedupe; by default from 2^20 occurrences per level on): forced
     on for small inputs here, stage by stage against the oracle -- reads, long repeats (phrases longer than a record: the
     mixed case with the hash table), uint16 tokens, 64-bit indices -- and with partitions that "overflow" (the level then
     falls back to the hash table)."""

@@ -114,15 +114,16 @@ def test_one_word_cells_in_64_bits(hip, oracle_mod, monkeypatch):
     parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
 
 
-@pytest.mark.parametrize("part_threads", ["256", "1024"])
-def test_partitioned_phrase_naming(hip, oracle_mod, monkeypatch, capfd, part_threads):
-    """prim::PartSort (forward passes + the re-ranking passes back) and prim::k_part_dedupe on the device: partitioned phrase
-    naming forced on for small inputs (by default it starts at 2^20 phrase occurrences per level), stage by stage against the
-    oracle; then with partitions that cannot fit their LDS table (one partition for 3 M distinct phrases).  Both tile forms of
-    the partition sort: 4096 records with the values staged in LDS (the default), and 16384 records with the values moved directly
-    (GRLBWT_PART_THREADS=1024: measured slower, kept behind the switch)."""
+@pytest.mark.parametrize("part_bits", ["", "9", "17", "20"])
+def test_partitioned_phrase_naming(hip, oracle_mod, monkeypatch, capfd, part_bits):
+    """prim::RecSort (forward passes over (key, hi) record words on 16384-record tiles, the digit taken from a hash of the key; the
+    re-ranking passes back from the stored digits) and prim::k_rec_dedupe on the device: partitioned phrase naming forced on for
+    small inputs (by default it starts at 2^20 phrase occurrences per level), stage by stage against the oracle -- with the
+    engine's own number of partitions, with one 9-bit pass (per-wave counters in 16-bit halves), two passes (9 + 8) and three
+    (7 + 7 + 6); then with partitions that cannot fit their LDS table (one bit of partition for 3 M distinct phrases)."""
     monkeypatch.setenv("GRLBWT_PART_MIN_OCC", "0")
-    monkeypatch.setenv("GRLBWT_PART_THREADS", part_threads)
+    if part_bits:
+        monkeypatch.setenv("GRLBWT_PART_BITS", part_bits)
     parity.check_stagewise(hip, workloads.sampled_reads(20000, 100, 100000, seed=11).tobytes(), 1)
     parity.check_stagewise(hip, workloads.repetitive_copies(40, 50000, seed=3).tobytes(), 1)
     parity.check_stagewise(hip, workloads.zipf_tokens(200000, doc_len=500, vocab=20000).tobytes(), 2, engine.FLAG_FORCE_IDX64)
