@@ -157,6 +157,20 @@ def pmc_traffic(kernel_fragments):
         return None
 
 
+def pmc_traffic_stale(kernel_fragments):
+    """The name fragments of a group that match NO kernel of the committed PMC summary: a kernel that was renamed or re-templated
+    since the summary was taken silently drops out of `traffic` otherwise (rounds 3-4 reported A+B without its later radix passes
+    that way).  A non-empty list goes into the line as `traffic_stale`."""
+    files = pmc_traffic_files()
+    if not files:
+        return []
+    try:
+        names = list(json.load(open(files[-1]))["kernels"])
+    except Exception:
+        return list(kernel_fragments)
+    return [f for f in kernel_fragments if not any(f in n for n in names)]
+
+
 def spawn_ranks(args, argv):
     """--gpus N without a launcher: start N ranks as a CHILD (this process has not imported torch or touched the
     GPU), relay rank 0's line, exit with the child's code."""
@@ -318,6 +332,9 @@ def main():
         devices = gathered
 
     dt = timed(step, args.steps, args.warmup)
+    # (the collectives of the warm-up and timed steps only: the steps after the timed region -- the gathered image, the profiled
+    # build -- do not count into collectives_per_step)
+    comm_timed = (comm.n_allgather, comm.n_alltoall, comm.bytes_moved, comm.seconds) if comm is not None else None
     ms_per_step = dt / args.steps * 1e3
     value = total_bytes * args.steps / dt / 1e6
 
@@ -463,6 +480,7 @@ def main():
             return {"bound": "hbm", "kernel": gname, "launches": launches, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr,
                     "traffic_source": (pmc_traffic_source() + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)") if tr else None,
+                    "traffic_stale": pmc_traffic_stale(GROUP_KERNELS[gname]) or None,
                     "algorithmic_bytes": nb, "kernel_ms_total": round(ms, 4),
                     "share_of_kernel_time": round(ms / max(total_kernel_ms, 1e-9), 4)}
 
@@ -568,6 +586,10 @@ def main():
                                        "the ONE collection sharded by record over %d GPUs (%d reads each): local LMS parsing/hashing/emission, "
                                        "hash-partitioned dictionary merge (all-to-all) + key-range-sharded dictionary stage per round, induction "
                                        "sharded by output piece (cells and BWT_{r+1} windows cross the fabric once per level), RCCL" % (world, hi - lo))},
+            # what the TIMED steps leave behind: the whole image on one device (N = 1, and N > 1 with GRLBWT_BENCH_GATHER_IMAGE=1), or -- the
+            # definition of the metric at N > 1 since round 5 -- the image in parts on the ranks that induced them (rounds 1-4 timed the
+            # all-gather to every rank as well: SCALE records of r01-r04 and of r05 on are not comparable)
+            "image_layout": "parts" if keep_parts else "whole",
             "roofline": roofline, "cpu_baseline": cpu, "image": image, "cli_end_to_end": cli_e2e,
             "roofline_groups": groups, "pass_efficiency": pass_eff[:12],
             "stage_seconds": {k: round(v, 5) for k, v in cnt.items() if k.startswith("t_")},
@@ -587,9 +609,9 @@ def main():
         out["devices"] = devices
         out["distinct_devices"] = len({d.get("uuid") or d.get("pci_bus_id") or (d["local_rank"], d["hip_device"]) for d in devices})
         if comm is not None:     # totals over warmup + timed + profile steps on rank 0
-            nsteps = args.warmup + args.steps + 1 + (1 if keep_parts else 0)
-            out["collectives_per_step"] = {"allgather": comm.n_allgather // nsteps, "alltoallv": comm.n_alltoall // nsteps,
-                                           "bytes": comm.bytes_moved // nsteps, "ms_in_callbacks": round(comm.seconds / nsteps * 1e3, 3)}
+            nsteps = max(1, args.warmup + args.steps)
+            out["collectives_per_step"] = {"allgather": comm_timed[0] // nsteps, "alltoallv": comm_timed[1] // nsteps,
+                                           "bytes": comm_timed[2] // nsteps, "ms_in_callbacks": round(comm_timed[3] / nsteps * 1e3, 3)}
             # the sharded result against a single-GPU build of the WHOLE collection on this rank (outside the timed region;
             # the other ranks wait at the final barrier): the .rl_bwt images must be the same bytes
             if os.environ.get("GRLBWT_BENCH_VERIFY", "1") != "0":

@@ -211,7 +211,7 @@ static int rank_main(const arguments &args, int rank, int size, uint64_t off_byt
         if (!all_written) { if (code == 0) code = 2; }
         else {
             const auto t_written = std::chrono::steady_clock::now();
-            std::cout << "The resulting BCR BWT was stored in " << args.output_file << std::endl;
+            // (the parts sit in the temporary file: the parent says "stored" once it has moved the file into place)
             auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
             const double tr = sec(t_start, t_loaded), tb = sec(t_loaded, t_built), tw = sec(t_built, t_written), tt = sec(t_start, t_written);
             std::printf("grlbwt-timing: read+upload %.3f s, build %.3f s, write %.3f s, total %.3f s, %.1f MB/s (input bytes / total), %d GPUs\n", tr, tb, tw, tt,
@@ -304,6 +304,7 @@ static int run_multi_gpu(const arguments &args) {
         worst = 2;
     }
     if (worst != 0) unlink(tmp_out.c_str());
+    else std::cout << "The resulting BCR BWT was stored in " << args.output_file << std::endl;   // grl_bwt.hpp:78 -- true from here on
     return worst;
 }
 

@@ -471,7 +471,7 @@ void load_fastx(grlbwt_ctx *ctx, const char *path, uint32_t fx_flags, uint64_t *
 // 8.3 GB image of the 10 GB build.)
 // (part = true: the nb bytes go to offset file_off of `path` itself, created if needed and never truncated -- one of N ranks
 // writing one file, grlbwt_result_write_part; publishing the complete file is the caller's business)
-void write_image(const uint8_t *dev_image, uint64_t nb, const char *path, bool part = false, uint64_t file_off = 0) {
+void write_image(const uint8_t *dev_image, uint64_t nb, const char *path, bool part = false, uint64_t file_off = 0, uint64_t image_total = 0) {
     // The image goes to <path>.tmp~<pid> and is renamed over the target once it is complete and closed (the reference renames
     // bwt_lev_0 to the output name, grl_bwt.hpp:77): an existing output stays intact until then, and a run that is killed or fails
     // leaves at most the temporary behind -- removed on every error path here.  What replacing an existing output costs is the
@@ -558,6 +558,9 @@ void write_image(const uint8_t *dev_image, uint64_t nb, const char *path, bool p
         throw;
     }
     for (int k = 0; k < NBUF; k++) { prim::fence_destroy(fences[k]); prim::pinned_free(bufs[k]); }
+    // (a part: the rank whose part ends the image gives the file its size -- a longer file that was there before, a caller that
+    // reuses a path, keeps no stale tail)
+    if (ok && part && image_total && file_off + nb == image_total && ftruncate(fd, (off_t)image_total) != 0) ok = false;
     if (close(fd) != 0) ok = false;
     if (ok && !part && rename(tmp.c_str(), path) != 0) ok = false;
     if (!ok) { if (!part) unlink(tmp.c_str()); throw prim::Error(GRLBWT_EINVAL, std::string("short write to ") + path); }
@@ -997,7 +1000,7 @@ int grlbwt_result_part(const grlbwt_ctx *ctx, uint64_t *offset, uint64_t *bytes)
 }
 int grlbwt_result_write_part(const grlbwt_ctx *ctx, const char *path) {
     if (!HAS_ENG(ctx) || !path || ENG(ctx, image_bytes) == 0) return GRLBWT_EINVAL;
-    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { write_image(ENG(ctx, image.p), ENG(ctx, image_part_bytes), path, true, ENG(ctx, image_part_off)); });
+    return guarded(const_cast<grlbwt_ctx *>(ctx), [&] { write_image(ENG(ctx, image.p), ENG(ctx, image_part_bytes), path, true, ENG(ctx, image_part_off), ENG(ctx, image_bytes)); });
 }
 
 int grlbwt_level_text_size(const grlbwt_ctx *ctx, int level, uint64_t *n_cells) {

@@ -2189,6 +2189,14 @@ struct PackRunsFn {
 };
 
 // -------------------------------------------------------------- stats (a1)
+struct ForeignByteIn {     // 1 for a sampled cell whose value is not in the set the statistics found (a borrowed text that changed since)
+    const u8 *t; u64 stride; u64 p0, p1, p2, p3;
+    GRL_DEV u64 operator()(u64 i) const {
+        const u32 c = t[i * stride];
+        const u64 w = (c >> 6) == 0 ? p0 : ((c >> 6) == 1 ? p1 : ((c >> 6) == 2 ? p2 : p3));
+        return ((w >> (c & 63)) & 1ull) ? 0ull : 1ull;
+    }
+};
 template <class cell_t>
 struct EqIn {
     const cell_t *t; cell_t v;
@@ -3136,7 +3144,7 @@ class Engine {
         int rec_b = 0;
         u32 rec_cmax = 0;
         bool part = false;
-        if (allow_part && !FIRST && sizeof(cell_t) == 4 && !getenv("GRLBWT_NO_PART")) {
+        if (allow_part && !FIRST && sizeof(cell_t) == 4 && !prim::dev_env("GRLBWT_NO_PART")) {
             rec_b = (int)bitlen64(L.sigma > 1 ? (u64)L.sigma - 1 : 1);
             rec_cmax = (u32)std::min<int>(7, 124 / rec_b);
             const u64 min_occ = getenv("GRLBWT_PART_MIN_OCC") ? (u64)atoll(getenv("GRLBWT_PART_MIN_OCC")) : ((u64)1 << 20);
@@ -3207,7 +3215,7 @@ class Engine {
                 cap = 4096;
                 while (cap < want) cap <<= 1;
                 if (cap > cap_max) cap = cap_max;
-                if (const char *ov = getenv("GRLBWT_TABLE_LOG2")) {      // experiments: "l0,l1,..." log2 of the slots per level (0 = keep)
+                if (const char *ov = prim::dev_env("GRLBWT_TABLE_LOG2")) {      // experiments: "l0,l1,..." log2 of the slots per level (0 = keep)
                     int lvl = prim::rt().tag, k = 0;
                     const char *q = ov;
                     while (k < lvl && *q) { if (*q == ',') k++; q++; }
@@ -3244,7 +3252,7 @@ class Engine {
         bool direct = false;
         u32 dir_b[3] = {0, 0, 0};
         u64 sym_of_code = 0;
-        if (HashInsertFn<cell_t, FIRST>::kExact && aggregate && (s_n || force_direct) && !part && sym_present_known && !getenv("GRLBWT_NO_DIRECT_INDEX")) {
+        if (HashInsertFn<cell_t, FIRST>::kExact && aggregate && (s_n || force_direct) && !part && sym_present_known && !prim::test_env("GRLBWT_NO_DIRECT_INDEX")) {
             int syms[256], ns = 0;
             for (int i = 0; i < 256; i++) if ((sym_present[i >> 6] >> (i & 63)) & 1ull) syms[ns++] = i;
             for (u32 a = 0; a < 8 && !direct && ns <= 8; a++) for (u32 b = a + 1; b < 8 && !direct; b++) for (u32 c = b + 1; c < 8 && !direct; c++) {
@@ -3258,6 +3266,16 @@ class Engine {
                 if (ok) { direct = true; dir_b[0] = a; dir_b[1] = b; dir_b[2] = c; sym_of_code = soc; }
             }
         }
+        if (direct && (const void *)t == text0 && text0 != (const void *)own0.p) {      // (level 0 of a text the caller lent)
+            // The direct index trusts the set of cell values the statistics found: a value outside it would take another symbol's
+            // code and two phrases one slot.  The engine's own copies cannot change; a buffer the caller lent (grlbwt_text_attach_device)
+            // must not -- a strided sample of it is looked at again here (the whole text would cost another 4 ms per 10 GB).
+            if constexpr (sizeof(cell_t) == 1) {
+                const u64 stride = n >= (1ull << 22) ? n >> 20 : 1, m = n / stride;
+                const u64 foreign = prim::reduce_sum<u64>(m, ForeignByteIn{(const u8 *)t, stride, sym_present[0], sym_present[1], sym_present[2], sym_present[3]}, "hash_prepare");
+                if (foreign) throw prim::Error(-22, "the attached text has changed since its statistics were taken (a cell value that was not there)");
+            }
+        }
         if (direct) {
             cap_hot = HashInsertFn<cell_t, FIRST>::kDirectSlots;
             if (cap_max > (1ull << 30)) cap_max = 1ull << 30;             // slot ids of both regions stay below 2^31
@@ -3265,7 +3283,7 @@ class Engine {
             if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: direct index on bits %u, %u, %u of a cell (%llu slots in front of the table)\n", prim::rt().tag,
                                                       dir_b[0], dir_b[1], dir_b[2], (unsigned long long)cap_hot);
         } else
-        if (aggregate && s_n && !part && !getenv("GRLBWT_NO_HOT_TABLE")) {
+        if (aggregate && s_n && !part && !prim::test_env("GRLBWT_NO_HOT_TABLE")) {
             cap_hot = 1024;
             while (cap_hot < 4 * s_distinct) cap_hot <<= 1;               // load <= 0.25: short probe chains
             if (cap_max > (1ull << 30)) cap_max = 1ull << 30;             // slot ids of both tables stay below 2^31
@@ -3328,7 +3346,7 @@ class Engine {
                         lbits.release(); lbase.release();
                         if (nl) prim::for_each_agg(nl, ListedFn<HF>{f, lpos.p, claim.p}, SlotCountAdd{cnt, cs}, false, "hash_long_phrases");
                     } else launch_hash<cell_t, FIRST>(f, cnt, cs, n, aggregate);
-                } else if (direct && n_occ < 0xFFFFFFF0ull && !getenv("GRLBWT_NO_NAME_STREAM")) {
+                } else if (direct && n_occ < 0xFFFFFFF0ull && !prim::dev_env("GRLBWT_NO_NAME_STREAM")) {
                     // the direct index in a kernel of its own (prim::name_stream): what it cannot name -- phrases of more than 7 cells,
                     // the last cells of the text -- is marked and takes the general code from a list afterwards
                     DBuf<u64> lbits(nwords + 1);
@@ -3481,7 +3499,7 @@ class Engine {
         // count matrix): blocks above the limit go in several rounds, the same number on every rank.  (torch 2.10 + RCCL
         // 2.26 delivers HALF of an all-to-all block of 2 GB, silently, and is fine at 1 GiB: tools/gpu_rccl_sizes.py.)
         void alltoall(const void *send, const std::vector<u64> &scnt, void *recv, const std::vector<u64> &rcnt, u64 elem, u64 max_block) const {
-            static const u64 limit = getenv("GRLBWT_A2A_BLOCK") ? (u64)atoll(getenv("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
+            static const u64 limit = prim::test_env("GRLBWT_A2A_BLOCK") ? (u64)atoll(prim::test_env("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
             const u64 per = std::max<u64>(limit / elem, 1);
             const u64 rounds = std::max<u64>((max_block + per - 1) / per, 1);
             std::vector<u64> sb(size), so(size), rb(size), ro(size), sbase(size + 1, 0), rbase(size + 1, 0);
@@ -3526,7 +3544,7 @@ class Engine {
             static const bool self_via_comm = getenv("GRLBWT_A2A_SELF_VIA_COMM") != nullptr;
             if (!self_via_comm || !a2a) prim::d2d(dest + base[rank], send, count * sizeof(T));
             if ((size == 1 && !self_via_comm) || !a2a) return dense;
-            static const u64 limit = getenv("GRLBWT_A2A_BLOCK") ? (u64)atoll(getenv("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
+            static const u64 limit = prim::test_env("GRLBWT_A2A_BLOCK") ? (u64)atoll(prim::test_env("GRLBWT_A2A_BLOCK")) : ((u64)256 << 20);
             const u64 per = std::max<u64>(limit / sizeof(T), 1);
             u64 mx = 0;
             for (int g = 0; g < size; g++) mx = std::max(mx, base[g + 1] - base[g]);
@@ -3553,7 +3571,7 @@ class Engine {
     // (own_of given: positions travel as (owner, offset in the owner's part) -- own_of[i] is record i's owner, the position field its
     // offset; that is how a dictionary of 2^32 symbols and more is addressed with 32-bit fields)
     static u64 test_dict_part_pad() {
-        static const u64 pad = getenv("GRLBWT_TEST_DICT_PART_PAD") ? (u64)atoll(getenv("GRLBWT_TEST_DICT_PART_PAD")) : 0;
+        static const u64 pad = prim::test_env("GRLBWT_TEST_DICT_PART_PAD") ? (u64)atoll(prim::test_env("GRLBWT_TEST_DICT_PART_PAD")) : 0;
         return pad;
     }
     void bucket_by_owner(const Comm &C, const u64 *dsb, DBuf<u64> &rec, u64 n, std::vector<u64> &cnt, const char *name, DBuf<u32> *own_of = nullptr) {
@@ -3626,7 +3644,7 @@ class Engine {
         // its (key, position) record in the sample-sort exchange: no round trip for them afterwards (24 bytes per suffix over the
         // fabric and a gather pass on the owner -- 3.3 GB and ~14 ms per rank at N = 8 of the 10 GB collection).  The values a rank
         // sorts are then ARRIVAL INDICES; pos_arr[] / rec_arr[] give the position and the record of an arrival.
-        static const bool rec_round_trip = getenv("GRLBWT_DIST_REC_ROUND_TRIP") != nullptr;
+        static const bool rec_round_trip = prim::test_env("GRLBWT_DIST_REC_ROUND_TRIP") != nullptr;
         const bool carry = sharded && maxfreq < 0xFFFFFFFFull && !rec_round_trip;
         // In this form a position is (owner, OFFSET in the owner's part): the owner of an arrival is the rank it came from (arrivals
         // sit in sender order), so 32-bit fields address a dictionary whose parts are each below 2^32 symbols, whatever their sum.
@@ -3672,7 +3690,7 @@ class Engine {
             if (K < 1) K = 1;
             if (K > 16) K = 16;
             // (GRLBWT_SORT_KMAX: fewer symbols in the first sort's key -- fewer radix passes, more left to the refinement)
-            static const int kmax = getenv("GRLBWT_SORT_KMAX") ? atoi(getenv("GRLBWT_SORT_KMAX")) : 16;
+            static const int kmax = prim::dev_env("GRLBWT_SORT_KMAX") ? atoi(prim::dev_env("GRLBWT_SORT_KMAX")) : 16;
             if (kmax >= 1 && K > kmax) K = kmax;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
             if (rk.rb && K * b + rk.rb > 64) rk.rb = 0;                     // (symbols too wide to share a key with a run field: plain keys)
@@ -3709,7 +3727,7 @@ class Engine {
                     // 4.6 GB over ONE xGMI link at level 2 of the 10 GB build, 40-75 ms -- to save 10 ms of key computation.  Below
                     // GRLBWT_SORT_EXCHANGE_MIN ranks (default 4) every rank looks at all S positions and keeps its own key range:
                     // two replicated streaming passes, nothing on the wire.
-                    static const int xmin = getenv("GRLBWT_SORT_EXCHANGE_MIN") ? atoi(getenv("GRLBWT_SORT_EXCHANGE_MIN")) : 4;
+                    static const int xmin = prim::test_env("GRLBWT_SORT_EXCHANGE_MIN") ? atoi(prim::test_env("GRLBWT_SORT_EXCHANGE_MIN")) : 4;
                     const bool exchange = N >= xmin;
                     std::vector<u64> scnt(N, 0), rcnt(N, 0);
                     DBuf<u64> sk;
@@ -3728,7 +3746,7 @@ class Engine {
                         // symbols its suffixes stand for (phrase frequencies), not by their number.  Measured on the 10 GB collection at
                         // N = 8 (profiles/r05): pass C of a piece costs by its cells and runs, not by its symbols -- slowest / fastest rank of
                         // the induction 55 / 35 ms by count, 55 / 32 ms by mass, largest image part 1.9 -> 2.5 GB: left off.
-                        if (S * 16 < L.info.n_in && getenv("GRLBWT_DIST_SPLIT_BY_MASS")) {      // (opt-in: measured no better -- see below)
+                        if (S * 16 < L.info.n_in && prim::dev_env("GRLBWT_DIST_SPLIT_BY_MASS")) {      // (opt-in: measured no better -- see below)
                             DBuf<u64> sw(ns);
                             prim::for_each(ns, SampleWeightFn{dict_phr.p, ph_freq, stride, sw.p}, "dist.sample_keys");
                             std::vector<u64> hw = sw.to_host(ns);
@@ -3883,7 +3901,7 @@ class Engine {
             int K = 64 / b;
             if (K < 1) K = 1;
             if (K > 16) K = 16;
-            static const int kmax = getenv("GRLBWT_SORT_KMAX") ? atoi(getenv("GRLBWT_SORT_KMAX")) : 16;
+            static const int kmax = prim::dev_env("GRLBWT_SORT_KMAX") ? atoi(prim::dev_env("GRLBWT_SORT_KMAX")) : 16;
             if (kmax >= 1 && K > kmax) K = kmax;
             if ((u64)K > (u64)maxlen + 1) K = (int)maxlen + 1;
             const int kbits = K * b;
@@ -4077,7 +4095,7 @@ class Engine {
             if (fused_vals || carry) gphr.alloc(G); else pslot.alloc(D);      // (carry: gphr[g] = slot of the group's whole-phrase member)
             if (C && !carry) pslot.fill_ff();    // (sharded: phrases whose whole-phrase suffix sorted elsewhere keep the mark)
             {
-                static const int fly_min = getenv("GRLBWT_DIST_REC_FLY_MIN") ? atoi(getenv("GRLBWT_DIST_REC_FLY_MIN")) : 8;
+                static const int fly_min = prim::test_env("GRLBWT_DIST_REC_FLY_MIN") ? atoi(prim::test_env("GRLBWT_DIST_REC_FLY_MIN")) : 8;
                 const bool fly = C && C->size >= fly_min;
                 DBuf<SufRec> rec;
                 DBuf<u32> coff(G + 1);
@@ -4144,7 +4162,7 @@ class Engine {
             // 8.9 GB sent per rank of the 10 GB collection at N = 2, 17.8 GB received at any N -- and every rank merged and
             // scanned the WHOLE pre-BWT; GRLBWT_DIST_REPLICATED_PREBWT=1 keeps that form.)  Runs are merged inside a piece
             // only: a run cut by a piece boundary stays two runs, which describe the same symbols.
-            static const bool replicated_pre = getenv("GRLBWT_DIST_REPLICATED_PREBWT") != nullptr || getenv("GRLBWT_DIST_REPLICATED_INDUCTION") != nullptr;      // (the replicated induction wants the whole pre-BWT)
+            static const bool replicated_pre = prim::test_env("GRLBWT_DIST_REPLICATED_PREBWT") != nullptr || prim::test_env("GRLBWT_DIST_REPLICATED_INDUCTION") != nullptr;      // (the replicated induction wants the whole pre-BWT)
             const bool pre_local = C && !replicated_pre;
             prim::for_each(G, GroupEmitFn{gflag.p, grank.p, pidx.p, gmin.p, gacc.p, gstart.p, carry ? nullptr : perm.p, bwt_code, hocc_code, pre_local ? 0u : (u32)Moff,
                                           pre_local ? 0u : (u32)P0off, psym0.p, plen0.p, L.has_hocc.p, repq.p, u_to_p0.p, pu0.p}, "prebwt_emit");
@@ -4172,7 +4190,7 @@ class Engine {
             {
                 DBuf<u32> ginfo(G);
                 prim::for_each(G, PackGroupInfoFn{grank.p, gflag.p, (u32)Moff, ginfo.p}, "grammar_ginfo");
-                static const bool replicated_grammar = getenv("GRLBWT_DIST_REPLICATED_GRAMMAR") != nullptr;
+                static const bool replicated_grammar = prim::test_env("GRLBWT_DIST_REPLICATED_GRAMMAR") != nullptr;
                 if (C && sbase && (!replicated_grammar || sharded)) {      // (a dictionary sharded by owner has no other form)
                     // Sharded by the owner of the dictionary position (round 5): I hold dm[] of MY part of the dictionary only.  The marks
                     // of my groups go to the owners of their positions, the walks of my metasymbols are done by the owners of their
@@ -4221,7 +4239,7 @@ class Engine {
                         prim::for_each(nmr, ApplyMetaPairsFn{mine.p, dm.p, s0}, "grammar_marks");
                         mine.release();
                         DBuf<u64> stops;             // (very long phrases only: the walks jump to their stops)
-                        if (maxlen >= 4096 || getenv("GRLBWT_GRAMMAR_JUMP")) {
+                        if (maxlen >= 4096 || prim::test_env("GRLBWT_GRAMMAR_JUMP")) {
                             stops.alloc((Sme + 63) / 64 + 1);
                             prim::for_each((Sme + 63) / 64, DmStopBitsFn{dm.p, Sme, stops.p}, "grammar_marks");
                         }
@@ -4247,7 +4265,7 @@ class Engine {
                     prim::for_each(bb[C->size], ApplyMetaPairsFn{all.p, dm.p}, "grammar_marks");
                 }
                 DBuf<u64> stops;                 // (very long phrases only: the walks jump to their stops)
-                if (maxlen >= 4096 || getenv("GRLBWT_GRAMMAR_JUMP")) {
+                if (maxlen >= 4096 || prim::test_env("GRLBWT_GRAMMAR_JUMP")) {
                     stops.alloc((S + 63) / 64 + 1);
                     prim::for_each((S + 63) / 64, DmStopBitsFn{dm.p, S, stops.p}, "grammar_marks");
                 }
@@ -4285,7 +4303,13 @@ class Engine {
                 std::vector<u64> mat = C->allgather_u64(scnt);
                 u64 got = 0, maxb = 0;
                 for (int g = 0; g < N; g++) { rcnt[g] = mat[(u64)g * N + me]; got += rcnt[g]; for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]); }
-                if (got != Dl) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+                // (checked for EVERY rank's column on every rank -- the matrix and the owners' phrase ranges are known to all: a rank that
+                // threw alone here would leave the others waiting in the exchange below)
+                for (int d = 0; d < N; d++) {
+                    u64 col = 0;
+                    for (int g = 0; g < N; g++) col += mat[(u64)g * N + d];
+                    if (col != (*dbase)[d + 1] - (*dbase)[d]) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+                }
                 DBuf<u64> mine(got);
                 DBuf<u32> phrase_rank(Dl);
                 C->named("phrase.rank_pairs").alltoall(fp.p, scnt, mine.p, rcnt, 8, maxb);
@@ -4310,7 +4334,11 @@ class Engine {
                     std::vector<u64> mat = C->allgather_u64(scnt);
                     u64 got = 0, maxb = 0;
                     for (int g = 0; g < N; g++) { rcnt[g] = mat[(u64)g * N + me]; got += rcnt[g]; for (int d = 0; d < N; d++) maxb = std::max(maxb, mat[(u64)g * N + d]); }
-                    if (got != (*dbase)[me + 1] - (*dbase)[me]) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+                    for (int d = 0; d < N; d++) {      // (every rank's column on every rank: see above)
+                        u64 col = 0;
+                        for (int g = 0; g < N; g++) col += mat[(u64)g * N + d];
+                        if (col != (*dbase)[d + 1] - (*dbase)[d]) throw prim::Error(-71, "dist dictionary: whole-phrase suffix count does not match the phrase count");
+                    }
                     DBuf<u64> mine(got);
                     C->named("phrase.rank_pairs").alltoall(fp.p, scnt, mine.p, rcnt, 8, maxb);
                     if (sharded) {               // (my phrases' arrays are local: ranks, frequencies and values by local phrase number)
@@ -4835,7 +4863,7 @@ class Engine {
                 // (GRLBWT_TEST_FAIL_RANK=<rank>: the tests make one rank fail here)
                 if (test_fail_rank("GRLBWT_TEST_FAIL_RANK", me)) throw prim::Error(-28, "phrase hash table overflow (injected by the test)");
                 // (levels above 0: partitioned naming as on one GPU -- short phrases are records in P.ph_key, not text positions)
-                hash_local<cell_t, FIRST>(t, n, ops, P, L, !getenv("GRLBWT_DIST_NO_PART"));
+                hash_local<cell_t, FIRST>(t, n, ops, P, L, !prim::dev_env("GRLBWT_DIST_NO_PART"));
                 if (P.n_occ >= 0xFFFFFFF0ull) throw prim::Error(-75, "a shard's parse has >= 2^32 phrases (its frequencies travel as u32): use more ranks");
                 DBuf<u32> owner(P.D), owner2(P.D), idx(P.D), idx2(P.D), soff(P.D + 1);
                 DBuf<u64> bound(2 * ((u64)N + 1));
@@ -4963,7 +4991,7 @@ class Engine {
                 for (int g = 0; g < N; g++) { mx = std::max(mx, mf[3 * g]); fs += mf[3 * g + 1]; maxfreq = std::max(maxfreq, mf[3 * g + 2]); }
                 if (fs != occ_total) throw prim::Error(-71, "merged phrase frequencies do not add up to the global parse size");
                 static const u64 run_min = getenv("GRLBWT_RUN_KEYS_MIN") ? (u64)atoll(getenv("GRLBWT_RUN_KEYS_MIN")) : 512;
-                static const bool gathered = getenv("GRLBWT_DIST_GATHERED_DICT") != nullptr || getenv("GRLBWT_DIST_REPLICATED_DICT") != nullptr;
+                static const bool gathered = getenv("GRLBWT_DIST_GATHERED_DICT") != nullptr || prim::test_env("GRLBWT_DIST_REPLICATED_DICT") != nullptr;
                 // (GRLBWT_DIST_SHARDED_DICT_MIN=<ranks>: from how many ranks on -- see the figures in DESIGN.md section 6)
                 static const int sd_min = getenv("GRLBWT_DIST_SHARDED_DICT_MIN") ? atoi(getenv("GRLBWT_DIST_SHARDED_DICT_MIN")) : 4;
                 // (... and from how many dictionary symbols on: a small dictionary's all-gather costs less than the collectives of the
@@ -5004,7 +5032,7 @@ class Engine {
         }
         // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar passes and dictionary by owner ----
         DBuf<u32> gval;
-        dict_stage<u32, false>(getenv("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
+        dict_stage<u32, false>(prim::test_env("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
                                ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase, sharded_dict, maxfreq);
         // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
@@ -5225,7 +5253,7 @@ class Engine {
                 for (int g = 0; g < N; g++) for (int d = 0; d < N; d++) maxc = std::max(maxc, mat[(u64)g * 2 * N + d]);
                 const int bits = kb;
                 // (the received blocks are bucket-sorted: merged by block offsets; GRLBWT_MERGE_CELLS=sort keeps the stable radix sort)
-                static const bool merge_by_blocks = !(getenv("GRLBWT_MERGE_CELLS") && getenv("GRLBWT_MERGE_CELLS")[0] == 's');
+                static const bool merge_by_blocks = !(prim::test_env("GRLBWT_MERGE_CELLS") && prim::test_env("GRLBWT_MERGE_CELLS")[0] == 's');
                 const u32 mu0 = (u32)sp[4 * me + 1], mu1 = (u32)sp[4 * (me + 1) + 1];
                 if (c_sfused32.p) {
                     DBuf<u32> rf(Er);
@@ -5401,7 +5429,7 @@ class Engine {
     void dist_build(const Comm &C) {
         dist_stats(C);
         while (!dist_parse_round(C)) {}
-        if (getenv("GRLBWT_DIST_REPLICATED_INDUCTION")) dist_induce_replicated(C);
+        if (prim::test_env("GRLBWT_DIST_REPLICATED_INDUCTION")) dist_induce_replicated(C);
         else dist_induce(C);
     }
 

@@ -130,7 +130,9 @@ int grlbwt_text_load_file(grlbwt_ctx *ctx, const char *path, int cell_bytes);
 /* the same for bytes [offset_bytes, offset_bytes + n_bytes) of the file: a record shard of the collection-level mode
  * (the caller cuts at record boundaries; both numbers are multiples of cell_bytes) */
 int grlbwt_text_load_file_range(grlbwt_ctx *ctx, const char *path, uint64_t offset_bytes, uint64_t n_bytes, int cell_bytes);
-/* use cells already resident in HBM (borrowed until the context is reset/destroyed; 16-byte aligned) */
+/* use cells already resident in HBM (borrowed until the context is reset/destroyed; 16-byte aligned).  The statistics are
+ * taken here: the buffer must not change between this call and the end of the build (a build that finds a cell value in it
+ * that was not there fails with GRLBWT_EINVAL; other changes give the image of neither text). */
 int grlbwt_text_attach_device(grlbwt_ctx *ctx, const void *dev_cells, uint64_t n_cells, int cell_bytes);
 int grlbwt_get_stats(const grlbwt_ctx *ctx, grlbwt_stats *out);
 
@@ -183,8 +185,9 @@ int grlbwt_result_write_file(const grlbwt_ctx *ctx, const char *path);
  * rank's part after a grlbwt_dist_build with GRLBWT_COMM_KEEP_PARTS (bytes may be 0 on a rank whose slice merged into a
  * neighbour's run). */
 int grlbwt_result_part(const grlbwt_ctx *ctx, uint64_t *offset, uint64_t *bytes);
-/* The part at its offset of `path` (created if missing, never truncated: the caller removes a stale file first and publishes
- * the complete one -- a barrier and a rename -- once every rank has returned; the grlbwt executable's --gpus does). */
+/* The part at its offset of `path` (created if missing; the rank whose part ends the image sets the file's size, so a longer
+ * file that was there before keeps no tail).  The file is a valid image only once EVERY rank has returned GRLBWT_OK: the caller
+ * writes to a temporary name and publishes the complete file -- a barrier and a rename -- as the grlbwt executable's --gpus does. */
 int grlbwt_result_write_part(const grlbwt_ctx *ctx, const char *path);
 
 /* ---- .rl_bwt consumers: scripts/grl2plain.cpp (expand the runs) + scripts/reverse_bwt.cpp with

@@ -63,6 +63,7 @@ inline void *dev_alloc(size_t bytes) {
 inline void dev_free(void *p) { std::free(p); }
 inline void dev_shrink(void *, size_t) {}
 inline const char *dev_env(const char *) { return nullptr; }      // (experiment switches: development builds of the device library only)
+inline const char *test_env(const char *name) { return getenv(name); }      // (switches of the CPU test suites: read here, never by the device library)
 inline void h2d(void *d, const void *h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void d2h(void *h, const void *d, size_t n) { if (n) std::memcpy(h, d, n); }
 inline void d2d(void *dst, const void *src, size_t n) { if (n) std::memmove(dst, src, n); }

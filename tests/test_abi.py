@@ -93,5 +93,22 @@ def test_fault_injection_is_not_in_the_product(hip_lib):
     """The failure-agreement tests inject faults through GRLBWT_TEST_FAIL_RANK* -- in the serial test stand-in only: the product
     library never reads those variables (an environment variable could make a production rank throw)."""
     blob = open(hip_lib, "rb").read()
-    assert b"GRLBWT_TEST_FAIL_RANK" not in blob
+    assert b"GRLBWT_TEST_" not in blob              # no test hook of any kind (the dictionary-part padding of round 5 included)
     assert b"injected by the test" not in blob
+
+
+def test_environment_switches_of_the_product_are_few(hip_lib):
+    """Every GRLBWT_* variable the device library reads is a diagnostic (traces), a debugging aid of the allocator, or a limit the
+    GPU tests lower to send small inputs down a large-input branch.  Experiment switches live in development builds
+    (prim::dev_env, tools/build_dev.sh), the switches of the CPU suites in the test stand-in (prim::test_env): neither reaches
+    the product binary (56 names, a dozen of them rejected experiments)."""
+    blob = open(hip_lib, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"GRLBWT_[A-Z0-9_]+", blob))
+    names -= {"GRLBWT_FLAG_CLASSIC_POOL", "GRLBWT_FLAG_FORCE_IDX64", "GRLBWT_BENCH_", "GRLBWT_HIP_LIB", "GRLBWT_E2E_TMP", "GRLBWT_SIM_LIB", "GRLBWT_"}
+    assert not [n for n in names if n.startswith("GRLBWT_DEV_")], names
+    assert len(names) <= 35, sorted(names)
+    src = ""
+    for f in ("engine_impl.hpp", "prim_hip.hpp", "capi_impl.hpp"):
+        src += open(os.path.join(ROOT, "grlbwt_amd", "csrc", f)).read()
+    read = set(re.findall(r'(?<![a-z_])getenv\("(GRLBWT_[A-Z0-9_]+)"\)', src))
+    assert len(read) <= 35, sorted(read)
