@@ -782,13 +782,12 @@ struct PhraseRecordFn {
     u64 *long_bits;       // bit p: the phrase starting at p is left to the walk (a counter for a list of them serialised the pass:
                           // 38 M same-address atomics at level 2 of the 10 GB build, 171 ms)
     u32 *scal;
-    GRL_DEV void operator()(u64 p) const {
-        const u64 w = startbits[p >> 6];
-        bool listed = false;
-        if ((w >> (p & 63)) & 1ull) {
-            const u64 ord = (u64)wordbase[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+    // (p is a phrase start, ord its ordinal: prim::for_each_set_bit over the start bits -- every lane of a wave on a phrase of its own,
+    // consecutive lanes at consecutive ordinals.  Rounds 3-5 ran one lane per text POSITION: two lanes in three idle.)
+    GRL_DEV void operator()(u64 p, u64 ord) const {
+        bool listed = true;
+        {
             const u32 cmax = B ? (u32)CMAX : rec_cmax;
-            listed = true;
             if (p + (u64)cmax + 1 <= n) {
                 const u64 b0 = p + 1;
                 u64 bits = startbits[b0 >> 6] >> (b0 & 63);
@@ -824,7 +823,7 @@ struct PhraseRecordFn {
                 }
             }
         }
-        prim::wave_word_store(long_bits, p, listed);
+        if (listed) prim::atomic_or(long_bits + (p >> 6), 1ull << (p & 63));      // (rare, and every word another address; the bits start out zero)
     }
 };
 struct BitPositionsFn {      // the positions of the set bits of words[], in order: pos[base[w] ..] for word w
@@ -3328,8 +3327,8 @@ class Engine {
                         DBuf<u64> lbits(nwords + 1);
                         lbits.zero();
                         auto records = [&](auto bw) {
-                            prim::for_each(n, PhraseRecordFn<cell_t, decltype(bw)::value>{t, ops, startbits.p, wordbase.p, n, n_occ, rec_k.p, rec_hi.p, rec_b,
-                                                                                          rec_cmax, lbits.p, scal.p}, "hash_phrases");
+                            prim::for_each_set_bit<idx_t>(n, startbits.p, wordbase.p, PhraseRecordFn<cell_t, decltype(bw)::value>{t, ops, startbits.p, wordbase.p, n, n_occ,
+                                                                                                                           rec_k.p, rec_hi.p, rec_b, rec_cmax, lbits.p, scal.p}, "hash_phrases");
                         };
                         switch (rec_b) {
 #define GRL_REC_CASE(BW) case BW: records(std::integral_constant<int, BW>()); break;

@@ -651,6 +651,50 @@ inline void for_each(u64 n, F f, const char *name = "for_each") {
     after_launch(name);
 }
 
+// --------------------------------------------------- a functor over the set bits of a bit-vector
+// f(p, ord) for every set bit p of words[] (ord = the number of set bits in front of p; wordbase[w] = set bits in front of word w).
+// A wave walks a contiguous span of words, compacts each word's set bits into an LDS ring (the word IS the ballot of its 64
+// positions) and runs f on 64 of them at a time: every lane busy, consecutive lanes at consecutive ordinals.
+// (One lane per POSITION with the work behind an `if (bit set)` leaves two lanes in three idle where a third of the positions are
+// phrase starts -- the record pass of the phrase naming: 14.8 ms for the 2.9 G positions of level 1 of the 10 GB build.)
+template <class IDX, class F>
+__global__ void __launch_bounds__(kBlock) k_for_each_set_bit(u64 nwords, const u64 *words, const IDX *wordbase, u32 span, F f) {
+    constexpr u32 QCAP = 128;
+    __shared__ u32 s_queue[kBlock / 64][QCAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    volatile u32 *queue = s_queue[w];
+    const u64 w0 = ((u64)blockIdx.x * (kBlock / 64) + (u64)w) * (u64)span;
+    if (w0 < nwords) {                               // (wave-uniform; the kernel has no workgroup barrier)
+        const u64 w1 = w0 + span < nwords ? w0 + span : nwords;
+        const u64 p0 = w0 * 64;
+        u64 ord = (u64)wordbase[w0];
+        u32 qh = 0, qt = 0;                          // ring positions (items are offsets from p0: a span is below 2^32 positions)
+        for (u64 x = w0; x < w1; x++) {
+            const u64 word = words[x];
+            if ((word >> lane) & 1ull) queue[(qt + (u32)__popcll(word & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (u32)((x - w0) * 64) + (u32)lane;
+            qt += (u32)__popcll(word);
+            if (qt - qh >= 64u) {
+                f(p0 + (u64)queue[(qh + (u32)lane) & (QCAP - 1)], ord + (u64)lane);
+                qh += 64u; ord += 64u;
+            }
+        }
+        if ((u32)lane < qt - qh) f(p0 + (u64)queue[(qh + (u32)lane) & (QCAP - 1)], ord + (u64)lane);
+    }
+}
+template <class IDX, class F>
+inline void for_each_set_bit(u64 nbits, const u64 *words, const IDX *wordbase, F f, const char *name = "for_each_set_bit") {
+    const u64 nwords = (nbits + 63) / 64;
+    if (nwords == 0) return;
+    // spans of 64 words (4096 positions) per wave -- shorter when that leaves the CUs short of waves
+    u32 span = 64;
+    while (span > 4 && (nwords + span - 1) / span < (u64)rt().num_cus * 32) span >>= 1;
+    const u64 waves = (nwords + span - 1) / span;
+    prof_begin(name);
+    hipLaunchKernelGGL((k_for_each_set_bit<IDX, F>), dim3((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, rt().stream, nwords, words, wordbase, span, f);
+    prof_end();
+    after_launch(name);
+}
+
 // --------------------------------------------------- bit-vector from predicate
 // words[i/64] bit (i%64) = pred(i); one wave64 ballot per word, lane 0 stores.
 template <class F>
@@ -1869,11 +1913,12 @@ struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays 
 // the tile size: 4096 records of 16 bytes already take 64 KB, and with 512-1024 bins such a tile leaves runs of 4-8 records = 64-128
 // bytes of values and 16-32 bytes of keys at the write front.  Keys only in LDS: 16384 records per tile, runs four times as long;
 // the value stores of a run come from different lanes and rows but reach the same lines of one L2 within the tile's lifetime.)
-// (dig_out: the digit of every key, in input order -- what the way back of a RecSort pass re-ranks from: 2 bytes instead of the key)
+// (rank_out: where every key went INSIDE its tile's sorted order, in input order -- 2 bytes per key: the way back of a RecSort pass
+// reads it instead of ranking again)
 template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock, bool DIRECT = false, bool MIX = false>
 __global__ void __launch_bounds__(TB)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
-                        const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles, u16 *dig_out = nullptr) {
+                        const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles, u16 *rank_out = nullptr) {
     constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
     constexpr bool STAGED = !std::is_same<V, NoVal>::value && !DIRECT;
     constexpr int EB = (STAGED && sizeof(V) > sizeof(K)) ? sizeof(V) : sizeof(K);
@@ -1901,10 +1946,6 @@ __global__ void __launch_bounds__(TB)
     u32 dig[kRsKeys];
 #pragma unroll
     for (int q = 0; q < kRsKeys; q++) dig[q] = rs_digit<MIX>(key[q], shift, dmask);
-    if (dig_out) {
-#pragma unroll
-        for (int q = 0; q < kRsKeys; q++) { const u32 t = wbase + q * 64 + lane; if (t < tile_n) dig_out[base + t] = (u16)dig[q]; }
-    }
     wave_rank<DB, kRsKeys, true, CT>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
     __syncthreads();
     {   // thread t, bins [t*BPT, (t+1)*BPT): wave bases, tile-local digit starts, global bases (threads behind the last bin idle)
@@ -1948,6 +1989,7 @@ __global__ void __launch_bounds__(TB)
         if (t < tile_n) {
             idx[q] += (u32)s_cnt[w][dig[q]];
             kb[idx[q]] = key[q];
+            if (rank_out) rank_out[base + t] = (u16)idx[q];
         }
     }
     if constexpr (STAGED) {
@@ -2363,14 +2405,14 @@ inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *na
 
 template <class K, class V, int SITE, int DB, int TB = kBlock, bool DIRECT = false, bool MIX = false>
 inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shift, u32 dmask, u32 tiles, u32 *counts, u64 *offsets,
-                    u32 *chunk_sums, u64 *chunk_off, const char *name, u16 *dig_out = nullptr) {
+                    u32 *chunk_sums, u64 *chunk_off, const char *name, u16 *rank_out = nullptr) {
     prof_begin(std::string(name) + ".hist", n * sizeof(K));
     hipLaunchKernelGGL((k_rs_hist<K, SITE, DB, TB, MIX>), dim3(tiles), dim3(TB), 0, rt().stream, kin, n, shift, dmask, counts, tiles);
     prof_end();
     after_launch(name);
     rs_offsets<(1 << DB)>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
     prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
-    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB, DIRECT, MIX>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles, dig_out);
+    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB, DIRECT, MIX>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles, rank_out);
     prof_end();
     after_launch(name);
 }
@@ -2473,89 +2515,91 @@ struct alignas(16) U128 {
 static constexpr u32 kNoId = 0xFFFFFFFFu;
 
 // One pass of RecSort::backward: src holds one element per record in the OUTPUT order of the forward pass, dst gets them in its
-// INPUT order.  The ranking of k_rs_scatter is recomputed from the pass's input keys; the elements are gathered (runs of
-// equal digits are neighbours in src) and written linearly.
-// (The other form -- the forward pass stores where every element went, the way back is a plain gather -- was measured slower on
-// the 964 M records of level 1 of the 10 GB build: forward 36 + back 22.8 ms against 32.4 + 19.2 ms; the 4 bytes per element per
-// pass of destinations cost more than the ballot ranking they save.)
-// (STAGED, round 5: the elements are READ in the output order of the forward pass -- neighbouring lanes take neighbouring elements of
-// a digit's run, as the forward write-out stores them -- and brought to input order through LDS, instead of one gather per element
-// whose 64 lanes hit 64 different runs: a wave instruction then touches ~8 lines instead of 64.)
-template <class K, class W, int DB = 8, int TB = kBlock>
+// INPUT order.  The forward pass left every record's place inside its tile's sorted order (rank_in, 2 bytes); the tile's digit
+// runs follow from the pass's offsets (a run's length = the next tile's offset of the same digit - mine).  So: the digit of every
+// output slot by one prefix-maximum over the run starts, the elements read run by run -- neighbouring lanes, neighbouring
+// addresses -- into LDS in the tile's sorted order, and every record picks its own by its stored rank.  No ranking on the way back.
+// (Rounds 3-5 recomputed the ballot ranking of the forward pass from its input keys -- and round 6 first from stored digits --:
+// the pass then costs per RECORD what the forward pass costs, 7 ms per pass over the 964 M records of level 1 of the 10 GB build
+// for 10 bytes per record.  Storing where every element went and gathering through that -- 4 bytes per element and pass -- was
+// measured slower than re-ranking in round 3; two bytes of tile-local rank + the offsets the pass has anyway carry the same.)
+template <class W, int DB, int TB>
 __global__ void __launch_bounds__(TB)
-    k_rs_unscatter(const K *keys_in, const W *src, W *dst, u64 n, int shift, u32 dmask, const u64 *offsets /*[tiles][NB]*/) {
-    constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
-    typedef typename std::conditional<(NW * NB > 4096), u16, u32>::type CT;      // (as in k_rs_scatter)
-    __shared__ u32 s_e[TILE];                    // by output position of the tile: input position << 10 | digit
-    __shared__ W s_v[TILE];                      // by input position: the element
-    __shared__ __attribute__((aligned(4))) CT s_cnt[NW][NB];
-    __shared__ u64 s_gbase[NB];
+    k_rs_unscatter(const u16 *rank_in, const W *src, W *dst, u64 n, const u64 *offsets /*[tiles][NB]*/, u32 tiles) {
+    constexpr int NB = 1 << DB, TILE = TB * kRsItems, NW = TB / 64;
+    static_assert(NB <= TB, "one thread per digit");
+    __shared__ u16 s_d[TILE];                    // digit of every output slot of the tile
+    __shared__ W s_v[TILE];                      // the elements in the tile's sorted order
+    __shared__ u64 s_gbase[NB];                  // global position of slot 0 of the digit's run, minus the run's first slot
     __shared__ u32 s_wsum[NW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < NW * NB; i += TB) (&s_cnt[0][0])[i] = 0;
-    const u64 base = (u64)blockIdx.x * TILE;
+    const u32 tile = blockIdx.x;
+    const u64 base = (u64)tile * TILE;
     const u64 left = n - base;
     const u32 tile_n = left < (u64)TILE ? (u32)left : (u32)TILE;
-    const u32 wbase = (u32)w * (64 * kRsKeys);
-    u32 dig[kRsKeys], idx[kRsKeys];
+    // (my records' ranks first: the kernel's workgroup is alone on its CU and waits out every trip to memory -- this one is back
+    // when the elements are in LDS)
+    u16 rk[kRsItems];
 #pragma unroll
-    for (int q = 0; q < kRsKeys; q++) {
-        u32 t = wbase + q * 64 + lane;
-        dig[q] = t < tile_n ? ((u32)(keys_in[base + t] >> shift) & dmask) : 0u;
+    for (int j = 0; j < kRsItems; j++) { const u32 t = (u32)j * TB + threadIdx.x; rk[j] = t < tile_n ? rank_in[base + t] : (u16)0; }
+    for (u32 t = threadIdx.x; t < (u32)TILE; t += TB) s_d[t] = 0;
+    // ---- run lengths and starts of my digits
+    u32 cnt = 0;
+    u64 g0 = 0;
+    if ((int)threadIdx.x < NB) {
+        const u32 d = threadIdx.x;
+        g0 = offsets[(u64)tile * NB + d];
+        const u64 nx = tile + 1 < tiles ? offsets[(u64)(tile + 1) * NB + d] : (d + 1 < (u32)NB ? offsets[d + 1] : n);      // (digit-major: behind the last tile of d comes tile 0 of d + 1)
+        cnt = (u32)(nx - g0);
+    }
+    u32 incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 o = (u32)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    u32 start = incl - cnt;
+    for (int k = 0; k < w; k++) start += s_wsum[k];
+    if ((int)threadIdx.x < NB) {
+        s_gbase[threadIdx.x] = g0 - (u64)start;
+        if (cnt) s_d[start] = (u16)threadIdx.x;         // the run's first slot names its digit (slot 0: digit of the first non-empty run, possibly 0)
     }
     __syncthreads();
-    wave_rank<DB, kRsKeys, true, CT>([&](int q) { return dig[q]; }, wbase + (u32)lane, tile_n, (u32)kRsKeys, &s_cnt[w][0], idx);
-    __syncthreads();
+    // ---- digit of every slot: the last run start at or in front of it (digits ascend with the slots: a prefix maximum)
     {
-        u32 cw[BPT][NW], tt[BPT], sum = 0;
-        const bool has = (int)threadIdx.x * BPT < NB;
+        const u32 t0 = threadIdx.x * kRsItems;
+        u32 dloc[kRsItems], m = 0;
 #pragma unroll
-        for (int e = 0; e < BPT; e++) {
-            const int d = threadIdx.x * BPT + e;
-            tt[e] = 0;
-#pragma unroll
-            for (int k = 0; k < NW; k++) { cw[e][k] = has ? (u32)s_cnt[k][d] : 0u; tt[e] += cw[e][k]; }
-            sum += tt[e];
-        }
-        u32 incl = sum;
+        for (int j = 0; j < kRsItems; j++) { const u32 h = s_d[t0 + j]; m = h > m ? h : m; dloc[j] = m; }
+        u32 pm = m;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            u32 o = (u32)__shfl_up((int)incl, off);
-            if (lane >= off) incl += o;
+            u32 o = (u32)__shfl_up((int)pm, off);
+            if (lane >= off) pm = o > pm ? o : pm;
         }
-        if (lane == 63) s_wsum[w] = incl;
+        __syncthreads();                                 // (everybody has read its heads; s_wsum is free again)
+        if (lane == 63) s_wsum[w] = pm;
         __syncthreads();
-        u32 start = incl - sum;
-        for (int k = 0; k < w; k++) start += s_wsum[k];
-        if (has) {
+        u32 before = (u32)__shfl_up((int)pm, 1);
+        if (lane == 0) before = 0;
+        for (int k = 0; k < w; k++) before = s_wsum[k] > before ? s_wsum[k] : before;
 #pragma unroll
-            for (int e = 0; e < BPT; e++) {
-                const int d = threadIdx.x * BPT + e;
-                u32 run = start;
-#pragma unroll
-                for (int k = 0; k < NW; k++) { s_cnt[k][d] = (CT)run; run += cw[e][k]; }
-                s_gbase[d] = offsets[(u64)blockIdx.x * NB + d] - (u64)start;
-                start += tt[e];
-            }
-        }
+        for (int j = 0; j < kRsItems; j++) s_d[t0 + j] = (u16)(dloc[j] > before ? dloc[j] : before);
     }
     __syncthreads();
+    // ---- the elements, run by run, into the tile's sorted order
 #pragma unroll
-    for (int q = 0; q < kRsKeys; q++) {
-        const u32 t = wbase + q * 64 + lane;
-        if (t < tile_n) s_e[idx[q] + (u32)s_cnt[w][dig[q]]] = (t << 10) | dig[q];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kRsKeys; j++) {
+    for (int j = 0; j < kRsItems; j++) {
         const u32 t = (u32)j * TB + threadIdx.x;
-        if (t < tile_n) { const u32 e = s_e[t]; s_v[e >> 10] = src[s_gbase[e & 1023u] + t]; }
+        if (t < tile_n) s_v[t] = src[s_gbase[s_d[t]] + t];
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kRsKeys; j++) {
+    for (int j = 0; j < kRsItems; j++) {
         const u32 t = (u32)j * TB + threadIdx.x;
-        if (t < tile_n) dst[base + t] = s_v[t];
+        if (t < tile_n) dst[base + t] = s_v[rk[j]];
     }
 }
 
@@ -2572,7 +2616,7 @@ struct RecSort {
     u64 n = 0;
     int bits = 0, passes = 0, shifts[4] = {0, 0, 0, 0}, widths[4] = {0, 0, 0, 0};
     u32 tiles = 0;
-    u16 *dig[4] = {nullptr, nullptr, nullptr, nullptr};       // digit of every record at the input of pass p
+    u16 *rnk[4] = {nullptr, nullptr, nullptr, nullptr};       // every record's place inside its tile's sorted order, by input position of pass p
     u64 *offs[4] = {nullptr, nullptr, nullptr, nullptr};
     static constexpr int kThreads = 1024;
     GRL_HD static u64 part_of(u64 key, int bits_) { return bits_ ? (key * kMixMul) >> (64 - bits_) : 0; }
@@ -2598,12 +2642,12 @@ struct RecSort {
         int cur = 0;
         for (int p = 0; p < passes; p++) {
             const int db = widths[p] <= 8 ? 8 : 9;
-            dig[p] = (u16 *)dev_alloc(n * sizeof(u16));
+            rnk[p] = (u16 *)dev_alloc(n * sizeof(u16));
             offs[p] = (u64 *)dev_alloc(((u64)1 << db) * tiles * sizeof(u64));
             const u32 dmask = (1u << widths[p]) - 1u;
             u64 *kin = cur ? key_b : key_a, *kout = cur ? key_a : key_b, *vin = cur ? hi_b : hi_a, *vout = cur ? hi_a : hi_b;
-            if (db == 8) rs_pass<u64, u64, 2, 8, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, dig[p]);
-            else rs_pass<u64, u64, 2, 9, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, dig[p]);
+            if (db == 8) rs_pass<u64, u64, 2, 8, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, rnk[p]);
+            else rs_pass<u64, u64, 2, 9, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, rnk[p]);
             cur ^= 1;
         }
         dev_free(counts); dev_free(chunk_sums); dev_free(chunk_off);
@@ -2618,10 +2662,9 @@ struct RecSort {
         W *src = in;
         for (int p = passes - 1; p >= 0; p--) {
             W *dst = (p == 0) ? out : ((src == tmp) ? in : tmp);
-            const u32 dmask = (1u << widths[p]) - 1u;
             prof_begin(name, n * (sizeof(u16) + 2 * sizeof(W)));
-            if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<u16, W, 8, kThreads>), dim3(tiles), dim3(kThreads), 0, rt().stream, (const u16 *)dig[p], src, dst, n, 0, dmask, offs[p]);
-            else hipLaunchKernelGGL((k_rs_unscatter<u16, W, 9, kThreads>), dim3(tiles), dim3(kThreads), 0, rt().stream, (const u16 *)dig[p], src, dst, n, 0, dmask, offs[p]);
+            if (widths[p] <= 8) hipLaunchKernelGGL((k_rs_unscatter<W, 8, kThreads>), dim3(tiles), dim3(kThreads), 0, rt().stream, (const u16 *)rnk[p], src, dst, n, offs[p], tiles);
+            else hipLaunchKernelGGL((k_rs_unscatter<W, 9, kThreads>), dim3(tiles), dim3(kThreads), 0, rt().stream, (const u16 *)rnk[p], src, dst, n, offs[p], tiles);
             prof_end();
             after_launch(name);
             src = dst;
@@ -2629,9 +2672,9 @@ struct RecSort {
     }
     void release() {
         for (int p = 0; p < 4; p++) {
-            if (dig[p]) dev_free(dig[p]);
+            if (rnk[p]) dev_free(rnk[p]);
             if (offs[p]) dev_free(offs[p]);
-            dig[p] = nullptr; offs[p] = nullptr;
+            rnk[p] = nullptr; offs[p] = nullptr;
         }
         passes = 0; n = 0; bits = 0;
     }
@@ -2680,8 +2723,14 @@ __global__ void __launch_bounds__(kPdThreads) k_rec_dedupe(const u64 *pstart, co
     if (threadIdx.x == 0) s_fail = (b - a >= (1ull << 26)) ? 1u : 0u;
     __syncthreads();
     const bool usable = s_fail == 0;
-    for (u64 i = a + threadIdx.x; i < b && usable; i += kPdThreads) {
-        const u64 vk = skey[i], vh = shi[i];
+    // (a thread's first kPdMine records keep the slot they found in registers until the slots have their dense numbers: one
+    // store of lid per record instead of a store, a load and a store -- and one round trip to memory less in a kernel whose
+    // workgroup, the only one on its CU, waits out every one of them)
+    constexpr int kPdMine = 8;
+    u32 myres[kPdMine];
+#pragma unroll
+    for (int k = 0; k < kPdMine; k++) myres[k] = kNoId;
+    auto insert = [&](u64 i, u64 vk, u64 vh) -> u32 {
         u32 res = kNoId;
         if (valid(vh)) {
             u64 g = (vk ^ (vh * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
@@ -2713,7 +2762,22 @@ __global__ void __launch_bounds__(kPdThreads) k_rec_dedupe(const u64 *pstart, co
             if (done) { atomicAdd(&s_cnt[slot], 1u); res = slot; }
             else s_fail = 1u;                       // table full
         }
-        lid[i] = res;
+        return res;
+    };
+    if (usable) {
+        u64 vk[kPdMine], vh[kPdMine];             // (all of a thread's records in flight before the first probe)
+#pragma unroll
+        for (int k = 0; k < kPdMine; k++) {
+            const u64 i = a + (u64)k * kPdThreads + threadIdx.x;
+            vk[k] = i < b ? skey[i] : 0ull;
+            vh[k] = i < b ? shi[i] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < kPdMine; k++) {
+            const u64 i = a + (u64)k * kPdThreads + threadIdx.x;
+            if (i < b) myres[k] = insert(i, vk[k], vh[k]);
+        }
+        for (u64 i = a + (u64)kPdMine * kPdThreads + threadIdx.x; i < b; i += kPdThreads) lid[i] = insert(i, skey[i], shi[i]);
     }
     __syncthreads();
     // dense numbering of the occupied slots (slot order): thread t takes slots [8t, 8t + 8)
@@ -2748,7 +2812,12 @@ __global__ void __launch_bounds__(kPdThreads) k_rec_dedupe(const u64 *pstart, co
     }
     __syncthreads();
     if (s_fail) { if (threadIdx.x == 0) { *overflow = 1u; pcount[blockIdx.x] = 0; } return; }
-    for (u64 i = a + threadIdx.x; i < b; i += kPdThreads) {
+#pragma unroll
+    for (int k = 0; k < kPdMine; k++) {
+        const u64 i = a + (u64)k * kPdThreads + threadIdx.x;
+        if (i < b) lid[i] = myres[k] != kNoId ? s_idx[myres[k]] : kNoId;
+    }
+    for (u64 i = a + (u64)kPdMine * kPdThreads + threadIdx.x; i < b; i += kPdThreads) {
         const u32 sl = lid[i];
         if (sl != kNoId) lid[i] = s_idx[sl];
     }

@@ -95,6 +95,13 @@ template <class F>
 inline void for_each(u64 n, F f, const char * = "") {
     for (u64 i = 0; i < n; i++) f(i);
 }
+template <class IDX, class F>
+inline void for_each_set_bit(u64 nbits, const u64 *words, const IDX *wordbase, F f, const char * = "") {      // f(p, ord) for every set bit p, in order
+    for (u64 w = 0; w < (nbits + 63) / 64; w++) {
+        u64 ord = (u64)wordbase[w];
+        for (u64 x = words[w]; x; x &= x - 1) f(w * 64 + (u64)__builtin_ctzll(x), ord++);
+    }
+}
 template <class F>
 inline void bitvector_from_pred(u64 n, F pred, u64 *words, const char * = "") {
     u64 nw = (n + 63) / 64;
