@@ -1989,7 +1989,6 @@ __global__ void __launch_bounds__(TB)
         if (t < tile_n) {
             idx[q] += (u32)s_cnt[w][dig[q]];
             kb[idx[q]] = key[q];
-            if (rank_out) rank_out[base + t] = (u16)idx[q];
         }
     }
     if constexpr (STAGED) {
@@ -2019,6 +2018,10 @@ __global__ void __launch_bounds__(TB)
             dpack[j >> 1] |= d << (16 * (j & 1));
             keys_out[s_gbase[d] + t] = k;
         }
+    }
+    if (rank_out) {          // (behind the keys' write-out: in front of it these stores cost the level-1 passes of the 10 GB build 1.5-2 ms)
+#pragma unroll
+        for (int q = 0; q < kRsKeys; q++) { const u32 t = wbase + q * 64 + lane; if (t < tile_n) rank_out[base + t] = (u16)idx[q]; }
     }
     if constexpr (STAGED) {
         __syncthreads();
