@@ -911,23 +911,39 @@ struct ClaimCompactFn {     // step 2, one lane per phrase: its table entry (a r
     CompactTableFn<cell_t, FIRST> c;
     GRL_DEV void operator()(u64 k) const { c.emit((u64)c.ph_slot[k], k); }
 };
-struct PartPhraseFn {      // distinct phrase k of the partitioned naming: from the staging area of its partition
-    const u32 *pbase; u64 nparts; const u64 *pstart; const u64 *dkey; const u64 *dhi; const u32 *dcnt; u32 slot0;
+// (Both run ONE WAVE PER PARTITION -- lane i handles partition i >> 6, elements (i & 63), + 64, ... of it: a partition's distinct records
+// sit together in the staging area and its occurrences together in the sorted order, so every access is a coalesced run and nobody
+// searches for its partition.  Rounds 3-5: one lane per phrase with a binary search over the partitions' bases -- 18 dependent
+// loads per wave, 11 ms per 10 GB build -- and one lane per record that took its partition from a hash of the sorted key.)
+struct PartPhraseFn {      // the distinct phrases of the partitioned naming: from the staging areas of their partitions
+    const u32 *pbase; const u64 *pstart; const u64 *dkey; const u64 *dhi; const u32 *dcnt; u32 slot0;
     prim::U128 *ph_key; u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
-    GRL_DEV void operator()(u64 k) const {
-        const u64 p = upper_bound<u32>(pbase, nparts, (u32)k) - 1;
-        const u64 src = pstart[p] + (k - (u64)pbase[p]);
-        const u64 hi = dhi[src];
-        const prim::U128 r(rec_lo(dkey[src], hi), hi);
-        ph_key[k] = r; ph_pos[k] = 0; ph_freq[k] = (idx_t)dcnt[src]; ph_len[k] = rec_len(r); ph_slot[k] = slot0 + (u32)k;
-        ph_lastT[k] = (r.hi & kPhrLastT) ? 1 : 0;
+    GRL_DEV void operator()(u64 i) const {
+        const u64 p = i >> 6;
+        const u64 k0 = pbase[p], cnt = (u64)pbase[p + 1] - k0, src0 = pstart[p];
+        for (u64 j = i & 63; j < cnt; j += 64) {
+            const u64 k = k0 + j, src = src0 + j;
+            const u64 hi = dhi[src];
+            const prim::U128 r(rec_lo(dkey[src], hi), hi);
+            ph_key[k] = r; ph_pos[k] = 0; ph_freq[k] = (idx_t)dcnt[src]; ph_len[k] = rec_len(r); ph_slot[k] = slot0 + (u32)k;
+            ph_lastT[k] = (r.hi & kPhrLastT) ? 1 : 0;
+        }
     }
 };
-struct PartValFn {         // record at sorted position i -> the value of its phrase (read where GroupPhraseValFn put it)
-    const u64 *skey; int bits; const u32 *pbase; const u32 *lid; const u32 *slot_val; u32 slot0; u32 *out;
+struct PartValFn {         // the records of a partition, in sorted order -> the values of their phrases (read where GroupPhraseValFn put them)
+    const u64 *pstart; const u32 *pbase; const u32 *lid; const u32 *slot_val; u32 slot0; u32 *out;
     GRL_DEV void operator()(u64 i) const {
-        const u32 l = lid[i];
-        out[i] = l == prim::kNoId ? 0u : slot_val[(u64)slot0 + (u64)pbase[prim::RecSort::part_of(skey[i], bits)] + (u64)l];
+        const u64 p = i >> 6;
+        const u64 a = pstart[p], e = pstart[p + 1], v0 = (u64)slot0 + (u64)pbase[p];
+        for (u64 x = a + (i & 63); x < e; x += 256) {       // (four elements per step: their loads are in flight together)
+            u32 l[4], v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) l[j] = x + 64u * j < e ? lid[x + 64u * j] : prim::kNoId;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = l[j] == prim::kNoId ? 0u : slot_val[v0 + (u64)l[j]];
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (x + 64u * j < e) out[x + 64u * j] = v[j];
+        }
     }
 };
 struct PartCombineFn {     // the parse: occurrences that went through the table read their slot's value, the others take the value that came back
@@ -3100,12 +3116,12 @@ class Engine {
         u64 Ds = 0; int part_bits = 0, rec_b = 0; u32 slot0 = 0;
         DBuf<prim::U128> ph_key;
         DBuf<u32> lid, pbase;
-        DBuf<u64> skey;            // the records' keys in partition order (the emission reads every record's partition from them)
+        DBuf<u64> pstart;          // first record of every partition in the sorted order (the emission walks the partitions)
         prim::RecSort psort;
         void clear() {
             n_occ = D = S = cap = Ds = 0; maxlen = 0; part_bits = rec_b = 0; slot0 = 0;
             next_text.release(); ph_pos.release(); ph_freq.release(); ph_len.release(); ph_slot.release(); ph_off.release(); ph_lastT.release();
-            ph_key.release(); skey.release(); lid.release(); pbase.release(); psort.release();
+            ph_key.release(); pstart.release(); lid.release(); pbase.release(); psort.release();
         }
     };
 
@@ -3379,36 +3395,36 @@ class Engine {
 
         // ---- partitioned naming: group the records, de-duplicate and count per partition -------------------------------
         u64 Ds = 0;
-        DBuf<u64> pstart;
         DBuf<u32> dcnt;
         DBuf<u64> dkey, dhi;                      // the partitions' distinct records (staging: partition p's at pstart[p] ..)
         if (part) {
             StageTimer st(&tm.hash, "hash");
             DBuf<u64> rec_k2(n_occ), rec_hi2(n_occ);
             const int res = P.psort.forward(rec_k.p, rec_hi.p, rec_k2.p, rec_hi2.p, n_occ, part_bits, "phrase_part");
-            DBuf<u64> shi;
-            if (res) { P.skey = std::move(rec_k2); shi = std::move(rec_hi2); dkey = std::move(rec_k); dhi = std::move(rec_hi); }
-            else { P.skey = std::move(rec_k); shi = std::move(rec_hi); dkey = std::move(rec_k2); dhi = std::move(rec_hi2); }
+            DBuf<u64> skey, shi;
+            if (res) { skey = std::move(rec_k2); shi = std::move(rec_hi2); dkey = std::move(rec_k); dhi = std::move(rec_hi); }
+            else { skey = std::move(rec_k); shi = std::move(rec_hi); dkey = std::move(rec_k2); dhi = std::move(rec_hi2); }
             const u64 nparts = (u64)1 << part_bits;
+            DBuf<u64> &pstart = P.pstart;
             pstart.alloc(nparts + 1);
-            prim::for_each(nparts + 1, prim::RecBoundsFn{P.skey.p, n_occ, part_bits, nparts, pstart.p}, "phrase_part.bounds");
+            prim::for_each(nparts + 1, prim::RecBoundsFn{skey.p, n_occ, part_bits, nparts, pstart.p}, "phrase_part.bounds");
             P.lid.alloc(n_occ); P.pbase.alloc(nparts + 1); dcnt.alloc(n_occ);
             DBuf<u32> pcount(nparts), ovf(1);
             ovf.zero();
-            prim::rec_dedupe(nparts, pstart.p, P.skey.p, shi.p, RecValid{}, P.lid.p, pcount.p, dkey.p, dhi.p, dcnt.p, ovf.p, "phrase_dedupe");
+            prim::rec_dedupe(nparts, pstart.p, skey.p, shi.p, RecValid{}, P.lid.p, pcount.p, dkey.p, dhi.p, dcnt.p, ovf.p, "phrase_dedupe");
             if (ovf.get(0)) {
                 // a partition with more distinct phrases than its LDS table takes (or an injected limit in the tests): this level
                 // goes through the hash table after all
                 if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: a phrase partition overflowed, falling back to the hash table\n", prim::rt().tag);
                 L.info.table_retries++;
-                shi.release(); dkey.release(); dhi.release(); keys.release(); counts.release(); rep_pos.release(); claim.release();
-                startbits.release(); wordbase.release(); pstart.release(); dcnt.release();
+                skey.release(); shi.release(); dkey.release(); dhi.release(); keys.release(); counts.release(); rep_pos.release(); claim.release();
+                startbits.release(); wordbase.release(); dcnt.release();
                 P.clear();
                 hash_local<cell_t, FIRST>(t, n, ops, P, L, false);
                 return;
             }
             Ds = (u64)prim::exclusive_scan<u32>(nparts, PtrU32In{pcount.p}, P.pbase.p, true, "phrase_dedupe.scan");
-            shi.release();                                // the sorted hi words are no longer needed (the keys are: the emission's partitions)
+            skey.release(); shi.release();                // the sorted records are no longer needed (the emission walks the partitions: pstart, lid)
             P.Ds = Ds; P.part_bits = part_bits; P.rec_b = rec_b; P.slot0 = (u32)P.cap;
             if (P.cap + Ds >= (1ull << 32)) throw prim::Error(-75, "phrase tables beyond 2^32 entries");
             P.cap += Ds;                                  // values of the record phrases live behind the table's slots
@@ -3425,9 +3441,9 @@ class Engine {
             P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
             if (part) {                                   // phrases [0, Ds): from the partitions' staging areas
                 P.ph_key.alloc(Ds);
-                prim::for_each(Ds, PartPhraseFn{P.pbase.p, (u64)1 << part_bits, pstart.p, dkey.p, dhi.p, dcnt.p, P.slot0, P.ph_key.p, P.ph_pos.p, P.ph_freq.p,
-                                                P.ph_len.p, P.ph_slot.p, P.ph_lastT.p}, "phrase_dedupe.phrases");
-                dkey.release(); dhi.release(); dcnt.release(); pstart.release();
+                prim::for_each(((u64)1 << part_bits) * 64, PartPhraseFn{P.pbase.p, P.pstart.p, dkey.p, dhi.p, dcnt.p, P.slot0, P.ph_key.p, P.ph_pos.p, P.ph_freq.p,
+                                                                     P.ph_len.p, P.ph_slot.p, P.ph_lastT.p}, "phrase_dedupe.phrases");
+                dkey.release(); dhi.release(); dcnt.release();
             }
             // ... and the phrases of the table behind them
             prim::for_each(nwords, ClaimSlotsFn{claim.p, cbase.p, startbits.p, wordbase.p, P.next_text.p, P.ph_slot.p + Ds}, "table_compact");
@@ -4375,8 +4391,8 @@ class Engine {
             // neighbours in the value array), the values go back to text order through the sort's passes in reverse, and the
             // occurrences that went through the table read theirs from their slot
             DBuf<u32> va(P.n_occ), vb(P.n_occ), vc(P.n_occ);
-            prim::for_each(P.n_occ, PartValFn{P.skey.p, P.part_bits, P.pbase.p, P.lid.p, sv, P.slot0, va.p}, "emit_part.values");
-            P.skey.release();
+            prim::for_each(((u64)1 << P.part_bits) * 64, PartValFn{P.pstart.p, P.pbase.p, P.lid.p, sv, P.slot0, va.p}, "emit_part.values");
+            P.pstart.release();
             P.psort.backward(va.p, vb.p, vc.p, "emit_part.back");
             prim::for_each(P.n_occ, PartCombineFn{sv, vc.p, P.next_text.p}, "emit_parse");
             P.psort.release(); P.lid.release(); P.pbase.release(); P.ph_key.release();
@@ -4740,7 +4756,10 @@ class Engine {
                 check_totals();
                 Ro = plan.heads;
                 out.sym.shrink(Ro); out.pos.shrink(Ro + 1);
-            } else { out.sym.release(); out.pos.release(); }
+            } else {
+                out.sym.release(); out.pos.release();
+                if (getenv("GRLBWT_TABLE_TRACE")) fprintf(stderr, "[grlbwt] level %d: the one-walk form of pass C gave up, taking count + emit\n", r);
+            }
         }
         if (!done) {
             prim::stream_merge_count<AsmSeg, idx_t>(G, seg, plan, "asm", mostly_plain);      // (few pre-BWT runs among the segments: small tiles, see prim_hip.hpp)

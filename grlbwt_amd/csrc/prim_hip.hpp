@@ -3467,6 +3467,7 @@ inline bool stream_merge_onepass(u64 G, SEG seg, SmPlan<IDX> &plan, u32 *osym, I
     SmLb lbk;
     lbk.st_head = st; lbk.res = st + T;
     lbk.patience = 200000000ull;                        // two seconds of the 100 MHz clock
+    if (const char *pt = dev_env("GRLBWT_DEV_LB_PATIENCE")) lbk.patience = (u64)atoll(pt);      // (development builds: tools/gpu_lookback_giveup.py makes the tiles give up)
     SmWide<IDX> *queue = (SmWide<IDX> *)dev_alloc((queue_cap ? queue_cap : 1) * sizeof(SmWide<IDX>));
     unsigned long long *wide = (unsigned long long *)(dres + 4);      // [1] atoms of the queued segments, [2] queue fill
     (void)out_cap;
