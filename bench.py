@@ -117,11 +117,11 @@ GROUP_KERNELS = {
     "induce_AB": ["k_xs_count", "k_xs_scatter", "PackGrammarFn", "ChainCountFn", "ChainExpandFn", "NoVal, 1, ", "k_rs_hist<unsigned long, 1,", "k_rs_hist<unsigned int, 1,"],
     "induce_C": ["k_sm_sums", "k_sm_merge", "k_sm_wide", "SmHeadsIn", "SmWideCountIn", "TermHeadIn", "RankCellPopcIn", "PrePlaceFn", "BucketEdgesFn",
                  "BucketSizeIn", "NotCodeIn", "BuildBitsFn"],
-    "hash_emit": ["HashInsertFn", "k_giant", "k_start_bits", "MapFn", "ScatterValFn", "PhraseRecordFn", "BitPositionsFn", "k_rec_dedupe", "k_rs_unscatter",
-                  "unsigned long, 2,", "k_rs_hist<unsigned long, 2,", "RecBoundsFn", "PartPhraseFn", "PartValFn", "PartCombineFn"],
+    "hash_emit": ["HashInsertFn", "k_giant", "k_start_bits", "::MapFn>", "ScatterValFn", "PhraseRecordFn", "BitPositionsFn", "k_rec_dedupe", "k_rs_unscatter",
+                  "k_rs_scatter<unsigned long, unsigned long, 2,", "k_rs_hist<unsigned long, 2,", "RecBoundsFn", "PartPhraseFn", "PartValFn", "PartCombineFn"],
     "dict_stage": ["ClaimCompactFn", "DictBuildFn", "Key0KeepFn", "unsigned int, 0, ", "k_rs_hist<unsigned long, 0,", "k_rs_hist<unsigned int, 0,", "HeadFlagFn", "FirstUnresolvedFn",
                    "ExtKeyFn", "SegStartFn", "SegSortSmallFn", "SegBig", "GroupStartsFn", "DenseGidFn", "SuffixRecFn", "GroupAccum", "GroupDecideFn",
-                   "GroupEmitFn", "PackGroupInfoFn", "MetaPosFn", "GrammarFn", "PhraseValFn", "ComposeMapFn", "PreToMetaFn", "BuildBits32Fn"],
+                   "GroupEmitFn", "PackGroupInfoFn", "MetaPosFn", "::GrammarFn>", "PhraseValFn", "ComposeMapFn", "PreToMetaFn", "BuildBits32Fn"],
 }
 
 

@@ -45,3 +45,28 @@ def test_launch_site_groups():
     assert g["induce_AB"]("induce.xscatter", "i") and g["induce_AB"]("induce_pack_grammar", "i") and not g["induce_AB"]("asm.cell_atoms", "i")
     assert g["induce_C"]("asm.take_scan", "i") and g["induce_C"]("merge_runs.scan", "i") and not g["induce_C"]("merge_runs.scan", "p")
     assert g["hash_emit"]("hash_phrases", "p") and g["hash_emit"]("emit_parse", "p") and not g["hash_emit"]("suffix_sort0.scatter", "p")
+
+
+def test_traffic_groups_against_the_committed_pmc_summary():
+    """`traffic` of a group = the HBM bytes of the kernels whose rocprofv3 names hold one of the group's fragments, from the newest
+    committed PMC summary.  No kernel of that summary may be counted in two groups (round 6 found `unsigned long, 2,` -- meant for
+    the record sort -- matching the one-walk kernel of pass C, and `MapFn` matching ComposeMapFn), no fragment of a kernel the
+    headline workload launches may match nothing (`traffic_stale`: rounds 3-4 lost the later radix passes of A+B that way), and the
+    big kernels must all belong to a group."""
+    import json
+    b = load_bench()
+    files = b.pmc_traffic_files()
+    assert files, "no profiles/*/pmc_traffic.json committed"
+    d = json.load(open(files[-1]))
+    names = list(d["kernels"])
+    for n in names:
+        groups = [g for g, fr in b.GROUP_KERNELS.items() if any(f in n for f in fr)]
+        assert len(groups) <= 1, (n[:100], groups)
+    for g, fr in b.GROUP_KERNELS.items():
+        assert b.pmc_traffic_stale(fr) == [], (g, b.pmc_traffic_stale(fr))
+        assert b.pmc_traffic(fr) > 0
+    builds = max(1, int(d.get("builds_profiled", 1)))
+    loose = [(e["hbm_bytes_total"] / builds, n) for n, e in d["kernels"].items()
+             if "prim::k_" in n and not any(f in n for fr in b.GROUP_KERNELS.values() for f in fr)
+             and not any(s in n for s in ("k_reduce", "k_scan_tile", "k_pack_records", "k_byte_hist", "k_rs_chunk_sums", "k_rs_tile_offsets", "DictMetaInitFn", "DiffFn", "PackPhraseInfoFn", "ClaimSlotsFn"))]
+    assert all(bytes_ < 5e9 for bytes_, _ in loose), sorted(loose, reverse=True)[:5]
