@@ -2130,21 +2130,45 @@ __global__ void __launch_bounds__(kBlock) k_xs_count(u64 n, GEN gen, u32 dmask, 
     u32 *h = s_h[threadIdx.x >> 6];
     const u64 base = (u64)blockIdx.x * kXsTileItems;
     u32 mx = 0;
-    for (int b = 0; b < kXsTileItems / kBlock; b++) {
-        const u64 i = base + (u64)b * kBlock + threadIdx.x;
-        if (i < n) {
-            u32 c = 0;
-            const u32 cur = gen.start(i);
-            u64 rec = gen.node(cur);
-            if (gen.owns(rec)) { atomicAdd(&h[(u32)gen.key_own(cur, 0) & dmask], 1u); c++; }
-            while (gen.more(rec)) {
-                const u32 nx = gen.next(rec);
-                atomicAdd(&h[(u32)gen.key_step(rec, nx, 0) & dmask], 1u);
-                c++;
-                rec = gen.node(nx);
+    // (four chains per lane walked together, as in k_xs_scatter: every step of the walk is four independent gathers -- one chain per
+    // lane left the walk at the latency of its dependent loads whatever the occupancy)
+    constexpr int CH = 4;
+    for (int b = 0; b < kXsTileItems / (kBlock * CH); b++) {
+        u64 item[CH], rec[CH];
+        u32 cur[CH], c[CH];
+        bool act[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            item[j] = base + ((u64)b * CH + (u64)j) * kBlock + threadIdx.x;
+            act[j] = item[j] < n;
+            cur[j] = gen.start(act[j] ? item[j] : 0);
+            c[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) rec[j] = gen.node(cur[j]);
+#pragma unroll
+        for (int j = 0; j < CH; j++) if (act[j] && gen.owns(rec[j])) { atomicAdd(&h[(u32)gen.key_own(cur[j], 0) & dmask], 1u); c[j]++; }
+        for (;;) {
+            bool m[CH], any = false;
+            u32 nx[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) { m[j] = act[j] && gen.more(rec[j]); any = any || m[j]; nx[j] = m[j] ? gen.next(rec[j]) : 0u; }
+            if (!any) break;
+            u64 nrec[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) nrec[j] = gen.node(nx[j]);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                if (m[j]) {
+                    atomicAdd(&h[(u32)gen.key_step(rec[j], nx[j], 0) & dmask], 1u);
+                    c[j]++;
+                    rec[j] = nrec[j];
+                }
             }
-            cnt8[i] = (u8)(c < 255u ? c : 255u);
-            mx = c > mx ? c : mx;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            if (act[j]) { cnt8[item[j]] = (u8)(c[j] < 255u ? c[j] : 255u); mx = c[j] > mx ? c[j] : mx; }
         }
     }
     mx = wave_reduce<u32, Op::Max>(mx);

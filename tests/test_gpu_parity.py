@@ -728,3 +728,26 @@ def test_sharded_equals_single_gpu_image(hip, tmp_path):
                        env=dict(os.environ, GRLBWT_A2A_SELF_VIA_COMM="1", GRLBWT_DIST_SHARDED_DICT_MIN="1", GRLBWT_DIST_SHARDED_DICT_MIN_SYMS="0"))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]      # (this leg with the dictionary sharded by owner: its round trips through RCCL)
     assert open(tmp_path / "illumina_dev.rank0.md5").read() == want
+
+
+def test_borrowed_text_that_changes_after_attach_is_refused(hip):
+    """grlbwt_text_attach_device takes the statistics -- and with them the alphabet the level-0 direct index trusts -- at attach time; the
+    buffer stays the caller's.  A cell value that was not there at attach time would take another symbol's 3-bit code: the build
+    looks at a strided sample of a borrowed text again and refuses it.  The engine's own copies (upload, file) cannot change."""
+    import torch
+    data = workloads.sampled_reads(40000, 150, 300000, seed=77)            # 6 MB: large enough for the sampled direct index
+    t = torch.from_numpy(data.copy()).to("cuda:0")
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(t.data_ptr(), t.numel(), 1, keepalive=t)
+        ctx.build()
+        good = ctx.result_bytes()
+    with engine.Context(0, 0, hip) as ctx:
+        ctx.attach_device(t.data_ptr(), t.numel(), 1, keepalive=t)
+        t[1::2] = torch.where(t[1::2] == ord("A"), torch.full_like(t[1::2], ord("R")), t[1::2])      # a value the statistics did not see
+        torch.cuda.synchronize()
+        with pytest.raises(engine.GrlbwtError, match="has changed since its statistics"):
+            ctx.build()
+    with engine.Context(0, 0, hip) as ctx:               # the same bytes, attached as they are now: a text like any other
+        ctx.attach_device(t.data_ptr(), t.numel(), 1, keepalive=t)
+        ctx.build()
+        assert ctx.result_bytes() != good
