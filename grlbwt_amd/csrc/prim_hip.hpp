@@ -1908,19 +1908,16 @@ static constexpr int kRsKeys = kRsTile / kBlock;
 struct NoVal { unsigned char unused; };      // keys-only sort: no value arrays are read or written
 // (DB = digit bits, 8-10: thread t owns the BPT = 2^DB / 256 neighbouring bins [t * BPT, (t + 1) * BPT) in the offset phase)
 // (second launch bound: 4 waves per SIMD = 4 / 2 / 1 workgroups of 256 / 512 / 1024 threads per CU, what the LDS tile leaves room for)
-// (DIRECT: the values are not staged in LDS -- every lane moves its value straight from where it was to where it goes, once the
-// keys' ranking has told it where.  For wide values (the 16-byte phrase records of the partition sort) the LDS tile is what limits
-// the tile size: 4096 records of 16 bytes already take 64 KB, and with 512-1024 bins such a tile leaves runs of 4-8 records = 64-128
-// bytes of values and 16-32 bytes of keys at the write front.  Keys only in LDS: 16384 records per tile, runs four times as long;
-// the value stores of a run come from different lanes and rows but reach the same lines of one L2 within the tile's lifetime.)
+// (Values moved directly instead of staged in LDS -- 16384-record tiles for 16-byte values -- were measured slower in round 5:
+// the 16-byte stores of a wave then go to 64 different lines; round 6 split the record into two staged words instead: RecSort.)
 // (rank_out: where every key went INSIDE its tile's sorted order, in input order -- 2 bytes per key: the way back of a RecSort pass
 // reads it instead of ranking again)
-template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock, bool DIRECT = false, bool MIX = false>
+template <class K, class V, int SITE = 0, int DB = 8, int TB = kBlock, bool MIX = false>
 __global__ void __launch_bounds__(TB)
     k_rs_scatter(const K *keys_in, const V *vals_in, K *keys_out, V *vals_out, u64 n, int shift, u32 dmask,
                         const u64 *offsets /*[tiles][NB] exclusive*/, u32 tiles, u16 *rank_out = nullptr) {
     constexpr int NB = 1 << DB, BPT = NB / TB > 0 ? NB / TB : 1, NW = TB / 64, TILE = TB * kRsItems;
-    constexpr bool STAGED = !std::is_same<V, NoVal>::value && !DIRECT;
+    constexpr bool STAGED = !std::is_same<V, NoVal>::value;
     constexpr int EB = (STAGED && sizeof(V) > sizeof(K)) ? sizeof(V) : sizeof(K);
     typedef typename std::conditional<(NW * NB > 4096), u16, u32>::type CT;      // (per-wave counters: halves when the words would not fit, see wave_rank)
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[TILE * EB];
@@ -1996,13 +1993,6 @@ __global__ void __launch_bounds__(TB)
         for (int q = 0; q < kRsKeys; q++) {
             u32 t = wbase + q * 64 + lane;
             val[q] = t < tile_n ? vals_in[base + t] : V(0);
-        }
-    }
-    if constexpr (DIRECT && !std::is_same<V, NoVal>::value) {
-#pragma unroll
-        for (int q = 0; q < kRsKeys; q++) {
-            u32 t = wbase + q * 64 + lane;
-            if (t < tile_n) vals_out[s_gbase[dig[q]] + idx[q]] = vals_in[base + t];
         }
     }
     __syncthreads();
@@ -2430,7 +2420,7 @@ inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *na
     return sort_keys_fwd(buf_a, buf_b, plan.E, plan.db, plan.bits, name);
 }
 
-template <class K, class V, int SITE, int DB, int TB = kBlock, bool DIRECT = false, bool MIX = false>
+template <class K, class V, int SITE, int DB, int TB = kBlock, bool MIX = false>
 inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shift, u32 dmask, u32 tiles, u32 *counts, u64 *offsets,
                     u32 *chunk_sums, u64 *chunk_off, const char *name, u16 *rank_out = nullptr) {
     prof_begin(std::string(name) + ".hist", n * sizeof(K));
@@ -2439,7 +2429,7 @@ inline void rs_pass(const K *kin, const V *vin, K *kout, V *vout, u64 n, int shi
     after_launch(name);
     rs_offsets<(1 << DB)>(counts, tiles, chunk_sums, chunk_off, offsets, nullptr, name);
     prof_begin(std::string(name) + ".scatter", n * (sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V))) * 2);   // pairs read once + written once
-    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB, DIRECT, MIX>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles, rank_out);
+    hipLaunchKernelGGL((k_rs_scatter<K, V, SITE, DB, TB, MIX>), dim3(tiles), dim3(TB), 0, rt().stream, kin, vin, kout, vout, n, shift, dmask, offsets, tiles, rank_out);
     prof_end();
     after_launch(name);
 }
@@ -2480,10 +2470,9 @@ inline int sort_pairs_tb(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int 
         K *kout = cur ? keys_a : keys_b;
         V *vout = cur ? vals_a : vals_b;
         if (wd <= 8) rs_pass<K, V, SITE, 8, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
-        else if constexpr (TB <= 512) {      // (1024-thread workgroups: 8-bit digits only -- the per-wave counters of a wider digit do not fit LDS)
-            if (wd == 9) rs_pass<K, V, SITE, 9, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
-            else rs_pass<K, V, SITE, 10, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
-        } else throw Error(-71, "sort_pairs: digit too wide for 1024-thread workgroups");
+        else if (wd == 9) rs_pass<K, V, SITE, 9, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);      // (1024 threads: counters in 16-bit halves)
+        else if constexpr (TB <= 512) rs_pass<K, V, SITE, 10, TB>(kin, vin, kout, vout, n, shift, dmask, tiles, counts, offsets, chunk_sums, chunk_off, name);
+        else throw Error(-71, "sort_pairs: digit too wide for 1024-thread workgroups");      // (the per-wave counters of a 10-bit digit do not fit beside the tile)
         shift += wd;
         cur ^= 1;
     }
@@ -2505,10 +2494,17 @@ inline int sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n, int beg
         // (large tiles want many of them: 16384-key tiles from 2^24 keys on -- 1024 tiles, four per CU --, 8192-key tiles from 2^22)
         const int tb = ov ? ov : (SITE == 1 ? 256 : (n >= ((u64)1 << 24) ? 1024 : 512));
         if (n >= (u64)1 << 22 || (ov && n >= (u64)1 << 20)) {
+            // 9-bit digits on the 16384-key tiles where they save a pass (round 6: the per-wave counters of a 9-bit digit fit beside the
+            // tile as 16-bit halves; 32 instead of 64 keys per bin at the write front cost a pass ~15 %, a pass of seven saved is ~14 % --
+            // measured on the 10 GB build: suffix_sort0 of level 2, 54 key bits, 7 x 3.10 -> 6 x 3.16 ms; level 1, 51 bits, 14.5 -> 13.5 ms;
+            // the dictionary stage 322 -> 317 ms.  Not on the smaller tiles: 8 or 16 keys per bin, rounds 3 and 5.)
+            struct Widen { int old; Widen(int d) : old(rs_digit_override()) { if (d) rs_digit_override() = d; } ~Widen() { rs_digit_override() = old; } };
+            const int nbits = end_bit - begin_bit;
+            Widen widen((tb >= 1024 && SITE == 0 && !rs_digit_override() && rs_max_digit() == 8 && (nbits + 8) / 9 < (nbits + 7) / 8) ? 9 : 0);
             int widths[16], maxw = 0;
             const int passes = rs_plan(end_bit - begin_bit, widths);
             for (int p = 0; p < passes; p++) if (widths[p] > maxw) maxw = widths[p];
-            if (tb >= 1024 && maxw <= 8) return sort_pairs_tb<K, V, SITE, 1024>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, name);
+            if (tb >= 1024 && maxw <= 9) return sort_pairs_tb<K, V, SITE, 1024>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, name);
             if (tb >= 512) return sort_pairs_tb<K, V, SITE, 512>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, name);
         }
     }
@@ -2673,8 +2669,8 @@ struct RecSort {
             offs[p] = (u64 *)dev_alloc(((u64)1 << db) * tiles * sizeof(u64));
             const u32 dmask = (1u << widths[p]) - 1u;
             u64 *kin = cur ? key_b : key_a, *kout = cur ? key_a : key_b, *vin = cur ? hi_b : hi_a, *vout = cur ? hi_a : hi_b;
-            if (db == 8) rs_pass<u64, u64, 2, 8, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, rnk[p]);
-            else rs_pass<u64, u64, 2, 9, kThreads, false, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, rnk[p]);
+            if (db == 8) rs_pass<u64, u64, 2, 8, kThreads, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, rnk[p]);
+            else rs_pass<u64, u64, 2, 9, kThreads, true>(kin, vin, kout, vout, n, shifts[p], dmask, tiles, counts, offs[p], chunk_sums, chunk_off, name, rnk[p]);
             cur ^= 1;
         }
         dev_free(counts); dev_free(chunk_sums); dev_free(chunk_off);
