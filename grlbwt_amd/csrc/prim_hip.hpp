@@ -2403,7 +2403,7 @@ inline int expand_sort(GEN gen, XsPlan &plan, K *buf_a, K *buf_b, const char *na
     const u32 dmask = plan.bits >= plan.db ? (u32)NB - 1u : (1u << plan.bits) - 1u;
     // XCD-contiguous tile ranges were measured 7 % SLOWER for this kernel on the 10 GB build (32.8 vs 30.6 ms at level 0,
     // 16.9 vs 14.8 at level 1): the round-robin deal already lets the 8 L2s share every digit's write front; opt-in only
-    const int xcd_aware = 0;
+    static const int xcd_aware = dev_env("GRLBWT_XCD_MAP") ? 1 : 0;      // (development builds)
     prof_begin(std::string(name) + ".xscatter", plan.E * sizeof(K));
     // (three workgroups per CU: at two the kernel keeps everything in registers, at three it spills ~100 bytes per lane and is the
     // faster one -- it hides its gathers with waves, not with registers: round 3)
