@@ -918,6 +918,7 @@ struct ClaimCompactFn {     // step 2, one lane per phrase: its table entry (a r
 struct PartPhraseFn {      // the distinct phrases of the partitioned naming: from the staging areas of their partitions
     const u32 *pbase; const u64 *pstart; const u64 *dkey; const u64 *dhi; const u32 *dcnt; u32 slot0;
     prim::U128 *ph_key; u64 *ph_pos; idx_t *ph_freq; u32 *ph_len; u32 *ph_slot; u8 *ph_lastT;
+    u8 *ph_vflag;          // the two low bits of the phrase's value in the next text: (frequency > 1) << 1 | ends-a-string
     GRL_DEV void operator()(u64 i) const {
         const u64 p = i >> 6;
         const u64 k0 = pbase[p], cnt = (u64)pbase[p + 1] - k0, src0 = pstart[p];
@@ -925,22 +926,25 @@ struct PartPhraseFn {      // the distinct phrases of the partitioned naming: fr
             const u64 k = k0 + j, src = src0 + j;
             const u64 hi = dhi[src];
             const prim::U128 r(rec_lo(dkey[src], hi), hi);
-            ph_key[k] = r; ph_pos[k] = 0; ph_freq[k] = (idx_t)dcnt[src]; ph_len[k] = rec_len(r); ph_slot[k] = slot0 + (u32)k;
+            const u32 f = dcnt[src];
+            ph_key[k] = r; ph_pos[k] = 0; ph_freq[k] = (idx_t)f; ph_len[k] = rec_len(r); ph_slot[k] = slot0 + (u32)k;
             ph_lastT[k] = (r.hi & kPhrLastT) ? 1 : 0;
+            ph_vflag[k] = (u8)((f > 1 ? 2u : 0u) | ((r.hi & kPhrLastT) ? 1u : 0u));
         }
     }
 };
 struct PartValFn {         // the records of a partition, in sorted order -> the values of their phrases (read where GroupPhraseValFn put them)
     const u64 *pstart; const u32 *pbase; const u32 *lid; const u32 *slot_val; u32 slot0; u32 *out;
+    const u8 *vflag;       // (single-GPU rounds: the slot holds the phrase's rank << 2, its two flag bits come from here -- see GroupPhraseValFn)
     GRL_DEV void operator()(u64 i) const {
         const u64 p = i >> 6;
-        const u64 a = pstart[p], e = pstart[p + 1], v0 = (u64)slot0 + (u64)pbase[p];
+        const u64 a = pstart[p], e = pstart[p + 1], k0 = (u64)pbase[p], v0 = (u64)slot0 + k0;
         for (u64 x = a + (i & 63); x < e; x += 256) {       // (four elements per step: their loads are in flight together)
             u32 l[4], v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) l[j] = x + 64u * j < e ? lid[x + 64u * j] : prim::kNoId;
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = l[j] == prim::kNoId ? 0u : slot_val[v0 + (u64)l[j]];
+            for (int j = 0; j < 4; j++) v[j] = l[j] == prim::kNoId ? 0u : (slot_val[v0 + (u64)l[j]] | (vflag ? (u32)vflag[k0 + (u64)l[j]] : 0u));
 #pragma unroll
             for (int j = 0; j < 4; j++) if (x + 64u * j < e) out[x + 64u * j] = v[j];
         }
@@ -1748,10 +1752,19 @@ struct PackPhraseInfoFn {  // pinfo[k] = slot | (freq > 1) << 32 | ends-a-string
 };
 struct GroupPhraseValFn {
     const u8 *gfull; const u32 *gphr; const u32 *grank; const u64 *pinfo; u32 *slot_val;
+    // Phrases [0, Ds) are the record phrases of the partitioned naming: their slots are slot0 + k, so the rank goes there with ONE
+    // random store and the two flag bits of the value are OR-ed in where the value is read (PartValFn: a byte per phrase, read next to
+    // the value).  Only the table phrases behind them -- 1-12 % -- take the gather of (slot, flags) this pass used to pay for everyone
+    // (two random accesses per phrase: 27 ms per 10 GB build).
+    u64 Ds; u32 slot0;
     GRL_DEV void operator()(u64 g) const {
         if (gfull[g]) {
-            const u64 pi = pinfo[gphr[g]];
-            slot_val[(u32)pi] = (grank[g] << 2) | ((pi >> 32) & 1ull ? 2u : 0u) | ((pi >> 33) & 1ull ? 1u : 0u);
+            const u32 k = gphr[g];
+            if ((u64)k < Ds) slot_val[slot0 + k] = grank[g] << 2;
+            else {
+                const u64 pi = pinfo[(u64)k - Ds];
+                slot_val[(u32)pi] = (grank[g] << 2) | ((pi >> 32) & 1ull ? 2u : 0u) | ((pi >> 33) & 1ull ? 1u : 0u);
+            }
         }
     }
 };
@@ -3116,12 +3129,13 @@ class Engine {
         u64 Ds = 0; int part_bits = 0, rec_b = 0; u32 slot0 = 0;
         DBuf<prim::U128> ph_key;
         DBuf<u32> lid, pbase;
+        DBuf<u8> ph_vflag;         // record phrases: the two flag bits of their values (PartPhraseFn)
         DBuf<u64> pstart;          // first record of every partition in the sorted order (the emission walks the partitions)
         prim::RecSort psort;
         void clear() {
             n_occ = D = S = cap = Ds = 0; maxlen = 0; part_bits = rec_b = 0; slot0 = 0;
             next_text.release(); ph_pos.release(); ph_freq.release(); ph_len.release(); ph_slot.release(); ph_off.release(); ph_lastT.release();
-            ph_key.release(); pstart.release(); lid.release(); pbase.release(); psort.release();
+            ph_key.release(); ph_vflag.release(); pstart.release(); lid.release(); pbase.release(); psort.release();
         }
     };
 
@@ -3440,9 +3454,9 @@ class Engine {
             P.D = D;
             P.ph_pos.alloc(D); P.ph_freq.alloc(D); P.ph_len.alloc(D); P.ph_slot.alloc(D); P.ph_lastT.alloc(D); P.ph_off.alloc(D + 1);
             if (part) {                                   // phrases [0, Ds): from the partitions' staging areas
-                P.ph_key.alloc(Ds);
+                P.ph_key.alloc(Ds); P.ph_vflag.alloc(Ds);
                 prim::for_each(((u64)1 << part_bits) * 64, PartPhraseFn{P.pbase.p, P.pstart.p, dkey.p, dhi.p, dcnt.p, P.slot0, P.ph_key.p, P.ph_pos.p, P.ph_freq.p,
-                                                                     P.ph_len.p, P.ph_slot.p, P.ph_lastT.p}, "phrase_dedupe.phrases");
+                                                                     P.ph_len.p, P.ph_slot.p, P.ph_lastT.p, P.ph_vflag.p}, "phrase_dedupe.phrases");
                 dkey.release(); dhi.release(); dcnt.release();
             }
             // ... and the phrases of the table behind them
@@ -3641,6 +3655,7 @@ class Engine {
                     const u32 *ph_off, const u8 *ph_lastT, u32 sigma, LevelData &L, DBuf<u32> &phrase_val,
                     const u32 *fused_ph_slot = nullptr, u32 *fused_slot_val = nullptr,        // (both set: the values go straight to the slots)
                     const prim::U128 *pkeys = nullptr, u64 pDs = 0, int pkb = 0,              // (phrases [0, pDs) given by their records)
+                    u32 pslot0 = 0,                                   // (... and their slots are pslot0 + k: GroupPhraseValFn)
                     const std::vector<u64> *dbase = nullptr,          // (collection-level mode: rank g merged the phrases [dbase[g], dbase[g + 1])
                     const std::vector<u64> *sbase = nullptr,          //  = the dictionary positions [sbase[g], sbase[g + 1]))
                     bool sharded_dict = false,                        // (t, ph_* describe MY part of the dictionary only: see below)
@@ -4295,9 +4310,10 @@ class Engine {
             }
             // ---- a9: metasymbol of every phrase --------------------------------
             if (fused_vals) {
-                DBuf<u64> pinfo(D);
-                prim::for_each(D, PackPhraseInfoFn{fused_ph_slot, ph_freq, ph_lastT, pinfo.p}, "phrase_values");
-                prim::for_each(G, GroupPhraseValFn{gfull.p, gphr.p, grank.p, pinfo.p, fused_slot_val}, "slot_values");
+                const u64 Dt = D - pDs;                  // the table phrases: (slot, flags) packed for one gather
+                DBuf<u64> pinfo(Dt);
+                prim::for_each(Dt, PackPhraseInfoFn{fused_ph_slot + pDs, ph_freq + pDs, ph_lastT + pDs, pinfo.p}, "phrase_values");
+                prim::for_each(G, GroupPhraseValFn{gfull.p, gphr.p, grank.p, pinfo.p, fused_slot_val, pDs, pslot0}, "slot_values");
             } else phrase_val.alloc(sharded ? Dl : D);
             if (fused_vals) {}
             else if (!C) prim::for_each(D, PhraseValFn{pslot.p, ph_freq, ph_lastT, grank.p, phrase_val.p}, "phrase_values");
@@ -4378,7 +4394,8 @@ class Engine {
 
     // a10: the local parse: slot id of every occurrence -> (rank<<2 | rep<<1 | T) of its phrase
     // (slot_val given: the dictionary stage has already put every phrase's value at its slot)
-    void emit_local(LocalParse &P, const u32 *val_of_local_phrase, DBuf<u32> *slot_val_filled = nullptr) {
+    // (rank_only: the slots of the record phrases hold rank << 2, the flag bits are P.ph_vflag's -- dict_stage with fused values)
+    void emit_local(LocalParse &P, const u32 *val_of_local_phrase, DBuf<u32> *slot_val_filled = nullptr, bool rank_only = false) {
         StageTimer st(&tm.emit, "emit");
         DBuf<u32> own;
         if (!slot_val_filled) {
@@ -4391,11 +4408,11 @@ class Engine {
             // neighbours in the value array), the values go back to text order through the sort's passes in reverse, and the
             // occurrences that went through the table read theirs from their slot
             DBuf<u32> va(P.n_occ), vb(P.n_occ), vc(P.n_occ);
-            prim::for_each(((u64)1 << P.part_bits) * 64, PartValFn{P.pstart.p, P.pbase.p, P.lid.p, sv, P.slot0, va.p}, "emit_part.values");
+            prim::for_each(((u64)1 << P.part_bits) * 64, PartValFn{P.pstart.p, P.pbase.p, P.lid.p, sv, P.slot0, va.p, rank_only ? P.ph_vflag.p : nullptr}, "emit_part.values");
             P.pstart.release();
             P.psort.backward(va.p, vb.p, vc.p, "emit_part.back");
             prim::for_each(P.n_occ, PartCombineFn{sv, vc.p, P.next_text.p}, "emit_parse");
-            P.psort.release(); P.lid.release(); P.pbase.release(); P.ph_key.release();
+            P.psort.release(); P.lid.release(); P.pbase.release(); P.ph_key.release(); P.ph_vflag.release();
         } else prim::for_each((P.n_occ + 3) / 4, MapFn{sv, P.next_text.p, P.n_occ}, "emit_parse");
     }
 
@@ -4426,8 +4443,8 @@ class Engine {
         hash_local<cell_t, FIRST>(t, n, ops, P, L, true);
         DBuf<u32> phrase_val, slot_val(P.cap);
         dict_stage<cell_t, FIRST>(nullptr, t, ops, P.D, P.S, P.maxlen, P.ph_pos.p, P.ph_freq.p, P.ph_off.p, P.ph_lastT.p, sigma, L, phrase_val,
-                                  P.ph_slot.p, slot_val.p, P.ph_key.p, P.Ds, P.rec_b);
-        emit_local(P, nullptr, &slot_val);
+                                  P.ph_slot.p, slot_val.p, P.ph_key.p, P.Ds, P.rec_b, P.slot0);
+        emit_local(P, nullptr, &slot_val, true);
         finish_round(P, L, stats.n_strings, P.n_occ);
     }
 
@@ -5051,7 +5068,7 @@ class Engine {
         // ---- dictionary stage: suffix sort + group stage sharded by key range, grammar passes and dictionary by owner ----
         DBuf<u32> gval;
         dict_stage<u32, false>(prim::test_env("GRLBWT_DIST_REPLICATED_DICT") ? nullptr : &C, gcells.p, CellOps<u32, false>{0u}, D, S, maxlen, ph_pos.p, ph_freq.p,
-                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, &dbase, &sbase, sharded_dict, maxfreq);
+                               ph_off.p, ph_lastT.p, sigma, L, gval, nullptr, nullptr, nullptr, 0, 0, 0, &dbase, &sbase, sharded_dict, maxfreq);
         // ---- back to the shards: the value of every phrase I merged returns to its sender, in the order it came ----
         DBuf<u32> lval(P.D);
         {
