@@ -1185,22 +1185,15 @@ __global__ void __launch_bounds__(kBlock) k_name_stream(u64 n, u64 per_block, F 
             qh = qt - qh >= 64u * B ? qh + 64u * B : qt;
         }
     };
-    // (the start bits of the NEXT 256 positions are asked for before the batches of these 256 run: a wave that waited for its bits,
-    // then for its cells, one round trip after the other, moved 100 MB/s -- the kernel ran at what 6144 such waves add up to)
-    bool stn[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const u64 i = wstart + (u64)k * 64 + lane; stn[k] = (i < wend) && f.is_start(i); }
     for (u64 cbase = wstart; cbase < wend; cbase += 256) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const u64 i = cbase + (u64)k * 64 + lane;
-            const bool st = stn[k];
+            const bool st = (i < wend) && f.is_start(i);
             const unsigned long long m = __ballot(st);
             if (st) queue[(qt + (u32)__popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (u32)(i - wstart);
             qt += (u32)__popcll(m);
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const u64 i = cbase + 256 + (u64)k * 64 + lane; stn[k] = (i < wend) && f.is_start(i); }
         run(false);            // leaves fewer than 256 items: the next 256 positions' starts still fit the ring
     }
     run(true);
