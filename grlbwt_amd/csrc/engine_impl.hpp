@@ -4769,7 +4769,9 @@ class Engine {
         // a run + every run of T a run) and the arrays give their tails back.  GRLBWT_ASM_TWO_PASS=1 (the tests) and a walk that
         // gave up take the two-pass form.
         // Where the segments are almost all plain cells (level 0 of a read collection: 2.6 M tiles of 1024 segments, 100+ tiles per
-        // microsecond) the look-back costs more than the count pass it saves -- 37-44 ms against 30 -- and the two-pass form stays.
+        // microsecond) the look-back costs what the count pass it saves costs -- 41 ms against 36.6 with tiles of 1024 segments, 35.1
+        // with tiles of 2048 (GRLBWT_DEV_SM1_SPT=8) -- and needs 12 bytes per SEGMENT of upper-bound arrays (32 GB at level 0 of the
+        // 10 GB build, where the runs take 20): the two-pass form stays.
         // (GRLBWT_ASM_ONE_WALK=1: the tests take the one-walk form at every level, plain or not)
         const bool two_pass = getenv("GRLBWT_ASM_TWO_PASS") != nullptr;
         const bool plain_too = getenv("GRLBWT_ASM_ONE_WALK") != nullptr;
